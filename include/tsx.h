@@ -1,0 +1,149 @@
+/*
+ * tsx.h -- C-ABI of libtsx: the MI355X-native pprts diffuse/direct back-end.
+ *
+ * Drop-in boundary for TenStream's pprts hot path.  Every entry point cites the reference
+ * interface (tenstream/tenstream, file:line) it replaces or is called from.  Plain C: pointers,
+ * sizes, no torch / HIP types in the signatures (streams travel as void*).
+ *
+ * The seam: inside `pprts()` the reference branches
+ *     if (lexplicit_diff) call explicit_ediff(solver, prefix, solver%b, solution%ediff, solution, ierr)
+ *     else                call ediff(A, Aperm, ksp, prefix)                   (src/pprts.F90:2794-2813)
+ * A third branch (option `-<prefix>hip`) calls tsx_diff_solve through the ISO_C_BINDING shim in
+ * tenstream_amd/fortran/m_pprts_hip.F90.
+ *
+ * Conventions
+ *  - Arrays handed over use the reference's own layouts and kinds (ireals = real64):
+ *      diffuse vectors  (0:D-1, zs:ze, xs:xe, ys:ye)   dof fastest        src/pprts_base.F90:140,256
+ *      diff2diff        (1:D*D, zs:ze-1, xs:xe, ys:ye) c(src,dst), src fastest   src/pprts.F90:3471
+ *      a11/a12/kabs/... (zs:ze-1, xs:xe, ys:ye);  albedo (xs:xe, ys:ye);  l1d (zs:ze-1)
+ *    Only the rank-local (owned, un-ghosted) part is passed; ghosts/halos are the library's job.
+ *  - `where`: TSX_HOST pointers are copied with hipMemcpy; TSX_DEVICE pointers are used in place.
+ *  - Return value: 0 = ok, >0 = usage/runtime error (tsx_last_error() has the text).  Solver outcome
+ *    is reported PETSc-style in tsx_ksp_result.reason (2 rtol, 3 atol, -3 its, -4 dtol, -5 breakdown,
+ *    -9 nan) exactly as MyKSPConverged does (src/pprts.F90:4437-4486); the Fortran shim turns a
+ *    negative reason into CHKERR like `solve` does (src/pprts.F90:4298-4302).
+ *  - One handle per solver per rank; calls on one handle are not concurrent.  With nranks > 1 every
+ *    rank of the solver's communicator must call set_coeffs/apply/solve collectively.
+ *  - No CPU fallback exists: without a HIP device every compute entry point fails with
+ *    TSX_ERR_NO_DEVICE.
+ */
+#ifndef TSX_H
+#define TSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSX_VERSION 100
+
+enum { TSX_HOST = 0, TSX_DEVICE = 1 };
+
+enum {
+  TSX_OK = 0,
+  TSX_ERR_ARG = 1,
+  TSX_ERR_NO_DEVICE = 2,
+  TSX_ERR_HIP = 3,
+  TSX_ERR_STATE = 4,
+  TSX_ERR_UNSUPPORTED = 5,
+  TSX_ERR_COMM = 6
+};
+
+/* solver ids: c_wrapper/f2c_solver_ids.h (SOLVER_ID_PPRTS_3_10 = 310, _8_16 = 816) */
+enum { TSX_SOLVER_3_10 = 310, TSX_SOLVER_8_16 = 816 };
+
+/* preconditioners for the flexible BiCGStab (reference default: PCILU / PCBJACOBI+ILU(0),
+ * src/pprts.F90:4350-4371, 4415-4425; here GPU-native equivalents) */
+enum { TSX_PC_NONE = 0, TSX_PC_COLUMN_GS = 1 };
+
+typedef struct tsx_solver tsx_solver; /* opaque */
+
+/* Mirrors t_coord for C_diff (src/pprts_base.F90:92-109) plus the solver's stream layout
+ * (src/pprts.F90:332-349, 413-425 are implied by solver_id). */
+typedef struct {
+  int32_t solver_id;          /* TSX_SOLVER_3_10 | TSX_SOLVER_8_16 */
+  int32_t Nz;                 /* layers of the diffuse grid: C_diff%zm - 1 */
+  int32_t xm, ym;             /* owned columns: C%xm, C%ym */
+  int32_t xs, ys;             /* global start of the owned block: C%xs, C%ys (0-based) */
+  int32_t glob_xm, glob_ym;   /* C%glob_xm, C%glob_ym */
+  int32_t rank, nranks;       /* solver%myid, size of solver%comm */
+  int32_t neigh_w, neigh_e;   /* C%neighbors(10), (16)  (src/pprts_base.F90:812-825) */
+  int32_t neigh_s, neigh_n;   /* C%neighbors(4),  (22) */
+  int32_t device;             /* HIP device ordinal, <0 = current device */
+  int32_t force_halo;         /* testing: route even self-neighbour faces through halo buffers */
+} tsx_grid;
+
+/* tolerances as determine_ksp_tolerances + -<prefix>ksp_* overrides deliver them
+ * (src/pprts_base.F90:1097-1142, src/pprts.F90:4245-4260) */
+typedef struct {
+  double rtol, atol, dtol;
+  int32_t maxit;
+  int32_t pc;                 /* TSX_PC_* */
+  int32_t pc_sweeps;          /* sweeps of the preconditioner per application (>=1) */
+  int32_t check_every;        /* host looks at the device convergence flag every n iterations */
+} tsx_ksp_opts;
+
+/* what `solve` stores on the solution: Niter_diff, diff_ksp_residual_history(100)
+ * (src/pprts.F90:4232-4236, 4266; src/pprts_base.F90:163-166) */
+typedef struct {
+  int32_t reason;
+  int32_t niter;
+  double rnorm0, rnorm;
+  double res_hist[100];
+  int32_t nhist;
+  float solve_ms;             /* device time of the Krylov loop (HIP events on the solver stream) */
+  float import_ms, export_ms; /* layout conversion of b,x0 / x */
+} tsx_ksp_result;
+
+const char *tsx_last_error(void);
+int tsx_version(void);
+int tsx_device_count(void);
+
+/* ---- lifetime: init_pprts/setup_grid allocate C_diff and the vectors (src/pprts.F90:213, 830-1097);
+ *      destroy_pprts frees them (src/pprts_base.F90:877) */
+int tsx_create(const tsx_grid *grid, tsx_solver **out);
+int tsx_destroy(tsx_solver *s);
+void tsx_default_ksp_opts(tsx_ksp_opts *o);
+/* determine_ksp_tolerances (src/pprts_base.F90:1097-1142): rtol 1e-5, atol max(1e-8, 1e-4*Nx*Ny*(Nz+1)*f) */
+int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstrained_fraction, double *rtol,
+                                 double *atol, int32_t *maxit);
+/* run on an existing HIP stream (hipStream_t as void*), e.g. the caller's current stream; NULL = own stream */
+int tsx_set_stream(tsx_solver *s, void *hip_stream);
+
+/* ---- communicator (nranks > 1): RCCL over xGMI replaces the MPI point-to-point of
+ *      halo_fill_5pt / exchange_diffuse_boundary and imp_allreduce (src/pprts_base.F90:1622-1731,
+ *      src/pprts_explicit.F90:715-848, 626).  Rank 0 creates the 128-byte id, the host broadcasts it
+ *      (MPI_Bcast in TenStream, torch.distributed in bench.py), every rank calls tsx_comm_init. */
+int tsx_comm_unique_id(void *id128);
+int tsx_comm_init(tsx_solver *s, const void *id128);
+
+/* ---- operator values.  Replaces set_diff_coeff (src/pprts.F90:5511-5796): instead of one
+ *      MatSetValuesStencil per cell the blocks are transposed once into stream-major planes.
+ *      coeff_kind: 8 = real64 (ireals), 4 = real32.  Blocks whose real64 values are exactly
+ *      representable in real32 (always true for LUT output, src/pprts.F90:3457) are stored as fp32. */
+int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coeff_kind, const uint8_t *l1d,
+                        const double *a11, const double *a12, const double *albedo, int where);
+
+/* ---- y = (I - T) x : op_mat_mult_ediff (src/pprts_shell.F90:366-541), assembled semantics for the
+ *      surface row (albedo/streams on every up/down pair, src/pprts.F90:5755-5794) */
+int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int where);
+
+/* ---- solve (I - T) x = b : replaces ediff()/KSPSolve (src/pprts.F90:2931-3031, 4206-4303).
+ *      x is in/out (nonzero initial guess, src/pprts.F90:4343). */
+int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int where, const tsx_ksp_opts *opts,
+                   tsx_ksp_result *res);
+
+/* ---- measurement helpers (bench.py): time `reps` launches of the dominant kernel with HIP events on
+ *      the solver's stream.  kernel: 0 = SpMV (diffuse operator apply), 1 = one full BiCGStab iteration */
+int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_ms);
+/* algorithmic bytes per launch of that kernel (Nc*D^2*sc + 2*N*sv for the SpMV) */
+int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes);
+/* device STREAM-like copy bandwidth probe (GB/s) for reporting against the measured peak */
+int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSX_H */

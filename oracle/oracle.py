@@ -1,0 +1,202 @@
+"""ctypes front-end of the CPU parity oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under tenstream_amd/ may import this module.
+
+Arrays use the reference's Fortran layouts (see pprts_oracle.h); numpy arrays here are
+C-contiguous with *reversed* axis order, e.g. a diffuse vector is ``x[j, i, k, d]`` and a
+coefficient field is ``c[j, i, k, dst*D+src]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ORC_MAXDOF = 32
+
+
+class Layout(C.Structure):
+    _fields_ = [
+        ("ntop", C.c_int),
+        ("nside", C.c_int),
+        ("top_inward", C.c_int * ORC_MAXDOF),
+        ("side_inward", C.c_int * ORC_MAXDOF),
+        ("Nz", C.c_int),
+        ("xm", C.c_int),
+        ("ym", C.c_int),
+    ]
+
+    @property
+    def D(self):
+        return self.ntop + 2 * self.nside
+
+
+class KspTol(C.Structure):
+    _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double), ("maxit", C.c_int)]
+
+
+class SorOpts(C.Structure):
+    _fields_ = [
+        ("rtol", C.c_double),
+        ("atol", C.c_double),
+        ("maxit", C.c_int),
+        ("omega", C.c_double),
+        ("adaptive_omega", C.c_int),
+    ]
+
+
+class Csr(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("nnz", C.c_int64),
+        ("rowptr", C.POINTER(C.c_int64)),
+        ("col", C.POINTER(C.c_int32)),
+        ("val", C.POINTER(C.c_double)),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/liboracle.so with gcc (building the checker is not using it)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("pprts_oracle.c", "pprts_oracle_phys.c", "pprts_oracle.h", "pprts_oracle_phys.h")]
+    srcs = [s for s in srcs if os.path.exists(s)]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "liboracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_fbcgs.restype = C.c_int
+        _LIB.orc_diff_solve_matfree.restype = C.c_int
+        _LIB.orc_diff_solve_ilu.restype = C.c_int
+        _LIB.orc_explicit_ediff_1rank.restype = C.c_int
+        _LIB.orc_diff_assemble_csr_1rank.restype = C.c_int
+    return _LIB
+
+
+def _p(a, ct=C.c_double):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def layout(solver: str, Nz: int, xm: int, ym: int) -> Layout:
+    lay = Layout()
+    if solver in ("3_10", 310):
+        lib().orc_layout_3_10(C.byref(lay), Nz, xm, ym)
+    elif solver in ("8_16", 816):
+        lib().orc_layout_8_16(C.byref(lay), Nz, xm, ym)
+    else:
+        raise ValueError(solver)
+    return lay
+
+
+def _chk(lay: Layout, coeff, l1d, a11, a12, albedo):
+    D, Nz, xm, ym = lay.D, lay.Nz, lay.xm, lay.ym
+    coeff = np.ascontiguousarray(coeff, dtype=np.float64)
+    assert coeff.shape == (ym, xm, Nz, D * D), coeff.shape
+    l1d = np.ascontiguousarray(l1d, dtype=np.uint8)
+    assert l1d.shape == (Nz,)
+    a11 = np.ascontiguousarray(a11, dtype=np.float64)
+    a12 = np.ascontiguousarray(a12, dtype=np.float64)
+    assert a11.shape == (ym, xm, Nz) and a12.shape == (ym, xm, Nz)
+    albedo = np.ascontiguousarray(albedo, dtype=np.float64)
+    assert albedo.shape == (ym, xm)
+    return coeff, l1d, a11, a12, albedo
+
+
+def diff_apply(lay: Layout, coeff, l1d, a11, a12, albedo, x):
+    """y = (I - T) x, matrix-free, restating pprts_shell.F90:366-541 (one periodic rank)."""
+    coeff, l1d, a11, a12, albedo = _chk(lay, coeff, l1d, a11, a12, albedo)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    assert x.shape == (lay.ym, lay.xm, lay.Nz + 1, lay.D)
+    y = np.empty_like(x)
+    lib().orc_diff_apply_1rank(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12), _p(albedo), _p(x), _p(y))
+    return y
+
+
+def op_local(lay: Layout, coeff, l1d, a11, a12, albedo, xx_g):
+    """Cell loop only (pprts_shell.F90:413-508) on a ghosted local array; returns ghosted xb."""
+    coeff, l1d, a11, a12, albedo = _chk(lay, coeff, l1d, a11, a12, albedo)
+    xx_g = np.ascontiguousarray(xx_g, dtype=np.float64)
+    assert xx_g.shape == (lay.ym + 2, lay.xm + 2, lay.Nz + 1, lay.D)
+    xb = np.zeros_like(xx_g)
+    lib().orc_op_mat_mult_ediff_local(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12), _p(albedo),
+                                      _p(xx_g), _p(xb))
+    return xb
+
+
+def assemble_csr(lay: Layout, coeff, l1d, a11, a12, albedo):
+    """CSR of A = I - T as set_diff_coeff builds it (pprts.F90:5511-5796). Returns scipy CSR."""
+    import scipy.sparse as sp
+
+    coeff, l1d, a11, a12, albedo = _chk(lay, coeff, l1d, a11, a12, albedo)
+    A = Csr()
+    rc = lib().orc_diff_assemble_csr_1rank(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12), _p(albedo),
+                                           C.byref(A))
+    if rc:
+        raise RuntimeError(f"assemble rc={rc}")
+    n, nnz = A.n, A.nnz
+    rowptr = np.ctypeslib.as_array(A.rowptr, shape=(n + 1,)).copy()
+    col = np.ctypeslib.as_array(A.col, shape=(nnz,)).copy()
+    val = np.ctypeslib.as_array(A.val, shape=(nnz,)).copy()
+    lib().orc_csr_free(C.byref(A))
+    return sp.csr_matrix((val, col, rowptr), shape=(n, n))
+
+
+def default_tolerances(glob_xm, glob_ym, glob_zm, unconstrained_fraction=1.0):
+    rtol, atol, maxit = C.c_double(), C.c_double(), C.c_int()
+    lib().orc_determine_ksp_tolerances(glob_xm, glob_ym, glob_zm, C.c_double(unconstrained_fraction),
+                                       C.byref(rtol), C.byref(atol), C.byref(maxit))
+    return rtol.value, atol.value, maxit.value
+
+
+def solve_matfree(lay, coeff, l1d, a11, a12, albedo, b, x0=None, rtol=1e-5, atol=1e-8, maxit=1000, dtol=1e4):
+    coeff, l1d, a11, a12, albedo = _chk(lay, coeff, l1d, a11, a12, albedo)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64, order="C", copy=True)
+    tol = KspTol(rtol, atol, dtol, maxit)
+    nit = C.c_int()
+    hist = np.full(maxit + 2, -1.0)
+    reason = lib().orc_diff_solve_matfree(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12), _p(albedo),
+                                          _p(b), _p(x), C.byref(tol), C.byref(nit), _p(hist), len(hist))
+    return x, dict(reason=reason, niter=nit.value, res_hist=hist[: nit.value + 1])
+
+
+def solve_ilu(lay, coeff, l1d, a11, a12, albedo, b, x0=None, rtol=1e-5, atol=1e-8, maxit=1000, dtol=1e4):
+    """The reference's default 1-rank path: assembled AIJ + KSPFBCGS + ILU(0)."""
+    coeff, l1d, a11, a12, albedo = _chk(lay, coeff, l1d, a11, a12, albedo)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64, order="C", copy=True)
+    tol = KspTol(rtol, atol, dtol, maxit)
+    nit = C.c_int()
+    hist = np.full(maxit + 2, -1.0)
+    ta, tf, ts = C.c_double(), C.c_double(), C.c_double()
+    reason = lib().orc_diff_solve_ilu(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12), _p(albedo),
+                                      _p(b), _p(x), C.byref(tol), C.byref(nit), _p(hist), len(hist),
+                                      C.byref(ta), C.byref(tf), C.byref(ts))
+    return x, dict(reason=reason, niter=nit.value, res_hist=hist[: nit.value + 1], t_assemble=ta.value,
+                   t_factor=tf.value, t_solve=ts.value)
+
+
+def solve_sor(lay, coeff, l1d, a11, a12, albedo, b, x0=None, rtol=1e-5, atol=1e-8, maxit=10000, omega=1.0,
+              adaptive=True):
+    """The reference's PETSc-free explicit solver (pprts_explicit.F90:461-713)."""
+    coeff, l1d, a11, a12, albedo = _chk(lay, coeff, l1d, a11, a12, albedo)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64, order="C", copy=True)
+    o = SorOpts(rtol, atol, maxit, omega, int(adaptive))
+    nit = C.c_int()
+    hist = np.zeros(100)
+    rc = lib().orc_explicit_ediff_1rank(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12), _p(albedo),
+                                        _p(b), _p(x), C.byref(o), C.byref(nit), _p(hist), len(hist))
+    return x, dict(converged=(rc == 0), niter=nit.value, res_hist=hist[: min(nit.value, 100)])

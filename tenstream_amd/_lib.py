@@ -1,0 +1,89 @@
+"""ctypes binding of libtsx (include/tsx.h).  Plumbing only: the product is the HIP library.
+
+The library must exist in-tree (tenstream_amd/lib/libtsx.so, built by __graft_entry__.build()
+or `make -C tenstream_amd/csrc`); there is no Python/CPU fallback -- a missing library or a
+missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtsx.so")
+
+TSX_HOST, TSX_DEVICE = 0, 1
+TSX_SOLVER_3_10, TSX_SOLVER_8_16 = 310, 816
+TSX_PC_NONE, TSX_PC_COLUMN_GS = 0, 1
+TSX_ERR_NO_DEVICE = 2
+
+
+class TsxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libtsx error {code}: {msg}")
+        self.code = code
+
+
+class Grid(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "solver_id", "Nz", "xm", "ym", "xs", "ys", "glob_xm", "glob_ym", "rank", "nranks",
+        "neigh_w", "neigh_e", "neigh_s", "neigh_n", "device", "force_halo")]
+
+
+class KspOpts(C.Structure):
+    _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double), ("maxit", C.c_int32),
+                ("pc", C.c_int32), ("pc_sweeps", C.c_int32), ("check_every", C.c_int32)]
+
+
+class KspResult(C.Structure):
+    _fields_ = [("reason", C.c_int32), ("niter", C.c_int32), ("rnorm0", C.c_double), ("rnorm", C.c_double),
+                ("res_hist", C.c_double * 100), ("nhist", C.c_int32), ("solve_ms", C.c_float),
+                ("import_ms", C.c_float), ("export_ms", C.c_float)]
+
+
+# every symbol include/tsx.h declares (tests check the .so exports exactly these)
+SYMBOLS = (
+    "tsx_last_error", "tsx_version", "tsx_device_count", "tsx_create", "tsx_destroy", "tsx_default_ksp_opts",
+    "tsx_determine_ksp_tolerances", "tsx_set_stream", "tsx_comm_unique_id", "tsx_comm_init",
+    "tsx_diff_set_coeffs", "tsx_diff_apply", "tsx_diff_solve", "tsx_bench_kernel", "tsx_algorithmic_bytes",
+    "tsx_probe_copy_bandwidth",
+)
+
+_lib = None
+
+
+def load():
+    """dlopen libtsx.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C tenstream_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, ip, dp = C.c_void_p, C.c_int, C.POINTER(C.c_double)
+    lib.tsx_last_error.restype = C.c_char_p
+    lib.tsx_version.restype = ip
+    lib.tsx_device_count.restype = ip
+    lib.tsx_create.argtypes = [C.POINTER(Grid), C.POINTER(vp)]
+    lib.tsx_destroy.argtypes = [vp]
+    lib.tsx_default_ksp_opts.argtypes = [C.POINTER(KspOpts)]
+    lib.tsx_default_ksp_opts.restype = None
+    lib.tsx_determine_ksp_tolerances.argtypes = [vp, C.c_double, dp, dp, C.POINTER(C.c_int32)]
+    lib.tsx_set_stream.argtypes = [vp, vp]
+    lib.tsx_comm_unique_id.argtypes = [vp]
+    lib.tsx_comm_init.argtypes = [vp, vp]
+    lib.tsx_diff_set_coeffs.argtypes = [vp, vp, ip, vp, vp, vp, vp, ip]
+    lib.tsx_diff_apply.argtypes = [vp, vp, vp, ip]
+    lib.tsx_diff_solve.argtypes = [vp, vp, vp, ip, C.POINTER(KspOpts), C.POINTER(KspResult)]
+    lib.tsx_bench_kernel.argtypes = [vp, ip, ip, C.POINTER(C.c_float)]
+    lib.tsx_algorithmic_bytes.argtypes = [vp, ip, dp]
+    lib.tsx_probe_copy_bandwidth.argtypes = [vp, C.c_size_t, ip, dp]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise TsxError(rc, load().tsx_last_error().decode())

@@ -1,0 +1,718 @@
+// tsx_api.hip -- C-ABI of libtsx (see include/tsx.h).  Host orchestration: HIP streams/events,
+// device-resident Krylov loop (no host round trip per iteration), RCCL halo exchange.
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+
+#include "tsx_kernels.hpp"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+void tsx_set_error(const std::string &msg) { g_err = msg; }
+extern "C" const char *tsx_last_error(void) { return g_err.c_str(); }
+extern "C" int tsx_version(void) { return TSX_VERSION; }
+
+#define HIPCHK(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      tsx_set_error(std::string(#call) + ": " + hipGetErrorString(e_) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); \
+      return e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? TSX_ERR_NO_DEVICE : TSX_ERR_HIP; \
+    }                                                                                     \
+  } while (0)
+
+#define ARGCHK(cond, msg)          \
+  do {                             \
+    if (!(cond)) {                 \
+      tsx_set_error(msg);          \
+      return TSX_ERR_ARG;          \
+    }                              \
+  } while (0)
+
+extern "C" int tsx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, bound lazily (dlopen by soname so that a process that already loaded RCCL -- e.g. through
+// torch.distributed -- shares that copy).
+typedef struct { char internal[128]; } tsx_ncclUniqueId;
+typedef void *tsx_ncclComm_t;
+struct RcclApi {
+  void *h = nullptr;
+  int (*GetUniqueId)(tsx_ncclUniqueId *) = nullptr;
+  int (*CommInitRank)(tsx_ncclComm_t *, int, tsx_ncclUniqueId, int) = nullptr;
+  int (*CommDestroy)(tsx_ncclComm_t) = nullptr;
+  int (*Send)(const void *, size_t, int, int, tsx_ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, tsx_ncclComm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, tsx_ncclComm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+enum { TSX_NCCL_FLOAT64 = 8, TSX_NCCL_SUM = 0 };  // ncclFloat64 / ncclSum in rccl.h
+
+static int rccl_load() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.h) return TSX_OK;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    tsx_set_error(std::string("cannot dlopen librccl: ") + dlerror());
+    return TSX_ERR_COMM;
+  }
+#define BIND(field, sym)                                         \
+  *(void **)(&g_rccl.field) = dlsym(h, sym);                     \
+  if (!g_rccl.field) {                                           \
+    tsx_set_error(std::string("librccl lacks ") + sym);          \
+    return TSX_ERR_COMM;                                         \
+  }
+  BIND(GetUniqueId, "ncclGetUniqueId");
+  BIND(CommInitRank, "ncclCommInitRank");
+  BIND(CommDestroy, "ncclCommDestroy");
+  BIND(Send, "ncclSend");
+  BIND(Recv, "ncclRecv");
+  BIND(AllReduce, "ncclAllReduce");
+  BIND(GroupStart, "ncclGroupStart");
+  BIND(GroupEnd, "ncclGroupEnd");
+  BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+  g_rccl.h = h;
+  return TSX_OK;
+}
+#define NCCLCHK(call)                                                                  \
+  do {                                                                                 \
+    int r_ = (call);                                                                   \
+    if (r_ != 0) {                                                                     \
+      tsx_set_error(std::string(#call) + ": " + g_rccl.GetErrorString(r_));            \
+      return TSX_ERR_COMM;                                                             \
+    }                                                                                  \
+  } while (0)
+
+extern "C" int tsx_comm_unique_id(void *id128) {
+  ARGCHK(id128, "tsx_comm_unique_id: null");
+  int rc = rccl_load();
+  if (rc) return rc;
+  tsx_ncclUniqueId id;
+  NCCLCHK(g_rccl.GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return TSX_OK;
+}
+
+extern "C" int tsx_comm_init(tsx_solver *s, const void *id128) {
+  ARGCHK(s && id128, "tsx_comm_init: null");
+  int rc = rccl_load();
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(s->device));
+  tsx_ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  tsx_ncclComm_t comm = nullptr;
+  NCCLCHK(g_rccl.CommInitRank(&comm, s->grid.nranks, id, s->grid.rank));
+  s->nccl_comm = comm;
+  s->comm_ready = true;
+  return TSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline int grid_for(long long n, int cap = 2048) {
+  long long b = (n + TSX_BLOCK - 1) / TSX_BLOCK;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
+  if (!o) return;
+  o->rtol = 1e-5;   // determine_ksp_tolerances, src/pprts_base.F90:1128
+  o->atol = 1e-8;
+  o->dtol = 1e4;    // PETSc KSP default divergence tolerance
+  o->maxit = 1000;  // src/pprts_base.F90:1118
+  o->pc = TSX_PC_NONE;
+  o->pc_sweeps = 1;
+  o->check_every = 4;
+}
+
+extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstrained_fraction, double *rtol,
+                                            double *atol, int32_t *maxit) {
+  ARGCHK(s && rtol && atol && maxit, "tsx_determine_ksp_tolerances: null");
+  // src/pprts_base.F90:1126-1131 with C = C_diff: glob_zm = Nz + 1
+  *maxit = 1000;
+  *rtol = 1e-5;
+  double a = 1e-4 * (double)s->grid.glob_xm * (double)s->grid.glob_ym * (double)(s->grid.Nz + 1) * unconstrained_fraction;
+  *atol = a > 1e-8 ? a : 1e-8;
+  return TSX_OK;
+}
+
+extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
+  ARGCHK(grid && out, "tsx_create: null argument");
+  ARGCHK(grid->solver_id == TSX_SOLVER_3_10 || grid->solver_id == TSX_SOLVER_8_16,
+         "tsx_create: solver_id must be 310 (3_10) or 816 (8_16)");
+  ARGCHK(grid->Nz >= 1 && grid->xm >= 1 && grid->ym >= 1, "tsx_create: empty grid");
+  ARGCHK(grid->nranks >= 1 && grid->rank >= 0 && grid->rank < grid->nranks, "tsx_create: bad rank/nranks");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    tsx_set_error("tsx_create: no HIP device available (libtsx has no CPU fallback)");
+    return TSX_ERR_NO_DEVICE;
+  }
+  tsx_solver *s = new tsx_solver();
+  memset((void *)s, 0, sizeof(*s));
+  s->grid = *grid;
+  if (grid->device >= 0) s->device = grid->device;
+  else HIPCHK(hipGetDevice(&s->device));
+  HIPCHK(hipSetDevice(s->device));
+
+  TsxGeo &g = s->geo;
+  g.Nz = grid->Nz;
+  g.xm = grid->xm;
+  g.ym = grid->ym;
+  g.ncol = g.xm * g.ym;
+  g.Nc = (long long)g.Nz * g.ncol;
+  g.ntop = grid->solver_id == TSX_SOLVER_3_10 ? 2 : 8;
+  g.nside = 4;
+  g.D = g.ntop + 2 * g.nside;
+  g.N = (long long)g.D * (g.Nc + g.ncol);
+  const bool self_x = grid->nranks == 1 || (grid->neigh_w == grid->rank && grid->neigh_e == grid->rank);
+  const bool self_y = grid->nranks == 1 || (grid->neigh_s == grid->rank && grid->neigh_n == grid->rank);
+  g.wrap_x = self_x && !grid->force_halo;
+  g.wrap_y = self_y && !grid->force_halo;
+
+  HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  s->own_stream = true;
+  HIPCHK(hipEventCreate(&s->ev0));
+  HIPCHK(hipEventCreate(&s->ev1));
+
+  const size_t nb = (size_t)g.N * sizeof(double);
+  double **vecs[] = {&s->vx, &s->vb, &s->vr, &s->vrhat, &s->vp, &s->vv, &s->vs, &s->vt};
+  for (double **v : vecs) {
+    HIPCHK(hipMalloc((void **)v, nb));
+    HIPCHK(hipMemsetAsync(*v, 0, nb, s->stream));
+  }
+  s->vph = s->vp;  // no preconditioner: p-hat aliases p
+  s->vsh = s->vs;
+  s->halo_x_elems = (size_t)(g.nside / 2) * g.Nz * g.ym;
+  s->halo_y_elems = (size_t)(g.nside / 2) * g.Nz * g.xm;
+  double **hx[] = {&s->sendW, &s->sendE, &s->recvW, &s->recvE};
+  double **hy[] = {&s->sendS, &s->sendN, &s->recvS, &s->recvN};
+  for (double **v : hx) {
+    HIPCHK(hipMalloc((void **)v, s->halo_x_elems * sizeof(double)));
+    HIPCHK(hipMemsetAsync(*v, 0, s->halo_x_elems * sizeof(double), s->stream));
+  }
+  for (double **v : hy) {
+    HIPCHK(hipMalloc((void **)v, s->halo_y_elems * sizeof(double)));
+    HIPCHK(hipMemsetAsync(*v, 0, s->halo_y_elems * sizeof(double), s->stream));
+  }
+  HIPCHK(hipMalloc((void **)&s->partials, sizeof(double) * TSX_NSLOTS * TSX_MAX_PARTIAL_BLOCKS));
+  HIPCHK(hipMemsetAsync(s->partials, 0, sizeof(double) * TSX_NSLOTS * TSX_MAX_PARTIAL_BLOCKS, s->stream));
+  HIPCHK(hipMalloc((void **)&s->scal, sizeof(TsxScalars)));
+  HIPCHK(hipMemsetAsync(s->scal, 0, sizeof(TsxScalars), s->stream));
+  HIPCHK(hipHostMalloc((void **)&s->scal_host, sizeof(TsxScalars), hipHostMallocDefault));
+  HIPCHK(hipMalloc((void **)&s->l1d, (size_t)g.Nz));
+  HIPCHK(hipMalloc((void **)&s->albedo, sizeof(double) * g.ncol));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  *out = s;
+  return TSX_OK;
+}
+
+extern "C" int tsx_destroy(tsx_solver *s) {
+  if (!s) return TSX_OK;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  void *ptrs[] = {s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
+                  s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
+                  s->recvE, s->recvS, s->recvN, s->partials, s->scal};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (s->vph && s->vph != s->vp) (void)hipFree(s->vph);
+  if (s->vsh && s->vsh != s->vs) (void)hipFree(s->vsh);
+  if (s->scal_host) (void)hipHostFree(s->scal_host);
+  if (s->comm_ready && g_rccl.CommDestroy) g_rccl.CommDestroy(s->nccl_comm);
+  (void)hipEventDestroy(s->ev0);
+  (void)hipEventDestroy(s->ev1);
+  if (s->own_stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return TSX_OK;
+}
+
+extern "C" int tsx_set_stream(tsx_solver *s, void *hip_stream) {
+  ARGCHK(s, "tsx_set_stream: null");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->own_stream) HIPCHK(hipStreamDestroy(s->stream));
+  if (hip_stream) {
+    s->stream = (hipStream_t)hip_stream;
+    s->own_stream = false;
+  } else {
+    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    s->own_stream = true;
+  }
+  return TSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exchange the four face buffers with the W/E/S/N neighbours.  recvW <- west's sendE, recvE <- east's
+// sendW, recvS <- south's sendN, recvN <- north's sendS.  Point-to-point messages to one peer are
+// matched in issue order, so receives are posted E,W,N,S against sends W,E,S,N (matters when both
+// x-neighbours are the same rank, e.g. 2 ranks along a periodic axis).
+static int face_exchange(tsx_solver *s) {
+  const TsxGeo &g = s->geo;
+  const size_t bx = s->halo_x_elems, by = s->halo_y_elems;
+  if (s->comm_ready) {
+    tsx_ncclComm_t c = s->nccl_comm;
+    const tsx_grid &gr = s->grid;
+    NCCLCHK(g_rccl.GroupStart());
+    if (!g.wrap_x) {
+      NCCLCHK(g_rccl.Send(s->sendW, bx, TSX_NCCL_FLOAT64, gr.neigh_w, c, s->stream));
+      NCCLCHK(g_rccl.Send(s->sendE, bx, TSX_NCCL_FLOAT64, gr.neigh_e, c, s->stream));
+      NCCLCHK(g_rccl.Recv(s->recvE, bx, TSX_NCCL_FLOAT64, gr.neigh_e, c, s->stream));
+      NCCLCHK(g_rccl.Recv(s->recvW, bx, TSX_NCCL_FLOAT64, gr.neigh_w, c, s->stream));
+    }
+    if (!g.wrap_y) {
+      NCCLCHK(g_rccl.Send(s->sendS, by, TSX_NCCL_FLOAT64, gr.neigh_s, c, s->stream));
+      NCCLCHK(g_rccl.Send(s->sendN, by, TSX_NCCL_FLOAT64, gr.neigh_n, c, s->stream));
+      NCCLCHK(g_rccl.Recv(s->recvN, by, TSX_NCCL_FLOAT64, gr.neigh_n, c, s->stream));
+      NCCLCHK(g_rccl.Recv(s->recvS, by, TSX_NCCL_FLOAT64, gr.neigh_s, c, s->stream));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    return TSX_OK;
+  }
+  if (s->grid.nranks > 1) {
+    tsx_set_error("face_exchange: nranks > 1 but tsx_comm_init was not called");
+    return TSX_ERR_STATE;
+  }
+  // single rank with force_halo: every neighbour is this rank
+  if (!g.wrap_x) {
+    HIPCHK(hipMemcpyAsync(s->recvE, s->sendW, bx * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->recvW, s->sendE, bx * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  }
+  if (!g.wrap_y) {
+    HIPCHK(hipMemcpyAsync(s->recvN, s->sendS, by * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->recvS, s->sendN, by * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  }
+  return TSX_OK;
+}
+
+template <int NTOP, int NSIDE>
+static int halo_update(tsx_solver *s, const double *v, bool in_solve) {
+  const TsxGeo &g = s->geo;
+  if (g.wrap_x && g.wrap_y) return TSX_OK;
+  const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
+  hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, v, s->sendW,
+                     s->sendE, s->sendS, s->sendN, in_solve ? &s->scal->done : (const int *)nullptr);
+  return face_exchange(s);
+}
+
+template <int NTOP, int NSIDE, int FUSE>
+static int launch_spmv(tsx_solver *s, const double *x, double *y, const double *w, bool in_solve) {
+  const TsxGeo &g = s->geo;
+  int rc = halo_update<NTOP, NSIDE>(s, x, in_solve);
+  if (rc) return rc;
+  const int nb = grid_for(g.Nc, TSX_MAX_PARTIAL_BLOCKS);
+  const int *done = in_solve ? &s->scal->done : nullptr;
+  if (s->coef_bytes == 4)
+    hipLaunchKernelGGL((tsx_k_spmv<NTOP, NSIDE, float, FUSE>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
+                       (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS,
+                       s->recvN, w, s->partials, done);
+  else
+    hipLaunchKernelGGL((tsx_k_spmv<NTOP, NSIDE, double, FUSE>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
+                       (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS,
+                       s->recvN, w, s->partials, done);
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+static inline int spmv_nblocks(const tsx_solver *s) { return grid_for(s->geo.Nc, TSX_MAX_PARTIAL_BLOCKS); }
+
+// reduce partials -> (all-reduce) -> scalar algebra
+static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {
+  if (s->comm_ready && s->grid.nranks > 1) {
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1);
+    NCCLCHK(g_rccl.AllReduce(s->scal->red, s->scal->red, TSX_NSLOTS, TSX_NCCL_FLOAT64, TSX_NCCL_SUM, s->nccl_comm,
+                             s->stream));
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 2);
+  } else {
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 3);
+  }
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NTOP, int NSIDE>
+static int import_vec(tsx_solver *s, const double *ref_dev, double *v) {
+  const TsxGeo &g = s->geo;
+  const long long total = (long long)(g.Nz + 1) * g.ncol;
+  hipLaunchKernelGGL((tsx_k_convert_vec<NTOP, NSIDE, false>), dim3(grid_for(total)), dim3(TSX_BLOCK), 0, s->stream, g,
+                     const_cast<double *>(ref_dev), v, s->sendW, s->sendS);
+  HIPCHK(hipGetLastError());
+  if (!(g.wrap_x && g.wrap_y)) {
+    // only the W-ward / S-ward messages carry data; E/N-ward buffers travel as they are (ignored)
+    int rc = face_exchange(s);
+    if (rc) return rc;
+    const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
+    // a direction that wraps in-kernel has nothing to unpack: pass through harmlessly by guarding in host
+    if (!g.wrap_x || !g.wrap_y) {
+      TsxGeo g2 = g;
+      hipLaunchKernelGGL((tsx_k_import_unpack<NTOP, NSIDE>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g2, v,
+                         g.wrap_x ? (const double *)nullptr : s->recvE, g.wrap_y ? (const double *)nullptr : s->recvN);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  return TSX_OK;
+}
+
+template <int NTOP, int NSIDE>
+static int export_vec(tsx_solver *s, const double *v, double *ref_dev) {
+  const TsxGeo &g = s->geo;
+  int rc = halo_update<NTOP, NSIDE>(s, v, false);
+  if (rc) return rc;
+  const long long total = (long long)(g.Nz + 1) * g.ncol;
+  hipLaunchKernelGGL((tsx_k_convert_vec<NTOP, NSIDE, true>), dim3(grid_for(total)), dim3(TSX_BLOCK), 0, s->stream, g,
+                     ref_dev, const_cast<double *>(v), s->recvW, s->recvS);
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+static int ensure_stage(tsx_solver *s) {
+  const size_t nb = (size_t)s->geo.N * sizeof(double);
+  if (!s->stage_a) HIPCHK(hipMalloc((void **)&s->stage_a, nb));
+  if (!s->stage_b) HIPCHK(hipMalloc((void **)&s->stage_b, nb));
+  return TSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coeff_kind, const uint8_t *l1d,
+                                   const double *a11, const double *a12, const double *albedo, int where) {
+  ARGCHK(s && diff2diff && l1d && albedo, "tsx_diff_set_coeffs: null argument");
+  ARGCHK(coeff_kind == 4 || coeff_kind == 8, "tsx_diff_set_coeffs: coeff_kind must be 4 or 8");
+  HIPCHK(hipSetDevice(s->device));
+  const TsxGeo &g = s->geo;
+  const int DD = g.D * g.D;
+  const size_t ncoef = (size_t)DD * g.Nc;
+  const hipMemcpyKind mk = where == TSX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+
+  // l1d (needed on the host too: are a11/a12 required?)
+  std::vector<uint8_t> l1d_h(g.Nz);
+  if (where == TSX_HOST) memcpy(l1d_h.data(), l1d, g.Nz);
+  else HIPCHK(hipMemcpy(l1d_h.data(), l1d, g.Nz, hipMemcpyDeviceToHost));
+  s->any_l1d = false;
+  for (int k = 0; k < g.Nz; ++k) s->any_l1d |= l1d_h[k] != 0;
+  HIPCHK(hipMemcpyAsync(s->l1d, l1d_h.data(), g.Nz, hipMemcpyHostToDevice, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  ARGCHK(!s->any_l1d || (a11 && a12), "tsx_diff_set_coeffs: a11/a12 required when any layer is 1-D");
+  HIPCHK(hipMemcpyAsync(s->albedo, albedo, sizeof(double) * g.ncol, mk, s->stream));
+
+  // coefficient blocks
+  const void *src_dev = diff2diff;
+  void *tmp = nullptr;
+  if (where == TSX_HOST) {
+    HIPCHK(hipMalloc(&tmp, ncoef * coeff_kind));
+    HIPCHK(hipMemcpyAsync(tmp, diff2diff, ncoef * coeff_kind, hipMemcpyHostToDevice, s->stream));
+    src_dev = tmp;
+  }
+  int out_bytes = 4;
+  if (coeff_kind == 8) {  // keep fp64 unless every value survives the round trip through fp32
+    int *flag = nullptr;
+    HIPCHK(hipMalloc((void **)&flag, sizeof(int)));
+    HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), s->stream));
+    hipLaunchKernelGGL(tsx_k_check_fp32_lossless, dim3(grid_for((long long)ncoef)), dim3(TSX_BLOCK), 0, s->stream,
+                       (long long)ncoef, (const double *)src_dev, flag);
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipFree(flag));
+    out_bytes = bad ? 8 : 4;
+  }
+  if (s->coef && s->coef_bytes != out_bytes) {
+    HIPCHK(hipFree(s->coef));
+    s->coef = nullptr;
+  }
+  if (!s->coef) HIPCHK(hipMalloc(&s->coef, ncoef * out_bytes));
+  s->coef_bytes = out_bytes;
+  const int TI = DD > 128 ? 16 : 32;  // keep the LDS tile under 64 KiB for D = 16
+  const int nbk = grid_for((long long)((g.xm + TI - 1) / TI) * g.ym * g.Nz * TSX_BLOCK, 8192);
+  const size_t lds = (size_t)TI * (DD + 1) * out_bytes;
+  if (coeff_kind == 8 && out_bytes == 8)
+    hipLaunchKernelGGL((tsx_k_import_coeff<double, double>), dim3(nbk), dim3(TSX_BLOCK), lds, s->stream, g, DD, TI,
+                       (const double *)src_dev, (double *)s->coef);
+  else if (coeff_kind == 8)
+    hipLaunchKernelGGL((tsx_k_import_coeff<double, float>), dim3(nbk), dim3(TSX_BLOCK), lds, s->stream, g, DD, TI,
+                       (const double *)src_dev, (float *)s->coef);
+  else
+    hipLaunchKernelGGL((tsx_k_import_coeff<float, float>), dim3(nbk), dim3(TSX_BLOCK), lds, s->stream, g, DD, TI,
+                       (const float *)src_dev, (float *)s->coef);
+  HIPCHK(hipGetLastError());
+
+  if (s->any_l1d) {
+    if (!s->a11) HIPCHK(hipMalloc((void **)&s->a11, sizeof(double) * g.Nc));
+    if (!s->a12) HIPCHK(hipMalloc((void **)&s->a12, sizeof(double) * g.Nc));
+    double *t11 = nullptr, *t12 = nullptr;
+    const double *p11 = a11, *p12 = a12;
+    if (where == TSX_HOST) {
+      HIPCHK(hipMalloc((void **)&t11, sizeof(double) * g.Nc));
+      HIPCHK(hipMalloc((void **)&t12, sizeof(double) * g.Nc));
+      HIPCHK(hipMemcpyAsync(t11, a11, sizeof(double) * g.Nc, hipMemcpyHostToDevice, s->stream));
+      HIPCHK(hipMemcpyAsync(t12, a12, sizeof(double) * g.Nc, hipMemcpyHostToDevice, s->stream));
+      p11 = t11;
+      p12 = t12;
+    }
+    hipLaunchKernelGGL(tsx_k_import_cellfield, dim3(grid_for(g.Nc)), dim3(TSX_BLOCK), 0, s->stream, g, p11, s->a11);
+    hipLaunchKernelGGL(tsx_k_import_cellfield, dim3(grid_for(g.Nc)), dim3(TSX_BLOCK), 0, s->stream, g, p12, s->a12);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (t11) HIPCHK(hipFree(t11));
+    if (t12) HIPCHK(hipFree(t12));
+  }
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (tmp) HIPCHK(hipFree(tmp));
+  s->have_coeffs = true;
+  return TSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NTOP, int NSIDE>
+static int diff_apply_t(tsx_solver *s, const double *x, double *y, int where) {
+  const TsxGeo &g = s->geo;
+  const size_t nb = (size_t)g.N * sizeof(double);
+  int rc = ensure_stage(s);
+  if (rc) return rc;
+  const double *xd = x;
+  double *yd = y;
+  if (where == TSX_HOST) {
+    HIPCHK(hipMemcpyAsync(s->stage_a, x, nb, hipMemcpyHostToDevice, s->stream));
+    xd = s->stage_a;
+    yd = s->stage_b;
+  }
+  if ((rc = import_vec<NTOP, NSIDE>(s, xd, s->vp))) return rc;
+  if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, s->vp, s->vv, nullptr, false))) return rc;
+  if ((rc = export_vec<NTOP, NSIDE>(s, s->vv, yd))) return rc;
+  if (where == TSX_HOST) HIPCHK(hipMemcpyAsync(y, s->stage_b, nb, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return TSX_OK;
+}
+
+extern "C" int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int where) {
+  ARGCHK(s && x && y, "tsx_diff_apply: null argument");
+  if (!s->have_coeffs) {
+    tsx_set_error("tsx_diff_apply: call tsx_diff_set_coeffs first");
+    return TSX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  return s->geo.ntop == 2 ? diff_apply_t<2, 4>(s, x, y, where) : diff_apply_t<8, 4>(s, x, y, where);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One BiCGStab iteration on the stream (no host synchronisation).
+template <int NTOP, int NSIDE>
+static int enqueue_iteration(tsx_solver *s, bool first) {
+  const TsxGeo &g = s->geo;
+  const long long n2 = g.N / 2;
+  const int nbv = grid_for(n2);
+  int rc;
+  if (!first) {
+    hipLaunchKernelGGL(tsx_k_pupdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
+                       (double2 *)s->vp, (const double2 *)s->vv);
+  }
+  if ((rc = launch_spmv<NTOP, NSIDE, 1>(s, s->vph, s->vv, s->vrhat, true))) return rc;
+  if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
+  hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
+                     (const double2 *)s->vv, (double2 *)s->vs);
+  if ((rc = launch_spmv<NTOP, NSIDE, 2>(s, s->vsh, s->vt, nullptr, true))) return rc;
+  if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
+  hipLaunchKernelGGL(tsx_k_xrupdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (double2 *)s->vx,
+                     (const double2 *)s->vph, (const double2 *)s->vsh, (const double2 *)s->vs, (const double2 *)s->vt,
+                     (const double2 *)s->vrhat, (double2 *)s->vr, s->partials);
+  if ((rc = scalar_stage(s, nbv, 2, TSX_STAGE_RHO))) return rc;
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+template <int NTOP, int NSIDE>
+static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o) {
+  const TsxGeo &g = s->geo;
+  int rc;
+  TsxScalars init;
+  memset(&init, 0, sizeof(init));
+  init.rtol = o->rtol;
+  init.atol = o->atol;
+  init.dtol = o->dtol;
+  init.maxit = o->maxit;
+  *s->scal_host = init;
+  HIPCHK(hipMemcpyAsync(s->scal, s->scal_host, sizeof(TsxScalars), hipMemcpyHostToDevice, s->stream));
+  // r = b - A x0 (nonzero initial guess, src/pprts.F90:4343); rhat = p = r
+  if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, s->vx, s->vt, nullptr, false))) return rc;
+  const int nbv = grid_for(g.N);
+  hipLaunchKernelGGL(tsx_k_residual0, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr, s->vrhat,
+                     s->vp, s->partials);
+  if ((rc = scalar_stage(s, nbv, 1, TSX_STAGE_INIT))) return rc;
+  return TSX_OK;
+}
+
+template <int NTOP, int NSIDE>
+static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, const tsx_ksp_opts *o,
+                        tsx_ksp_result *res) {
+  const TsxGeo &g = s->geo;
+  const size_t nb = (size_t)g.N * sizeof(double);
+  int rc;
+  const double *bd = b;
+  double *xd = x;
+  hipEvent_t e_imp0, e_imp1, e_exp1;
+  HIPCHK(hipEventCreate(&e_imp0));
+  HIPCHK(hipEventCreate(&e_imp1));
+  HIPCHK(hipEventCreate(&e_exp1));
+  if (where == TSX_HOST) {
+    if ((rc = ensure_stage(s))) return rc;
+    HIPCHK(hipMemcpyAsync(s->stage_a, b, nb, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->stage_b, x, nb, hipMemcpyHostToDevice, s->stream));
+    bd = s->stage_a;
+    xd = s->stage_b;
+  }
+  HIPCHK(hipEventRecord(e_imp0, s->stream));
+  if ((rc = import_vec<NTOP, NSIDE>(s, bd, s->vb))) return rc;
+  if ((rc = import_vec<NTOP, NSIDE>(s, xd, s->vx))) return rc;
+  HIPCHK(hipEventRecord(e_imp1, s->stream));
+
+  HIPCHK(hipEventRecord(s->ev0, s->stream));
+  if ((rc = krylov_begin<NTOP, NSIDE>(s, o))) return rc;
+  const int chunk = o->check_every > 0 ? o->check_every : 4;
+  int enq = 0;
+  bool done = false;
+  while (!done) {
+    const int todo = (o->maxit - enq) < chunk ? (o->maxit - enq) : chunk;
+    for (int q = 0; q < todo; ++q, ++enq)
+      if ((rc = enqueue_iteration<NTOP, NSIDE>(s, enq == 0))) return rc;
+    HIPCHK(hipMemcpyAsync(s->scal_host, s->scal, sizeof(TsxScalars), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    done = s->scal_host->done != 0 || enq >= o->maxit;
+  }
+  HIPCHK(hipEventRecord(s->ev1, s->stream));
+  if ((rc = export_vec<NTOP, NSIDE>(s, s->vx, xd))) return rc;
+  HIPCHK(hipEventRecord(e_exp1, s->stream));
+  if (where == TSX_HOST) HIPCHK(hipMemcpyAsync(x, s->stage_b, nb, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+
+  if (res) {
+    const TsxScalars &h = *s->scal_host;
+    memset(res, 0, sizeof(*res));
+    res->reason = h.done ? h.reason : -3;  // KSP_DIVERGED_ITS
+    res->niter = h.its;
+    res->rnorm0 = h.rnorm0;
+    res->rnorm = h.rnorm;
+    res->nhist = h.nhist;
+    memcpy(res->res_hist, h.hist, sizeof(double) * 100);
+    HIPCHK(hipEventElapsedTime(&res->solve_ms, s->ev0, s->ev1));
+    HIPCHK(hipEventElapsedTime(&res->import_ms, e_imp0, e_imp1));
+    HIPCHK(hipEventElapsedTime(&res->export_ms, s->ev1, e_exp1));
+  }
+  (void)hipEventDestroy(e_imp0);
+  (void)hipEventDestroy(e_imp1);
+  (void)hipEventDestroy(e_exp1);
+  return TSX_OK;
+}
+
+extern "C" int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int where, const tsx_ksp_opts *opts,
+                              tsx_ksp_result *res) {
+  ARGCHK(s && b && x, "tsx_diff_solve: null argument");
+  if (!s->have_coeffs) {
+    tsx_set_error("tsx_diff_solve: call tsx_diff_set_coeffs first");
+    return TSX_ERR_STATE;
+  }
+  tsx_ksp_opts o;
+  if (opts) o = *opts;
+  else tsx_default_ksp_opts(&o);
+  ARGCHK(o.maxit >= 1, "tsx_diff_solve: maxit < 1");
+  ARGCHK(o.pc == TSX_PC_NONE, "tsx_diff_solve: unsupported preconditioner");
+  HIPCHK(hipSetDevice(s->device));
+  return s->geo.ntop == 2 ? diff_solve_t<2, 4>(s, b, x, where, &o, res) : diff_solve_t<8, 4>(s, b, x, where, &o, res);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes) {
+  ARGCHK(s && bytes, "tsx_algorithmic_bytes: null");
+  const TsxGeo &g = s->geo;
+  const double sc = s->coef_bytes ? s->coef_bytes : 4, sv = 8;
+  // B_spmv = Nc*D^2*sc + 2*N*sv ; B_iter = 2*B_spmv + 16*N*sv
+  const double bspmv = (double)g.Nc * g.D * g.D * sc + 2.0 * (double)g.N * sv;
+  if (kernel == 0) *bytes = bspmv;
+  else if (kernel == 1) *bytes = 2.0 * bspmv + 16.0 * (double)g.N * sv;
+  else {
+    tsx_set_error("tsx_algorithmic_bytes: kernel must be 0 or 1");
+    return TSX_ERR_ARG;
+  }
+  return TSX_OK;
+}
+
+template <int NTOP, int NSIDE>
+static int bench_kernel_t(tsx_solver *s, int kernel, int reps, float *avg_ms) {
+  int rc;
+  if (kernel == 0) {
+    if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, s->vp, s->vv, nullptr, false))) return rc;  // warm
+    HIPCHK(hipEventRecord(s->ev0, s->stream));
+    for (int q = 0; q < reps; ++q)
+      if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, s->vp, s->vv, nullptr, false))) return rc;
+    HIPCHK(hipEventRecord(s->ev1, s->stream));
+  } else {
+    // iterations on whatever state the vectors hold; scalars are neutralised so nothing diverges/stops
+    tsx_ksp_opts o;
+    tsx_default_ksp_opts(&o);
+    o.rtol = 0;
+    o.atol = 0;
+    o.dtol = 1e300;
+    o.maxit = 1 << 30;
+    HIPCHK(hipMemsetAsync(s->vx, 0, sizeof(double) * s->geo.N, s->stream));
+    if ((rc = krylov_begin<NTOP, NSIDE>(s, &o))) return rc;
+    if ((rc = enqueue_iteration<NTOP, NSIDE>(s, true))) return rc;
+    HIPCHK(hipEventRecord(s->ev0, s->stream));
+    for (int q = 0; q < reps; ++q)
+      if ((rc = enqueue_iteration<NTOP, NSIDE>(s, false))) return rc;
+    HIPCHK(hipEventRecord(s->ev1, s->stream));
+  }
+  HIPCHK(hipStreamSynchronize(s->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  *avg_ms = ms / (float)reps;
+  return TSX_OK;
+}
+
+extern "C" int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_ms) {
+  ARGCHK(s && avg_ms && reps >= 1, "tsx_bench_kernel: bad argument");
+  ARGCHK(kernel == 0 || kernel == 1, "tsx_bench_kernel: kernel must be 0 or 1");
+  if (!s->have_coeffs) {
+    tsx_set_error("tsx_bench_kernel: call tsx_diff_set_coeffs first");
+    return TSX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  return s->geo.ntop == 2 ? bench_kernel_t<2, 4>(s, kernel, reps, avg_ms) : bench_kernel_t<8, 4>(s, kernel, reps, avg_ms);
+}
+
+extern "C" int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps) {
+  ARGCHK(s && gbps && reps >= 1 && bytes >= 16, "tsx_probe_copy_bandwidth: bad argument");
+  HIPCHK(hipSetDevice(s->device));
+  void *a = nullptr, *b = nullptr;
+  HIPCHK(hipMalloc(&a, bytes));
+  HIPCHK(hipMalloc(&b, bytes));
+  HIPCHK(hipMemsetAsync(a, 1, bytes, s->stream));
+  const long long n = (long long)(bytes / 16);
+  hipLaunchKernelGGL(tsx_k_copy16, dim3(grid_for(n, 8192)), dim3(TSX_BLOCK), 0, s->stream, n, (const float4 *)a, (float4 *)b);
+  HIPCHK(hipEventRecord(s->ev0, s->stream));
+  for (int q = 0; q < reps; ++q)
+    hipLaunchKernelGGL(tsx_k_copy16, dim3(grid_for(n, 8192)), dim3(TSX_BLOCK), 0, s->stream, n, (const float4 *)a, (float4 *)b);
+  HIPCHK(hipEventRecord(s->ev1, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  *gbps = 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9;
+  HIPCHK(hipFree(a));
+  HIPCHK(hipFree(b));
+  return TSX_OK;
+}

@@ -1,0 +1,85 @@
+// tsx_internal.hpp -- internal types of libtsx (MI355X / gfx950 only).
+//
+// Data layout in HBM (see DESIGN.md "Data layout"):
+//   The reference stores unknowns as (dof, z, x, y), dof fastest, owned by the column they sit on
+//   (src/pprts_base.F90:140).  Every unknown is the *destination* of exactly one cell (the cell the
+//   stream leaves, src/pprts.F90:5558-5648), so internally an unknown is stored at the index of that
+//   cell, one plane per stream:
+//        v[d * Nc + cell],  cell = (k * ym + j) * xm + i      (x fastest -> coalesced along i)
+//   plus a "tail" of D values per column for the rows no cell writes:
+//        Edn at level 0 (TOA), Eup at level Nz (surface/albedo row), side streams at level Nz (dummies)
+//        v[D * Nc + d * ncol + col],  col = j * xm + i
+//   N = D * (Nc + ncol) = D * L * xm * ym, the same unknown count as the reference.
+//   Coefficients: one plane per (dst,src) pair, C[(dst * D + src) * Nc + cell], fp32 when lossless.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tsx.h"
+
+#define TSX_MAX_PARTIAL_BLOCKS 4096
+#define TSX_NSLOTS 3
+
+struct TsxGeo {
+  int Nz, xm, ym;
+  int ncol;        // xm*ym
+  long long Nc;    // Nz*xm*ym
+  long long N;     // D*(Nc+ncol)
+  int D, ntop, nside;
+  int wrap_x, wrap_y;  // 1: neighbour in that direction is this rank itself and faces wrap in-kernel
+};
+
+// device-resident scalars of the Krylov loop (one instance per solver)
+struct TsxScalars {
+  double rho, rho_old, alpha, omega, beta;
+  double rnorm, rnorm0;
+  double red[TSX_NSLOTS];  // reduced (and, multi-rank, all-reduced) sums of the last stage
+  double rtol, atol, dtol;
+  int maxit;
+  int its;
+  int reason;
+  int done;
+  int nhist;
+  double hist[100];
+};
+
+struct tsx_solver {
+  tsx_grid grid;
+  TsxGeo geo;
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+
+  // operator
+  void *coef;          // planes, float or double
+  int coef_bytes;      // 4 or 8
+  uint8_t *l1d;        // [Nz]
+  double *a11, *a12;   // [Nc] cell-indexed (only read where l1d)
+  double *albedo;      // [ncol]
+  bool have_coeffs;
+  bool any_l1d;
+
+  // Krylov work vectors (internal layout, N doubles each)
+  double *vx, *vb, *vr, *vrhat, *vp, *vv, *vs, *vt, *vph, *vsh;
+  // staging in reference layout (for TSX_HOST callers and conversion)
+  double *stage_a, *stage_b;
+
+  // halo buffers: [nside/2][Nz][edge] doubles per direction
+  double *sendW, *sendE, *sendS, *sendN;
+  double *recvW, *recvE, *recvS, *recvN;
+  size_t halo_x_elems, halo_y_elems;
+
+  double *partials;    // [TSX_NSLOTS][TSX_MAX_PARTIAL_BLOCKS]
+  TsxScalars *scal;    // device
+  TsxScalars *scal_host;  // pinned host mirror
+
+  void *nccl_comm;     // ncclComm_t when nranks > 1 (or force_halo with comm)
+  bool comm_ready;
+
+  hipEvent_t ev0, ev1;
+};
+
+void tsx_set_error(const std::string &msg);

@@ -1,0 +1,504 @@
+// tsx_kernels.hpp -- hand-written HIP kernels for gfx950 (MI355X): 64-wide wavefronts, HBM-bound.
+//
+// All kernels are bandwidth-bound streaming kernels (arithmetic intensity ~0.36 flop/B, no MFMA):
+// lanes run along x (i), the fastest index of every plane, so each wave instruction touches one
+// contiguous 256/512-byte span per plane.  Reductions are wavefront-reduced (__shfl_down over 64
+// lanes), one LDS hop per block, then per-block partials that a single-block scalar stage sums in a
+// fixed order (deterministic; no float atomics).
+#pragma once
+#include "tsx_internal.hpp"
+
+#define TSX_BLOCK 256
+
+// stream direction tables (src/pprts.F90:339-343 for 3_10, :416-419 for 8_16): both solvers use
+// is_inward = [F,T,F,T,...] for top and side streams, so parity of the index decides.
+__host__ __device__ constexpr bool tsx_inward(int q) { return (q & 1) != 0; }
+
+__device__ __forceinline__ double tsx_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// block-wide sum of NS values; thread 0 of the block writes partials[s * TSX_MAX_PARTIAL_BLOCKS + blockIdx.x]
+template <int NS>
+__device__ __forceinline__ void tsx_block_reduce_store(double (&v)[NS], double *__restrict__ partials) {
+  __shared__ double sm[NS][TSX_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    double r = tsx_wave_sum(v[s]);
+    if (lane == 0) sm[s][wv] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      double r = 0;
+#pragma unroll
+      for (int q = 0; q < TSX_BLOCK / 64; ++q) r += sm[s][q];
+      partials[(size_t)s * TSX_MAX_PARTIAL_BLOCKS + blockIdx.x] = r;
+    }
+  }
+}
+
+// XCD-aware chunk assignment: blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
+// so give each XCD one contiguous eighth of the window of chunks in flight: the +-1 row (xm) and
+// +-1 lane neighbours a cell reads are then served by that XCD's own L2.
+__device__ __forceinline__ long long tsx_swizzle(long long b, long long nb) {
+  return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = (I - T) x.  Restates op_mat_mult_ediff (src/pprts_shell.F90:413-519) in dst-owned form: the
+// thread of cell (k,i,j) gathers the cell's D source streams and writes the D streams leaving it.
+// Surface row uses the assembled semantics (src/pprts.F90:5755-5794).
+// FUSE bit0: partial slot0 += w.y            (BiCGStab (rhat, v))
+// FUSE bit1: partial slot1 += x.y, slot2 += y.y   (BiCGStab (s,t), (t,t))
+template <int NTOP, int NSIDE, typename CT, int FUSE>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv(
+    TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
+    const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ x,
+    double *__restrict__ y, const double *__restrict__ hW, const double *__restrict__ hE,
+    const double *__restrict__ hS, const double *__restrict__ hN, const double *__restrict__ w,
+    double *__restrict__ partials, const int *__restrict__ done) {
+  constexpr int D = NTOP + 2 * NSIDE;
+  if (done && *done) return;
+  double sum[3] = {0.0, 0.0, 0.0};
+  const long long Nc = g.Nc;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
+  const long long nchunks = (Nc + TSX_BLOCK - 1) / TSX_BLOCK;
+  const double *__restrict__ xt = x + (size_t)D * Nc;
+  double *__restrict__ yt = y + (size_t)D * Nc;
+  const double *__restrict__ wt = (FUSE & 1) ? w + (size_t)D * Nc : nullptr;
+
+  for (long long base = 0; base < nchunks; base += gridDim.x) {
+    const long long nb = (nchunks - base) < (long long)gridDim.x ? (nchunks - base) : (long long)gridDim.x;
+    if ((long long)blockIdx.x >= nb) break;
+    const long long c = (base + tsx_swizzle(blockIdx.x, nb)) * TSX_BLOCK + threadIdx.x;
+    if (c >= Nc) continue;
+    const int i = (int)(c % xm);
+    const long long t = c / xm;
+    const int j = (int)(t % ym);
+    const int k = (int)(t / ym);
+    const int col = j * xm + i;
+
+    double xs[D], xo[D], acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xo[d] = x[(size_t)d * Nc + c];
+#pragma unroll
+    for (int q = 0; q < NTOP; ++q) {
+      if (tsx_inward(q))
+        xs[q] = k > 0 ? x[(size_t)q * Nc + c - ncol] : xt[(size_t)q * ncol + col];
+      else
+        xs[q] = k + 1 < Nz ? x[(size_t)q * Nc + c + ncol] : xt[(size_t)q * ncol + col];
+    }
+#pragma unroll
+    for (int q = 0; q < NSIDE; ++q) {
+      const int d = NTOP + q, slot = q >> 1;
+      if (tsx_inward(q)) {  // +x moving, enters through face i, leaves cell i-1
+        if (i > 0) xs[d] = x[(size_t)d * Nc + c - 1];
+        else if (g.wrap_x) xs[d] = x[(size_t)d * Nc + c + (xm - 1)];
+        else xs[d] = hW[((size_t)slot * Nz + k) * ym + j];
+      } else {  // -x moving, enters through face i+1, leaves cell i+1
+        if (i < xm - 1) xs[d] = x[(size_t)d * Nc + c + 1];
+        else if (g.wrap_x) xs[d] = x[(size_t)d * Nc + c - (xm - 1)];
+        else xs[d] = hE[((size_t)slot * Nz + k) * ym + j];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NSIDE; ++q) {
+      const int d = NTOP + NSIDE + q, slot = q >> 1;
+      if (tsx_inward(q)) {
+        if (j > 0) xs[d] = x[(size_t)d * Nc + c - xm];
+        else if (g.wrap_y) xs[d] = x[(size_t)d * Nc + c + (size_t)(ym - 1) * xm];
+        else xs[d] = hS[((size_t)slot * Nz + k) * xm + i];
+      } else {
+        if (j < ym - 1) xs[d] = x[(size_t)d * Nc + c + xm];
+        else if (g.wrap_y) xs[d] = x[(size_t)d * Nc + c - (size_t)(ym - 1) * xm];
+        else xs[d] = hN[((size_t)slot * Nz + k) * xm + i];
+      }
+    }
+
+    if (l1d[k]) {  // 1-D (Eddington) layer: src/pprts_shell.F90:417-427; side rows are identity
+      const double t11 = a11[c], t12 = a12[c];
+#pragma unroll
+      for (int q = 0; q < NTOP; ++q) acc[q] = xo[q] - t11 * xs[q] - t12 * xs[q ^ 1];
+#pragma unroll
+      for (int d = NTOP; d < D; ++d) acc[d] = xo[d];
+    } else {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        double a = 0.0;
+#pragma unroll
+        for (int s = 0; s < D; ++s) a += (double)C[(size_t)(d * D + s) * Nc + c] * xs[s];
+        acc[d] = xo[d] - a;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      y[(size_t)d * Nc + c] = acc[d];
+      if (FUSE & 1) sum[0] += w[(size_t)d * Nc + c] * acc[d];
+      if (FUSE & 2) {
+        sum[1] += xo[d] * acc[d];
+        sum[2] += acc[d] * acc[d];
+      }
+    }
+    if (k == Nz - 1) {  // rows no cell writes: TOA Edn, surface Eup (albedo), bottom side dummies
+      const double alb = albedo[col] / (double)(NTOP / 2);
+      double down = 0.0;  // sum of inward top streams at level Nz == this cell's own inward outputs' inputs
+#pragma unroll
+      for (int q = 0; q < NTOP; ++q)
+        if (tsx_inward(q)) down += xo[q];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const double xv = xt[(size_t)d * ncol + col];
+        double yv = xv;
+        if (d < NTOP && !tsx_inward(d)) yv = xv - alb * down;
+        yt[(size_t)d * ncol + col] = yv;
+        if (FUSE & 1) sum[0] += wt[(size_t)d * ncol + col] * yv;
+        if (FUSE & 2) {
+          sum[1] += xv * yv;
+          sum[2] += yv * yv;
+        }
+      }
+    }
+  }
+  if (FUSE) tsx_block_reduce_store<3>(sum, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BLAS-1 stages of the flexible BiCGStab (KSPFBCGS, selected at src/pprts.F90:4342), fused so that a
+// full iteration moves 19 N-vectors besides the two operator applications.
+// r = b - y (y = A x0); rhat = r; p = r; slot0 = (r,r)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_residual0(long long n, const double *__restrict__ b,
+                                                             const double *__restrict__ y, double *__restrict__ r,
+                                                             double *__restrict__ rhat, double *__restrict__ p,
+                                                             double *__restrict__ partials) {
+  double sum[1] = {0.0};
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double v = b[q] - y[q];
+    r[q] = v;
+    rhat[q] = v;
+    p[q] = v;
+    sum[0] += v * v;
+  }
+  tsx_block_reduce_store<1>(sum, partials);
+}
+
+// p = r + beta (p - omega v)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pupdate(long long n2, const TsxScalars *__restrict__ sc,
+                                                           const double2 *__restrict__ r, double2 *__restrict__ p,
+                                                           const double2 *__restrict__ v) {
+  if (sc->done) return;
+  const double beta = sc->beta, omega = sc->omega;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double2 rr = r[q], pp = p[q], vv = v[q];
+    double2 o;
+    o.x = rr.x + beta * (pp.x - omega * vv.x);
+    o.y = rr.y + beta * (pp.y - omega * vv.y);
+    p[q] = o;
+  }
+}
+
+// s = r - alpha v
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_supdate(long long n2, const TsxScalars *__restrict__ sc,
+                                                           const double2 *__restrict__ r, const double2 *__restrict__ v,
+                                                           double2 *__restrict__ s) {
+  if (sc->done) return;
+  const double alpha = sc->alpha;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double2 rr = r[q], vv = v[q];
+    double2 o;
+    o.x = rr.x - alpha * vv.x;
+    o.y = rr.y - alpha * vv.y;
+    s[q] = o;
+  }
+}
+
+// x += alpha ph + omega sh; r = s - omega t; slot0 = (rhat, r), slot1 = (r, r)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xrupdate(long long n2, const TsxScalars *__restrict__ sc,
+                                                            double2 *__restrict__ x, const double2 *__restrict__ ph,
+                                                            const double2 *__restrict__ sh, const double2 *__restrict__ s,
+                                                            const double2 *__restrict__ t, const double2 *__restrict__ rhat,
+                                                            double2 *__restrict__ r, double *__restrict__ partials) {
+  if (sc->done) return;
+  const double alpha = sc->alpha, omega = sc->omega;
+  double sum[2] = {0.0, 0.0};
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double2 xx = x[q], pp = ph[q], ss2 = sh[q], ss = s[q], tt = t[q], rh = rhat[q];
+    double2 xo, ro;
+    xo.x = xx.x + alpha * pp.x + omega * ss2.x;
+    xo.y = xx.y + alpha * pp.y + omega * ss2.y;
+    ro.x = ss.x - omega * tt.x;
+    ro.y = ss.y - omega * tt.y;
+    x[q] = xo;
+    r[q] = ro;
+    sum[0] += rh.x * ro.x + rh.y * ro.y;
+    sum[1] += ro.x * ro.x + ro.y * ro.y;
+  }
+  tsx_block_reduce_store<2>(sum, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scalar stage: one block.  mode bit0: reduce the per-block partials into sc->red (fixed order);
+// mode bit1: run the stage's scalar algebra (after the all-reduce when ranks > 1).
+// Stop rule restates MyKSPConverged (src/pprts.F90:4437-4486).
+enum { TSX_STAGE_INIT = 0, TSX_STAGE_ALPHA = 1, TSX_STAGE_OMEGA = 2, TSX_STAGE_RHO = 3 };
+
+__global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc, const double *__restrict__ partials,
+                                                     int nblocks, int nslots, int stage, int mode) {
+  __shared__ double sm[TSX_NSLOTS][16];
+  if (sc->done) return;
+  if (mode & 1) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int s = 0; s < nslots; ++s) {
+      double v = 0.0;
+      for (int q = threadIdx.x; q < nblocks; q += 1024) v += partials[(size_t)s * TSX_MAX_PARTIAL_BLOCKS + q];
+      v = tsx_wave_sum(v);
+      if (lane == 0) sm[s][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int s = 0; s < nslots; ++s) {
+        double v = 0.0;
+        for (int q = 0; q < 16; ++q) v += sm[s][q];
+        sc->red[s] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (!(mode & 2) || threadIdx.x != 0) return;
+  const double tiny = 2.2250738585072014e-308;
+  switch (stage) {
+    case TSX_STAGE_INIT: {
+      const double rn = sqrt(sc->red[0]);
+      sc->rnorm0 = rn > tiny ? rn : tiny;  // n == 0: store initial norm, no test (:4455-4458)
+      sc->rnorm = rn;
+      sc->hist[0] = rn;
+      sc->nhist = 1;
+      sc->its = 0;
+      sc->rho = sc->red[0];
+      sc->rho_old = 1.0;
+      sc->alpha = 1.0;
+      sc->omega = 1.0;
+      sc->beta = 0.0;
+      sc->reason = 0;
+      if (sc->red[0] == 0.0) {  // exact initial guess: nothing to do
+        sc->reason = 2;
+        sc->done = 1;
+      } else if (rn != rn) {
+        sc->reason = -9;
+        sc->done = 1;
+      }
+    } break;
+    case TSX_STAGE_ALPHA: {
+      const double d1 = sc->red[0];
+      if (d1 == 0.0 || d1 != d1) {
+        sc->reason = d1 != d1 ? -9 : -5;
+        sc->done = 1;
+      } else {
+        sc->alpha = sc->rho / d1;
+      }
+    } break;
+    case TSX_STAGE_OMEGA: {
+      const double ts = sc->red[1], tt = sc->red[2];
+      sc->omega = tt == 0.0 ? 0.0 : ts / tt;
+    } break;
+    case TSX_STAGE_RHO: {
+      sc->rho_old = sc->rho;
+      sc->rho = sc->red[0];
+      const double rn = sqrt(sc->red[1]);
+      sc->rnorm = rn;
+      sc->its += 1;
+      if (sc->nhist < 100) sc->hist[sc->nhist++] = rn;
+      int reason = 0;
+      if (rn / sc->rnorm0 <= sc->rtol) reason = 2;
+      else if (rn <= sc->atol) reason = 3;
+      else if (sc->its > sc->maxit) reason = -3;
+      else if (rn / sc->rnorm0 >= sc->dtol) reason = -4;
+      else if (rn != rn) reason = -9;
+      else if (sc->rho == 0.0 || sc->omega == 0.0) reason = -5;
+      if (reason) {
+        sc->reason = reason;
+        sc->done = 1;
+      } else {
+        sc->beta = (sc->rho / sc->rho_old) * (sc->alpha / sc->omega);
+      }
+    } break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layout conversion reference <-> internal (see tsx_internal.hpp).  One thread per (level, i, j).
+// Streams that leave the *neighbouring* cell across the low x / low y face of the owned block belong to
+// the neighbour rank's cell: they are routed through the halo buffers.
+//   import: ref value of +x stream at face i=0  -> sendW (west rank stores it at its cell xm-1)
+//           ref value of +y stream at face j=0  -> sendS
+//   export: ref value of +x stream at face i=0  <- recvW (== SpMV halo of x), same for y
+template <int NTOP, int NSIDE, bool EXPORT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_convert_vec(TsxGeo g, double *__restrict__ ref,
+                                                               double *__restrict__ v, double *__restrict__ bufW,
+                                                               double *__restrict__ bufS) {
+  constexpr int D = NTOP + 2 * NSIDE;
+  const int L = g.Nz + 1, xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
+  const long long Nc = g.Nc;
+  const long long total = (long long)L * ncol;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < total; q += (long long)gridDim.x * TSX_BLOCK) {
+    // q enumerates (i fastest, j, k) so that internal accesses coalesce
+    const int i = (int)(q % xm);
+    const long long t = q / xm;
+    const int j = (int)(t % ym);
+    const int k = (int)(t / ym);
+    const int col = j * xm + i;
+    double *__restrict__ rp = ref + (size_t)D * ((size_t)k + (size_t)L * ((size_t)i + (size_t)xm * j));
+    double *__restrict__ vt = v + (size_t)D * Nc;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      double *loc = nullptr;  // internal location of ref (d,k,i,j)
+      if (d < NTOP) {
+        if (tsx_inward(d)) loc = k >= 1 ? v + (size_t)d * Nc + ((size_t)(k - 1) * ym + j) * xm + i : vt + (size_t)d * ncol + col;
+        else loc = k < Nz ? v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + i : vt + (size_t)d * ncol + col;
+      } else if (k == Nz) {
+        loc = vt + (size_t)d * ncol + col;
+      } else if (d < NTOP + NSIDE) {
+        const int qd = d - NTOP;
+        if (!tsx_inward(qd)) loc = v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + i;
+        else if (i > 0) loc = v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + (i - 1);
+        else if (g.wrap_x) loc = v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + (xm - 1);
+        else loc = bufW + ((size_t)(qd >> 1) * Nz + k) * ym + j;
+      } else {
+        const int qd = d - NTOP - NSIDE;
+        if (!tsx_inward(qd)) loc = v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + i;
+        else if (j > 0) loc = v + (size_t)d * Nc + ((size_t)k * ym + (j - 1)) * xm + i;
+        else if (g.wrap_y) loc = v + (size_t)d * Nc + ((size_t)k * ym + (ym - 1)) * xm + i;
+        else loc = bufS + ((size_t)(qd >> 1) * Nz + k) * xm + i;
+      }
+      if (EXPORT) rp[d] = *loc;
+      else *loc = rp[d];
+    }
+  }
+}
+
+// after an import exchange: +x streams received from the east rank (its face i=0) land on my cells xm-1,
+// +y streams received from the north rank land on my cells ym-1.
+template <int NTOP, int NSIDE>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_import_unpack(TsxGeo g, double *__restrict__ v,
+                                                                 const double *__restrict__ recvE,
+                                                                 const double *__restrict__ recvN) {
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  const long long Nc = g.Nc;
+  const long long nx = (long long)(NSIDE / 2) * Nz * ym, ny = (long long)(NSIDE / 2) * Nz * xm;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < nx + ny; q += (long long)gridDim.x * TSX_BLOCK) {
+    if (q < nx) {
+      const int j = (int)(q % ym);
+      const int k = (int)((q / ym) % Nz);
+      const int slot = (int)(q / ((long long)ym * Nz));
+      const int d = NTOP + 2 * slot + 1;
+      if (recvE) v[(size_t)d * Nc + ((size_t)k * ym + j) * xm + (xm - 1)] = recvE[q];
+    } else {
+      const long long p = q - nx;
+      const int i = (int)(p % xm);
+      const int k = (int)((p / xm) % Nz);
+      const int slot = (int)(p / ((long long)xm * Nz));
+      const int d = NTOP + NSIDE + 2 * slot + 1;
+      if (recvN) v[(size_t)d * Nc + ((size_t)k * ym + (ym - 1)) * xm + i] = recvN[p];
+    }
+  }
+}
+
+// SpMV halo pack (exchange_diffuse_boundary, src/pprts_explicit.F90:769-800, in dst-owned storage):
+//   sendE = +x streams of my cells i = xm-1   (east rank reads them as its west halo)
+//   sendW = -x streams of my cells i = 0
+//   sendN = +y streams of my cells j = ym-1 ; sendS = -y streams of my cells j = 0
+template <int NTOP, int NSIDE>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_halo_pack(TsxGeo g, const double *__restrict__ v,
+                                                             double *__restrict__ sendW, double *__restrict__ sendE,
+                                                             double *__restrict__ sendS, double *__restrict__ sendN,
+                                                             const int *__restrict__ done) {
+  if (done && *done) return;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  const long long Nc = g.Nc;
+  const long long nx = (long long)(NSIDE / 2) * Nz * ym, ny = (long long)(NSIDE / 2) * Nz * xm;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < nx + ny; q += (long long)gridDim.x * TSX_BLOCK) {
+    if (q < nx) {
+      const int j = (int)(q % ym);
+      const int k = (int)((q / ym) % Nz);
+      const int slot = (int)(q / ((long long)ym * Nz));
+      const size_t row = ((size_t)k * ym + j) * xm;
+      if (!g.wrap_x) {
+        sendE[q] = v[(size_t)(NTOP + 2 * slot + 1) * Nc + row + (xm - 1)];
+        sendW[q] = v[(size_t)(NTOP + 2 * slot) * Nc + row];
+      }
+    } else {
+      const long long p = q - nx;
+      const int i = (int)(p % xm);
+      const int k = (int)((p / xm) % Nz);
+      const int slot = (int)(p / ((long long)xm * Nz));
+      if (!g.wrap_y) {
+        sendN[p] = v[(size_t)(NTOP + NSIDE + 2 * slot + 1) * Nc + ((size_t)k * ym + (ym - 1)) * xm + i];
+        sendS[p] = v[(size_t)(NTOP + NSIDE + 2 * slot) * Nc + (size_t)k * ym * xm + i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Operator values: reference block layout (c = dst*D+src fastest, then k, i, j) -> one plane per c,
+// x fastest.  LDS-tiled transpose so both sides coalesce.
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_import_coeff(TsxGeo g, int DD, int TI, const TIN *__restrict__ ref,
+                                                                TOUT *__restrict__ C) {
+  // one block per (j,k, tile of TI i): tile[TI][DD+1]
+  extern __shared__ unsigned char smem_raw[];
+  TOUT *tile = reinterpret_cast<TOUT *>(smem_raw);
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  const int tiles_x = (xm + TI - 1) / TI;
+  const long long nt = (long long)tiles_x * ym * Nz;
+  for (long long b = blockIdx.x; b < nt; b += gridDim.x) {
+    const int tx = (int)(b % tiles_x);
+    const int j = (int)((b / tiles_x) % ym);
+    const int k = (int)(b / ((long long)tiles_x * ym));
+    const int i0 = tx * TI;
+    const int ni = xm - i0 < TI ? xm - i0 : TI;
+    for (int q = threadIdx.x; q < ni * DD; q += TSX_BLOCK) {
+      const int ii = q / DD, c = q % DD;
+      tile[ii * (DD + 1) + c] =
+          (TOUT)ref[(size_t)c + (size_t)DD * ((size_t)k + (size_t)Nz * ((size_t)(i0 + ii) + (size_t)xm * j))];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < ni * DD; q += TSX_BLOCK) {
+      const int c = q / ni, ii = q % ni;
+      C[(size_t)c * g.Nc + ((size_t)k * ym + j) * xm + i0 + ii] = tile[ii * (DD + 1) + c];
+    }
+    __syncthreads();
+  }
+}
+
+// flag[0] |= 1 if any value is not exactly representable in fp32
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_check_fp32_lossless(long long n, const double *__restrict__ v,
+                                                                       int *__restrict__ flag) {
+  int bad = 0;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double a = v[q];
+    if ((double)(float)a != a) bad = 1;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// (k,i,j) reference scalar field (z fastest) -> cell-indexed (i fastest)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_import_cellfield(TsxGeo g, const double *__restrict__ ref,
+                                                                    double *__restrict__ out) {
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < g.Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int i = (int)(c % xm);
+    const long long t = c / xm;
+    const int j = (int)(t % ym);
+    const int k = (int)(t / ym);
+    out[c] = ref[(size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j)];
+  }
+}
+
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_copy16(long long n, const float4 *__restrict__ a, float4 *__restrict__ b) {
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) b[q] = a[q];
+}

@@ -1,0 +1,197 @@
+"""Host-side handle of the MI355X diffuse back-end (thin wrapper over the C-ABI, include/tsx.h).
+
+Mirrors the seam in the reference's `pprts()` (src/pprts.F90:2794-2813): coefficients in
+(`solver%diff2diff`, `atm%a11/a12/albedo/l1d`), `solver%b` and `solution%ediff` in/out, iteration
+count and residual history out.  Arrays are numpy (host) or torch CUDA tensors (device, used in
+place) in the reference's layouts with reversed (C-order) axes:
+    vectors      x[j, i, k, d]            <->  Fortran (0:D-1, zs:ze, xs:xe, ys:ye)
+    coefficients c[j, i, k, dst*D + src]  <->  Fortran (1:D*D, zs:ze-1, xs:xe, ys:ye)
+    a11/a12      a[j, i, k];  albedo[j, i];  l1d[k]
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import TSX_DEVICE, TSX_HOST
+
+SOLVER_IDS = {"3_10": 310, "8_16": 816, 310: 310, 816: 816}
+STREAMS = {310: (2, 4), 816: (8, 4)}  # (difftop%dof, diffside%dof)  src/pprts.F90:332-349, 413-425
+
+
+@dataclass
+class KspInfo:
+    reason: int
+    niter: int
+    rnorm0: float
+    rnorm: float
+    res_hist: np.ndarray
+    solve_ms: float
+    import_ms: float
+    export_ms: float
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a, dtype):
+    """(void*, where) of a numpy array or torch CUDA tensor; checks dtype and contiguity."""
+    if a is None:
+        return None, None
+    if _is_torch(a):
+        import torch
+
+        want = {np.float64: torch.float64, np.float32: torch.float32, np.uint8: torch.uint8}[dtype]
+        if a.dtype != want or not a.is_contiguous() or not a.is_cuda:
+            raise TypeError("device arrays must be contiguous CUDA tensors of the right dtype")
+        return C.c_void_p(a.data_ptr()), TSX_DEVICE
+    if a.dtype != dtype or not a.flags.c_contiguous:
+        raise TypeError(f"host arrays must be C-contiguous {dtype}")
+    return C.c_void_p(a.ctypes.data), TSX_HOST
+
+
+class DiffuseSolver:
+    """One diffuse system (I - T) x = b on one rank/GPU."""
+
+    def __init__(self, solver, Nz, xm, ym, *, xs=0, ys=0, glob_xm=None, glob_ym=None, rank=0, nranks=1,
+                 neighbors=None, device=-1, force_halo=False):
+        self.lib = _lib.load()
+        sid = SOLVER_IDS[solver]
+        self.ntop, self.nside = STREAMS[sid]
+        self.D = self.ntop + 2 * self.nside
+        self.Nz, self.xm, self.ym = int(Nz), int(xm), int(ym)
+        w, e, s_, n = neighbors if neighbors is not None else (rank, rank, rank, rank)
+        self.grid = _lib.Grid(sid, Nz, xm, ym, xs, ys, glob_xm or xm, glob_ym or ym, rank, nranks, w, e, s_, n,
+                              device, int(force_halo))
+        h = C.c_void_p()
+        _lib.check(self.lib.tsx_create(C.byref(self.grid), C.byref(h)))
+        self.h = h
+        self._keep = []
+
+    # -- shapes ------------------------------------------------------------------------------------
+    @property
+    def vec_shape(self):
+        return (self.ym, self.xm, self.Nz + 1, self.D)
+
+    @property
+    def coeff_shape(self):
+        return (self.ym, self.xm, self.Nz, self.D * self.D)
+
+    @property
+    def n_unknowns(self):
+        return self.D * (self.Nz + 1) * self.xm * self.ym
+
+    @property
+    def n_cells(self):
+        return self.Nz * self.xm * self.ym
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- communicator --------------------------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _lib.check(self.lib.tsx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid: bytes):
+        buf = C.create_string_buffer(uid, 128)
+        _lib.check(self.lib.tsx_comm_init(self.h, buf))
+
+    def set_stream(self, stream_ptr):
+        _lib.check(self.lib.tsx_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    # -- operator ------------------------------------------------------------------------------------
+    def set_coeffs(self, diff2diff, l1d, a11, a12, albedo):
+        """Replaces set_diff_coeff (src/pprts.F90:5511-5796): hand over the per-cell blocks."""
+        if tuple(diff2diff.shape) != self.coeff_shape:
+            raise ValueError(f"diff2diff shape {tuple(diff2diff.shape)} != {self.coeff_shape}")
+        if _is_torch(diff2diff):
+            import torch
+
+            kind = 8 if diff2diff.dtype == torch.float64 else 4
+        else:
+            kind = 8 if diff2diff.dtype == np.float64 else 4
+        cp, where = _ptr(diff2diff, np.float64 if kind == 8 else np.float32)
+        lp, w2 = _ptr(l1d, np.uint8)
+        ap, w3 = _ptr(albedo, np.float64)
+        p11, w4 = _ptr(a11, np.float64)
+        p12, w5 = _ptr(a12, np.float64)
+        ws = {w for w in (where, w2, w3, w4, w5) if w is not None}
+        if len(ws) != 1:
+            raise TypeError("all arrays of one call must live on the same side (host or device)")
+        _lib.check(self.lib.tsx_diff_set_coeffs(self.h, cp, kind, lp, p11, p12, ap, where))
+
+    def apply(self, x, out=None):
+        """y = (I - T) x  (op_mat_mult_ediff, src/pprts_shell.F90:366-541)."""
+        if tuple(x.shape) != self.vec_shape:
+            raise ValueError(f"x shape {tuple(x.shape)} != {self.vec_shape}")
+        if out is None:
+            if _is_torch(x):
+                import torch
+
+                out = torch.empty_like(x)
+            else:
+                out = np.empty_like(x)
+        xp, where = _ptr(x, np.float64)
+        yp, w2 = _ptr(out, np.float64)
+        if where != w2:
+            raise TypeError("x and out must live on the same side")
+        _lib.check(self.lib.tsx_diff_apply(self.h, xp, yp, where))
+        return out
+
+    def default_tolerances(self, unconstrained_fraction=1.0):
+        rtol, atol, maxit = C.c_double(), C.c_double(), C.c_int32()
+        _lib.check(self.lib.tsx_determine_ksp_tolerances(self.h, unconstrained_fraction, C.byref(rtol), C.byref(atol),
+                                                         C.byref(maxit)))
+        return rtol.value, atol.value, maxit.value
+
+    def solve(self, b, x, *, rtol=None, atol=None, maxit=None, dtol=None, pc=None, pc_sweeps=None,
+              check_every=None) -> KspInfo:
+        """Solve in place: x holds the initial guess on entry (src/pprts.F90:4343) and the solution on exit."""
+        if tuple(b.shape) != self.vec_shape or tuple(x.shape) != self.vec_shape:
+            raise ValueError("b/x shape mismatch")
+        o = _lib.KspOpts()
+        self.lib.tsx_default_ksp_opts(C.byref(o))
+        drt, dat, dmx = self.default_tolerances()
+        o.rtol, o.atol, o.maxit = drt, dat, dmx
+        for name, val in (("rtol", rtol), ("atol", atol), ("maxit", maxit), ("dtol", dtol), ("pc", pc),
+                          ("pc_sweeps", pc_sweeps), ("check_every", check_every)):
+            if val is not None:
+                setattr(o, name, val)
+        bp, where = _ptr(b, np.float64)
+        xp, w2 = _ptr(x, np.float64)
+        if where != w2:
+            raise TypeError("b and x must live on the same side")
+        r = _lib.KspResult()
+        _lib.check(self.lib.tsx_diff_solve(self.h, bp, xp, where, C.byref(o), C.byref(r)))
+        return KspInfo(r.reason, r.niter, r.rnorm0, r.rnorm, np.array(r.res_hist[: r.nhist]), r.solve_ms,
+                       r.import_ms, r.export_ms)
+
+    # -- measurement ---------------------------------------------------------------------------------
+    def bench_kernel(self, kernel: int, reps: int) -> float:
+        ms = C.c_float()
+        _lib.check(self.lib.tsx_bench_kernel(self.h, kernel, reps, C.byref(ms)))
+        return ms.value
+
+    def algorithmic_bytes(self, kernel: int) -> float:
+        b = C.c_double()
+        _lib.check(self.lib.tsx_algorithmic_bytes(self.h, kernel, C.byref(b)))
+        return b.value
+
+    def probe_copy_bandwidth(self, nbytes=1 << 30, reps=10) -> float:
+        g = C.c_double()
+        _lib.check(self.lib.tsx_probe_copy_bandwidth(self.h, nbytes, reps, C.byref(g)))
+        return g.value
