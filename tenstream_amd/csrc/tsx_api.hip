@@ -8,7 +8,13 @@
 #include <mutex>
 #include <string>
 
+#include <stdlib.h>
+
 #include "tsx_kernels.hpp"
+
+#ifndef TSX_DEFAULT_CPT
+#define TSX_DEFAULT_CPT 2
+#endif
 
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -314,25 +320,46 @@ static int halo_update(tsx_solver *s, const double *v, bool in_solve) {
   return face_exchange(s);
 }
 
+// TSX_SPMV_CPT=1|2|4 selects cells per thread (experimentation knob; default picks the widest that divides xm)
+static int spmv_cpt(const tsx_solver *s) {
+  static int env = -1;
+  if (env < 0) {
+    const char *e = getenv("TSX_SPMV_CPT");
+    env = e ? atoi(e) : 0;
+  }
+  int want = env > 0 ? env : TSX_DEFAULT_CPT;
+  while (want > 1 && (s->geo.xm % want) != 0) want >>= 1;
+  return want;
+}
+
+template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT>
+static void launch_spmv_variant(tsx_solver *s, const double *x, double *y, const double *w, const int *done) {
+  const TsxGeo &g = s->geo;
+  const int nb = grid_for(g.Nc / CPT, TSX_MAX_PARTIAL_BLOCKS);
+  hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
+                     (const CT *)s->coef, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS, s->recvN,
+                     w, s->partials, done);
+}
+
 template <int NTOP, int NSIDE, int FUSE>
 static int launch_spmv(tsx_solver *s, const double *x, double *y, const double *w, bool in_solve) {
-  const TsxGeo &g = s->geo;
   int rc = halo_update<NTOP, NSIDE>(s, x, in_solve);
   if (rc) return rc;
-  const int nb = grid_for(g.Nc, TSX_MAX_PARTIAL_BLOCKS);
   const int *done = in_solve ? &s->scal->done : nullptr;
-  if (s->coef_bytes == 4)
-    hipLaunchKernelGGL((tsx_k_spmv<NTOP, NSIDE, float, FUSE>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
-                       (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS,
-                       s->recvN, w, s->partials, done);
-  else
-    hipLaunchKernelGGL((tsx_k_spmv<NTOP, NSIDE, double, FUSE>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
-                       (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS,
-                       s->recvN, w, s->partials, done);
+  const int cpt = spmv_cpt(s);
+  if (s->coef_bytes == 4) {
+    if (cpt == 4) launch_spmv_variant<NTOP, NSIDE, FUSE, float, 4>(s, x, y, w, done);
+    else if (cpt == 2) launch_spmv_variant<NTOP, NSIDE, FUSE, float, 2>(s, x, y, w, done);
+    else launch_spmv_variant<NTOP, NSIDE, FUSE, float, 1>(s, x, y, w, done);
+  } else {
+    if (cpt == 4) launch_spmv_variant<NTOP, NSIDE, FUSE, double, 4>(s, x, y, w, done);
+    else if (cpt == 2) launch_spmv_variant<NTOP, NSIDE, FUSE, double, 2>(s, x, y, w, done);
+    else launch_spmv_variant<NTOP, NSIDE, FUSE, double, 1>(s, x, y, w, done);
+  }
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
-static inline int spmv_nblocks(const tsx_solver *s) { return grid_for(s->geo.Nc, TSX_MAX_PARTIAL_BLOCKS); }
+static inline int spmv_nblocks(const tsx_solver *s) { return grid_for(s->geo.Nc / spmv_cpt(s), TSX_MAX_PARTIAL_BLOCKS); }
 
 // reduce partials -> (all-reduce) -> scalar algebra
 static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {

@@ -168,6 +168,202 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wide variant: each thread owns CPT consecutive cells along x so that every plane is read with
+// 8/16-byte (fp32 coefficients) and 16/32-byte (fp64 vectors) loads per lane; the +-x neighbours inside
+// the group come from registers.  Requires xm % CPT == 0.
+template <int CPT> struct TsxVec;
+template <> struct TsxVec<1> {
+  static __device__ __forceinline__ void ld(const double *p, double *o) { o[0] = p[0]; }
+  static __device__ __forceinline__ void ld(const float *p, double *o) { o[0] = (double)p[0]; }
+  static __device__ __forceinline__ void st(double *p, const double *v) { p[0] = v[0]; }
+};
+template <> struct TsxVec<2> {
+  static __device__ __forceinline__ void ld(const double *p, double *o) {
+    const double2 v = *reinterpret_cast<const double2 *>(p);
+    o[0] = v.x; o[1] = v.y;
+  }
+  static __device__ __forceinline__ void ld(const float *p, double *o) {
+    const float2 v = *reinterpret_cast<const float2 *>(p);
+    o[0] = (double)v.x; o[1] = (double)v.y;
+  }
+  static __device__ __forceinline__ void st(double *p, const double *v) {
+    double2 o; o.x = v[0]; o.y = v[1];
+    *reinterpret_cast<double2 *>(p) = o;
+  }
+};
+template <> struct TsxVec<4> {
+  static __device__ __forceinline__ void ld(const double *p, double *o) {
+    const double2 a = reinterpret_cast<const double2 *>(p)[0], b = reinterpret_cast<const double2 *>(p)[1];
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+  }
+  static __device__ __forceinline__ void ld(const float *p, double *o) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    o[0] = (double)v.x; o[1] = (double)v.y; o[2] = (double)v.z; o[3] = (double)v.w;
+  }
+  static __device__ __forceinline__ void st(double *p, const double *v) {
+    double2 a, b; a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
+    reinterpret_cast<double2 *>(p)[0] = a;
+    reinterpret_cast<double2 *>(p)[1] = b;
+  }
+};
+
+template <int NTOP, int NSIDE, typename CT, int FUSE, int CPT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
+    TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
+    const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ x,
+    double *__restrict__ y, const double *__restrict__ hW, const double *__restrict__ hE,
+    const double *__restrict__ hS, const double *__restrict__ hN, const double *__restrict__ w,
+    double *__restrict__ partials, const int *__restrict__ done) {
+  constexpr int D = NTOP + 2 * NSIDE;
+  using V = TsxVec<CPT>;
+  if (done && *done) return;
+  double sum[3] = {0.0, 0.0, 0.0};
+  const long long Nc = g.Nc;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
+  const long long ngroups = Nc / CPT;
+  const long long nchunks = (ngroups + TSX_BLOCK - 1) / TSX_BLOCK;
+  const double *__restrict__ xt = x + (size_t)D * Nc;
+  double *__restrict__ yt = y + (size_t)D * Nc;
+  const double *__restrict__ wt = (FUSE & 1) ? w + (size_t)D * Nc : nullptr;
+
+  for (long long base = 0; base < nchunks; base += gridDim.x) {
+    const long long nb = (nchunks - base) < (long long)gridDim.x ? (nchunks - base) : (long long)gridDim.x;
+    if ((long long)blockIdx.x >= nb) break;
+    const long long grp = (base + tsx_swizzle(blockIdx.x, nb)) * TSX_BLOCK + threadIdx.x;
+    if (grp >= ngroups) continue;
+    const long long c = grp * CPT;
+    const int i = (int)(c % xm);
+    const long long t = c / xm;
+    const int j = (int)(t % ym);
+    const int k = (int)(t / ym);
+    const int col = j * xm + i;
+
+    double xs[D][CPT];
+    // ---- gather the D source streams of the CPT cells
+#pragma unroll
+    for (int q = 0; q < NTOP; ++q) {
+      if (tsx_inward(q)) {
+        if (k > 0) V::ld(x + (size_t)q * Nc + c - ncol, xs[q]);
+        else V::ld(xt + (size_t)q * ncol + col, xs[q]);
+      } else {
+        if (k + 1 < Nz) V::ld(x + (size_t)q * Nc + c + ncol, xs[q]);
+        else V::ld(xt + (size_t)q * ncol + col, xs[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NSIDE; ++q) {
+      const int d = NTOP + q, slot = q >> 1;
+      double own[CPT];
+      V::ld(x + (size_t)d * Nc + c, own);
+      if (tsx_inward(q)) {
+        if (i > 0) xs[d][0] = x[(size_t)d * Nc + c - 1];
+        else if (g.wrap_x) xs[d][0] = x[(size_t)d * Nc + c + (xm - 1)];
+        else xs[d][0] = hW[((size_t)slot * Nz + k) * ym + j];
+#pragma unroll
+        for (int m = 1; m < CPT; ++m) xs[d][m] = own[m - 1];
+      } else {
+        if (i + CPT < xm) xs[d][CPT - 1] = x[(size_t)d * Nc + c + CPT];
+        else if (g.wrap_x) xs[d][CPT - 1] = x[(size_t)d * Nc + c + CPT - xm];
+        else xs[d][CPT - 1] = hE[((size_t)slot * Nz + k) * ym + j];
+#pragma unroll
+        for (int m = 0; m < CPT - 1; ++m) xs[d][m] = own[m + 1];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NSIDE; ++q) {
+      const int d = NTOP + NSIDE + q, slot = q >> 1;
+      if (tsx_inward(q)) {
+        if (j > 0) V::ld(x + (size_t)d * Nc + c - xm, xs[d]);
+        else if (g.wrap_y) V::ld(x + (size_t)d * Nc + c + (size_t)(ym - 1) * xm, xs[d]);
+        else V::ld(hS + ((size_t)slot * Nz + k) * xm + i, xs[d]);
+      } else {
+        if (j < ym - 1) V::ld(x + (size_t)d * Nc + c + xm, xs[d]);
+        else if (g.wrap_y) V::ld(x + (size_t)d * Nc + c - (size_t)(ym - 1) * xm, xs[d]);
+        else V::ld(hN + ((size_t)slot * Nz + k) * xm + i, xs[d]);
+      }
+    }
+
+    const bool is1d = l1d[k] != 0;
+    double t11[CPT], t12[CPT];
+    if (is1d) {
+      V::ld(a11 + c, t11);
+      V::ld(a12 + c, t12);
+    }
+    double down[CPT];
+#pragma unroll
+    for (int m = 0; m < CPT; ++m) down[m] = 0.0;
+    // ---- one destination stream at a time: keeps only xs live
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      double xo[CPT], acc[CPT];
+      V::ld(x + (size_t)d * Nc + c, xo);
+      if (is1d) {
+#pragma unroll
+        for (int m = 0; m < CPT; ++m)
+          acc[m] = d < NTOP ? xo[m] - t11[m] * xs[d][m] - t12[m] * xs[d < NTOP ? (d ^ 1) : d][m] : xo[m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < CPT; ++m) acc[m] = 0.0;
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          double cf[CPT];
+          V::ld(C + (size_t)(d * D + s) * Nc + c, cf);
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) acc[m] += cf[m] * xs[s][m];
+        }
+#pragma unroll
+        for (int m = 0; m < CPT; ++m) acc[m] = xo[m] - acc[m];
+      }
+      V::st(y + (size_t)d * Nc + c, acc);
+      if (d < NTOP && tsx_inward(d)) {
+#pragma unroll
+        for (int m = 0; m < CPT; ++m) down[m] += xo[m];
+      }
+      if (FUSE & 1) {
+        double wv[CPT];
+        V::ld(w + (size_t)d * Nc + c, wv);
+#pragma unroll
+        for (int m = 0; m < CPT; ++m) sum[0] += wv[m] * acc[m];
+      }
+      if (FUSE & 2) {
+#pragma unroll
+        for (int m = 0; m < CPT; ++m) {
+          sum[1] += xo[m] * acc[m];
+          sum[2] += acc[m] * acc[m];
+        }
+      }
+    }
+    if (k == Nz - 1) {
+      double alb[CPT];
+      V::ld(albedo + col, alb);
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        double xv[CPT], yv[CPT];
+        V::ld(xt + (size_t)d * ncol + col, xv);
+#pragma unroll
+        for (int m = 0; m < CPT; ++m)
+          yv[m] = (d < NTOP && !tsx_inward(d)) ? xv[m] - alb[m] / (double)(NTOP / 2) * down[m] : xv[m];
+        V::st(yt + (size_t)d * ncol + col, yv);
+        if (FUSE & 1) {
+          double wv[CPT];
+          V::ld(wt + (size_t)d * ncol + col, wv);
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) sum[0] += wv[m] * yv[m];
+        }
+        if (FUSE & 2) {
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) {
+            sum[1] += xv[m] * yv[m];
+            sum[2] += yv[m] * yv[m];
+          }
+        }
+      }
+    }
+  }
+  if (FUSE) tsx_block_reduce_store<3>(sum, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
 // BLAS-1 stages of the flexible BiCGStab (KSPFBCGS, selected at src/pprts.F90:4342), fused so that a
 // full iteration moves 19 N-vectors besides the two operator applications.
 // r = b - y (y = A x0); rhat = r; p = r; slot0 = (r,r)
