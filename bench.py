@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--nz", type=int, default=64)
     ap.add_argument("--solver", default="3_10")
     ap.add_argument("--pc", type=int, default=0)
+    ap.add_argument("--pc-sweeps", type=int, default=1)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=48, help="edge of the CPU-baseline sample tile (columns)")
@@ -128,12 +129,12 @@ def main():
     infos = []
     for _ in range(args.warmup):
         x.zero_()
-        s.solve(b, x, pc=args.pc)
+        s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x.zero_()
-        infos.append(s.solve(b, x, pc=args.pc))
+        infos.append(s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

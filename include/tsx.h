@@ -56,7 +56,7 @@ enum { TSX_SOLVER_3_10 = 310, TSX_SOLVER_8_16 = 816 };
 
 /* preconditioners for the flexible BiCGStab (reference default: PCILU / PCBJACOBI+ILU(0),
  * src/pprts.F90:4350-4371, 4415-4425; here GPU-native equivalents) */
-enum { TSX_PC_NONE = 0, TSX_PC_COLUMN_GS = 1 };
+enum { TSX_PC_NONE = 0, TSX_PC_COLUMN = 1 };
 
 typedef struct tsx_solver tsx_solver; /* opaque */
 
@@ -134,6 +134,10 @@ int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int where);
  *      x is in/out (nonzero initial guess, src/pprts.F90:4343). */
 int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int where, const tsx_ksp_opts *opts,
                    tsx_ksp_result *res);
+
+/* ---- z = M^-1 v with the preconditioner the solve uses (exposed for parity tests: M is the column-block
+ *      diagonal of the assembled matrix in the dst-owned numbering) */
+int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps);
 
 /* ---- measurement helpers (bench.py): time `reps` launches of the dominant kernel with HIP events on
  *      the solver's stream.  kernel: 0 = SpMV (diffuse operator apply), 1 = one full BiCGStab iteration */

@@ -200,3 +200,92 @@ def solve_sor(lay, coeff, l1d, a11, a12, albedo, b, x0=None, rtol=1e-5, atol=1e-
     rc = lib().orc_explicit_ediff_1rank(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12), _p(albedo),
                                         _p(b), _p(x), C.byref(o), C.byref(nit), _p(hist), len(hist))
     return x, dict(converged=(rc == 0), niter=nit.value, res_hist=hist[: min(nit.value, 100)])
+
+
+# ---- coefficient / source pieces (pprts_oracle_phys.h) ---------------------------------------------------
+ORC_LUT_MAXDIM = 8
+
+
+class Lut(C.Structure):
+    _fields_ = [("ndim", C.c_int), ("n", C.c_int * ORC_LUT_MAXDIM), ("axis", C.POINTER(C.c_float) * ORC_LUT_MAXDIM),
+                ("nvec", C.c_int), ("table", C.POINTER(C.c_float))]
+
+
+def search_sorted_bisection(arr, val, dtype=np.float64):
+    """src/search.fypp:177-228: 1-based fractional location of val in the sorted array."""
+    a = np.ascontiguousarray(arr, dtype=dtype)
+    if dtype == np.float64:
+        f = lib().orc_search_sorted_bisection_f64
+        f.restype = C.c_double
+        return f(_p(a), len(a), C.c_double(val))
+    f = lib().orc_search_sorted_bisection_f32
+    f.restype = C.c_float
+    return f(_p(a, C.c_float), len(a), C.c_float(val))
+
+
+def interp_vec_nd(pti, db, shape):
+    """interp_vec_simplex_nd -> interp_vec_bilinear_iterative (src/interpolation.F90:317-360).
+    db: (nentries, nvec) C-order == Fortran (nvec, nentries); shape: extents of the unravelled dims."""
+    pti = np.ascontiguousarray(pti, dtype=np.float32)
+    db = np.ascontiguousarray(db, dtype=np.float32)
+    nvec = db.shape[1]
+    shp = (C.c_int * len(shape))(*shape)
+    offs = (C.c_int64 * len(shape))()
+    lib().orc_ndarray_offsets(shp, len(shape), offs)
+    out = np.zeros(nvec, dtype=np.float32)
+    lib().orc_interp_vec_nd_f32(_p(pti, C.c_float), len(shape), _p(db, C.c_float), nvec, offs, _p(out, C.c_float))
+    return out
+
+
+def make_lut(axes, table):
+    """axes: list of float32 arrays; table: (prod(n), nvec) C-order float32 (== Fortran (nvec, nentries))."""
+    lut = Lut()
+    lut.ndim = len(axes)
+    keep = []
+    for d, a in enumerate(axes):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        keep.append(a)
+        lut.n[d] = len(a)
+        lut.axis[d] = _p(a, C.c_float)
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    keep.append(table)
+    lut.nvec = table.shape[1]
+    lut.table = _p(table, C.c_float)
+    lut._keep = keep
+    return lut
+
+
+def get_coeff_diff2diff(lut, kabs, ksca, g, dz, dx):
+    out = np.zeros(lut.nvec, dtype=np.float32)
+    lib().orc_get_coeff_diff2diff(C.byref(lut), C.c_double(kabs), C.c_double(ksca), C.c_double(g), C.c_double(dz),
+                                  C.c_double(dx), _p(out, C.c_float))
+    return out
+
+
+def alloc_coeff_diff2diff(lut, kabs, ksca, g, dz, dx, l1d):
+    """alloc_coeff_diff2diff (src/pprts.F90:3433-3462) for fields shaped (ym, xm, Nz)."""
+    kabs, ksca, g, dz = (np.ascontiguousarray(a, dtype=np.float64) for a in (kabs, ksca, g, dz))
+    ym, xm, Nz = kabs.shape
+    l1d = np.ascontiguousarray(l1d, dtype=np.uint8)
+    out = np.zeros((ym, xm, Nz, lut.nvec), dtype=np.float64)
+    lib().orc_alloc_coeff_diff2diff(C.byref(lut), Nz, xm, ym, _p(kabs), _p(ksca), _p(g), _p(dz), C.c_double(dx),
+                                    _p(l1d, C.c_uint8), _p(out))
+    return out
+
+
+def delta_scale(kabs, ksca, g, f=None):
+    a, b, c = C.c_double(kabs), C.c_double(ksca), C.c_double(g)
+    lib().orc_delta_scale(C.byref(a), C.byref(b), C.byref(c), 0 if f is None else 1, C.c_double(0.0 if f is None else f))
+    return a.value, b.value, c.value
+
+
+def eddington_coeff_ec(dtau, w0, g, mu0):
+    o = [C.c_double() for _ in range(5)]
+    lib().orc_eddington_coeff_ec(C.c_double(dtau), C.c_double(w0), C.c_double(g), C.c_double(mu0), *[C.byref(v) for v in o])
+    return [v.value for v in o]
+
+
+def B_eff(B_far, B_near, tau):
+    f = lib().orc_B_eff
+    f.restype = C.c_double
+    return f(C.c_double(B_far), C.c_double(B_near), C.c_double(tau))

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtsx.so")
 
 TSX_HOST, TSX_DEVICE = 0, 1
 TSX_SOLVER_3_10, TSX_SOLVER_8_16 = 310, 816
-TSX_PC_NONE, TSX_PC_COLUMN_GS = 0, 1
+TSX_PC_NONE, TSX_PC_COLUMN = 0, 1
 TSX_ERR_NO_DEVICE = 2
 
 
@@ -45,7 +45,7 @@ class KspResult(C.Structure):
 SYMBOLS = (
     "tsx_last_error", "tsx_version", "tsx_device_count", "tsx_create", "tsx_destroy", "tsx_default_ksp_opts",
     "tsx_determine_ksp_tolerances", "tsx_set_stream", "tsx_comm_unique_id", "tsx_comm_init",
-    "tsx_diff_set_coeffs", "tsx_diff_apply", "tsx_diff_solve", "tsx_bench_kernel", "tsx_algorithmic_bytes",
+    "tsx_diff_set_coeffs", "tsx_diff_apply", "tsx_diff_solve", "tsx_diff_pc_apply", "tsx_bench_kernel", "tsx_algorithmic_bytes",
     "tsx_probe_copy_bandwidth",
 )
 
@@ -77,6 +77,7 @@ def load():
     lib.tsx_diff_set_coeffs.argtypes = [vp, vp, ip, vp, vp, vp, vp, ip]
     lib.tsx_diff_apply.argtypes = [vp, vp, vp, ip]
     lib.tsx_diff_solve.argtypes = [vp, vp, vp, ip, C.POINTER(KspOpts), C.POINTER(KspResult)]
+    lib.tsx_diff_pc_apply.argtypes = [vp, vp, vp, ip, ip, ip]
     lib.tsx_bench_kernel.argtypes = [vp, ip, ip, C.POINTER(C.c_float)]
     lib.tsx_algorithmic_bytes.argtypes = [vp, ip, dp]
     lib.tsx_probe_copy_bandwidth.argtypes = [vp, C.c_size_t, ip, dp]

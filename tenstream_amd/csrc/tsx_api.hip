@@ -238,7 +238,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
-                  s->recvE, s->recvS, s->recvN, s->partials, s->scal};
+                  s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->vph && s->vph != s->vp) (void)hipFree(s->vph);
@@ -363,7 +363,7 @@ static inline int spmv_nblocks(const tsx_solver *s) { return grid_for(s->geo.Nc 
 
 // reduce partials -> (all-reduce) -> scalar algebra
 static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {
-  if (s->comm_ready && s->grid.nranks > 1) {
+  if (s->comm_ready) {  // also with a 1-rank communicator (exercised by the single-GPU RCCL test)
     hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1);
     NCCLCHK(g_rccl.AllReduce(s->scal->red, s->scal->red, TSX_NSLOTS, TSX_NCCL_FLOAT64, TSX_NCCL_SUM, s->nccl_comm,
                              s->stream));
@@ -539,6 +539,52 @@ extern "C" int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int whe
 }
 
 // ------------------------------------------------------------------------------------------------
+// z = M^-1 v with the column preconditioner; sweeps > 1 adds stationary refinement sweeps
+//   z <- z + M^-1 (v - A z)     (block-Jacobi iteration on column blocks)
+template <int NTOP, int NSIDE>
+static int pc_column_once(tsx_solver *s, const double *v, double *z, const int *done) {
+  const TsxGeo &g = s->geo;
+  const int nb = (g.ncol + 63) / 64;
+  if (s->coef_bytes == 4)
+    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float>), dim3(nb), dim3(64), 0, s->stream, g, (const float *)s->coef,
+                       s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
+  else
+    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double>), dim3(nb), dim3(64), 0, s->stream, g, (const double *)s->coef,
+                       s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+template <int NTOP, int NSIDE>
+static int apply_pc(tsx_solver *s, const double *v, double *z, bool in_solve) {
+  const TsxGeo &g = s->geo;
+  const int *done = in_solve ? &s->scal->done : nullptr;
+  int rc;
+  if ((rc = pc_column_once<NTOP, NSIDE>(s, v, z, done))) return rc;
+  const long long n2 = g.N / 2;
+  const int nbv = grid_for(n2);
+  for (int sw = 1; sw < s->pc_sweeps; ++sw) {
+    if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, z, s->vt, nullptr, in_solve))) return rc;
+    hipLaunchKernelGGL(tsx_k_sub, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)v, (const double2 *)s->vt,
+                       (double2 *)s->vt, done);
+    if ((rc = pc_column_once<NTOP, NSIDE>(s, s->vt, s->vw, done))) return rc;
+    hipLaunchKernelGGL(tsx_k_addto, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)s->vw, (double2 *)z, done);
+  }
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+template <int NTOP>
+static int ensure_pc_buffers(tsx_solver *s) {
+  const TsxGeo &g = s->geo;
+  const size_t nb = (size_t)g.N * sizeof(double);
+  if (!s->pc_tmp) HIPCHK(hipMalloc((void **)&s->pc_tmp, sizeof(double) * (size_t)tsx_pc_ntmp<NTOP>() * g.Nc));
+  if (s->vph == s->vp || !s->vph) HIPCHK(hipMalloc((void **)&s->vph, nb));
+  if (s->vsh == s->vs || !s->vsh) HIPCHK(hipMalloc((void **)&s->vsh, nb));
+  if (!s->vw) HIPCHK(hipMalloc((void **)&s->vw, nb));
+  return TSX_OK;
+}
+
 // One BiCGStab iteration on the stream (no host synchronisation).
 template <int NTOP, int NSIDE>
 static int enqueue_iteration(tsx_solver *s, bool first) {
@@ -550,14 +596,23 @@ static int enqueue_iteration(tsx_solver *s, bool first) {
     hipLaunchKernelGGL(tsx_k_pupdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
                        (double2 *)s->vp, (const double2 *)s->vv);
   }
-  if ((rc = launch_spmv<NTOP, NSIDE, 1>(s, s->vph, s->vv, s->vrhat, true))) return rc;
+  const double *ph = s->vp, *sh = s->vs;
+  if (s->pc != TSX_PC_NONE) {
+    if ((rc = apply_pc<NTOP, NSIDE>(s, s->vp, s->vph, true))) return rc;
+    ph = s->vph;
+  }
+  if ((rc = launch_spmv<NTOP, NSIDE, 1>(s, ph, s->vv, s->vrhat, true))) return rc;
   if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
   hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
                      (const double2 *)s->vv, (double2 *)s->vs);
-  if ((rc = launch_spmv<NTOP, NSIDE, 2>(s, s->vsh, s->vt, nullptr, true))) return rc;
+  if (s->pc != TSX_PC_NONE) {
+    if ((rc = apply_pc<NTOP, NSIDE>(s, s->vs, s->vsh, true))) return rc;
+    sh = s->vsh;
+  }
+  if ((rc = launch_spmv<NTOP, NSIDE, 5>(s, sh, s->vt, s->vs, true))) return rc;
   if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
   hipLaunchKernelGGL(tsx_k_xrupdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (double2 *)s->vx,
-                     (const double2 *)s->vph, (const double2 *)s->vsh, (const double2 *)s->vs, (const double2 *)s->vt,
+                     (const double2 *)ph, (const double2 *)sh, (const double2 *)s->vs, (const double2 *)s->vt,
                      (const double2 *)s->vrhat, (double2 *)s->vr, s->partials);
   if ((rc = scalar_stage(s, nbv, 2, TSX_STAGE_RHO))) return rc;
   HIPCHK(hipGetLastError());
@@ -658,9 +713,53 @@ extern "C" int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int whe
   if (opts) o = *opts;
   else tsx_default_ksp_opts(&o);
   ARGCHK(o.maxit >= 1, "tsx_diff_solve: maxit < 1");
-  ARGCHK(o.pc == TSX_PC_NONE, "tsx_diff_solve: unsupported preconditioner");
+  ARGCHK(o.pc == TSX_PC_NONE || o.pc == TSX_PC_COLUMN, "tsx_diff_solve: unsupported preconditioner");
+  ARGCHK(o.pc_sweeps >= 1 && o.pc_sweeps <= 8, "tsx_diff_solve: pc_sweeps out of range");
   HIPCHK(hipSetDevice(s->device));
+  s->pc = o.pc;
+  s->pc_sweeps = o.pc_sweeps;
+  if (o.pc != TSX_PC_NONE) {
+    int rc = s->geo.ntop == 2 ? ensure_pc_buffers<2>(s) : ensure_pc_buffers<8>(s);
+    if (rc) return rc;
+  }
   return s->geo.ntop == 2 ? diff_solve_t<2, 4>(s, b, x, where, &o, res) : diff_solve_t<8, 4>(s, b, x, where, &o, res);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NTOP, int NSIDE>
+static int pc_apply_t(tsx_solver *s, const double *v, double *z, int where) {
+  const TsxGeo &g = s->geo;
+  const size_t nb = (size_t)g.N * sizeof(double);
+  int rc = ensure_stage(s);
+  if (rc) return rc;
+  const double *vd = v;
+  double *zd = z;
+  if (where == TSX_HOST) {
+    HIPCHK(hipMemcpyAsync(s->stage_a, v, nb, hipMemcpyHostToDevice, s->stream));
+    vd = s->stage_a;
+    zd = s->stage_b;
+  }
+  if ((rc = import_vec<NTOP, NSIDE>(s, vd, s->vp))) return rc;
+  if ((rc = apply_pc<NTOP, NSIDE>(s, s->vp, s->vph, false))) return rc;
+  if ((rc = export_vec<NTOP, NSIDE>(s, s->vph, zd))) return rc;
+  if (where == TSX_HOST) HIPCHK(hipMemcpyAsync(z, s->stage_b, nb, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  return TSX_OK;
+}
+
+extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps) {
+  ARGCHK(s && v && z, "tsx_diff_pc_apply: null argument");
+  ARGCHK(pc == TSX_PC_COLUMN && pc_sweeps >= 1 && pc_sweeps <= 8, "tsx_diff_pc_apply: bad preconditioner");
+  if (!s->have_coeffs) {
+    tsx_set_error("tsx_diff_pc_apply: call tsx_diff_set_coeffs first");
+    return TSX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  s->pc = pc;
+  s->pc_sweeps = pc_sweeps;
+  int rc = s->geo.ntop == 2 ? ensure_pc_buffers<2>(s) : ensure_pc_buffers<8>(s);
+  if (rc) return rc;
+  return s->geo.ntop == 2 ? pc_apply_t<2, 4>(s, v, z, where) : pc_apply_t<8, 4>(s, v, z, where);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -64,6 +64,9 @@ struct tsx_solver {
 
   // Krylov work vectors (internal layout, N doubles each)
   double *vx, *vb, *vr, *vrhat, *vp, *vv, *vs, *vt, *vph, *vsh;
+  double *vw;          // work vector of the multi-sweep preconditioner
+  double *pc_tmp;      // column preconditioner: tsx_pc_ntmp planes of Nc doubles
+  int pc, pc_sweeps;   // active preconditioner of the running solve
   // staging in reference layout (for TSX_HOST callers and conversion)
   double *stage_a, *stage_b;
 

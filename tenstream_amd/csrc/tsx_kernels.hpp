@@ -53,8 +53,9 @@ __device__ __forceinline__ long long tsx_swizzle(long long b, long long nb) {
 // y = (I - T) x.  Restates op_mat_mult_ediff (src/pprts_shell.F90:413-519) in dst-owned form: the
 // thread of cell (k,i,j) gathers the cell's D source streams and writes the D streams leaving it.
 // Surface row uses the assembled semantics (src/pprts.F90:5755-5794).
-// FUSE bit0: partial slot0 += w.y            (BiCGStab (rhat, v))
-// FUSE bit1: partial slot1 += x.y, slot2 += y.y   (BiCGStab (s,t), (t,t))
+// FUSE bit0 (1): partial slot0 += w.y   (BiCGStab (rhat, v) and (s, t))
+// FUSE bit1 (2): partial slot1 += x.y   (x = the operator's input at the same index)
+// FUSE bit2 (4): partial slot2 += y.y   (BiCGStab (t, t))
 template <int NTOP, int NSIDE, typename CT, int FUSE>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv(
     TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
@@ -139,10 +140,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv(
     for (int d = 0; d < D; ++d) {
       y[(size_t)d * Nc + c] = acc[d];
       if (FUSE & 1) sum[0] += w[(size_t)d * Nc + c] * acc[d];
-      if (FUSE & 2) {
-        sum[1] += xo[d] * acc[d];
-        sum[2] += acc[d] * acc[d];
-      }
+      if (FUSE & 2) sum[1] += xo[d] * acc[d];
+      if (FUSE & 4) sum[2] += acc[d] * acc[d];
     }
     if (k == Nz - 1) {  // rows no cell writes: TOA Edn, surface Eup (albedo), bottom side dummies
       const double alb = albedo[col] / (double)(NTOP / 2);
@@ -157,10 +156,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv(
         if (d < NTOP && !tsx_inward(d)) yv = xv - alb * down;
         yt[(size_t)d * ncol + col] = yv;
         if (FUSE & 1) sum[0] += wt[(size_t)d * ncol + col] * yv;
-        if (FUSE & 2) {
-          sum[1] += xv * yv;
-          sum[2] += yv * yv;
-        }
+        if (FUSE & 2) sum[1] += xv * yv;
+        if (FUSE & 4) sum[2] += yv * yv;
       }
     }
   }
@@ -327,10 +324,11 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
       }
       if (FUSE & 2) {
 #pragma unroll
-        for (int m = 0; m < CPT; ++m) {
-          sum[1] += xo[m] * acc[m];
-          sum[2] += acc[m] * acc[m];
-        }
+        for (int m = 0; m < CPT; ++m) sum[1] += xo[m] * acc[m];
+      }
+      if (FUSE & 4) {
+#pragma unroll
+        for (int m = 0; m < CPT; ++m) sum[2] += acc[m] * acc[m];
       }
     }
     if (k == Nz - 1) {
@@ -352,15 +350,285 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
         }
         if (FUSE & 2) {
 #pragma unroll
-          for (int m = 0; m < CPT; ++m) {
-            sum[1] += xv[m] * yv[m];
-            sum[2] += yv[m] * yv[m];
-          }
+          for (int m = 0; m < CPT; ++m) sum[1] += xv[m] * yv[m];
+        }
+        if (FUSE & 4) {
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) sum[2] += yv[m] * yv[m];
         }
       }
     }
   }
   if (FUSE) tsx_block_reduce_store<3>(sum, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column preconditioner  z = M^-1 r,  M = the column-diagonal blocks of A in dst-owned storage.
+// Inside one column only the top streams couple vertically (a cell's in-column sources are Eup(k+1) and
+// Edn(k)); the side streams leaving the column depend on those but nothing in the column depends on them.
+// So M^-1 is an exact two-stream (adding-method) solve per column followed by a substitution for the side
+// streams.  This is the GPU-native counterpart of the reference's ILU(0) in z-fastest ordering
+// (src/pprts.F90:4350-4371): ILU captures the strong vertical coupling approximately, this captures it
+// exactly, and every column is independent (no triangular-solve dependency across the domain).
+//   H = NTOP/2 up/down pairs.  With U_k (up, level k), V_k (down, level k):
+//     U_k     = ru_k     + Tuu U_{k+1} + Rud V_k
+//     V_{k+1} = rd_{k+1} + Rdu U_{k+1} + Tdd V_k ,   V_0 = rd_0 ,  U_Nz = ru_Nz + Alb V_Nz
+//   upward sweep:   U_k = A_k V_k + B_k  (A_Nz = Alb, B_Nz = ru_Nz), stores per cell Gw, GT, A_k, B_k with
+//                   G = (I - Rdu A_{k+1})^-1, Gw = G (rd_{k+1} + Rdu B_{k+1}), GT = G Tdd
+//   downward sweep: V_{k+1} = Gw + GT V_k ; U_k = A_k V_k + B_k ; side dst = r + c(up->d) U_{k+1} + c(dn->d) V_k
+// One thread per column, lanes along x: every plane access is a coalesced 256/512-byte span.
+template <int H>
+struct TsxSm {  // tiny dense helpers, fully unrolled
+  static __device__ __forceinline__ void matvec(const double (&M)[H][H], const double (&v)[H], double (&o)[H]) {
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      double t = 0.0;
+#pragma unroll
+      for (int b = 0; b < H; ++b) t += M[a][b] * v[b];
+      o[a] = t;
+    }
+  }
+  static __device__ __forceinline__ void matmul(const double (&X)[H][H], const double (&Y)[H][H], double (&O)[H][H]) {
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+#pragma unroll
+      for (int b = 0; b < H; ++b) {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < H; ++c) t += X[a][c] * Y[c][b];
+        O[a][b] = t;
+      }
+  }
+  // O = (I - X)^-1 by Gauss-Jordan without pivoting (I - Rdu*A is strictly diagonally dominant: entries of
+  // Rdu*A are products of energy-conserving transfer coefficients, row sums < 1)
+  static __device__ __forceinline__ void inv_i_minus(const double (&X)[H][H], double (&O)[H][H]) {
+    double W[H][H];
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+#pragma unroll
+      for (int b = 0; b < H; ++b) {
+        W[a][b] = (a == b ? 1.0 : 0.0) - X[a][b];
+        O[a][b] = (a == b ? 1.0 : 0.0);
+      }
+#pragma unroll
+    for (int c = 0; c < H; ++c) {
+      const double piv = 1.0 / W[c][c];
+#pragma unroll
+      for (int b = 0; b < H; ++b) {
+        W[c][b] *= piv;
+        O[c][b] *= piv;
+      }
+#pragma unroll
+      for (int a = 0; a < H; ++a) {
+        if (a == c) continue;
+        const double f = W[a][c];
+#pragma unroll
+        for (int b = 0; b < H; ++b) {
+          W[a][b] -= f * W[c][b];
+          O[a][b] -= f * O[c][b];
+        }
+      }
+    }
+  }
+};
+
+// temp planes per cell: [Gw: H][GT: H*H][A: H*H][B: H]
+template <int NTOP>
+__host__ __device__ constexpr int tsx_pc_ntmp() { return (NTOP / 2) * 2 * ((NTOP / 2) + 1); }
+
+template <int NTOP, int NSIDE, typename CT>
+__global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
+                                                      const double *__restrict__ a11, const double *__restrict__ a12,
+                                                      const double *__restrict__ albedo, const double *__restrict__ r,
+                                                      double *__restrict__ z, double *__restrict__ tmp,
+                                                      const int *__restrict__ done) {
+  constexpr int D = NTOP + 2 * NSIDE;
+  constexpr int H = NTOP / 2;
+  using SM = TsxSm<H>;
+  if (done && *done) return;
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= g.ncol) return;
+  const long long Nc = g.Nc;
+  const int Nz = g.Nz, ncol = g.ncol;
+  const double *__restrict__ rt = r + (size_t)D * Nc;
+  double *__restrict__ zt = z + (size_t)D * Nc;
+  double *__restrict__ tGw = tmp, *__restrict__ tGT = tmp + (size_t)H * Nc, *__restrict__ tA = tmp + (size_t)(H + H * H) * Nc,
+                      *__restrict__ tB = tmp + (size_t)(H + 2 * H * H) * Nc;
+
+  // ---- upward sweep
+  double A[H][H], B[H];
+  {
+    const double alb = albedo[col] / (double)H;  // assembled surface row: albedo/streams on every pair
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      B[a] = rt[(size_t)(2 * a) * ncol + col];
+#pragma unroll
+      for (int b = 0; b < H; ++b) A[a][b] = alb;
+    }
+  }
+  for (int k = Nz - 1; k >= 0; --k) {
+    const size_t c = (size_t)k * ncol + col;
+    double Tuu[H][H], Rud[H][H], Rdu[H][H], Tdd[H][H], ru[H], rd[H];
+    if (l1d[k]) {
+      const double t11 = a11[c], t12 = a12[c];
+#pragma unroll
+      for (int a = 0; a < H; ++a)
+#pragma unroll
+        for (int b = 0; b < H; ++b) {
+          Tuu[a][b] = Tdd[a][b] = (a == b ? t11 : 0.0);
+          Rud[a][b] = Rdu[a][b] = (a == b ? t12 : 0.0);
+        }
+    } else {
+#pragma unroll
+      for (int a = 0; a < H; ++a)
+#pragma unroll
+        for (int b = 0; b < H; ++b) {  // C[dst*D + src]
+          Tuu[a][b] = (double)C[(size_t)((2 * a) * D + 2 * b) * Nc + c];
+          Rud[a][b] = (double)C[(size_t)((2 * a) * D + 2 * b + 1) * Nc + c];
+          Rdu[a][b] = (double)C[(size_t)((2 * a + 1) * D + 2 * b) * Nc + c];
+          Tdd[a][b] = (double)C[(size_t)((2 * a + 1) * D + 2 * b + 1) * Nc + c];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      ru[a] = r[(size_t)(2 * a) * Nc + c];
+      rd[a] = r[(size_t)(2 * a + 1) * Nc + c];
+    }
+    double RA[H][H], G[H][H], GT[H][H], w[H], Gw[H], AGw[H], TA[H][H], An[H][H], Bn[H];
+    SM::matmul(Rdu, A, RA);
+    SM::inv_i_minus(RA, G);
+    SM::matvec(Rdu, B, w);
+#pragma unroll
+    for (int a = 0; a < H; ++a) w[a] += rd[a];
+    SM::matvec(G, w, Gw);
+    SM::matmul(G, Tdd, GT);
+    SM::matvec(A, Gw, AGw);
+#pragma unroll
+    for (int a = 0; a < H; ++a) AGw[a] += B[a];
+    SM::matvec(Tuu, AGw, Bn);
+    SM::matmul(Tuu, A, TA);
+    SM::matmul(TA, GT, An);
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      Bn[a] += ru[a];
+      tGw[(size_t)a * Nc + c] = Gw[a];
+      tB[(size_t)a * Nc + c] = Bn[a];
+      B[a] = Bn[a];
+#pragma unroll
+      for (int b = 0; b < H; ++b) {
+        An[a][b] += Rud[a][b];
+        tGT[(size_t)(a * H + b) * Nc + c] = GT[a][b];
+        tA[(size_t)(a * H + b) * Nc + c] = An[a][b];
+        A[a][b] = An[a][b];
+      }
+    }
+  }
+
+  // ---- downward sweep
+  double V[H];
+#pragma unroll
+  for (int a = 0; a < H; ++a) {
+    V[a] = rt[(size_t)(2 * a + 1) * ncol + col];       // V_0 = rd_0 (TOA identity row)
+    zt[(size_t)(2 * a + 1) * ncol + col] = V[a];
+  }
+  // U_0 = A_0 V_0 + B_0: A, B hold level 0 after the upward sweep
+  double U[H];
+  SM::matvec(A, V, U);
+#pragma unroll
+  for (int a = 0; a < H; ++a) U[a] += B[a];
+  for (int k = 0; k < Nz; ++k) {
+    const size_t c = (size_t)k * ncol + col;
+    double Gw[H], GT[H][H], Vn[H], Un[H];
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      Gw[a] = tGw[(size_t)a * Nc + c];
+#pragma unroll
+      for (int b = 0; b < H; ++b) GT[a][b] = tGT[(size_t)(a * H + b) * Nc + c];
+    }
+    SM::matvec(GT, V, Vn);
+#pragma unroll
+    for (int a = 0; a < H; ++a) Vn[a] += Gw[a];
+    // U_{k+1}
+    if (k + 1 < Nz) {
+      const size_t cn = c + ncol;
+      double An[H][H];
+#pragma unroll
+      for (int a = 0; a < H; ++a) {
+        Un[a] = tB[(size_t)a * Nc + cn];
+#pragma unroll
+        for (int b = 0; b < H; ++b) An[a][b] = tA[(size_t)(a * H + b) * Nc + cn];
+      }
+      double t[H];
+      SM::matvec(An, Vn, t);
+#pragma unroll
+      for (int a = 0; a < H; ++a) Un[a] += t[a];
+    } else {
+      const double alb = albedo[col] / (double)H;
+      double sv = 0.0;
+#pragma unroll
+      for (int a = 0; a < H; ++a) sv += Vn[a];
+#pragma unroll
+      for (int a = 0; a < H; ++a) {
+        Un[a] = rt[(size_t)(2 * a) * ncol + col] + alb * sv;
+        zt[(size_t)(2 * a) * ncol + col] = Un[a];
+      }
+    }
+    // outputs of cell k: up streams at level k, down streams at level k+1
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      z[(size_t)(2 * a) * Nc + c] = U[a];
+      z[(size_t)(2 * a + 1) * Nc + c] = Vn[a];
+    }
+    // side streams leaving cell k: sources Eup(k+1) = Un, Edn(k) = V
+    if (l1d[k]) {
+#pragma unroll
+      for (int d = NTOP; d < D; ++d) z[(size_t)d * Nc + c] = r[(size_t)d * Nc + c];
+    } else {
+#pragma unroll
+      for (int d = NTOP; d < D; ++d) {
+        double acc = r[(size_t)d * Nc + c];
+#pragma unroll
+        for (int a = 0; a < H; ++a) {
+          acc += (double)C[(size_t)(d * D + 2 * a) * Nc + c] * Un[a];
+          acc += (double)C[(size_t)(d * D + 2 * a + 1) * Nc + c] * V[a];
+        }
+        z[(size_t)d * Nc + c] = acc;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      V[a] = Vn[a];
+      U[a] = Un[a];
+    }
+  }
+  // bottom side dummies: identity rows
+#pragma unroll
+  for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = rt[(size_t)d * ncol + col];
+}
+
+// out = a - b   (second preconditioner sweep: residual of the first)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_sub(long long n2, const double2 *__restrict__ a, const double2 *__restrict__ b,
+                                                       double2 *__restrict__ o, const int *__restrict__ done) {
+  if (done && *done) return;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double2 x = a[q], y = b[q];
+    double2 r;
+    r.x = x.x - y.x;
+    r.y = x.y - y.y;
+    o[q] = r;
+  }
+}
+// o += a
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_addto(long long n2, const double2 *__restrict__ a, double2 *__restrict__ o,
+                                                         const int *__restrict__ done) {
+  if (done && *done) return;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double2 x = a[q];
+    double2 r = o[q];
+    r.x += x.x;
+    r.y += x.y;
+    o[q] = r;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,7 +766,7 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
       }
     } break;
     case TSX_STAGE_OMEGA: {
-      const double ts = sc->red[1], tt = sc->red[2];
+      const double ts = sc->red[0], tt = sc->red[2];  // SpMV_2 runs with w = s: slot0 = (s,t), slot2 = (t,t)
       sc->omega = tt == 0.0 ? 0.0 : ts / tt;
     } break;
     case TSX_STAGE_RHO: {

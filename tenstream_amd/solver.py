@@ -152,6 +152,22 @@ class DiffuseSolver:
         _lib.check(self.lib.tsx_diff_apply(self.h, xp, yp, where))
         return out
 
+    def pc_apply(self, v, pc=1, sweeps=1, out=None):
+        """z = M^-1 v with the solver's preconditioner (test hook)."""
+        if out is None:
+            if _is_torch(v):
+                import torch
+
+                out = torch.empty_like(v)
+            else:
+                out = np.empty_like(v)
+        vp_, where = _ptr(v, np.float64)
+        zp, w2 = _ptr(out, np.float64)
+        if where != w2:
+            raise TypeError("v and out must live on the same side")
+        _lib.check(self.lib.tsx_diff_pc_apply(self.h, vp_, zp, where, pc, sweeps))
+        return out
+
     def default_tolerances(self, unconstrained_fraction=1.0):
         rtol, atol, maxit = C.c_double(), C.c_double(), C.c_int32()
         _lib.check(self.lib.tsx_determine_ksp_tolerances(self.h, unconstrained_fraction, C.byref(rtol), C.byref(atol),

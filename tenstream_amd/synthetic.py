@@ -227,5 +227,11 @@ def make_problem(solver="3_10", Nx=32, Ny=32, Nz=16, dx=100.0, dz=50.0, albedo=0
     a11 = np.ascontiguousarray(t1 * 0.9)
     a12 = np.ascontiguousarray((1.0 - t1) * 0.4)
     b = solar_source(solver, kabs, ksca, g, dz, dx, alb)
+    # 1-D layers only couple the top streams; their side rows are identity rows with zero source
+    # (setup_b writes a13/a23 terms to top streams only, src/pprts.F90:4709-4721)
+    for k in range(n1d):
+        top_only = b[:, :, k, :ntop].copy()
+        b[:, :, k, :] = 0.0
+        b[:, :, k, :ntop] = top_only
     return dict(solver=solver, Nx=Nx, Ny=Ny, Nz=Nz, D=D, dx=dx, dz=dz, coeff=np.ascontiguousarray(coeff), l1d=l1d,
                 a11=a11, a12=a12, albedo=alb, b=np.ascontiguousarray(b), kabs=kabs, ksca=ksca, g=g)

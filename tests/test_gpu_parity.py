@@ -102,3 +102,86 @@ def test_solve_default_tolerances_and_warm_start(gpu):
     info2 = s.solve(P["b"], x, rtol=1e-3)
     assert info2.res_hist[0] == pytest.approx(info.rnorm, rel=1e-6)
     assert info2.niter < info.niter and info2.reason in (2, 3)
+
+
+def _column_block_matrix(P, lay):
+    """M = entries of the assembled matrix whose row and column unknowns leave the same cell column
+    (dst-owned numbering): the matrix the column preconditioner inverts exactly."""
+    import scipy.sparse as sp
+
+    D, L, Nx, Ny, Nz = lay.D, lay.Nz + 1, lay.xm, lay.ym, lay.Nz
+    A = O.assemble_csr(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"]).tocoo()
+    idx = np.arange(A.shape[0])
+    d, k = idx % D, (idx // D) % L
+    i, j = (idx // (D * L)) % Nx, idx // (D * L * Nx)
+    ntop, nside = lay.ntop, lay.nside
+    oi, oj = i.copy(), j.copy()
+    qx, qy = d - ntop, d - ntop - nside
+    mx = (qx >= 0) & (qx < nside) & (qx % 2 == 1) & (k < Nz)
+    my = (qy >= 0) & (qy < nside) & (qy % 2 == 1) & (k < Nz)
+    oi[mx] = (i[mx] - 1) % Nx
+    oj[my] = (j[my] - 1) % Ny
+    owner = oj * Nx + oi
+    same = owner[A.row] == owner[A.col]
+    return sp.csc_matrix((A.data[same], (A.row[same], A.col[same])), shape=A.shape), A.tocsr()
+
+
+@pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 9, 7, 6, 2), ("3_10", 70, 5, 12, 0), ("8_16", 6, 5, 4, 1)])
+def test_column_preconditioner_is_exact_block_inverse(gpu, solver, Nx, Ny, Nz, n1d):
+    import scipy.sparse.linalg as spla
+
+    P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
+    lay = O.layout(solver, Nz, Nx, Ny)
+    M, A = _column_block_matrix(P, lay)
+    s = DiffuseSolver(solver, Nz, Nx, Ny)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(s.vec_shape)
+    z = s.pc_apply(v, pc=1, sweeps=1)
+    z_ref = spla.spsolve(M, v.ravel()).reshape(v.shape)
+    assert np.abs(z - z_ref).max() <= 1e-12 * np.abs(z_ref).max()
+    # two sweeps: z2 = z1 + M^-1 (v - A z1)
+    z2 = s.pc_apply(v, pc=1, sweeps=2)
+    z2_ref = z_ref.ravel() + spla.spsolve(M, v.ravel() - A @ z_ref.ravel())
+    assert np.abs(z2.ravel() - z2_ref).max() <= 1e-12 * np.abs(z2_ref).max()
+
+
+@pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 16, 12, 10, 2), ("8_16", 8, 6, 6, 0)])
+@pytest.mark.parametrize("sweeps", [1, 2])
+def test_preconditioned_solve_same_fixed_point(gpu, solver, Nx, Ny, Nz, n1d, sweeps):
+    import scipy.sparse.linalg as spla
+
+    P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
+    lay = O.layout(solver, Nz, Nx, Ny)
+    A = O.assemble_csr(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x_ref = spla.spsolve(A.tocsc(), P["b"].ravel()).reshape(P["b"].shape)
+    s = DiffuseSolver(solver, Nz, Nx, Ny)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x0 = np.zeros(s.vec_shape)
+    plain = s.solve(P["b"], x0, rtol=1e-10, atol=1e-30)
+    x = np.zeros(s.vec_shape)
+    info = s.solve(P["b"], x, rtol=1e-10, atol=1e-30, pc=1, pc_sweeps=sweeps)
+    assert info.reason == 2 and info.niter < plain.niter
+    assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    # true residual agrees with the recurrence residual the stop rule used
+    r = P["b"].ravel() - A @ x.ravel()
+    assert np.linalg.norm(r) <= 1.5 * info.rnorm + 1e-12 * np.linalg.norm(P["b"])
+
+
+def test_rccl_transport_with_one_rank_communicator(gpu):
+    """Drives the RCCL code path (ncclSend/ncclRecv face exchange in one group, ncclAllReduce of the dot
+    products) on a single GPU: a 1-rank communicator whose four neighbours are the rank itself."""
+    P = synthetic.make_problem("3_10", Nx=20, Ny=12, Nz=9, n1d=1)
+    s = DiffuseSolver("3_10", 9, 20, 12, force_halo=True)
+    s.comm_init(s.comm_unique_id())
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    lay = O.layout("3_10", 9, 20, 12)
+    c64 = P["coeff"].astype(np.float64)
+    x = np.random.default_rng(2).standard_normal(s.vec_shape)
+    y = s.apply(x)
+    y_ref = O.diff_apply(lay, c64, P["l1d"], P["a11"], P["a12"], P["albedo"], x)
+    assert np.abs(y - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+    xs = np.zeros(s.vec_shape)
+    info = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30, pc=1)
+    x_ref, _ = O.solve_matfree(lay, c64, P["l1d"], P["a11"], P["a12"], P["albedo"], P["b"], rtol=1e-12, atol=1e-30)
+    assert info.reason == 2 and np.abs(xs - x_ref).max() <= 1e-8 * np.abs(x_ref).max()

@@ -1,0 +1,92 @@
+"""CPU tests of the host logic and of the C-ABI surface (no compute calls without a GPU)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tenstream_amd import _lib, coord
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tsx.h")).read()
+    declared = set(re.findall(r"\b(tsx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"tsx_solver"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.tsx_version() == 100
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (tsx_[a-z0-9_]+)", nm))
+    assert declared <= exported
+
+
+def test_product_never_references_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "tenstream_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".F90")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle" not in txt.lower() or f == "synthetic.py" and "import" not in "".join(
+                    l for l in txt.splitlines() if "oracle" in l.lower()), os.path.join(dp, f)
+    ldd = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "liboracle" not in ldd
+
+
+def test_no_gpu_means_loud_failure():
+    lib = _lib.load()
+    if lib.tsx_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    from tenstream_amd import DiffuseSolver
+
+    with pytest.raises(_lib.TsxError) as e:
+        DiffuseSolver("3_10", 4, 4, 4)
+    assert e.value.code == _lib.TSX_ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_create_rejects_bad_arguments():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    g = _lib.Grid(999, 4, 4, 4, 0, 0, 4, 4, 0, 1, 0, 0, 0, 0, -1, 0)
+    assert lib.tsx_create(ctypes.byref(g), ctypes.byref(h)) == 1
+    assert b"solver_id" in lib.tsx_last_error()
+    g = _lib.Grid(310, 0, 4, 4, 0, 0, 4, 4, 0, 1, 0, 0, 0, 0, -1, 0)
+    assert lib.tsx_create(ctypes.byref(g), ctypes.byref(h)) == 1
+
+
+def test_coord_one_rank_matches_reference_test():
+    c = json.load(open(os.path.join(G, "coord_native.json")))["one_rank"]
+    co = coord.coord(0, 1, c["Nx"], c["Ny"])
+    assert (co.xs, co.xe, co.xm, co.ys, co.ye, co.ym) == (c["xs"], c["xe"], c["xm"], c["ys"], c["ye"], c["ym"])
+    assert [co.west, co.east, co.south, co.north] == c["neighbors"]
+    assert (co.xs - 1, co.xe + 1, co.xm + 2) == (c["gxs"], c["gxe"], c["gxm"])
+
+
+def test_coord_four_ranks_invariants():
+    """tests/test_pprts_coord_native/test_pprts_coord_native.F90:79-176: coverage, bounds, neighbour reciprocity."""
+    c = json.load(open(os.path.join(G, "coord_native.json")))["four_rank"]
+    cs = [coord.coord(r, c["nproc"], c["Nx"], c["Ny"]) for r in range(c["nproc"])]
+    assert sum(co.xm * co.ym for co in cs) == c["Nx"] * c["Ny"]
+    for co in cs:
+        assert 0 <= co.xs <= co.xe < c["Nx"] and 0 <= co.ys <= co.ye < c["Ny"]
+        assert cs[co.west].east == co.rank and cs[co.east].west == co.rank
+        assert cs[co.south].north == co.rank and cs[co.north].south == co.rank
+
+
+@pytest.mark.parametrize("n,want", [(1, (1, 1)), (2, (1, 2)), (4, (2, 2)), (8, (2, 4)), (6, (2, 3))])
+def test_process_grid_like_mpi_dims_create(n, want):
+    # dims = [nyp, nxp] non-increasing (src/pprts_base.F90:757-763); 8 GPUs -> 2 x 4
+    assert coord.decompose(n) == want
+
+
+def test_uneven_split_matches_dmda_formula():
+    cs = [coord.coord(r, 3, 10, 7, nxp=3, nyp=1) for r in range(3)]
+    assert [(c.xs, c.xm) for c in cs] == [(0, 3), (3, 3), (6, 4)]
