@@ -119,6 +119,18 @@ int tsx_set_stream(tsx_solver *s, void *hip_stream);
 int tsx_comm_unique_id(void *id128);
 int tsx_comm_init(tsx_solver *s, const void *id128);
 
+/* Alternative transport: host-staged callbacks, for hosts whose communicator is MPI (TenStream's own
+ * solver%comm) without GPU-aware transport, and for multi-process tests on one GPU.  The library copies the
+ * four face buffers to pinned host memory, calls `exchange`, and copies the received faces back.
+ *   send/recv/count/peer are indexed W,E,S,N.  recv[W] must be filled with peer W's send[E], recv[E] with peer
+ *   E's send[W], recv[S] with peer S's send[N], recv[N] with peer N's send[S]  (exchange_diffuse_boundary,
+ *   src/pprts_explicit.F90:769-843).  `allreduce` sums `n` doubles in place over all ranks (imp_allreduce).
+ * Callbacks return 0 on success. */
+typedef int (*tsx_exchange_fn)(void *ctx, const double *const send[4], double *const recv[4], const size_t count[4],
+                               const int peer[4]);
+typedef int (*tsx_allreduce_fn)(void *ctx, double *inout, int n);
+int tsx_comm_set_callbacks(tsx_solver *s, tsx_exchange_fn exchange, tsx_allreduce_fn allreduce, void *ctx);
+
 /* ---- operator values.  Replaces set_diff_coeff (src/pprts.F90:5511-5796): instead of one
  *      MatSetValuesStencil per cell the blocks are transposed once into stream-major planes.
  *      coeff_kind: 8 = real64 (ireals), 4 = real32.  Blocks whose real64 values are exactly

@@ -41,10 +41,14 @@ class KspResult(C.Structure):
                 ("import_ms", C.c_float), ("export_ms", C.c_float)]
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double)),
+                         C.POINTER(C.c_size_t), C.POINTER(C.c_int))
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
 # every symbol include/tsx.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
     "tsx_last_error", "tsx_version", "tsx_device_count", "tsx_create", "tsx_destroy", "tsx_default_ksp_opts",
-    "tsx_determine_ksp_tolerances", "tsx_set_stream", "tsx_comm_unique_id", "tsx_comm_init",
+    "tsx_determine_ksp_tolerances", "tsx_set_stream", "tsx_comm_unique_id", "tsx_comm_init", "tsx_comm_set_callbacks",
     "tsx_diff_set_coeffs", "tsx_diff_apply", "tsx_diff_solve", "tsx_diff_pc_apply", "tsx_bench_kernel", "tsx_algorithmic_bytes",
     "tsx_probe_copy_bandwidth",
 )
@@ -74,6 +78,7 @@ def load():
     lib.tsx_set_stream.argtypes = [vp, vp]
     lib.tsx_comm_unique_id.argtypes = [vp]
     lib.tsx_comm_init.argtypes = [vp, vp]
+    lib.tsx_comm_set_callbacks.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp]
     lib.tsx_diff_set_coeffs.argtypes = [vp, vp, ip, vp, vp, vp, vp, ip]
     lib.tsx_diff_apply.argtypes = [vp, vp, vp, ip]
     lib.tsx_diff_solve.argtypes = [vp, vp, vp, ip, C.POINTER(KspOpts), C.POINTER(KspResult)]

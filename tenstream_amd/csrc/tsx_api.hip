@@ -131,6 +131,15 @@ extern "C" int tsx_comm_init(tsx_solver *s, const void *id128) {
   return TSX_OK;
 }
 
+extern "C" int tsx_comm_set_callbacks(tsx_solver *s, tsx_exchange_fn exchange, tsx_allreduce_fn allreduce, void *ctx) {
+  ARGCHK(s, "tsx_comm_set_callbacks: null");
+  ARGCHK((exchange == nullptr) == (allreduce == nullptr), "tsx_comm_set_callbacks: set both callbacks or neither");
+  s->xchg_cb = exchange;
+  s->allred_cb = allreduce;
+  s->cb_ctx = ctx;
+  return TSX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 static inline int grid_for(long long n, int cap = 2048) {
   long long b = (n + TSX_BLOCK - 1) / TSX_BLOCK;
@@ -244,6 +253,10 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   if (s->vph && s->vph != s->vp) (void)hipFree(s->vph);
   if (s->vsh && s->vsh != s->vs) (void)hipFree(s->vsh);
   if (s->scal_host) (void)hipHostFree(s->scal_host);
+  for (int q = 0; q < 4; ++q) {
+    if (s->host_send[q]) (void)hipHostFree(s->host_send[q]);
+    if (s->host_recv[q]) (void)hipHostFree(s->host_recv[q]);
+  }
   if (s->comm_ready && g_rccl.CommDestroy) g_rccl.CommDestroy(s->nccl_comm);
   (void)hipEventDestroy(s->ev0);
   (void)hipEventDestroy(s->ev1);
@@ -275,6 +288,27 @@ extern "C" int tsx_set_stream(tsx_solver *s, void *hip_stream) {
 static int face_exchange(tsx_solver *s) {
   const TsxGeo &g = s->geo;
   const size_t bx = s->halo_x_elems, by = s->halo_y_elems;
+  if (s->xchg_cb) {
+    const tsx_grid &gr = s->grid;
+    double *dsend[4] = {s->sendW, s->sendE, s->sendS, s->sendN};
+    double *drecv[4] = {s->recvW, s->recvE, s->recvS, s->recvN};
+    const size_t count[4] = {g.wrap_x ? 0 : bx, g.wrap_x ? 0 : bx, g.wrap_y ? 0 : by, g.wrap_y ? 0 : by};
+    const int peer[4] = {gr.neigh_w, gr.neigh_e, gr.neigh_s, gr.neigh_n};
+    for (int q = 0; q < 4; ++q) {
+      const size_t cap = (q < 2 ? bx : by) * sizeof(double);
+      if (!s->host_send[q]) HIPCHK(hipHostMalloc((void **)&s->host_send[q], cap, hipHostMallocDefault));
+      if (!s->host_recv[q]) HIPCHK(hipHostMalloc((void **)&s->host_recv[q], cap, hipHostMallocDefault));
+      if (count[q]) HIPCHK(hipMemcpyAsync(s->host_send[q], dsend[q], count[q] * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->xchg_cb(s->cb_ctx, (const double *const *)s->host_send, (double *const *)s->host_recv, count, peer)) {
+      tsx_set_error("face_exchange: exchange callback failed");
+      return TSX_ERR_COMM;
+    }
+    for (int q = 0; q < 4; ++q)
+      if (count[q]) HIPCHK(hipMemcpyAsync(drecv[q], s->host_recv[q], count[q] * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    return TSX_OK;
+  }
   if (s->comm_ready) {
     tsx_ncclComm_t c = s->nccl_comm;
     const tsx_grid &gr = s->grid;
@@ -295,7 +329,7 @@ static int face_exchange(tsx_solver *s) {
     return TSX_OK;
   }
   if (s->grid.nranks > 1) {
-    tsx_set_error("face_exchange: nranks > 1 but tsx_comm_init was not called");
+    tsx_set_error("face_exchange: nranks > 1 but neither tsx_comm_init nor tsx_comm_set_callbacks was called");
     return TSX_ERR_STATE;
   }
   // single rank with force_halo: every neighbour is this rank
@@ -363,6 +397,19 @@ static inline int spmv_nblocks(const tsx_solver *s) { return grid_for(s->geo.Nc 
 
 // reduce partials -> (all-reduce) -> scalar algebra
 static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {
+  if (s->allred_cb) {
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1);
+    HIPCHK(hipMemcpyAsync(s->scal_host->red, s->scal->red, sizeof(double) * TSX_NSLOTS, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->allred_cb(s->cb_ctx, s->scal_host->red, TSX_NSLOTS)) {
+      tsx_set_error("scalar_stage: allreduce callback failed");
+      return TSX_ERR_COMM;
+    }
+    HIPCHK(hipMemcpyAsync(s->scal->red, s->scal_host->red, sizeof(double) * TSX_NSLOTS, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 2);
+    HIPCHK(hipGetLastError());
+    return TSX_OK;
+  }
   if (s->comm_ready) {  // also with a 1-rank communicator (exercised by the single-GPU RCCL test)
     hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1);
     NCCLCHK(g_rccl.AllReduce(s->scal->red, s->scal->red, TSX_NSLOTS, TSX_NCCL_FLOAT64, TSX_NCCL_SUM, s->nccl_comm,

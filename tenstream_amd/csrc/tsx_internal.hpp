@@ -81,6 +81,10 @@ struct tsx_solver {
 
   void *nccl_comm;     // ncclComm_t when nranks > 1 (or force_halo with comm)
   bool comm_ready;
+  tsx_exchange_fn xchg_cb;      // host-staged transport (MPI hosts, tests)
+  tsx_allreduce_fn allred_cb;
+  void *cb_ctx;
+  double *host_send[4], *host_recv[4];  // pinned staging, order W,E,S,N
 
   hipEvent_t ev0, ev1;
 };

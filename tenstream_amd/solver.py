@@ -110,6 +110,35 @@ class DiffuseSolver:
         buf = C.create_string_buffer(uid, 128)
         _lib.check(self.lib.tsx_comm_init(self.h, buf))
 
+    def comm_set_callbacks(self, exchange, allreduce):
+        """Host-staged transport.  exchange(send: list of 4 numpy views W,E,S,N, recv: list of 4 writable views,
+        peers: list of 4 ranks) and allreduce(buf: writable numpy view) operate on pinned host memory."""
+        def _x(ctx, send, recv, count, peer):
+            try:
+                n = [int(count[q]) for q in range(4)]
+                sv = [np.ctypeslib.as_array(send[q], shape=(n[q],)) if n[q] else np.empty(0) for q in range(4)]
+                rv = [np.ctypeslib.as_array(recv[q], shape=(n[q],)) if n[q] else np.empty(0) for q in range(4)]
+                exchange(sv, rv, [int(peer[q]) for q in range(4)])
+                return 0
+            except Exception:  # never unwind through C
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def _a(ctx, buf, n):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(n),)))
+                return 0
+            except Exception:
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._cb = (_lib.EXCHANGE_FN(_x), _lib.ALLREDUCE_FN(_a))
+        _lib.check(self.lib.tsx_comm_set_callbacks(self.h, self._cb[0], self._cb[1], None))
+
     def set_stream(self, stream_ptr):
         _lib.check(self.lib.tsx_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
 
