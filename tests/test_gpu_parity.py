@@ -185,3 +185,16 @@ def test_rccl_transport_with_one_rank_communicator(gpu):
     info = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30, pc=1)
     x_ref, _ = O.solve_matfree(lay, c64, P["l1d"], P["a11"], P["a12"], P["albedo"], P["b"], rtol=1e-12, atol=1e-30)
     assert info.reason == 2 and np.abs(xs - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+
+
+def test_fortran_shim_driver(gpu):
+    """The ISO_C_BINDING shim (tenstream_amd/fortran/m_pprts_hip.F90) called from a Fortran program."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tenstream_amd", "lib", "test_shim")
+    if not os.path.exists(exe):
+        pytest.skip("amdflang not available when the tree was built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "shim ok" in r.stdout
