@@ -35,11 +35,11 @@ def parse():
     ap.add_argument("--ny", type=int, default=256, help="columns per GPU in y")
     ap.add_argument("--nz", type=int, default=64)
     ap.add_argument("--solver", default="3_10")
-    ap.add_argument("--pc", type=int, default=0)
+    ap.add_argument("--pc", type=int, default=1, help="0 none, 1 column-block preconditioner")
     ap.add_argument("--pc-sweeps", type=int, default=1)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="edge of the CPU-baseline sample tile (columns)")
+    ap.add_argument("--cpu-sample", type=int, default=112, help="edge of the CPU-baseline sample tile (columns)")
     return ap.parse_args()
 
 
