@@ -138,6 +138,26 @@ int tsx_comm_set_callbacks(tsx_solver *s, tsx_exchange_fn exchange, tsx_allreduc
 int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coeff_kind, const uint8_t *l1d,
                         const double *a11, const double *a12, const double *albedo, int where);
 
+/* ---- coefficient source on the device (replaces the per-cell get_coeff loop of alloc_coeff_diff2diff,
+ *      src/pprts.F90:3433-3462).  The table is the reference's LUT payload: real32 (nvec, nentries) column-major
+ *      with tau fastest, then w0, aspect_zx, g (src/optprop_base.F90:438-442); axes as in
+ *      src/optprop_parameters.F90 (tau31, w020, aspect23, g6 for LUT_3_10 / LUT_8_16).
+ *      tsx_lut_load_diffuse_mmap4 reads a `.mmap4` file as written by src/mmap.F90:63-127 (one page of size_t
+ *      header [dtype_size, n_elems, n_bytes, dim1, dim2, 0...], then the raw array) and applies the solver's
+ *      preset axes. */
+int tsx_lut_set_diffuse(tsx_solver *s, const float *table, int32_t nvec, int64_t nentries, int32_t ndim,
+                        const int32_t *n, const float *axes_concat, int where);
+int tsx_lut_load_diffuse_mmap4(tsx_solver *s, const char *path);
+/* optical properties (delta-scaled, as atm%kabs/ksca/g/dz hold them after set_optical_properties,
+ * src/pprts.F90:1903-1917) -> coefficient planes by N-linear interpolation with lattice snapping
+ * (src/interpolation.F90:317-360).  Arrays (zs:ze-1, xs:xe, ys:ye) real64; dx scalar. */
+int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz,
+                         double dx, const uint8_t *l1d, const double *a11, const double *a12, const double *albedo,
+                         int where);
+/* read the coefficient blocks back in the reference layout (1:D*D, zs:ze-1, xs:xe, ys:ye), real64 -- what
+ * solver%diff2diff holds (needed by calc_flx_div on the host, and by parity tests) */
+int tsx_diff_get_coeffs(tsx_solver *s, double *diff2diff, int where);
+
 /* ---- y = (I - T) x : op_mat_mult_ediff (src/pprts_shell.F90:366-541), assembled semantics for the
  *      surface row (albedo/streams on every up/down pair, src/pprts.F90:5755-5794) */
 int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int where);

@@ -49,7 +49,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 SYMBOLS = (
     "tsx_last_error", "tsx_version", "tsx_device_count", "tsx_create", "tsx_destroy", "tsx_default_ksp_opts",
     "tsx_determine_ksp_tolerances", "tsx_set_stream", "tsx_comm_unique_id", "tsx_comm_init", "tsx_comm_set_callbacks",
-    "tsx_diff_set_coeffs", "tsx_diff_apply", "tsx_diff_solve", "tsx_diff_pc_apply", "tsx_bench_kernel", "tsx_algorithmic_bytes",
+    "tsx_diff_set_coeffs", "tsx_lut_set_diffuse", "tsx_lut_load_diffuse_mmap4", "tsx_diff_set_optprop",
+    "tsx_diff_get_coeffs", "tsx_diff_apply", "tsx_diff_solve", "tsx_diff_pc_apply", "tsx_bench_kernel", "tsx_algorithmic_bytes",
     "tsx_probe_copy_bandwidth",
 )
 
@@ -80,6 +81,10 @@ def load():
     lib.tsx_comm_init.argtypes = [vp, vp]
     lib.tsx_comm_set_callbacks.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp]
     lib.tsx_diff_set_coeffs.argtypes = [vp, vp, ip, vp, vp, vp, vp, ip]
+    lib.tsx_lut_set_diffuse.argtypes = [vp, vp, C.c_int32, C.c_int64, C.c_int32, vp, vp, ip]
+    lib.tsx_lut_load_diffuse_mmap4.argtypes = [vp, C.c_char_p]
+    lib.tsx_diff_set_optprop.argtypes = [vp, vp, vp, vp, vp, C.c_double, vp, vp, vp, vp, ip]
+    lib.tsx_diff_get_coeffs.argtypes = [vp, vp, ip]
     lib.tsx_diff_apply.argtypes = [vp, vp, vp, ip]
     lib.tsx_diff_solve.argtypes = [vp, vp, vp, ip, C.POINTER(KspOpts), C.POINTER(KspResult)]
     lib.tsx_diff_pc_apply.argtypes = [vp, vp, vp, ip, ip, ip]

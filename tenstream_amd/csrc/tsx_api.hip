@@ -1,6 +1,9 @@
 // tsx_api.hip -- C-ABI of libtsx (see include/tsx.h).  Host orchestration: HIP streams/events,
 // device-resident Krylov loop (no host round trip per iteration), RCCL halo exchange.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -247,7 +250,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
-                  s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp};
+                  s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->vph && s->vph != s->vp) (void)hipFree(s->vph);
@@ -466,17 +469,10 @@ static int ensure_stage(tsx_solver *s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coeff_kind, const uint8_t *l1d,
-                                   const double *a11, const double *a12, const double *albedo, int where) {
-  ARGCHK(s && diff2diff && l1d && albedo, "tsx_diff_set_coeffs: null argument");
-  ARGCHK(coeff_kind == 4 || coeff_kind == 8, "tsx_diff_set_coeffs: coeff_kind must be 4 or 8");
-  HIPCHK(hipSetDevice(s->device));
+// l1d / a11 / a12 / albedo: shared by set_coeffs and set_optprop
+static int set_aux(tsx_solver *s, const uint8_t *l1d, const double *a11, const double *a12, const double *albedo, int where) {
   const TsxGeo &g = s->geo;
-  const int DD = g.D * g.D;
-  const size_t ncoef = (size_t)DD * g.Nc;
   const hipMemcpyKind mk = where == TSX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-
-  // l1d (needed on the host too: are a11/a12 required?)
   std::vector<uint8_t> l1d_h(g.Nz);
   if (where == TSX_HOST) memcpy(l1d_h.data(), l1d, g.Nz);
   else HIPCHK(hipMemcpy(l1d_h.data(), l1d, g.Nz, hipMemcpyDeviceToHost));
@@ -484,50 +480,8 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
   for (int k = 0; k < g.Nz; ++k) s->any_l1d |= l1d_h[k] != 0;
   HIPCHK(hipMemcpyAsync(s->l1d, l1d_h.data(), g.Nz, hipMemcpyHostToDevice, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
-  ARGCHK(!s->any_l1d || (a11 && a12), "tsx_diff_set_coeffs: a11/a12 required when any layer is 1-D");
+  ARGCHK(!s->any_l1d || (a11 && a12), "a11/a12 required when any layer is 1-D");
   HIPCHK(hipMemcpyAsync(s->albedo, albedo, sizeof(double) * g.ncol, mk, s->stream));
-
-  // coefficient blocks
-  const void *src_dev = diff2diff;
-  void *tmp = nullptr;
-  if (where == TSX_HOST) {
-    HIPCHK(hipMalloc(&tmp, ncoef * coeff_kind));
-    HIPCHK(hipMemcpyAsync(tmp, diff2diff, ncoef * coeff_kind, hipMemcpyHostToDevice, s->stream));
-    src_dev = tmp;
-  }
-  int out_bytes = 4;
-  if (coeff_kind == 8) {  // keep fp64 unless every value survives the round trip through fp32
-    int *flag = nullptr;
-    HIPCHK(hipMalloc((void **)&flag, sizeof(int)));
-    HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), s->stream));
-    hipLaunchKernelGGL(tsx_k_check_fp32_lossless, dim3(grid_for((long long)ncoef)), dim3(TSX_BLOCK), 0, s->stream,
-                       (long long)ncoef, (const double *)src_dev, flag);
-    int bad = 0;
-    HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    HIPCHK(hipFree(flag));
-    out_bytes = bad ? 8 : 4;
-  }
-  if (s->coef && s->coef_bytes != out_bytes) {
-    HIPCHK(hipFree(s->coef));
-    s->coef = nullptr;
-  }
-  if (!s->coef) HIPCHK(hipMalloc(&s->coef, ncoef * out_bytes));
-  s->coef_bytes = out_bytes;
-  const int TI = DD > 128 ? 16 : 32;  // keep the LDS tile under 64 KiB for D = 16
-  const int nbk = grid_for((long long)((g.xm + TI - 1) / TI) * g.ym * g.Nz * TSX_BLOCK, 8192);
-  const size_t lds = (size_t)TI * (DD + 1) * out_bytes;
-  if (coeff_kind == 8 && out_bytes == 8)
-    hipLaunchKernelGGL((tsx_k_import_coeff<double, double>), dim3(nbk), dim3(TSX_BLOCK), lds, s->stream, g, DD, TI,
-                       (const double *)src_dev, (double *)s->coef);
-  else if (coeff_kind == 8)
-    hipLaunchKernelGGL((tsx_k_import_coeff<double, float>), dim3(nbk), dim3(TSX_BLOCK), lds, s->stream, g, DD, TI,
-                       (const double *)src_dev, (float *)s->coef);
-  else
-    hipLaunchKernelGGL((tsx_k_import_coeff<float, float>), dim3(nbk), dim3(TSX_BLOCK), lds, s->stream, g, DD, TI,
-                       (const float *)src_dev, (float *)s->coef);
-  HIPCHK(hipGetLastError());
-
   if (s->any_l1d) {
     if (!s->a11) HIPCHK(hipMalloc((void **)&s->a11, sizeof(double) * g.Nc));
     if (!s->a12) HIPCHK(hipMalloc((void **)&s->a12, sizeof(double) * g.Nc));
@@ -548,8 +502,240 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
     if (t12) HIPCHK(hipFree(t12));
   }
   HIPCHK(hipStreamSynchronize(s->stream));
+  return TSX_OK;
+}
+
+static int ensure_coef_storage(tsx_solver *s, int out_bytes) {
+  const size_t ncoef = (size_t)s->geo.D * s->geo.D * s->geo.Nc;
+  if (s->coef && s->coef_bytes != out_bytes) {
+    HIPCHK(hipFree(s->coef));
+    s->coef = nullptr;
+  }
+  if (!s->coef) HIPCHK(hipMalloc(&s->coef, ncoef * out_bytes));
+  s->coef_bytes = out_bytes;
+  return TSX_OK;
+}
+
+extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coeff_kind, const uint8_t *l1d,
+                                   const double *a11, const double *a12, const double *albedo, int where) {
+  ARGCHK(s && diff2diff && l1d && albedo, "tsx_diff_set_coeffs: null argument");
+  ARGCHK(coeff_kind == 4 || coeff_kind == 8, "tsx_diff_set_coeffs: coeff_kind must be 4 or 8");
+  HIPCHK(hipSetDevice(s->device));
+  const TsxGeo &g = s->geo;
+  const int DD = g.D * g.D;
+  const size_t ncoef = (size_t)DD * g.Nc;
+  int rc = set_aux(s, l1d, a11, a12, albedo, where);
+  if (rc) return rc;
+
+  const void *src_dev = diff2diff;
+  void *tmp = nullptr;
+  if (where == TSX_HOST) {
+    HIPCHK(hipMalloc(&tmp, ncoef * coeff_kind));
+    HIPCHK(hipMemcpyAsync(tmp, diff2diff, ncoef * coeff_kind, hipMemcpyHostToDevice, s->stream));
+    src_dev = tmp;
+  }
+  int out_bytes = 4;
+  if (coeff_kind == 8) {  // keep fp64 unless every value survives the round trip through fp32
+    int *flag = nullptr;
+    HIPCHK(hipMalloc((void **)&flag, sizeof(int)));
+    HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), s->stream));
+    hipLaunchKernelGGL(tsx_k_check_fp32_lossless, dim3(grid_for((long long)ncoef)), dim3(TSX_BLOCK), 0, s->stream,
+                       (long long)ncoef, (const double *)src_dev, flag);
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipFree(flag));
+    out_bytes = bad ? 8 : 4;
+  }
+  if ((rc = ensure_coef_storage(s, out_bytes))) return rc;
+  const int TI = DD > 128 ? 16 : 32;  // keep the LDS tile under 64 KiB for D = 16
+  const int nbk = grid_for((long long)((g.xm + TI - 1) / TI) * g.ym * g.Nz * TSX_BLOCK, 8192);
+  const size_t lds = (size_t)TI * (DD + 1) * out_bytes;
+  if (coeff_kind == 8 && out_bytes == 8)
+    hipLaunchKernelGGL((tsx_k_import_coeff<double, double>), dim3(nbk), dim3(TSX_BLOCK), lds, s->stream, g, DD, TI,
+                       (const double *)src_dev, (double *)s->coef);
+  else if (coeff_kind == 8)
+    hipLaunchKernelGGL((tsx_k_import_coeff<double, float>), dim3(nbk), dim3(TSX_BLOCK), lds, s->stream, g, DD, TI,
+                       (const double *)src_dev, (float *)s->coef);
+  else
+    hipLaunchKernelGGL((tsx_k_import_coeff<float, float>), dim3(nbk), dim3(TSX_BLOCK), lds, s->stream, g, DD, TI,
+                       (const float *)src_dev, (float *)s->coef);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s->stream));
   if (tmp) HIPCHK(hipFree(tmp));
   s->have_coeffs = true;
+  return TSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LUT on the device
+// axes of LUT_3_10 / LUT_8_16 diffuse tables (src/optprop_base.F90:200-212, 228-240): presets from
+// src/optprop_parameters.F90:145-154 (tau31), :194-199 (w020), :107-110 (aspect23), :245 (g6)
+static const float k_preset_tau31[31] = {
+    1e-10f, 3.62266272998e-07f, 7.04565803675e-06f, 4.47545500233e-05f, 0.000172126759821f, 0.000495994753047f,
+    0.00119161313679f, 0.00251026980343f, 0.00480799264297f, 0.00856221891924f, 0.0143961482731f, 0.0231530284254f,
+    0.0358868239775f, 0.0541358315379f, 0.079959118223f, 0.11623968405f, 0.167882053841f, 0.246414427244f,
+    0.350199325489f, 0.502459974196f, 0.759082408765f, 1.08083180518f, 1.5415157991f, 2.19832932733f, 3.04549626819f,
+    4.27145477454f, 6.16953841432f, 9.43719309835f, 15.7335501106f, 29.5819342206f, 100.0f};
+static const float k_preset_w020[20] = {
+    0.0f, 0.152960717624f, 0.295085090042f, 0.416951893959f, 0.521358613652f, 0.610087211908f, 0.684967634054f,
+    0.747886390181f, 0.800286677013f, 0.84336972609f, 0.878674797098f, 0.906377786525f, 0.928097831502f,
+    0.943463164595f, 0.954135786554f, 0.963824066888f, 0.972632134967f, 0.981529289348f, 0.990759644674f, 0.99999f};
+static const float k_preset_aspect23[23] = {0.02f, 0.032f, 0.042f, 0.056f, 0.075f, 0.1f, 0.133f, 0.178f, 0.237f, 0.316f,
+                                            0.422f, 0.562f, 0.75f, 1.f, 1.25f, 1.562f, 1.953f, 2.441f, 3.052f, 3.815f,
+                                            4.768f, 5.96f, 7.451f};
+static const float k_preset_g6[6] = {0.0f, 0.2424f, 0.4137f, 0.5717f, 0.7144f, 0.85f};
+
+extern "C" int tsx_lut_set_diffuse(tsx_solver *s, const float *table, int32_t nvec, int64_t nentries, int32_t ndim,
+                                   const int32_t *n, const float *axes_concat, int where) {
+  ARGCHK(s && table && n && axes_concat, "tsx_lut_set_diffuse: null argument");
+  ARGCHK(ndim == 4, "tsx_lut_set_diffuse: diffuse tables have 4 dimensions (tau, w0, aspect_zx, g)");
+  ARGCHK(nvec == s->geo.D * s->geo.D, "tsx_lut_set_diffuse: nvec must be D*D");
+  long long prod = 1, nax = 0;
+  for (int d = 0; d < ndim; ++d) {
+    ARGCHK(n[d] >= 1, "tsx_lut_set_diffuse: empty axis");
+    prod *= n[d];
+    nax += n[d];
+  }
+  ARGCHK(prod == nentries, "tsx_lut_set_diffuse: nentries != product of axis lengths");
+  HIPCHK(hipSetDevice(s->device));
+  TsxLutHost &L = s->lut_diff;
+  if (L.d_axes) HIPCHK(hipFree(L.d_axes));
+  if (L.d_table) HIPCHK(hipFree(L.d_table));
+  L = TsxLutHost();
+  HIPCHK(hipMalloc((void **)&L.d_axes, sizeof(float) * nax));
+  HIPCHK(hipMalloc((void **)&L.d_table, sizeof(float) * (size_t)nvec * nentries));
+  const hipMemcpyKind mk = where == TSX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  HIPCHK(hipMemcpy(L.d_axes, axes_concat, sizeof(float) * nax, mk));
+  HIPCHK(hipMemcpy(L.d_table, table, sizeof(float) * (size_t)nvec * nentries, mk));
+  L.ndim = ndim;
+  L.nvec = nvec;
+  L.nentries = nentries;
+  for (int d = 0; d < ndim; ++d) L.n[d] = n[d];
+  L.ready = true;
+  return TSX_OK;
+}
+
+extern "C" int tsx_lut_load_diffuse_mmap4(tsx_solver *s, const char *path) {
+  ARGCHK(s && path, "tsx_lut_load_diffuse_mmap4: null argument");
+  // src/mmap.F90:129-203: header = one page of size_t, data starts at the page boundary
+  const long pagesize = sysconf(_SC_PAGESIZE);
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) {
+    tsx_set_error(std::string("tsx_lut_load_diffuse_mmap4: cannot open ") + path);
+    return TSX_ERR_ARG;
+  }
+  std::vector<size_t> header((size_t)pagesize / sizeof(size_t));
+  if (read(fd, header.data(), (size_t)pagesize) != pagesize) {
+    close(fd);
+    tsx_set_error("tsx_lut_load_diffuse_mmap4: short header");
+    return TSX_ERR_ARG;
+  }
+  const size_t dtype_size = header[0], n_elems = header[1], n_bytes = header[2], dim1 = header[3], dim2 = header[4];
+  if (dtype_size != 4 || n_bytes != 4 * n_elems || dim1 * dim2 != n_elems || header[5] != 0) {
+    close(fd);
+    tsx_set_error("tsx_lut_load_diffuse_mmap4: not a 2-D real32 mmap4 table");
+    return TSX_ERR_ARG;
+  }
+  void *m = mmap(nullptr, n_bytes + (size_t)pagesize, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) {
+    tsx_set_error("tsx_lut_load_diffuse_mmap4: mmap failed");
+    return TSX_ERR_ARG;
+  }
+  const int32_t n[4] = {31, 20, 23, 6};
+  std::vector<float> axes;
+  axes.insert(axes.end(), k_preset_tau31, k_preset_tau31 + 31);
+  axes.insert(axes.end(), k_preset_w020, k_preset_w020 + 20);
+  axes.insert(axes.end(), k_preset_aspect23, k_preset_aspect23 + 23);
+  axes.insert(axes.end(), k_preset_g6, k_preset_g6 + 6);
+  int rc = tsx_lut_set_diffuse(s, (const float *)((const char *)m + pagesize), (int32_t)dim1, (int64_t)dim2, 4, n,
+                               axes.data(), TSX_HOST);
+  munmap(m, n_bytes + (size_t)pagesize);
+  return rc;
+}
+
+extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const double *ksca, const double *g,
+                                    const double *dz, double dx, const uint8_t *l1d, const double *a11, const double *a12,
+                                    const double *albedo, int where) {
+  ARGCHK(s && kabs && ksca && g && dz && l1d && albedo, "tsx_diff_set_optprop: null argument");
+  ARGCHK(dx > 0, "tsx_diff_set_optprop: dx <= 0");
+  if (!s->lut_diff.ready) {
+    tsx_set_error("tsx_diff_set_optprop: load the diffuse LUT first (tsx_lut_set_diffuse / tsx_lut_load_diffuse_mmap4)");
+    return TSX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  const TsxGeo &gm = s->geo;
+  int rc = set_aux(s, l1d, a11, a12, albedo, where);
+  if (rc) return rc;
+  if ((rc = ensure_coef_storage(s, 4))) return rc;
+  const size_t nb = sizeof(double) * gm.Nc;
+  const double *p[4] = {kabs, ksca, g, dz};
+  double *tmp[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (where == TSX_HOST) {
+    for (int q = 0; q < 4; ++q) {
+      HIPCHK(hipMalloc((void **)&tmp[q], nb));
+      HIPCHK(hipMemcpyAsync(tmp[q], p[q], nb, hipMemcpyHostToDevice, s->stream));
+      p[q] = tmp[q];
+    }
+  }
+  TsxLutDev L;
+  memset(&L, 0, sizeof(L));
+  const TsxLutHost &H = s->lut_diff;
+  L.ndim = H.ndim;
+  L.nvec = H.nvec;
+  long long off = 1;
+  int aoff = 0;
+  for (int d = 0; d < H.ndim; ++d) {
+    L.n[d] = H.n[d];
+    L.axis_off[d] = aoff;
+    aoff += H.n[d];
+    L.offs[d] = off;
+    off *= H.n[d];
+  }
+  L.axes = H.d_axes;
+  L.table = H.d_table;
+  const int nbk = grid_for(gm.Nc, 8192);
+  if (gm.D == 10)
+    hipLaunchKernelGGL((tsx_k_lut_diff2diff<100>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, p[0], p[1], p[2], p[3], dx,
+                       s->l1d, (float *)s->coef);
+  else
+    hipLaunchKernelGGL((tsx_k_lut_diff2diff<256>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, p[0], p[1], p[2], p[3], dx,
+                       s->l1d, (float *)s->coef);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s->stream));
+  for (int q = 0; q < 4; ++q)
+    if (tmp[q]) HIPCHK(hipFree(tmp[q]));
+  s->have_coeffs = true;
+  return TSX_OK;
+}
+
+extern "C" int tsx_diff_get_coeffs(tsx_solver *s, double *diff2diff, int where) {
+  ARGCHK(s && diff2diff, "tsx_diff_get_coeffs: null argument");
+  if (!s->have_coeffs) {
+    tsx_set_error("tsx_diff_get_coeffs: no coefficients set");
+    return TSX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  const TsxGeo &g = s->geo;
+  const int DD = g.D * g.D;
+  const size_t ncoef = (size_t)DD * g.Nc;
+  double *out = diff2diff;
+  double *tmp = nullptr;
+  if (where == TSX_HOST) {
+    HIPCHK(hipMalloc((void **)&tmp, ncoef * sizeof(double)));
+    out = tmp;
+  }
+  if (s->coef_bytes == 4)
+    hipLaunchKernelGGL((tsx_k_export_coeff<float>), dim3(grid_for((long long)ncoef, 8192)), dim3(TSX_BLOCK), 0, s->stream, g,
+                       DD, (const float *)s->coef, out);
+  else
+    hipLaunchKernelGGL((tsx_k_export_coeff<double>), dim3(grid_for((long long)ncoef, 8192)), dim3(TSX_BLOCK), 0, s->stream, g,
+                       DD, (const double *)s->coef, out);
+  HIPCHK(hipGetLastError());
+  if (where == TSX_HOST) HIPCHK(hipMemcpyAsync(diff2diff, tmp, ncoef * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if (tmp) HIPCHK(hipFree(tmp));
   return TSX_OK;
 }
 

@@ -46,6 +46,15 @@ struct TsxScalars {
   double hist[100];
 };
 
+struct TsxLutHost {  // device copy of one LUT + its description
+  bool ready;
+  int ndim, nvec;
+  int n[8];
+  long long nentries;
+  float *d_axes;
+  float *d_table;
+};
+
 struct tsx_solver {
   tsx_grid grid;
   TsxGeo geo;
@@ -61,6 +70,7 @@ struct tsx_solver {
   double *albedo;      // [ncol]
   bool have_coeffs;
   bool any_l1d;
+  TsxLutHost lut_diff;
 
   // Krylov work vectors (internal layout, N doubles each)
   double *vx, *vb, *vr, *vrhat, *vp, *vv, *vs, *vt, *vph, *vsh;

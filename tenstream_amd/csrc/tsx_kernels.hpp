@@ -908,6 +908,142 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_halo_pack(TsxGeo g, const dou
 }
 
 // ------------------------------------------------------------------------------------------------
+// Coefficient lookup on the device: get_coeff -> LUT_get_diff2diff -> interp_vec_bilinear_iterative
+// (src/pprts_base.F90:1517-1542, src/optprop_LUT.F90:1560-1596, src/interpolation.F90:317-360, snapping :546-556,
+//  bisection src/search.fypp:177-228).  real32 arithmetic in the reference's operation order (explicit
+// __f*_rn intrinsics keep the compiler from contracting mul+add), so the planes are bit-identical to what
+// alloc_coeff_diff2diff stores.  One thread per cell; the table (34 MB for 3_10) lives in L2/Infinity Cache,
+// the D*D outputs are written plane-wise (coalesced along x).
+struct TsxLutDev {
+  int ndim;
+  int nvec;
+  int n[8];
+  int axis_off[8];      // offset of each axis in `axes`
+  long long offs[8];    // ndarray_offsets (src/helper_functions.fypp:2431-2437)
+  const float *axes;
+  const float *table;   // (nvec, nentries) column-major == src/mmap.F90 payload
+};
+
+__device__ __forceinline__ float tsx_search_sorted_bisection(const float *__restrict__ arr1, int n, float val) {
+  const float *arr = arr1 - 1;  // 1-based like the reference
+  int i = 1, j = n;
+  // ascending axes only (all LUT presets are ascending)
+  for (;;) {
+    const int k = (i + j) / 2;
+    if (val < arr[k]) j = k;
+    else i = k;
+    if (i + 1 >= j) {
+      float inc = 0.0f;
+      if (i != j) inc = __fdiv_rn(__fsub_rn(val, arr[i]), __fsub_rn(arr[j], arr[i]));
+      float res = __fadd_rn((float)i, inc);
+      res = fmaxf(1.0f, res);
+      res = fminf((float)n, res);
+      return res;
+    }
+  }
+}
+
+template <int NDIM>
+__device__ __forceinline__ void tsx_lut_weights(const TsxLutDev &L, const float (&sample)[NDIM], int &ninterp,
+                                                long long &ofs_base, long long (&ioff_lo)[NDIM], long long (&ioff_hi)[NDIM],
+                                                float (&wlo)[NDIM], float (&whi)[NDIM]) {
+  ninterp = 0;
+  ofs_base = 0;  // 0-based entry offset
+#pragma unroll
+  for (int d = 0; d < NDIM; ++d) {
+    const float pti = tsx_search_sorted_bisection(L.axes + L.axis_off[d], L.n[d], sample[d]);
+    const float frac = __fsub_rn(pti, (float)(int)pti);
+    const bool interp = !(frac < 1e-3f) && !(frac > __fsub_rn(1.0f, 1e-3f));
+    if (interp) {
+      const int b = (int)pti;
+      whi[ninterp] = __fsub_rn(pti, (float)b);
+      wlo[ninterp] = __fsub_rn(1.0f, whi[ninterp]);
+      ioff_lo[ninterp] = L.offs[d] * (b - 1);
+      ioff_hi[ninterp] = L.offs[d] * b;
+      ++ninterp;
+    } else {
+      ofs_base += L.offs[d] * ((long long)lrintf(pti) - 1);  // nint; .5 cannot occur (snapped range only)
+    }
+  }
+}
+
+// diffuse coefficients for every 3-D cell -> planes C[q*Nc + cell] (float).  Inputs in reference layout (k fastest).
+template <int DD>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_diff2diff(TsxGeo g, TsxLutDev L, const double *__restrict__ kabs,
+                                                                 const double *__restrict__ ksca, const double *__restrict__ gg,
+                                                                 const double *__restrict__ dz, double dx,
+                                                                 const uint8_t *__restrict__ l1d, float *__restrict__ C) {
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  const long long Nc = g.Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int i = (int)(c % xm);
+    const long long t = c / xm;
+    const int j = (int)(t % ym);
+    const int k = (int)(t / ym);
+    if (l1d[k]) continue;
+    const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
+    const double ka = kabs[r], ks = ksca[r], dzz = dz[r];
+    // src/pprts_base.F90:1517-1533
+    float aspect = (float)(dzz / dx);
+    float w0 = (float)(ks / fmax(ka + ks, 2.220446049250313e-16));
+    float tauz = (float)((ka + ks) * dzz);
+    const float *ax = L.axes;
+    aspect = fmaxf(ax[L.axis_off[2]], aspect);
+    tauz = fmaxf(ax[L.axis_off[0]], fminf(ax[L.axis_off[0] + L.n[0] - 1], tauz));
+    w0 = fmaxf(ax[L.axis_off[1]], fminf(ax[L.axis_off[1] + L.n[1] - 1], w0));
+    const float sample[4] = {tauz, w0, aspect, (float)gg[r]};
+    int ninterp;
+    long long ofs_base, ioff_lo[4], ioff_hi[4];
+    float wlo[4], whi[4];
+    tsx_lut_weights<4>(L, sample, ninterp, ofs_base, ioff_lo, ioff_hi, wlo, whi);
+    float acc[DD];
+#pragma unroll
+    for (int q = 0; q < DD; ++q) acc[q] = 0.0f;
+    for (int b = 0; b < (1 << ninterp); ++b) {
+      long long ofs = ofs_base;
+      float w = 1.0f;
+      for (int d = 0; d < ninterp; ++d) {
+        if (b & (1 << d)) {
+          ofs += ioff_hi[d];
+          w = __fmul_rn(w, whi[d]);
+        } else {
+          ofs += ioff_lo[d];
+          w = __fmul_rn(w, wlo[d]);
+        }
+      }
+      const float4 *__restrict__ colp = reinterpret_cast<const float4 *>(L.table + (size_t)ofs * DD);
+#pragma unroll
+      for (int q4 = 0; q4 < DD / 4; ++q4) {
+        const float4 v = colp[q4];
+        acc[4 * q4 + 0] = __fadd_rn(acc[4 * q4 + 0], __fmul_rn(w, v.x));
+        acc[4 * q4 + 1] = __fadd_rn(acc[4 * q4 + 1], __fmul_rn(w, v.y));
+        acc[4 * q4 + 2] = __fadd_rn(acc[4 * q4 + 2], __fmul_rn(w, v.z));
+        acc[4 * q4 + 3] = __fadd_rn(acc[4 * q4 + 3], __fmul_rn(w, v.w));
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < DD; ++q) C[(size_t)q * Nc + c] = acc[q];
+  }
+}
+
+// planes -> reference block layout (c fastest, then k, i, j), as real64: what solver%diff2diff holds
+template <typename CT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_export_coeff(TsxGeo g, int DD, const CT *__restrict__ C,
+                                                                double *__restrict__ ref) {
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  const long long total = g.Nc * DD;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < total; q += (long long)gridDim.x * TSX_BLOCK) {
+    const long long c = q % g.Nc;
+    const int cc = (int)(q / g.Nc);
+    const int i = (int)(c % xm);
+    const long long t = c / xm;
+    const int j = (int)(t % ym);
+    const int k = (int)(t / ym);
+    ref[(size_t)cc + (size_t)DD * ((size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j))] = (double)C[q];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Operator values: reference block layout (c = dst*D+src fastest, then k, i, j) -> one plane per c,
 // x fastest.  LDS-tiled transpose so both sides coalesce.
 template <typename TIN, typename TOUT>

@@ -11,6 +11,7 @@ place) in the reference's layouts with reversed (C-order) axes:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -162,6 +163,51 @@ class DiffuseSolver:
         if len(ws) != 1:
             raise TypeError("all arrays of one call must live on the same side (host or device)")
         _lib.check(self.lib.tsx_diff_set_coeffs(self.h, cp, kind, lp, p11, p12, ap, where))
+
+    def set_lut_diffuse(self, table, axes):
+        """Upload a diffuse LUT: table (nentries, D*D) float32 (tau fastest), axes = [tau, w0, aspect_zx, g]."""
+        t = table if _is_torch(table) else np.ascontiguousarray(table, dtype=np.float32)
+        tp, where = _ptr(t, np.float32)
+        n = (C.c_int32 * len(axes))(*[len(a) for a in axes])
+        ax = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float32) for a in axes]))
+        if where == TSX_DEVICE:
+            import torch
+
+            ax_dev = torch.from_numpy(ax).to(table.device)
+            axp = C.c_void_p(ax_dev.data_ptr())
+        else:
+            axp = C.c_void_p(ax.ctypes.data)
+        _lib.check(self.lib.tsx_lut_set_diffuse(self.h, tp, int(t.shape[1]), int(t.shape[0]), len(axes), n, axp, where))
+
+    def load_lut_diffuse_mmap4(self, path):
+        _lib.check(self.lib.tsx_lut_load_diffuse_mmap4(self.h, os.fsencode(path)))
+
+    def set_optprop(self, kabs, ksca, g, dz, dx, l1d, a11, a12, albedo):
+        """Replaces alloc_coeff_diff2diff + set_diff_coeff (src/pprts.F90:3396-3490, 5511-5796): coefficient
+        planes are interpolated from the LUT on the device.  Fields are (ym, xm, Nz) float64 (delta-scaled)."""
+        shp = (self.ym, self.xm, self.Nz)
+        for a in (kabs, ksca, g, dz):
+            if tuple(a.shape) != shp:
+                raise ValueError(f"optical property shape {tuple(a.shape)} != {shp}")
+        ptrs, wheres = [], set()
+        for a, dt in ((kabs, np.float64), (ksca, np.float64), (g, np.float64), (dz, np.float64), (l1d, np.uint8),
+                      (a11, np.float64), (a12, np.float64), (albedo, np.float64)):
+            p, w = _ptr(a, dt)
+            ptrs.append(p)
+            if w is not None:
+                wheres.add(w)
+        if len(wheres) != 1:
+            raise TypeError("all arrays of one call must live on the same side (host or device)")
+        _lib.check(self.lib.tsx_diff_set_optprop(self.h, ptrs[0], ptrs[1], ptrs[2], ptrs[3], float(dx), ptrs[4], ptrs[5],
+                                                 ptrs[6], ptrs[7], wheres.pop()))
+
+    def get_coeffs(self, out=None):
+        """The coefficient blocks in the reference layout, float64 (what solver%diff2diff holds)."""
+        if out is None:
+            out = np.empty(self.coeff_shape, dtype=np.float64)
+        p, where = _ptr(out, np.float64)
+        _lib.check(self.lib.tsx_diff_get_coeffs(self.h, p, where))
+        return out
 
     def apply(self, x, out=None):
         """y = (I - T) x  (op_mat_mult_ediff, src/pprts_shell.F90:366-541)."""

@@ -198,3 +198,46 @@ def test_fortran_shim_driver(gpu):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "shim ok" in r.stdout
+
+
+@pytest.mark.parametrize("solver,Nx,Ny,Nz", [("3_10", 21, 9, 12), ("8_16", 8, 5, 6)])
+def test_device_lut_lookup_bit_exact(gpu, solver, Nx, Ny, Nz, tmp_path):
+    """K4 on the device (clamp -> bisection -> N-linear interpolation with snapping) is bit-identical to the oracle's
+    restatement of get_coeff/LUT_get_diff2diff, both through tsx_lut_set_diffuse and through a `.mmap4` file."""
+    from tenstream_amd import lut
+
+    axes = lut.diffuse_axes(solver)
+    table = lut.synthetic_diffuse_table(solver)
+    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=3)
+    rng = np.random.default_rng(4)
+    ksca *= rng.uniform(0.2, 30.0, ksca.shape)  # spread over many table cells, some beyond the tau range
+    kabs[0, 0, :] = 0.0
+    ksca[0, 0, :] = 0.0                          # tau == 0 -> clamped to the first node
+    kabs, ksca, g = synthetic.delta_scale(kabs, ksca, g)
+    dz = rng.uniform(20.0, 400.0, kabs.shape)
+    l1d = np.zeros(Nz, dtype=np.uint8)
+    l1d[:2] = 1
+    a11 = np.full(kabs.shape, 0.5)
+    a12 = np.full(kabs.shape, 0.2)
+    alb = np.full((Ny, Nx), 0.1)
+    L = O.make_lut(axes, table)
+    ref = O.alloc_coeff_diff2diff(L, kabs, ksca, g, dz, 100.0, l1d)
+
+    s = DiffuseSolver(solver, Nz, Nx, Ny)
+    s.set_lut_diffuse(table, axes)
+    s.set_optprop(kabs, ksca, g, dz, 100.0, l1d, a11, a12, alb)
+    got = s.get_coeffs()
+    assert np.array_equal(got[:, :, 2:], ref[:, :, 2:])  # bit-exact (1-D layers hold no blocks)
+
+    if solver == "3_10":
+        p = tmp_path / lut.diffuse_lut_filename("LUT", solver)
+        lut.write_mmap4(p, table)
+        s2 = DiffuseSolver(solver, Nz, Nx, Ny)
+        s2.load_lut_diffuse_mmap4(str(p))
+        s2.set_optprop(kabs, ksca, g, dz, 100.0, l1d, a11, a12, alb)
+        assert np.array_equal(s2.get_coeffs()[:, :, 2:], ref[:, :, 2:])
+        # and the operator built from looked-up blocks equals the oracle operator on the oracle's blocks
+        lay = O.layout(solver, Nz, Nx, Ny)
+        x = rng.standard_normal(s2.vec_shape)
+        y_ref = O.diff_apply(lay, ref, l1d, a11, a12, alb, x)
+        assert np.abs(s2.apply(x) - y_ref).max() <= 1e-13 * np.abs(y_ref).max()

@@ -1,0 +1,54 @@
+"""CPU tests of the LUT plumbing: `.mmap4` container round trip (tests/test_mmap in the reference) and the oracle's
+coefficient lookup on the synthetic table."""
+import numpy as np
+
+from oracle import oracle as O
+from tenstream_amd import lut, synthetic
+
+
+def test_mmap4_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    t = rng.random((37, 100), dtype=np.float32)
+    p = tmp_path / lut.diffuse_lut_filename("LUT")
+    lut.write_mmap4(p, t)
+    assert p.name == "LUT_diffuse_10.tau31.w020.aspect_zx23.g6.ds1000.nc.Sdiff.mmap4"
+    hdr = np.fromfile(p, dtype=np.uint64, count=6)
+    assert list(hdr) == [4, 3700, 14800, 100, 37, 0]
+    assert p.stat().st_size == lut.PAGESIZE + 14800
+    back = lut.read_mmap4(p)
+    assert back.shape == (37, 100) and np.array_equal(back, t)
+
+
+def test_oracle_lookup_on_nodes_and_between():
+    axes = lut.diffuse_axes("3_10")
+    table = lut.synthetic_diffuse_table("3_10")
+    assert table.shape == (31 * 20 * 23 * 6, 100)
+    L = O.make_lut(axes, table)
+    tau, w0, asp, g = axes
+    dz, dx = 50.0, 100.0
+    kext = float(tau[20]) / dz
+    ksca = kext * float(w0[5])
+    c = O.get_coeff_diff2diff(L, kext - ksca, ksca, float(g[2]), dz, dx)
+    ia = 10  # aspect 0.5 lies between the nodes 0.422 and 0.562
+    lo = table[20 + 31 * (5 + 20 * (ia + 23 * 2))]
+    hi = table[20 + 31 * (5 + 20 * (ia + 1 + 23 * 2))]
+    wgt = (np.float32(0.5) - asp[ia]) / (asp[ia + 1] - asp[ia])
+    # tau/w0 computed in double then cast may sit 1 ulp off the node: still inside the 1e-3 snapping band
+    np.testing.assert_allclose(c, (1 - wgt) * lo + wgt * hi, rtol=2e-6)
+    C = c.reshape(10, 10)  # [dst, src]
+    assert np.all(C.sum(axis=0) <= 1 + 1e-6)  # energy conservation survives interpolation
+    # clamping: tau beyond the table -> last node
+    c2 = O.get_coeff_diff2diff(L, 0.0, 1e3, 0.0, dz, dx)
+    np.testing.assert_array_equal(c2, O.get_coeff_diff2diff(L, 0.0, 1e5, 0.0, dz, dx))
+
+
+def test_alloc_coeff_field_skips_1d_layers():
+    axes = lut.diffuse_axes("3_10")
+    L = O.make_lut(axes, lut.synthetic_diffuse_table("3_10"))
+    kabs, ksca, g = synthetic.cloud_field(5, 4, 6)
+    kabs, ksca, g = synthetic.delta_scale(kabs, ksca, g)
+    dz = np.full_like(kabs, 50.0)
+    l1d = np.array([1, 0, 0, 0, 0, 1], dtype=np.uint8)
+    c = O.alloc_coeff_diff2diff(L, kabs, ksca, g, dz, 100.0, l1d)
+    assert np.all(c[:, :, 0] == 0) and np.all(c[:, :, 5] == 0) and np.all(c[:, :, 1:5].sum(axis=-1) > 0)
+    assert np.array_equal(c.astype(np.float32).astype(np.float64), c)  # real(v, ireals): fp32-exact
