@@ -853,16 +853,22 @@ static int enqueue_iteration(tsx_solver *s, bool first) {
 }
 
 template <int NTOP, int NSIDE>
-static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o) {
+static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o, bool restart = false) {
   const TsxGeo &g = s->geo;
   int rc;
-  TsxScalars init;
-  memset(&init, 0, sizeof(init));
-  init.rtol = o->rtol;
-  init.atol = o->atol;
-  init.dtol = o->dtol;
-  init.maxit = o->maxit;
-  *s->scal_host = init;
+  if (!restart) {
+    TsxScalars init;
+    memset(&init, 0, sizeof(init));
+    init.rtol = o->rtol;
+    init.atol = o->atol;
+    init.dtol = o->dtol;
+    init.maxit = o->maxit;
+    *s->scal_host = init;
+  } else {  // breakdown restart: keep iteration count, history and the initial norm; new shadow residual
+    s->scal_host->done = 0;
+    s->scal_host->reason = 0;
+    s->scal_host->restart = 1;
+  }
   HIPCHK(hipMemcpyAsync(s->scal, s->scal_host, sizeof(TsxScalars), hipMemcpyHostToDevice, s->stream));
   // r = b - A x0 (nonzero initial guess, src/pprts.F90:4343); rhat = p = r
   if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, s->vx, s->vt, nullptr, false))) return rc;
@@ -900,15 +906,26 @@ static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, co
   HIPCHK(hipEventRecord(s->ev0, s->stream));
   if ((rc = krylov_begin<NTOP, NSIDE>(s, o))) return rc;
   const int chunk = o->check_every > 0 ? o->check_every : 4;
-  int enq = 0;
-  bool done = false;
+  int enq = 0, nrestart = 0;
+  bool done = false, first_after_begin = true;
   while (!done) {
     const int todo = (o->maxit - enq) < chunk ? (o->maxit - enq) : chunk;
-    for (int q = 0; q < todo; ++q, ++enq)
-      if ((rc = enqueue_iteration<NTOP, NSIDE>(s, enq == 0))) return rc;
+    for (int q = 0; q < todo; ++q, ++enq) {
+      if ((rc = enqueue_iteration<NTOP, NSIDE>(s, first_after_begin))) return rc;
+      first_after_begin = false;
+    }
     HIPCHK(hipMemcpyAsync(s->scal_host, s->scal, sizeof(TsxScalars), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     done = s->scal_host->done != 0 || enq >= o->maxit;
+    if (s->scal_host->done && s->scal_host->reason == -5 && nrestart < 3 && s->scal_host->its < o->maxit) {
+      // rho / (rhat,v) breakdown: restart from the current iterate with rhat = r (x keeps its progress).  The
+      // reference falls back to GMRES from a zero guess here (src/pprts.F90:4277-4296).
+      ++nrestart;
+      enq = s->scal_host->its;
+      if ((rc = krylov_begin<NTOP, NSIDE>(s, o, true))) return rc;
+      first_after_begin = true;
+      done = false;
+    }
   }
   HIPCHK(hipEventRecord(s->ev1, s->stream));
   if ((rc = export_vec<NTOP, NSIDE>(s, s->vx, xd))) return rc;

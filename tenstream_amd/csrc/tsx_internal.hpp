@@ -43,6 +43,7 @@ struct TsxScalars {
   int reason;
   int done;
   int nhist;
+  int restart;   // set by the host before a breakdown restart: INIT keeps its / history / rnorm0
   double hist[100];
 };
 

@@ -737,11 +737,13 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
   switch (stage) {
     case TSX_STAGE_INIT: {
       const double rn = sqrt(sc->red[0]);
-      sc->rnorm0 = rn > tiny ? rn : tiny;  // n == 0: store initial norm, no test (:4455-4458)
       sc->rnorm = rn;
-      sc->hist[0] = rn;
-      sc->nhist = 1;
-      sc->its = 0;
+      if (!sc->restart) {
+        sc->rnorm0 = rn > tiny ? rn : tiny;  // n == 0: store initial norm, no test (:4455-4458)
+        sc->hist[0] = rn;
+        sc->nhist = 1;
+        sc->its = 0;
+      }
       sc->rho = sc->red[0];
       sc->rho_old = 1.0;
       sc->alpha = 1.0;
@@ -753,6 +755,9 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
         sc->done = 1;
       } else if (rn != rn) {
         sc->reason = -9;
+        sc->done = 1;
+      } else if (sc->restart && (rn / sc->rnorm0 <= sc->rtol || rn <= sc->atol)) {
+        sc->reason = rn / sc->rnorm0 <= sc->rtol ? 2 : 3;
         sc->done = 1;
       }
     } break;

@@ -241,3 +241,22 @@ def test_device_lut_lookup_bit_exact(gpu, solver, Nx, Ny, Nz, tmp_path):
         x = rng.standard_normal(s2.vec_shape)
         y_ref = O.diff_apply(lay, ref, l1d, a11, a12, alb, x)
         assert np.abs(s2.apply(x) - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+
+
+def test_breakdown_restart(gpu):
+    """A right-hand side supported only on the TOA identity rows makes rho = (rhat, r) vanish after one step
+    (rhat = r0 sees nothing of the interior): a true BiCGStab breakdown.  The reference retries with GMRES
+    (src/pprts.F90:4277-4296); here the solve restarts from the current iterate with a fresh shadow residual."""
+    P = synthetic.make_problem("3_10", Nx=6, Ny=5, Nz=8)
+    s = DiffuseSolver("3_10", 8, 6, 5)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    b = np.zeros(s.vec_shape)
+    b[:, :, 0, 1] = 1.0
+    lay = O.layout("3_10", 8, 6, 5)
+    x_ref, _ = O.solve_ilu(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"], b, rtol=1e-13,
+                           atol=1e-30)
+    for pc in (0, 1):
+        x = np.zeros(s.vec_shape)
+        info = s.solve(b, x, rtol=1e-10, atol=1e-30, pc=pc)
+        assert info.reason == 2, (pc, info)
+        assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
