@@ -167,6 +167,39 @@ int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int where);
 int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int where, const tsx_ksp_opts *opts,
                    tsx_ksp_result *res);
 
+/* ======================= whole g-point on the device ===============================
+ * The pieces of `pprts()` around the diffuse solve (src/pprts.F90:2668-2820) and of restore_solution /
+ * pprts_get_result, so that only optical properties go in and four small flux arrays come out:
+ *   alloc_coeff_dir2dir/dir2diff (:3088-3391) -> tsx_lut_set_direct + lookup inside tsx_pprts_solve
+ *   explicit_edir (src/pprts_explicit.F90:60-459)   -> column-marching sweeps iterated to the same stop rule
+ *   setup_b (:4641-4987)                            -> written directly in dst-owned storage
+ *   calc_flx_div (:5152-5504), scale_flx (:3682-3988), pprts_get_result (:5799-5888) -> tsx_pprts_get_result
+ * Round 1: one rank (periodic wrap in-kernel), solver 3_10; nranks > 1 returns TSX_ERR_UNSUPPORTED here (the
+ * diffuse seam above is multi-rank). */
+/* set_angles (src/pprts.F90:1100-1183): sun azimuth phi0 / zenith theta0 in degrees as pprts_f2c_init takes them */
+int tsx_pprts_set_angles(tsx_solver *s, double phi0, double theta0);
+/* direct tables Tdir (S*S per entry) and Sdir (S*D per entry), 6 axes [tau, w0, aspect_zx, g, phi, theta]
+ * (src/optprop_base.F90:228-240); same payload layout as the diffuse table */
+int tsx_lut_set_direct(tsx_solver *s, const float *Tdir, const float *Sdir, int64_t nentries, int32_t ndim,
+                       const int32_t *n, const float *axes_concat, int where);
+/* optical properties of one g-point, (zs:ze-1, xs:xe, ys:ye) real64, already delta-scaled; a11..a33 only read for
+ * 1-D layers (eddington coefficients, src/pprts.F90:1962-1992); planck (zs:ze, xs:xe, ys:ye) or NULL for solar */
+int tsx_pprts_set_optprop(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz,
+                          double dx, double dy, const double *albedo, const uint8_t *l1d, const double *a11,
+                          const double *a12, const double *a13, const double *a23, const double *a33,
+                          const double *planck, int where);
+/* solve_pprts/pprts() for one g-point: lsolar = edirTOA > 0 semantics are the caller's (pprts_f2c_solve,
+ * c_wrapper/f2c_pprts.F90:340-341).  The previous solution of this handle is the initial guess
+ * (src/pprts.F90:2542-2558) unless tsx_pprts_zero_guess was called. */
+int tsx_pprts_solve(tsx_solver *s, double edirTOA, int lsolar, const tsx_ksp_opts *opts, tsx_ksp_result *res);
+int tsx_pprts_zero_guess(tsx_solver *s);
+/* restore_solution + pprts_get_result: edn, eup, edir (zs:ze, xs:xe, ys:ye), abso (zs:ze-1, xs:xe, ys:ye), W/m2 and
+ * W/m3, solar results multiplied by sun%mu (src/pprts.F90:5883-5888).  edir may be NULL. */
+int tsx_pprts_get_result(tsx_solver *s, double *edn, double *eup, double *abso, double *edir, int where);
+/* parity probes: which = 0 edir [W] (0:S-1, zs:ze, xs:xe, ys:ye); 1 b [W]; 2 ediff [W] (0:D-1, zs:ze, ...);
+ * 3 dir2dir (S*S, zs:ze-1, ...); 4 dir2diff (S*D, ...) -- reference layouts, real64 */
+int tsx_pprts_get_field(tsx_solver *s, int which, double *out, int where);
+
 /* ---- z = M^-1 v with the preconditioner the solve uses (exposed for parity tests: M is the column-block
  *      diagonal of the assembled matrix in the dst-owned numbering) */
 int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps);

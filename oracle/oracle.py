@@ -64,7 +64,8 @@ class Csr(C.Structure):
 def build(force: bool = False) -> str:
     """Compile oracle/liboracle.so with gcc (building the checker is not using it)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("pprts_oracle.c", "pprts_oracle_phys.c", "pprts_oracle.h", "pprts_oracle_phys.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("pprts_oracle.c", "pprts_oracle_phys.c", "pprts_oracle_pipe.c",
+                                             "pprts_oracle.h", "pprts_oracle_phys.h")]
     srcs = [s for s in srcs if os.path.exists(s)]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
@@ -289,3 +290,108 @@ def B_eff(B_far, B_near, tau):
     f = lib().orc_B_eff
     f.restype = C.c_double
     return f(C.c_double(B_far), C.c_double(B_near), C.c_double(tau))
+
+
+# ---- direct beam / source / post-processing (pprts_oracle_pipe.c) --------------------------------------------
+class DirLayout(C.Structure):
+    _fields_ = [("dtop", C.c_int), ("dside", C.c_int), ("top_div", C.c_int), ("side_div", C.c_int)]
+
+
+class SunInfo(C.Structure):
+    _fields_ = [("phi", C.c_double), ("theta", C.c_double), ("mu", C.c_double), ("costheta", C.c_double),
+                ("symmetry_phi", C.c_double), ("xinc", C.c_int), ("yinc", C.c_int)]
+
+
+def dir_layout_3_10():
+    d = DirLayout()
+    lib().orc_dir_layout_3_10(C.byref(d))
+    return d
+
+
+def suninfo(phi, theta):
+    s = SunInfo()
+    lib().orc_setup_suninfo(C.c_double(phi), C.c_double(theta), C.byref(s))
+    return s
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def alloc_coeff_dir(lut_, is_dir2dir, kabs, ksca, g, dz, dx, sun, l1d, S=3, D=10):
+    kabs, ksca, g, dz = (_c64(a) for a in (kabs, ksca, g, dz))
+    ym, xm, Nz = kabs.shape
+    l1d = np.ascontiguousarray(l1d, dtype=np.uint8)
+    out = np.zeros((ym, xm, Nz, lut_.nvec))
+    lib().orc_alloc_coeff_dir(C.byref(lut_), int(is_dir2dir), S, D, Nz, xm, ym, _p(kabs), _p(ksca), _p(g), _p(dz),
+                              C.c_double(dx), C.byref(sun), _p(l1d, C.c_uint8), _p(out))
+    return out
+
+
+def explicit_edir(lay, dlay, sun, dir2dir, l1d, a33, edirTOA, dx, dy, rtol=1e-5, atol=1e-8, maxit=1002, edir0=None):
+    S = dlay.dtop + 2 * dlay.dside
+    dir2dir, a33 = _c64(dir2dir), _c64(a33)
+    l1d = np.ascontiguousarray(l1d, dtype=np.uint8)
+    edir = np.zeros((lay.ym, lay.xm, lay.Nz + 1, S)) if edir0 is None else np.array(edir0, dtype=np.float64, order="C")
+    nit = C.c_int()
+    f = lib().orc_explicit_edir_1rank
+    f.restype = C.c_int
+    rc = f(C.byref(lay), C.byref(dlay), C.byref(sun), _p(dir2dir), _p(l1d, C.c_uint8), _p(a33), C.c_double(edirTOA),
+           C.c_double(dx), C.c_double(dy), C.c_double(rtol), C.c_double(atol), maxit, _p(edir), C.byref(nit))
+    return edir, dict(converged=rc == 0, niter=nit.value)
+
+
+def setup_b_solar(lay, dlay, sun, dir2diff, l1d, a13, a23, albedo, edir):
+    dir2diff, a13, a23, albedo, edir = (_c64(a) for a in (dir2diff, a13, a23, albedo, edir))
+    l1d = np.ascontiguousarray(l1d, dtype=np.uint8)
+    b = np.zeros((lay.ym, lay.xm, lay.Nz + 1, lay.D))
+    lib().orc_setup_b_solar_1rank(C.byref(lay), C.byref(dlay), C.byref(sun), _p(dir2diff), _p(l1d, C.c_uint8), _p(a13),
+                                  _p(a23), _p(albedo), _p(edir), _p(b))
+    return b
+
+
+def setup_b_thermal(lay, diff2diff, l1d, a11, a12, albedo, planck, kabs, dz, dx, dy):
+    diff2diff, a11, a12, albedo, planck, kabs, dz = (_c64(a) for a in (diff2diff, a11, a12, albedo, planck, kabs, dz))
+    l1d = np.ascontiguousarray(l1d, dtype=np.uint8)
+    b = np.zeros((lay.ym, lay.xm, lay.Nz + 1, lay.D))
+    lib().orc_setup_b_thermal_1rank(C.byref(lay), _p(diff2diff), _p(l1d, C.c_uint8), _p(a11), _p(a12), _p(albedo),
+                                    _p(planck), _p(kabs), _p(dz), C.c_double(dx), C.c_double(dy), _p(b))
+    return b
+
+
+def scale_diff(lay, dz, dx, dy, to_Wm2, ediff):
+    e = np.array(ediff, dtype=np.float64, order="C")
+    lib().orc_scale_diff(C.byref(lay), _p(_c64(dz)), C.c_double(dx), C.c_double(dy), int(to_Wm2), _p(e))
+    return e
+
+
+def scale_dir(lay, dlay, dz, dx, dy, to_Wm2, edir):
+    e = np.array(edir, dtype=np.float64, order="C")
+    lib().orc_scale_dir(C.byref(lay), C.byref(dlay), _p(_c64(dz)), C.c_double(dx), C.c_double(dy), int(to_Wm2), _p(e))
+    return e
+
+
+def calc_flx_div(lay, dlay, sun, dir2dir, dir2diff, diff2diff, l1d, a11, a12, kabs, dz, dx, dy, edir, ediff, b_thermal=None):
+    l1d = np.ascontiguousarray(l1d, dtype=np.uint8)
+    abso = np.zeros((lay.ym, lay.xm, lay.Nz))
+    none = C.POINTER(C.c_double)()
+    keep = [_c64(a) if a is not None else None for a in (dir2dir, dir2diff, diff2diff, a11, a12, kabs, dz, edir, ediff, b_thermal)]
+    ptr = [(_p(a) if a is not None else none) for a in keep]
+    lib().orc_calc_flx_div_1rank(C.byref(lay), C.byref(dlay) if dlay is not None else None,
+                                 C.byref(sun) if sun is not None else None, ptr[0], ptr[1], ptr[2], _p(l1d, C.c_uint8),
+                                 ptr[3], ptr[4], ptr[5], ptr[6], C.c_double(dx), C.c_double(dy), ptr[7], ptr[8], ptr[9],
+                                 _p(abso))
+    return abso
+
+
+def get_result(lay, dlay, sun, lsolar, edir, ediff, abso):
+    L = lay.Nz + 1
+    redir = np.zeros((lay.ym, lay.xm, L))
+    redn = np.zeros_like(redir)
+    reup = np.zeros_like(redir)
+    rabso = np.zeros((lay.ym, lay.xm, lay.Nz))
+    none = C.POINTER(C.c_double)()
+    ed = _c64(edir) if edir is not None else None
+    lib().orc_get_result(C.byref(lay), C.byref(dlay), C.byref(sun), int(lsolar), _p(ed) if ed is not None else none,
+                         _p(_c64(ediff)), _p(_c64(abso)), _p(redir), _p(redn), _p(reup), _p(rabso))
+    return redn, reup, rabso, redir

@@ -58,3 +58,68 @@ double orc_B_eff(double B_far, double B_near, double tau);
 }
 #endif
 #endif
+
+/* ============================ direct beam, source term, post-processing ============================== */
+#ifndef PPRTS_ORACLE_PIPE_H
+#define PPRTS_ORACLE_PIPE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int dtop, dside;          /* dirtop%dof, dirside%dof           src/pprts.F90:344-348 (3_10: 1,1), :420-423 (8_16: 4,2) */
+  int top_div, side_div;    /* dirtop/dirside%area_divider */
+} orc_dir_layout;
+void orc_dir_layout_3_10(orc_dir_layout *d);
+
+/* setup_suninfo: src/pprts.F90:1118-1183 (angles in degrees) */
+typedef struct {
+  double phi, theta, mu, costheta, symmetry_phi;
+  int xinc, yinc;
+} orc_suninfo;
+void orc_setup_suninfo(double phi, double theta, orc_suninfo *sun);
+
+/* get_coeff, direct branch (src/pprts_base.F90:1517-1542 -> src/optprop.F90:568-582 -> LUT_get_dir2dir /
+ * LUT_get_dir2diff src/optprop_LUT.F90), sample order [tauz, w0, aspect, g, phi, theta]; for 3_10 dir2dir has no
+ * symmetry swap, dir2diff uses dir3_to_diff10_coeff_symmetry (src/optprop.F90:1009-1045). */
+void orc_get_coeff_dir(const orc_lut *lut, int is_dir2dir, int S, int D, double kabs, double ksca, double g, double dz,
+                       double dx, double sym_phi, double theta, int lswitch_east, int lswitch_north, float *out);
+void orc_alloc_coeff_dir(const orc_lut *lut, int is_dir2dir, int S, int D, int Nz, int xm, int ym, const double *kabs,
+                         const double *ksca, const double *g, const double *dz, double dx, const orc_suninfo *sun,
+                         const uint8_t *l1d, double *coeffs);
+
+/* setup_incSolar + explicit_edir (+ forward sweep, exchange_direct_boundary with self neighbours):
+ * src/pprts_base.F90:1146-1181, src/pprts_explicit.F90:60-459.  edir in/out (S, L, xm, ym) [W]. */
+int orc_explicit_edir_1rank(const orc_layout *l, const orc_dir_layout *d, const orc_suninfo *sun, const double *dir2dir,
+                            const uint8_t *l1d, const double *a33, double edirTOA, double dx, double dy, double rtol,
+                            double atol, int maxit, double *edir, int *niter);
+
+/* setup_b: src/pprts.F90:4641-4987 (solar: edir given in W; thermal: planck (L, xm, ym) at levels) */
+void orc_setup_b_solar_1rank(const orc_layout *l, const orc_dir_layout *d, const orc_suninfo *sun, const double *dir2diff,
+                             const uint8_t *l1d, const double *a13, const double *a23, const double *albedo,
+                             const double *edir, double *b);
+void orc_setup_b_thermal_1rank(const orc_layout *l, const double *diff2diff, const uint8_t *l1d, const double *a11,
+                               const double *a12, const double *albedo, const double *planck, const double *kabs,
+                               const double *dz, double dx, double dy, double *b);
+
+/* gen_scale_*_flx_vec_arr: src/pprts.F90:3901-3987.  to_Wm2 = 1: W -> W/m2 */
+void orc_scale_diff(const orc_layout *l, const double *dz, double dx, double dy, int to_Wm2, double *ediff);
+void orc_scale_dir(const orc_layout *l, const orc_dir_layout *d, const double *dz, double dx, double dy, int to_Wm2,
+                   double *edir);
+
+/* calc_flx_div, default by_coeff_divergence branch: src/pprts.F90:5286-5398, 5477, 5483-5503.  fluxes in W;
+ * abso out (Nz, xm, ym) in W/m3.  b_thermal may be NULL (solar) */
+void orc_calc_flx_div_1rank(const orc_layout *l, const orc_dir_layout *d, const orc_suninfo *sun, const double *dir2dir,
+                            const double *dir2diff, const double *diff2diff, const uint8_t *l1d, const double *a11,
+                            const double *a12, const double *kabs, const double *dz, double dx, double dy,
+                            const double *edir /* NULL if thermal */, const double *ediff, const double *b_thermal,
+                            double *abso);
+
+/* pprts_get_result: src/pprts.F90:5871-5888 (inputs in W/m2) */
+void orc_get_result(const orc_layout *l, const orc_dir_layout *d, const orc_suninfo *sun, int lsolar, const double *edir,
+                    const double *ediff, const double *abso, double *redir, double *redn, double *reup, double *rabso);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

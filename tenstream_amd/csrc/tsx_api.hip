@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "tsx_kernels.hpp"
+#include "tsx_pipeline.hpp"
 
 #ifndef TSX_DEFAULT_CPT
 #define TSX_DEFAULT_CPT 2
@@ -250,12 +251,15 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
-                  s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table};
+                  s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
+                  s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
+                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->edir_a, s->edir_b, s->dsc, s->abso};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->vph && s->vph != s->vp) (void)hipFree(s->vph);
   if (s->vsh && s->vsh != s->vs) (void)hipFree(s->vsh);
   if (s->scal_host) (void)hipHostFree(s->scal_host);
+  if (s->dsc_host) (void)hipHostFree(s->dsc_host);
   for (int q = 0; q < 4; ++q) {
     if (s->host_send[q]) (void)hipHostFree(s->host_send[q]);
     if (s->host_recv[q]) (void)hipHostFree(s->host_recv[q]);
@@ -879,30 +883,11 @@ static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o, bool restart = fal
   return TSX_OK;
 }
 
+// The Krylov loop on the internal vectors s->vb (rhs) and s->vx (initial guess in, solution out).
+// Records ev0/ev1 around it; leaves the final scalars in s->scal_host.
 template <int NTOP, int NSIDE>
-static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, const tsx_ksp_opts *o,
-                        tsx_ksp_result *res) {
-  const TsxGeo &g = s->geo;
-  const size_t nb = (size_t)g.N * sizeof(double);
+static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
   int rc;
-  const double *bd = b;
-  double *xd = x;
-  hipEvent_t e_imp0, e_imp1, e_exp1;
-  HIPCHK(hipEventCreate(&e_imp0));
-  HIPCHK(hipEventCreate(&e_imp1));
-  HIPCHK(hipEventCreate(&e_exp1));
-  if (where == TSX_HOST) {
-    if ((rc = ensure_stage(s))) return rc;
-    HIPCHK(hipMemcpyAsync(s->stage_a, b, nb, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->stage_b, x, nb, hipMemcpyHostToDevice, s->stream));
-    bd = s->stage_a;
-    xd = s->stage_b;
-  }
-  HIPCHK(hipEventRecord(e_imp0, s->stream));
-  if ((rc = import_vec<NTOP, NSIDE>(s, bd, s->vb))) return rc;
-  if ((rc = import_vec<NTOP, NSIDE>(s, xd, s->vx))) return rc;
-  HIPCHK(hipEventRecord(e_imp1, s->stream));
-
   HIPCHK(hipEventRecord(s->ev0, s->stream));
   if ((rc = krylov_begin<NTOP, NSIDE>(s, o))) return rc;
   const int chunk = o->check_every > 0 ? o->check_every : 4;
@@ -928,27 +913,78 @@ static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, co
     }
   }
   HIPCHK(hipEventRecord(s->ev1, s->stream));
+  return TSX_OK;
+}
+
+static int fill_result(tsx_solver *s, tsx_ksp_result *res) {
+  if (!res) return TSX_OK;
+  const TsxScalars &h = *s->scal_host;
+  memset(res, 0, sizeof(*res));
+  res->reason = h.done ? h.reason : -3;  // KSP_DIVERGED_ITS
+  res->niter = h.its;
+  res->rnorm0 = h.rnorm0;
+  res->rnorm = h.rnorm;
+  res->nhist = h.nhist;
+  memcpy(res->res_hist, h.hist, sizeof(double) * 100);
+  HIPCHK(hipEventElapsedTime(&res->solve_ms, s->ev0, s->ev1));
+  return TSX_OK;
+}
+
+template <int NTOP, int NSIDE>
+static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, const tsx_ksp_opts *o,
+                        tsx_ksp_result *res) {
+  const TsxGeo &g = s->geo;
+  const size_t nb = (size_t)g.N * sizeof(double);
+  int rc;
+  const double *bd = b;
+  double *xd = x;
+  hipEvent_t e_imp0, e_imp1, e_exp1;
+  HIPCHK(hipEventCreate(&e_imp0));
+  HIPCHK(hipEventCreate(&e_imp1));
+  HIPCHK(hipEventCreate(&e_exp1));
+  if (where == TSX_HOST) {
+    if ((rc = ensure_stage(s))) return rc;
+    HIPCHK(hipMemcpyAsync(s->stage_a, b, nb, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->stage_b, x, nb, hipMemcpyHostToDevice, s->stream));
+    bd = s->stage_a;
+    xd = s->stage_b;
+  }
+  HIPCHK(hipEventRecord(e_imp0, s->stream));
+  if ((rc = import_vec<NTOP, NSIDE>(s, bd, s->vb))) return rc;
+  if ((rc = import_vec<NTOP, NSIDE>(s, xd, s->vx))) return rc;
+  HIPCHK(hipEventRecord(e_imp1, s->stream));
+
+  if ((rc = krylov_run<NTOP, NSIDE>(s, o))) return rc;
+  HIPCHK(hipEventRecord(s->ev1, s->stream));
   if ((rc = export_vec<NTOP, NSIDE>(s, s->vx, xd))) return rc;
   HIPCHK(hipEventRecord(e_exp1, s->stream));
   if (where == TSX_HOST) HIPCHK(hipMemcpyAsync(x, s->stage_b, nb, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
 
   if (res) {
-    const TsxScalars &h = *s->scal_host;
-    memset(res, 0, sizeof(*res));
-    res->reason = h.done ? h.reason : -3;  // KSP_DIVERGED_ITS
-    res->niter = h.its;
-    res->rnorm0 = h.rnorm0;
-    res->rnorm = h.rnorm;
-    res->nhist = h.nhist;
-    memcpy(res->res_hist, h.hist, sizeof(double) * 100);
-    HIPCHK(hipEventElapsedTime(&res->solve_ms, s->ev0, s->ev1));
+    if ((rc = fill_result(s, res))) return rc;
     HIPCHK(hipEventElapsedTime(&res->import_ms, e_imp0, e_imp1));
     HIPCHK(hipEventElapsedTime(&res->export_ms, s->ev1, e_exp1));
   }
   (void)hipEventDestroy(e_imp0);
   (void)hipEventDestroy(e_imp1);
   (void)hipEventDestroy(e_exp1);
+  return TSX_OK;
+}
+
+static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o) {
+  if (opts) *o = *opts;
+  else tsx_default_ksp_opts(o);
+  ARGCHK(o->maxit >= 1, "solve: maxit < 1");
+  ARGCHK(o->pc == TSX_PC_NONE || o->pc == TSX_PC_COLUMN, "solve: unsupported preconditioner");
+  ARGCHK(o->pc_sweeps >= 1 && o->pc_sweeps <= 8, "solve: pc_sweeps out of range");
+  HIPCHK(hipSetDevice(s->device));
+  s->pc = o->pc;
+  s->pc_sweeps = o->pc_sweeps;
+  if (o->pc != TSX_PC_NONE) {
+    int rc = s->geo.ntop == 2 ? ensure_pc_buffers<2>(s) : ensure_pc_buffers<8>(s);
+    if (rc) return rc;
+  }
   return TSX_OK;
 }
 
@@ -960,16 +996,8 @@ extern "C" int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int whe
     return TSX_ERR_STATE;
   }
   tsx_ksp_opts o;
-  if (opts) o = *opts;
-  else tsx_default_ksp_opts(&o);
-  ARGCHK(o.maxit >= 1, "tsx_diff_solve: maxit < 1");
-  ARGCHK(o.pc == TSX_PC_NONE || o.pc == TSX_PC_COLUMN, "tsx_diff_solve: unsupported preconditioner");
-  ARGCHK(o.pc_sweeps >= 1 && o.pc_sweeps <= 8, "tsx_diff_solve: pc_sweeps out of range");
-  HIPCHK(hipSetDevice(s->device));
-  s->pc = o.pc;
-  s->pc_sweeps = o.pc_sweeps;
-  if (o.pc != TSX_PC_NONE) {
-    int rc = s->geo.ntop == 2 ? ensure_pc_buffers<2>(s) : ensure_pc_buffers<8>(s);
+  {
+    int rc = prepare_ksp(s, opts, &o);
     if (rc) return rc;
   }
   return s->geo.ntop == 2 ? diff_solve_t<2, 4>(s, b, x, where, &o, res) : diff_solve_t<8, 4>(s, b, x, where, &o, res);
@@ -1092,3 +1120,5 @@ extern "C" int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, d
   HIPCHK(hipFree(b));
   return TSX_OK;
 }
+
+#include "tsx_pipeline_api.inc"

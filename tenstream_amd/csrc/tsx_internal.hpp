@@ -90,6 +90,25 @@ struct tsx_solver {
   TsxScalars *scal;    // device
   TsxScalars *scal_host;  // pinned host mirror
 
+  // ---- whole-g-point pipeline state (tsx_pipeline.hpp)
+  bool have_sun;
+  double sun_phi, sun_theta, sun_mu, sun_costheta, sun_symphi;
+  int sun_xinc, sun_yinc;
+  TsxLutHost lut_T, lut_S;
+  float *dirT, *dirS;            // direct coefficient planes (S*S, S*D)
+  bool dir_coeffs_valid;
+  double *d_kabs, *d_ksca, *d_g, *d_dz;  // device copies, reference layout (k fastest)
+  double opt_dx, opt_dy;
+  bool have_optprop;
+  double *a13, *a23, *a33;       // cell-indexed, 1-D layers only
+  double *planck;                // (L, xm, ym) reference layout
+  double *edir_a, *edir_b;       // direct streams, current / scratch
+  void *dsc, *dsc_host;          // TsxDirScalars device / pinned
+  double *abso;                  // (Nz, xm, ym) reference layout
+  int last_lsolar;
+  bool have_solution;
+  int niter_dir;
+
   void *nccl_comm;     // ncclComm_t when nranks > 1 (or force_halo with comm)
   bool comm_ready;
   tsx_exchange_fn xchg_cb;      // host-staged transport (MPI hosts, tests)

@@ -1,0 +1,488 @@
+// tsx_pipeline.hpp -- kernels around the diffuse solve so that a whole g-point stays resident on the GPU:
+// direct-beam coefficient lookup (K5), direct sweep (K6), source term (K7), flux divergence (K9), result
+// assembly (K8/K12).  Same conventions as tsx_kernels.hpp: lanes along x, one plane per stream.
+//
+// Direct streams are stored on the column they sit on (reference ownership), one plane per stream:
+//     E[s * Ncl + (k * ym + j) * xm + i],  k = 0..Nz (levels),  Ncl = (Nz+1) * ncol
+#pragma once
+#include "tsx_kernels.hpp"
+
+struct TsxSun {
+  double phi, theta, mu, costheta, symmetry_phi;
+  int xinc, yinc;
+};
+
+// ---- K5: 6-D lookup [tau, w0, aspect, g, phi, theta] -> NV planes.  For dir2diff of 3_10 the destination blocks are
+//      permuted for sun from east / north (dir3_to_diff10_coeff_symmetry, src/optprop.F90:1009-1045).
+template <int NV, int S, bool DIR2DIFF>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_dir(TsxGeo g, TsxLutDev L, const double *__restrict__ kabs,
+                                                           const double *__restrict__ ksca, const double *__restrict__ gg,
+                                                           const double *__restrict__ dz, double dx, float sym_phi, float theta,
+                                                           int lswitch_east, int lswitch_north,
+                                                           const uint8_t *__restrict__ l1d, float *__restrict__ C) {
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  const long long Nc = g.Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int i = (int)(c % xm);
+    const long long t = c / xm;
+    const int j = (int)(t % ym);
+    const int k = (int)(t / ym);
+    if (l1d[k]) continue;
+    const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
+    const double ka = kabs[r], ks = ksca[r], dzz = dz[r];
+    float aspect = (float)(dzz / dx);
+    float w0 = (float)(ks / fmax(ka + ks, 2.220446049250313e-16));
+    float tauz = (float)((ka + ks) * dzz);
+    const float *ax = L.axes;
+    aspect = fmaxf(ax[L.axis_off[2]], aspect);
+    tauz = fmaxf(ax[L.axis_off[0]], fminf(ax[L.axis_off[0] + L.n[0] - 1], tauz));
+    w0 = fmaxf(ax[L.axis_off[1]], fminf(ax[L.axis_off[1] + L.n[1] - 1], w0));
+    const float sample[6] = {tauz, w0, aspect, (float)gg[r], sym_phi, theta};
+    int ninterp;
+    long long ofs_base, ioff_lo[6], ioff_hi[6];
+    float wlo[6], whi[6];
+    tsx_lut_weights<6>(L, sample, ninterp, ofs_base, ioff_lo, ioff_hi, wlo, whi);
+    float acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = 0.0f;
+    for (int b = 0; b < (1 << ninterp); ++b) {
+      long long ofs = ofs_base;
+      float w = 1.0f;
+      for (int d = 0; d < ninterp; ++d) {
+        if (b & (1 << d)) {
+          ofs += ioff_hi[d];
+          w = __fmul_rn(w, whi[d]);
+        } else {
+          ofs += ioff_lo[d];
+          w = __fmul_rn(w, wlo[d]);
+        }
+      }
+      const float *__restrict__ colp = L.table + (size_t)ofs * NV;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) acc[q] = __fadd_rn(acc[q], __fmul_rn(w, colp[q]));
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      int qo = q;
+      if (DIR2DIFF && S == 3 && NV == 30) {  // dst block (1-based) swaps 3<->4, 5<->6 (east), 7<->8, 9<->10 (north)
+        int dstb = q / S;
+        const int src = q % S;
+        if (lswitch_east && dstb >= 2 && dstb <= 5) dstb ^= 1;
+        if (lswitch_north && dstb >= 6 && dstb <= 9) dstb ^= 1;
+        qo = dstb * S + src;
+      }
+      C[(size_t)qo * Nc + c] = acc[q];
+    }
+  }
+}
+
+// ---- K6: one sweep of the direct beam (explicit_edir_forward_sweep, src/pprts_explicit.F90:330-459): the thread of a
+//      column marches down in k (fresh top stream), side streams of the neighbouring columns come from the previous
+//      sweep.  Same fixed point as the reference's lexicographic sweep; iterated until ||x_new - x_old|| converges
+//      (src/pprts_explicit.F90:168-218).  slot0 += ||new - old||^2.
+template <int DTOP, int DSIDE>
+__global__ __launch_bounds__(64) void tsx_k_edir_sweep(TsxGeo g, TsxSun sun, const float *__restrict__ T,
+                                                       const uint8_t *__restrict__ l1d, const double *__restrict__ a33,
+                                                       double inc_solar, const double *__restrict__ xo, double *__restrict__ xn,
+                                                       double *__restrict__ partials, const int *__restrict__ done) {
+  constexpr int S = DTOP + 2 * DSIDE;
+  if (done && *done) return;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
+  const long long Nc = g.Nc, Ncl = (long long)(Nz + 1) * ncol;
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  double sum[1] = {0.0};
+  if (col < ncol) {
+    const int i = col % xm, j = col / xm;
+    // upwind neighbours (periodic): x-side source sits at face i+1-xinc, y-side at face j+1-yinc
+    const int iu = sun.xinc ? i : (i + 1 == xm ? 0 : i + 1);
+    const int ju = sun.yinc ? j : (j + 1 == ym ? 0 : j + 1);
+    // destination faces: i+xinc, j+yinc
+    const int id = sun.xinc ? (i + 1 == xm ? 0 : i + 1) : i;
+    const int jd = sun.yinc ? (j + 1 == ym ? 0 : j + 1) : j;
+    double top[DTOP];
+#pragma unroll
+    for (int q = 0; q < DTOP; ++q) {
+      top[q] = inc_solar;  // setup_incSolar: level 0 top streams (src/pprts_base.F90:1164-1176)
+      const double old = xo[(size_t)q * Ncl + col];
+      xn[(size_t)q * Ncl + col] = top[q];
+      sum[0] += (top[q] - old) * (top[q] - old);
+    }
+    for (int k = 0; k < Nz; ++k) {
+      const size_t c = (size_t)k * ncol + col;
+      if (l1d[k]) {
+        const double t33 = a33[c];
+#pragma unroll
+        for (int q = 0; q < DTOP; ++q) top[q] *= t33;
+        // side streams of 1-D layers are never written by the reference: carry the old values
+#pragma unroll
+        for (int q = 0; q < 2 * DSIDE; ++q) {
+          const size_t o = (size_t)(DTOP + q) * Ncl + c;
+          xn[o] = xo[o];
+        }
+      } else {
+        double src[S];
+#pragma unroll
+        for (int q = 0; q < DTOP; ++q) src[q] = top[q];
+#pragma unroll
+        for (int q = 0; q < DSIDE; ++q) {
+          src[DTOP + q] = xo[(size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + iu];
+          src[DTOP + DSIDE + q] = xo[(size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)ju * xm + i];
+        }
+        double out[S];
+#pragma unroll
+        for (int d = 0; d < S; ++d) {
+          double a = 0.0;
+#pragma unroll
+          for (int s = 0; s < S; ++s) a += src[s] * (double)T[(size_t)(d * S + s) * Nc + c];
+          out[d] = a;
+        }
+#pragma unroll
+        for (int q = 0; q < DTOP; ++q) top[q] = out[q];
+#pragma unroll
+        for (int q = 0; q < DSIDE; ++q) {
+          const size_t ox = (size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + id;
+          const size_t oy = (size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)jd * xm + i;
+          const double dx_ = out[DTOP + q] - xo[ox], dy_ = out[DTOP + DSIDE + q] - xo[oy];
+          xn[ox] = out[DTOP + q];
+          xn[oy] = out[DTOP + DSIDE + q];
+          sum[0] += dx_ * dx_ + dy_ * dy_;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < DTOP; ++q) {
+        const size_t o = (size_t)q * Ncl + (size_t)(k + 1) * ncol + col;
+        const double old = xo[o];
+        xn[o] = top[q];
+        sum[0] += (top[q] - old) * (top[q] - old);
+      }
+    }
+    // side entries at the bottom level are dummies: keep
+#pragma unroll
+    for (int q = 0; q < 2 * DSIDE; ++q) {
+      const size_t o = (size_t)(DTOP + q) * Ncl + (size_t)Nz * ncol + col;
+      xn[o] = xo[o];
+    }
+  }
+  // block of 64 = one wave
+  double r = tsx_wave_sum(sum[0]);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// scalar stage of the direct iteration: residual(iter) = max(tiny, sqrt(sum)); stop rule src/pprts_explicit.F90:175-208
+struct TsxDirScalars {
+  double res1, res, rtol, atol;
+  int iter, maxit, done, converged;
+};
+__global__ __launch_bounds__(1024) void tsx_k_edir_scalar(TsxDirScalars *__restrict__ sc, const double *__restrict__ partials,
+                                                          int nblocks) {
+  __shared__ double sm[16];
+  if (sc->done) return;
+  double v = 0.0;
+  for (int q = threadIdx.x; q < nblocks; q += 1024) v += partials[q];
+  v = tsx_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double t = 0.0;
+  for (int q = 0; q < 16; ++q) t += sm[q];
+  const double tiny = 2.2250738585072014e-308;
+  double res = sqrt(t);
+  res = res > tiny ? res : tiny;
+  sc->iter += 1;
+  if (sc->iter == 1) sc->res1 = res;
+  sc->res = res;
+  const double rel = sc->res1 <= 1.4916681462400413e-154 ? 0.0 : res / sc->res1;
+  if (res < sc->atol || rel < sc->rtol) {
+    sc->converged = 1;
+    sc->done = 1;
+  } else if (sc->iter >= sc->maxit) {
+    sc->done = 1;
+  }
+}
+
+// ---- K7: source term in dst-owned storage.  Solar: set_solar_source (src/pprts.F90:4684-4846): every contribution of
+//      cell (k,i,j) lands on a stream leaving that cell, i.e. on internal index c -- no halo reduce needed.
+template <int NTOP, int NSIDE, int DTOP, int DSIDE>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_setup_b_solar(TsxGeo g, TsxSun sun, const float *__restrict__ Sd,
+                                                                 const uint8_t *__restrict__ l1d, const double *__restrict__ a13,
+                                                                 const double *__restrict__ a23, const double *__restrict__ albedo,
+                                                                 const double *__restrict__ E, double *__restrict__ b) {
+  constexpr int D = NTOP + 2 * NSIDE, S = DTOP + 2 * DSIDE;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
+  const long long Nc = g.Nc, Ncl = (long long)(Nz + 1) * ncol;
+  const double streams = (double)(NTOP / 2);
+  double *__restrict__ bt = b + (size_t)D * Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int i = (int)(c % xm);
+    const long long t = c / xm;
+    const int j = (int)(t % ym);
+    const int k = (int)(t / ym);
+    const int col = j * xm + i;
+    const int iu = sun.xinc ? i : (i + 1 == xm ? 0 : i + 1);
+    const int ju = sun.yinc ? j : (j + 1 == ym ? 0 : j + 1);
+    double own[S], src[S];
+    bool any = false;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      own[s] = E[(size_t)s * Ncl + (size_t)k * ncol + col];
+      any |= own[s] > 2.220446049250313e-16;  // epsilon(one), :4706
+    }
+#pragma unroll
+    for (int q = 0; q < DTOP; ++q) src[q] = own[q];
+#pragma unroll
+    for (int q = 0; q < DSIDE; ++q) {
+      src[DTOP + q] = E[(size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + iu];
+      src[DTOP + DSIDE + q] = E[(size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)ju * xm + i];
+    }
+    double out[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) out[d] = 0.0;
+    if (any) {
+      if (l1d[k]) {
+        const double t13 = a13[c], t23 = a23[c];
+#pragma unroll
+        for (int s = 0; s < DTOP; ++s)
+#pragma unroll
+          for (int q = 0; q < NTOP; ++q) out[q] += own[s] * (tsx_inward(q) ? t23 : t13) / streams;
+      } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) out[d] += src[s] * (double)Sd[(size_t)(d * S + s) * Nc + c];
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) b[(size_t)d * Nc + c] = out[d];
+    if (k == Nz - 1) {  // tail rows: surface albedo reflecting the direct beam (:4829-4843); TOA and dummies carry no source
+      double esrf = 0.0;
+#pragma unroll
+      for (int q = 0; q < DTOP; ++q) esrf += E[(size_t)q * Ncl + (size_t)Nz * ncol + col];
+#pragma unroll
+      for (int d = 0; d < D; ++d)
+        bt[(size_t)d * ncol + col] = (d < NTOP && !tsx_inward(d)) ? esrf * albedo[col] / streams : 0.0;
+    }
+  }
+}
+
+// B_eff (src/schwarzschild.F90:36-67): 2-point Gauss-Legendre on (0,1)
+__device__ __forceinline__ double tsx_B_eff(double B_far, double B_near, double tau) {
+  const double pt[2] = {0.5 - 0.5 / 1.7320508075688772, 0.5 + 0.5 / 1.7320508075688772};
+  double B = 0.0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const double mu = pt[q];
+    const double dtau = tau / mu;
+    double bmu;
+    if (dtau < 1e-3) {
+      bmu = (B_far + B_near) * .5;
+    } else {
+      const double tm1 = expm1(-dtau);
+      bmu = (-B_near + B_far * (tm1 + 1)) / (tm1) + ((B_far - B_near) * mu) / tau;
+    }
+    B += bmu * mu * 0.5;
+  }
+  return B * 2;
+}
+
+// Thermal: set_thermal_source (src/pprts.F90:4848-4987); planck at levels, reference layout (k over L fastest)
+template <int NTOP, int NSIDE, typename CT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_setup_b_thermal(TsxGeo g, const CT *__restrict__ C,
+                                                                   const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
+                                                                   const double *__restrict__ a12, const double *__restrict__ albedo,
+                                                                   const double *__restrict__ planck, const double *__restrict__ kabs,
+                                                                   const double *__restrict__ dz, double dx, double dy,
+                                                                   double *__restrict__ b) {
+  constexpr int D = NTOP + 2 * NSIDE;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol, L = Nz + 1;
+  const long long Nc = g.Nc;
+  const double pi = 3.14159265358979323846;
+  const double tstreams = (double)(NTOP / 2), sstreams = (double)(NSIDE / 2);
+  const double Az = dx * dy;
+  double *__restrict__ bt = b + (size_t)D * Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int i = (int)(c % xm);
+    const long long t = c / xm;
+    const int j = (int)(t % ym);
+    const int k = (int)(t / ym);
+    const int col = j * xm + i;
+    const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
+    const size_t rl = (size_t)k + (size_t)L * ((size_t)i + (size_t)xm * j);
+    const double b0 = planck[rl], b1 = planck[rl + 1];
+    const double dzz = dz[r];
+    const double tauz = kabs[r] * dzz;
+    const double btop = tsx_B_eff(b1, b0, tauz), bbot = tsx_B_eff(b0, b1, tauz);
+    if (l1d[k]) {
+      const double bfac = pi * Az / tstreams;
+      double emis = 1.0 - a11[c] - a12[c];
+      emis = fmax(0.0, fmin(1.0, emis));
+#pragma unroll
+      for (int q = 0; q < NTOP; ++q) b[(size_t)q * Nc + c] = (tsx_inward(q) ? bbot : btop) * bfac * emis;
+#pragma unroll
+      for (int d = NTOP; d < D; ++d) b[(size_t)d * Nc + c] = 0.0;
+    } else {
+      const double Ax = dy * dzz, Ay = dx * dzz;
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        double sum = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) sum += (double)C[(size_t)(d * D + s) * Nc + c];
+        double emis = fmax(0.0, fmin(1.0, 1.0 - sum));
+        double v;
+        if (s < NTOP) {
+          v = (tsx_inward(s) ? bbot : btop) * (pi * Az / tstreams) * emis;
+        } else {
+          const int q = (s - NTOP) % NSIDE;
+          const double area = s < NTOP + NSIDE ? Ax : Ay;
+          v = ((q + 1 > NSIDE / 2) ? btop : bbot) * emis * (pi * area / sstreams);
+        }
+        b[(size_t)s * Nc + c] = v;  // every stream's emission lands on the face it leaves through == index c
+      }
+    }
+    if (k == Nz - 1) {
+      const double srf = planck[(size_t)Nz + (size_t)L * ((size_t)i + (size_t)xm * j)] * Az * (1.0 - albedo[col]) * pi / tstreams;
+#pragma unroll
+      for (int d = 0; d < D; ++d) bt[(size_t)d * ncol + col] = (d < NTOP && !tsx_inward(d)) ? srf : 0.0;
+    }
+  }
+}
+
+// ---- K9: absorption by coefficient divergence (calc_flx_div, src/pprts.F90:5286-5398) / volume (:5477, 5483-5503).
+//      ediff in internal storage (W), edir planes (W).  abso out: reference layout (k fastest), W/m3.
+template <int NTOP, int NSIDE, int DTOP, int DSIDE, typename CT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_flx_div(TsxGeo g, TsxSun sun, int lsolar, int lthermal,
+                                                           const CT *__restrict__ C, const float *__restrict__ T,
+                                                           const float *__restrict__ Sd, const uint8_t *__restrict__ l1d,
+                                                           const double *__restrict__ a11, const double *__restrict__ a12,
+                                                           const double *__restrict__ kabs, const double *__restrict__ dz,
+                                                           double dx, double dy, const double *__restrict__ E,
+                                                           const double *__restrict__ x, const double *__restrict__ bsrc,
+                                                           double *__restrict__ abso) {
+  constexpr int D = NTOP + 2 * NSIDE, S = DTOP + 2 * DSIDE;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
+  const long long Nc = g.Nc, Ncl = (long long)(Nz + 1) * ncol;
+  const double *__restrict__ xt = x + (size_t)D * Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int i = (int)(c % xm);
+    const long long t = c / xm;
+    const int j = (int)(t % ym);
+    const int k = (int)(t / ym);
+    const int col = j * xm + i;
+    const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
+    const bool is1d = l1d[k] != 0;
+    double a = 0.0;
+    if (lsolar) {
+      const int iu = sun.xinc ? i : (i + 1 == xm ? 0 : i + 1);
+      const int ju = sun.yinc ? j : (j + 1 == ym ? 0 : j + 1);
+      if (is1d) {
+        const double cdiv = kabs[r] * dz[r] / sun.costheta;
+#pragma unroll
+        for (int q = 0; q < DTOP; ++q) a += E[(size_t)q * Ncl + (size_t)k * ncol + col] * (-expm1(-cdiv));
+      } else {
+        double src[S];
+#pragma unroll
+        for (int q = 0; q < DTOP; ++q) src[q] = E[(size_t)q * Ncl + (size_t)k * ncol + col];
+#pragma unroll
+        for (int q = 0; q < DSIDE; ++q) {
+          src[DTOP + q] = E[(size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + iu];
+          src[DTOP + DSIDE + q] = E[(size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)ju * xm + i];
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+          for (int d = 0; d < S; ++d) s1 += (double)T[(size_t)(d * S + s) * Nc + c];
+#pragma unroll
+          for (int d = 0; d < D; ++d) s2 += (double)Sd[(size_t)(d * S + s) * Nc + c];
+          a += src[s] * (1.0 - s1 - s2);
+        }
+      }
+    }
+    // diffuse sources of the cell (same gather as the operator)
+    double xs[D];
+#pragma unroll
+    for (int q = 0; q < NTOP; ++q) {
+      if (tsx_inward(q)) xs[q] = k > 0 ? x[(size_t)q * Nc + c - ncol] : xt[(size_t)q * ncol + col];
+      else xs[q] = k + 1 < Nz ? x[(size_t)q * Nc + c + ncol] : xt[(size_t)q * ncol + col];
+    }
+    if (!is1d) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) {
+        const int d = NTOP + q;
+        if (tsx_inward(q)) xs[d] = x[(size_t)d * Nc + c + (i > 0 ? -1 : xm - 1)];
+        else xs[d] = x[(size_t)d * Nc + c + (i < xm - 1 ? 1 : -(xm - 1))];
+      }
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) {
+        const int d = NTOP + NSIDE + q;
+        if (tsx_inward(q)) xs[d] = x[(size_t)d * Nc + c + (j > 0 ? -(long long)xm : (long long)(ym - 1) * xm)];
+        else xs[d] = x[(size_t)d * Nc + c + (j < ym - 1 ? (long long)xm : -(long long)(ym - 1) * xm)];
+      }
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        double sum = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) sum += (double)C[(size_t)(d * D + s) * Nc + c];
+        a += xs[s] * (1.0 - sum);
+      }
+    } else {
+      const double cdiv = fmax(0.0, 1.0 - a11[c] - a12[c]);
+#pragma unroll
+      for (int q = 0; q < NTOP; ++q) a += xs[q] * cdiv;
+    }
+    if (lthermal) {  // minus the emitted source on every stream leaving the cell (:5373-5398) == b at index c
+#pragma unroll
+      for (int d = 0; d < D; ++d) a -= bsrc[(size_t)d * Nc + c];
+    }
+    abso[r] = a * (1.0 / (dx * dy * dz[r]));
+  }
+}
+
+// ---- K8 + K12: W -> W/m2 (gen_scale_*_flx_vec_arr, src/pprts.F90:3901-3987) and pprts_get_result (:5850-5888).
+//      Outputs in the reference layout (level fastest): redir/redn/reup (L, xm, ym), rabso (Nz, xm, ym) in place.
+template <int NTOP, int NSIDE, int DTOP, int DSIDE>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_get_result(TsxGeo g, TsxSun sun, int lsolar, double dx, double dy,
+                                                              int top_div, const double *__restrict__ E,
+                                                              const double *__restrict__ x, double *__restrict__ redir,
+                                                              double *__restrict__ redn, double *__restrict__ reup,
+                                                              double *__restrict__ rabso) {
+  constexpr int D = NTOP + 2 * NSIDE;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol, L = Nz + 1;
+  const long long Nc = g.Nc, Ncl = (long long)L * ncol;
+  const double mu = lsolar ? sun.mu : 1.0;
+  const double invA = 1.0 / (dx * dy);  // difftop%area_divider = 1
+  const double *__restrict__ xt = x + (size_t)D * Nc;
+  const long long total = (long long)L * ncol;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < total; q += (long long)gridDim.x * TSX_BLOCK) {
+    const int col = (int)(q % ncol);
+    const int k = (int)(q / ncol);
+    const int i = col % xm, j = col / xm;
+    double dn = 0.0, up = 0.0;
+#pragma unroll
+    for (int d = 0; d < NTOP; ++d) {
+      double v;  // stream d at level k
+      if (tsx_inward(d)) v = k >= 1 ? x[(size_t)d * Nc + (size_t)(k - 1) * ncol + col] : xt[(size_t)d * ncol + col];
+      else v = k < Nz ? x[(size_t)d * Nc + (size_t)k * ncol + col] : xt[(size_t)d * ncol + col];
+      if (tsx_inward(d)) dn += v * invA;
+      else up += v * invA;
+    }
+    const size_t o = (size_t)k + (size_t)L * ((size_t)i + (size_t)xm * j);
+    redn[o] = dn * mu;
+    reup[o] = up * mu;
+    if (redir) {
+      double di = 0.0;
+      if (lsolar) {
+#pragma unroll
+        for (int s = 0; s < DTOP; ++s) di += E[(size_t)s * Ncl + (size_t)k * ncol + col] * (1.0 / (dx * dy / (double)top_div));
+        di = di / (double)top_div * mu;
+      }
+      redir[o] = di;
+    }
+    if (k < Nz) {
+      const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
+      rabso[r] *= mu;
+    }
+  }
+}
+
+// scalar field in reference layout (k fastest) -> cell-indexed (i fastest) is tsx_k_import_cellfield (tsx_kernels.hpp)

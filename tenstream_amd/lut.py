@@ -14,6 +14,7 @@ import mmap
 import numpy as np
 
 from . import synthetic as S
+from . import synthetic as S_
 
 PAGESIZE = mmap.PAGESIZE
 
@@ -62,3 +63,51 @@ def synthetic_diffuse_table(solver="3_10"):
         for ia, av in enumerate(asp):
             out[ig, ia] = S.diff2diff_surrogate(solver, T, W, float(av), np.full_like(T, gv))
     return out.reshape(-1, D * D)
+
+
+# ---- direct tables (6-D: tau, w0, aspect_zx, g, phi, theta) ---------------------------------------------------
+def direct_axes(full=False):
+    """LUT_3_10 direct axes (src/optprop_base.F90:228-235): the 4 diffuse axes + phi19, theta19 = linspace(0, 90).
+    full=False gives a thinned version (same ranges) for tests and benches: the real Tdir/Sdir are 1.1 / 3.7 GB."""
+    if full:
+        return diffuse_axes() + [np.linspace(0, 90, 19, dtype=np.float32), np.linspace(0, 90, 19, dtype=np.float32)]
+    tau, w0, asp, g = diffuse_axes()
+    return [tau[::3].copy(), w0[::4].copy(), asp[[0, 6, 10, 13, 16, 22]].copy(), g[[0, 2, 5]].copy(),
+            np.array([0, 45, 90], dtype=np.float32), np.array([0, 20, 40, 60, 80], dtype=np.float32)]
+
+
+def synthetic_direct_tables(axes, solver="3_10"):
+    """Closed-form, energy-conserving stand-ins for Tdir (S*S) and Sdir (S*D), memory order [dst*S + src]:
+    beam geometry decides which face a ray leaves through, exp(-tau/mu) what survives, the scattered part
+    w0*(1-t) goes to the diffuse streams with forward bias g.  sum_dst(T) + sum_dst(S) = t + w0 (1 - t) <= 1."""
+    assert solver == "3_10"
+    S, D = 3, 10
+    tau, w0, asp, g, phi, theta = [np.asarray(a, dtype=np.float64) for a in axes]
+    TH, PH, G, A, W, T = np.meshgrid(theta, phi, g, asp, w0, tau, indexing="ij")  # tau fastest in C-order flatten
+    mu = np.maximum(np.cos(np.deg2rad(np.minimum(TH, 89.0))), 0.02)
+    tant = np.tan(np.deg2rad(np.minimum(TH, 89.0)))
+    ux = np.minimum(1.0, A * tant * np.sin(np.deg2rad(PH)))  # horizontal shift across the box / dx
+    uy = np.minimum(1.0, A * tant * np.cos(np.deg2rad(PH)))
+    t = np.exp(-T / mu)
+    geo = np.zeros(TH.shape + (S, S))  # [src, dst]
+    geo[..., 0, 0] = (1 - ux) * (1 - uy)
+    geo[..., 0, 1] = ux * (1 - uy / 2)
+    geo[..., 0, 2] = uy * (1 - ux / 2)
+    qbx = np.minimum(1.0, 1.0 / np.maximum(A * tant * np.sin(np.deg2rad(PH)), 1e-6))
+    qby = np.minimum(1.0, 1.0 / np.maximum(A * tant * np.cos(np.deg2rad(PH)), 1e-6))
+    geo[..., 1, 0] = qbx
+    geo[..., 1, 1] = (1 - qbx) * (1 - uy)
+    geo[..., 1, 2] = (1 - qbx) * uy
+    geo[..., 2, 0] = qby
+    geo[..., 2, 2] = (1 - qby) * (1 - ux)
+    geo[..., 2, 1] = (1 - qby) * ux
+    Tt = (t[..., None, None] * geo)  # [src, dst]
+    Tdir = np.swapaxes(Tt, -1, -2).reshape(-1, S * S).astype(np.float32)  # [dst*S + src]
+    _, I = S_.geometric_blocks(solver, 0.5)
+    fwd = np.zeros(D)
+    fwd[1] = 0.6
+    fwd[[2, 3, 6, 7]] = 0.1
+    share = G[..., None] * fwd + (1 - G[..., None]) * I  # [dst]
+    sc = (W * (1 - t))[..., None, None] * share[..., :, None] * np.ones(S)  # [dst, src]
+    Sdir = sc.reshape(-1, D * S).astype(np.float32)
+    return Tdir, Sdir

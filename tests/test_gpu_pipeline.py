@@ -1,0 +1,130 @@
+"""Whole g-point on the device (tsx_pprts_*) against the oracle's restatement of the reference pipeline:
+alloc_coeff_* -> explicit_edir -> setup_b -> diffuse solve -> calc_flx_div -> scale_flx -> pprts_get_result.
+Inputs are identical (same synthetic LUTs, same optical properties); coefficient lookups must be bit-exact,
+fluxes agree to solver tolerance."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tenstream_amd import lut, synthetic
+from tenstream_amd.pprts import PprtsSolver, eddington_coeff_ec
+
+
+
+def _setup(Nx, Ny, Nz, phi0, theta0, tall_top=0, seed=5):
+    dx = dy = 100.0
+    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=seed)
+    kabs *= 20.0  # some real absorption so that abso is not tiny
+    dz = np.full((Ny, Nx, Nz), 50.0)
+    if tall_top:
+        dz[:, :, :tall_top] = 400.0  # dz/dx > twostr_ratio -> 1-D layers at the top (src/pprts.F90:669-677)
+    P = PprtsSolver(Nz, Nx, Ny, dx, dy, phi0, theta0)
+    P.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
+    dax = lut.direct_axes()
+    Tdir, Sdir = lut.synthetic_direct_tables(dax)
+    P.set_lut_direct(Tdir, Sdir, dax)
+    return P, dict(kabs=kabs, ksca=ksca, g=g, dz=dz, dx=dx, dy=dy, dax=dax, Tdir=Tdir, Sdir=Sdir)
+
+
+def _oracle_pipeline(P, I, albedo, edirTOA, lsolar, planck=None, rtol=1e-10):
+    F = P.fields
+    Nz, Nx, Ny = P.Nz, P.Nx, P.Ny
+    lay = O.layout("3_10", Nz, Nx, Ny)
+    dlay = O.dir_layout_3_10()
+    sun = O.suninfo(P.phi0, P.theta0)
+    Ld = O.make_lut(lut.diffuse_axes("3_10"), lut.synthetic_diffuse_table("3_10"))
+    c = O.alloc_coeff_diff2diff(Ld, F["kabs"], F["ksca"], F["g"], F["dz"], I["dx"], P.l1d)
+    out = dict(diff2diff=c, sun=sun)
+    if lsolar:
+        LT, LS = O.make_lut(I["dax"], I["Tdir"]), O.make_lut(I["dax"], I["Sdir"])
+        t = O.alloc_coeff_dir(LT, True, F["kabs"], F["ksca"], F["g"], F["dz"], I["dx"], sun, P.l1d)
+        sd = O.alloc_coeff_dir(LS, False, F["kabs"], F["ksca"], F["g"], F["dz"], I["dx"], sun, P.l1d)
+        rt, at, _ = O.default_tolerances(Nx, Ny, Nz + 1)
+        edir, di = O.explicit_edir(lay, dlay, sun, t, P.l1d, F["a33"], edirTOA, I["dx"], I["dy"], rtol=rt, atol=at)
+        assert di["converged"]
+        b = O.setup_b_solar(lay, dlay, sun, sd, P.l1d, F["a13"], F["a23"], F["albedo"], edir)
+        out.update(dir2dir=t, dir2diff=sd, edir=edir, niter_dir=di["niter"])
+    else:
+        edir, t, sd = None, None, None
+        b = O.setup_b_thermal(lay, c, P.l1d, F["a11"], F["a12"], F["albedo"], planck, F["kabs"], F["dz"], I["dx"], I["dy"])
+    x, info = O.solve_ilu(lay, c, P.l1d, F["a11"], F["a12"], F["albedo"], b, rtol=rtol, atol=1e-30, maxit=3000)
+    assert info["reason"] == 2
+    abso = O.calc_flx_div(lay, dlay, sun, t, sd, c, P.l1d, F["a11"], F["a12"], F["kabs"], F["dz"], I["dx"], I["dy"], edir, x,
+                          None if lsolar else b)
+    ediff_wm2 = O.scale_diff(lay, F["dz"], I["dx"], I["dy"], True, x)
+    edir_wm2 = O.scale_dir(lay, dlay, F["dz"], I["dx"], I["dy"], True, edir) if lsolar else None
+    redn, reup, rabso, redir = O.get_result(lay, dlay, sun, lsolar, edir_wm2, ediff_wm2, abso)
+    out.update(b=b, ediff=x, edn=redn, eup=reup, abso=rabso, redir=redir)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("phi0,theta0,tall_top", [(180.0, 40.0, 0), (10.0, 60.0, 2), (250.0, 20.0, 0), (300.0, 0.0, 1)])
+def test_solar_pipeline_matches_oracle(gpu, phi0, theta0, tall_top):
+    Nx, Ny, Nz = 10, 8, 12
+    P, I = _setup(Nx, Ny, Nz, phi0, theta0, tall_top)
+    P.set_optical_properties(0.15, I["kabs"], I["ksca"], I["g"], I["dz"])
+    assert P.l1d.sum() == tall_top
+    info = P.solve(1000.0, rtol=1e-10, atol=1e-30, maxit=3000)
+    assert info.reason == 2
+    R = _oracle_pipeline(P, I, 0.15, 1000.0, True)
+    sl = slice(tall_top, None)  # 1-D layers hold no 3-D coefficient blocks
+    assert np.array_equal(P.get_field("dir2dir")[:, :, sl], R["dir2dir"][:, :, sl])      # K5 bit-exact
+    assert np.array_equal(P.get_field("dir2diff")[:, :, sl], R["dir2diff"][:, :, sl])    # incl. symmetry swaps
+    assert np.array_equal(P.core.get_coeffs()[:, :, sl], R["diff2diff"][:, :, sl])
+    # direct beam: same fixed point as the reference's sweep, both stopped by the same ||dx|| rule (rtol 1e-5)
+    e = P.get_field("edir")
+    assert np.abs(e - R["edir"]).max() <= 1e-4 * np.abs(R["edir"]).max()
+    b = P.get_field("b")
+    assert np.abs(b - R["b"]).max() <= 1e-4 * np.abs(R["b"]).max()
+    edn, eup, abso, edir = P.get_result()
+    for got, want in ((edn, R["edn"]), (eup, R["eup"]), (edir, R["redir"])):
+        assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30)
+    assert np.abs(abso - R["abso"]).max() <= 2e-4 * np.abs(R["abso"]).max()
+    # physics sanity on the device result: TOA direct flux is S0 * mu0, nothing negative
+    assert np.allclose(edir[:, :, 0], 1000.0 * np.cos(np.deg2rad(theta0)), rtol=1e-12)
+    assert edn.min() >= -1e-9 and eup.min() >= -1e-9 and abso.min() >= -1e-9
+
+
+@pytest.mark.gpu
+def test_solar_b_from_identical_edir_is_tight(gpu):
+    """With the direct beam converged hard on both sides the source term agrees to rounding."""
+    P, I = _setup(9, 7, 8, 200.0, 50.0)
+    P.set_optical_properties(0.1, I["kabs"], I["ksca"], I["g"], I["dz"])
+    # several solves: each one warm-starts the direct sweep from the previous edir -> hard convergence
+    for _ in range(4):
+        P.solve(800.0, rtol=1e-6)
+    lay, dlay, sun = O.layout("3_10", 8, 9, 7), O.dir_layout_3_10(), O.suninfo(200.0, 50.0)
+    F = P.fields
+    LT, LS = O.make_lut(I["dax"], I["Tdir"]), O.make_lut(I["dax"], I["Sdir"])
+    t = O.alloc_coeff_dir(LT, True, F["kabs"], F["ksca"], F["g"], F["dz"], 100.0, sun, P.l1d)
+    sd = O.alloc_coeff_dir(LS, False, F["kabs"], F["ksca"], F["g"], F["dz"], 100.0, sun, P.l1d)
+    edir, _ = O.explicit_edir(lay, dlay, sun, t, P.l1d, F["a33"], 800.0, 100.0, 100.0, rtol=1e-14, atol=1e-12, maxit=500)
+    assert np.abs(P.get_field("edir") - edir).max() <= 1e-9 * np.abs(edir).max()
+    b = O.setup_b_solar(lay, dlay, sun, sd, P.l1d, F["a13"], F["a23"], F["albedo"], P.get_field("edir"))
+    assert np.abs(P.get_field("b") - b).max() <= 1e-13 * np.abs(b).max()
+
+
+@pytest.mark.gpu
+def test_thermal_pipeline_matches_oracle(gpu):
+    Nx, Ny, Nz = 8, 6, 10
+    P, I = _setup(Nx, Ny, Nz, 0.0, 0.0, tall_top=1)
+    planck = np.linspace(2.0, 6.0, Nz + 1)[None, None, :] * np.ones((Ny, Nx, 1)) * (1 + 0.05 * np.random.default_rng(0).random((Ny, Nx, 1)))
+    P.set_optical_properties(0.05, I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck)
+    info = P.solve(0.0, rtol=1e-10, atol=1e-30, maxit=3000)
+    assert info.reason == 2
+    R = _oracle_pipeline(P, I, 0.05, 0.0, False, planck=planck)
+    b = P.get_field("b")
+    assert np.abs(b - R["b"]).max() <= 1e-13 * np.abs(R["b"]).max()
+    edn, eup, abso, _ = P.get_result()
+    assert np.abs(edn - R["edn"]).max() <= 1e-7 * np.abs(R["edn"]).max()
+    assert np.abs(eup - R["eup"]).max() <= 1e-7 * np.abs(R["eup"]).max()
+    assert np.abs(abso - R["abso"]).max() <= 1e-6 * np.abs(R["abso"]).max()
+
+
+def test_host_eddington_mirror_matches_oracle():
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        dtau, w0, g, mu0 = 10 ** rng.uniform(-8, 2), rng.uniform(0, 1), rng.uniform(0, 0.9), rng.uniform(0.05, 1)
+        got = [float(v) for v in eddington_coeff_ec(dtau, w0, g, mu0)]
+        np.testing.assert_allclose(got, O.eddington_coeff_ec(dtau, w0, g, mu0), rtol=1e-9, atol=1e-16)
