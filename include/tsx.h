@@ -182,6 +182,9 @@ int tsx_pprts_set_angles(tsx_solver *s, double phi0, double theta0);
  * (src/optprop_base.F90:228-240); same payload layout as the diffuse table */
 int tsx_lut_set_direct(tsx_solver *s, const float *Tdir, const float *Sdir, int64_t nentries, int32_t ndim,
                        const int32_t *n, const float *axes_concat, int where);
+/* the same from `.mmap4` files (LUT_direct_3_10.<dims>.ds1000.nc.{Tdir,Sdir}.mmap4, src/optprop_LUT.F90:505, 1348);
+ * axes = the LUT_3_10 preset unless a `<tdir_path>.axes` text sidecar (ndim, then "n v1..vn" per axis) exists */
+int tsx_lut_load_direct_mmap4(tsx_solver *s, const char *tdir_path, const char *sdir_path);
 /* optical properties of one g-point, (zs:ze-1, xs:xe, ys:ye) real64, already delta-scaled; a11..a33 only read for
  * 1-D layers (eddington coefficients, src/pprts.F90:1962-1992); planck (zs:ze, xs:xe, ys:ye) or NULL for solar */
 int tsx_pprts_set_optprop(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz,

@@ -481,7 +481,11 @@ static int set_aux(tsx_solver *s, const uint8_t *l1d, const double *a11, const d
   if (where == TSX_HOST) memcpy(l1d_h.data(), l1d, g.Nz);
   else HIPCHK(hipMemcpy(l1d_h.data(), l1d, g.Nz, hipMemcpyDeviceToHost));
   s->any_l1d = false;
-  for (int k = 0; k < g.Nz; ++k) s->any_l1d |= l1d_h[k] != 0;
+  s->n1d = 0;
+  for (int k = 0; k < g.Nz; ++k) {
+    s->any_l1d |= l1d_h[k] != 0;
+    s->n1d += l1d_h[k] != 0;
+  }
   HIPCHK(hipMemcpyAsync(s->l1d, l1d_h.data(), g.Nz, hipMemcpyHostToDevice, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   ARGCHK(!s->any_l1d || (a11 && a12), "a11/a12 required when any layer is 1-D");

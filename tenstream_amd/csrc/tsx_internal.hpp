@@ -71,6 +71,7 @@ struct tsx_solver {
   double *albedo;      // [ncol]
   bool have_coeffs;
   bool any_l1d;
+  int n1d;             // number of 1-D layers (unconstrained_fraction = 1 - n1d/Nz, src/pprts.F90:721-723)
   TsxLutHost lut_diff;
 
   // Krylov work vectors (internal layout, N doubles each)

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_get_result(TsxGeo g, TsxSun s
                                                               double *__restrict__ redn, double *__restrict__ reup,
                                                               double *__restrict__ rabso) {
   constexpr int D = NTOP + 2 * NSIDE;
-  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol, L = Nz + 1;
+  const int xm = g.xm, Nz = g.Nz, ncol = g.ncol, L = Nz + 1;
   const long long Nc = g.Nc, Ncl = (long long)L * ncol;
   const double mu = lsolar ? sun.mu : 1.0;
   const double invA = 1.0 / (dx * dy);  // difftop%area_divider = 1

@@ -128,3 +128,80 @@ def test_host_eddington_mirror_matches_oracle():
         dtau, w0, g, mu0 = 10 ** rng.uniform(-8, 2), rng.uniform(0, 1), rng.uniform(0, 0.9), rng.uniform(0.05, 1)
         got = [float(v) for v in eddington_coeff_ec(dtau, w0, g, mu0)]
         np.testing.assert_allclose(got, O.eddington_coeff_ec(dtau, w0, g, mu0), rtol=1e-9, atol=1e-16)
+
+
+def _write_axes_sidecar(path, axes):
+    with open(path, "w") as f:
+        f.write(f"{len(axes)}\n")
+        for a in axes:
+            f.write(f"{len(a)} " + " ".join(repr(float(v)) for v in a) + "\n")
+
+
+@pytest.mark.gpu
+def test_reference_c_abi_end_to_end(gpu, tmp_path):
+    """A plain C program using TenStream's own C-ABI (pprts_f2c_*), linked against libtsx_f2c.so, with the tables
+    found through $LUT_BASENAME like the reference does; its results equal the Python-driven pipeline on the same
+    inputs (which the tests above pin to the oracle) to float32 rounding."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "tenstream_amd", "lib")
+    base = str(tmp_path / "LUT")
+    lut.write_mmap4(base + "_diffuse_10.tau31.w020.aspect_zx23.g6.ds1000.nc.Sdiff.mmap4", lut.synthetic_diffuse_table("3_10"))
+    dax = lut.direct_axes()
+    Tdir, Sdir = lut.synthetic_direct_tables(dax)
+    dims = "tau{}.w0{}.aspect_zx{}.g{}.phi{}.theta{}".format(*[len(a) for a in dax])
+    tpath = f"{base}_direct_3_10.{dims}.ds1000.nc.Tdir.mmap4"
+    lut.write_mmap4(tpath, Tdir)
+    lut.write_mmap4(f"{base}_direct_3_10.{dims}.ds1000.nc.Sdir.mmap4", Sdir)
+    _write_axes_sidecar(tpath + ".axes", dax)
+    exe = str(tmp_path / "f2c_demo")
+    subprocess.run(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "f2c_demo.c"), "-o", exe,
+                    "-L", libdir, "-ltsx_f2c", "-ltsx", f"-Wl,-rpath,{libdir}"], check=True)
+    Nx, Ny, Nz, phi0, theta0 = 6, 5, 12, 200.0, 35.0
+    out = str(tmp_path / "out.bin")
+    env = dict(os.environ, LUT_BASENAME=base, TSX_LUT_DIRECT_DIMS=dims)
+    r = subprocess.run([exe, out, str(Nx), str(Ny), str(Nz), str(phi0), str(theta0)], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(out, dtype=np.float32)
+    nl, nc = (Nz + 1) * Nx * Ny, Nz * Nx * Ny
+    parts, o = [], 0
+    for n in (nl, nl, nc, nl, nl, nl, nc, nl):
+        parts.append(raw[o:o + n])
+        o += n
+    assert o == raw.size
+    # the same g-points through the Python host mirror (float32 inputs exactly as the C program builds them)
+    kabs = np.full((Ny, Nx, Nz), np.float32(1e-4), dtype=np.float32)
+    ksca = np.full((Ny, Nx, Nz), np.float32(1e-4), dtype=np.float32)
+    g = np.zeros((Ny, Nx, Nz), dtype=np.float32)
+    for j in range(Ny):
+        for i in range(Nx):
+            if (i + 2 * j) % 5 < 2:
+                ksca[j, i, Nz // 3:Nz // 2] = np.float32(2e-2)
+                kabs[j, i, Nz // 3:Nz // 2] = np.float32(1e-5)
+                g[j, i, Nz // 3:Nz // 2] = np.float32(0.85)
+    hhl = (np.float32(40.41) * (Nz - np.arange(Nz + 1)).astype(np.float32)).astype(np.float32)
+    dz1d = hhl[:-1].astype(np.float64) - hhl[1:].astype(np.float64)
+    P = PprtsSolver(Nz, Nx, Ny, 100.0, 100.0, np.float32(phi0), np.float32(theta0))
+    P.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
+    P.set_lut_direct(Tdir, Sdir, dax)
+    dz = np.broadcast_to(dz1d, (Ny, Nx, Nz))
+    P.set_optical_properties(float(np.float32(0.1)), kabs.astype(np.float64), ksca.astype(np.float64), g.astype(np.float64), dz)
+    P.solve(float(np.float32(1000.0)))
+    edn, eup, abso, edir = P.get_result()
+    for got, want in zip(parts[:4], (edn, eup, abso, edir)):
+        assert np.abs(got - want.ravel().astype(np.float32)).max() <= 2e-6 * np.abs(want).max() + 1e-30
+    planck = (3.0 + 2.0 * (np.arange(nl) % (Nz + 1)).astype(np.float32) / np.float32(Nz)).astype(np.float32).reshape(Ny, Nx, Nz + 1)
+    P2 = PprtsSolver(Nz, Nx, Ny, 100.0, 100.0, np.float32(phi0), np.float32(theta0))
+    P2.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
+    P2.set_optical_properties(float(np.float32(0.1)), kabs.astype(np.float64), ksca.astype(np.float64), g.astype(np.float64), dz,
+                              planck=planck.astype(np.float64))
+    P2.solve(0.0, lsolar=False)
+    edn, eup, abso, _ = P2.get_result()
+    # the C run warm-starts the thermal solve from the solar solution (same handle, src/pprts.F90:2542-2558): both stop
+    # at rtol 1e-5 from different guesses, so agreement is at solver tolerance here
+    for got, want in zip(parts[4:7], (edn, eup, abso)):
+        assert np.abs(got - want.ravel().astype(np.float32)).max() <= 3e-4 * np.abs(want).max()
+    assert np.all(parts[7] == 0)  # thermal: edir = 0
