@@ -56,7 +56,7 @@ enum { TSX_SOLVER_3_10 = 310, TSX_SOLVER_8_16 = 816 };
 
 /* preconditioners for the flexible BiCGStab (reference default: PCILU / PCBJACOBI+ILU(0),
  * src/pprts.F90:4350-4371, 4415-4425; here GPU-native equivalents) */
-enum { TSX_PC_NONE = 0, TSX_PC_COLUMN = 1 };
+enum { TSX_PC_NONE = 0, TSX_PC_COLUMN = 1, TSX_PC_ZEBRA = 2 };
 
 typedef struct tsx_solver tsx_solver; /* opaque */
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtsx.so")
 
 TSX_HOST, TSX_DEVICE = 0, 1
 TSX_SOLVER_3_10, TSX_SOLVER_8_16 = 310, 816
-TSX_PC_NONE, TSX_PC_COLUMN = 0, 1
+TSX_PC_NONE, TSX_PC_COLUMN, TSX_PC_ZEBRA = 0, 1, 2
 TSX_ERR_NO_DEVICE = 2
 
 

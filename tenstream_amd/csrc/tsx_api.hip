@@ -782,33 +782,46 @@ extern "C" int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int whe
 // ------------------------------------------------------------------------------------------------
 // z = M^-1 v with the column preconditioner; sweeps > 1 adds stationary refinement sweeps
 //   z <- z + M^-1 (v - A z)     (block-Jacobi iteration on column blocks)
-template <int NTOP, int NSIDE>
-static int pc_column_once(tsx_solver *s, const double *v, double *z, const int *done) {
+template <int NTOP, int NSIDE, int ROWS, bool GS>
+static int pc_column_launch(tsx_solver *s, const double *v, double *z, const int *done) {
   const TsxGeo &g = s->geo;
-  const int nb = (g.ncol + 63) / 64;
+  const int ncols = ROWS == 0 ? g.ncol : (ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2) * g.xm;
+  if (ncols == 0) return TSX_OK;
+  const int nb = (ncols + 63) / 64;
   if (s->coef_bytes == 4)
-    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float>), dim3(nb), dim3(64), 0, s->stream, g, (const float *)s->coef,
-                       s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
+    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS>), dim3(nb), dim3(64), 0, s->stream, g,
+                       (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
   else
-    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double>), dim3(nb), dim3(64), 0, s->stream, g, (const double *)s->coef,
-                       s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
+    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double, ROWS, GS>), dim3(nb), dim3(64), 0, s->stream, g,
+                       (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
 
+// z = M^-1 v.
+//  TSX_PC_COLUMN: block-Jacobi over columns; sweeps > 1 adds stationary refinement  z <- z + M^-1 (v - A z)
+//  TSX_PC_ZEBRA:  line Gauss-Seidel in y over the same column blocks: even rows, then odd rows with the even rows'
+//                 +-y streams on the right-hand side; sweeps = 2 adds a second pass over the even rows (symmetric)
 template <int NTOP, int NSIDE>
 static int apply_pc(tsx_solver *s, const double *v, double *z, bool in_solve) {
   const TsxGeo &g = s->geo;
   const int *done = in_solve ? &s->scal->done : nullptr;
   int rc;
-  if ((rc = pc_column_once<NTOP, NSIDE>(s, v, z, done))) return rc;
+  if (s->pc == TSX_PC_ZEBRA) {
+    if ((rc = pc_column_launch<NTOP, NSIDE, 1, false>(s, v, z, done))) return rc;
+    if ((rc = pc_column_launch<NTOP, NSIDE, 2, true>(s, v, z, done))) return rc;
+    if (s->pc_sweeps > 1)
+      if ((rc = pc_column_launch<NTOP, NSIDE, 1, true>(s, v, z, done))) return rc;
+    return TSX_OK;
+  }
+  if ((rc = pc_column_launch<NTOP, NSIDE, 0, false>(s, v, z, done))) return rc;
   const long long n2 = g.N / 2;
   const int nbv = grid_for(n2);
   for (int sw = 1; sw < s->pc_sweeps; ++sw) {
     if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, z, s->vt, nullptr, in_solve))) return rc;
     hipLaunchKernelGGL(tsx_k_sub, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)v, (const double2 *)s->vt,
                        (double2 *)s->vt, done);
-    if ((rc = pc_column_once<NTOP, NSIDE>(s, s->vt, s->vw, done))) return rc;
+    if ((rc = pc_column_launch<NTOP, NSIDE, 0, false>(s, s->vt, s->vw, done))) return rc;
     hipLaunchKernelGGL(tsx_k_addto, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)s->vw, (double2 *)z, done);
   }
   HIPCHK(hipGetLastError());
@@ -980,7 +993,7 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   if (opts) *o = *opts;
   else tsx_default_ksp_opts(o);
   ARGCHK(o->maxit >= 1, "solve: maxit < 1");
-  ARGCHK(o->pc == TSX_PC_NONE || o->pc == TSX_PC_COLUMN, "solve: unsupported preconditioner");
+  ARGCHK(o->pc == TSX_PC_NONE || o->pc == TSX_PC_COLUMN || o->pc == TSX_PC_ZEBRA, "solve: unsupported preconditioner");
   ARGCHK(o->pc_sweeps >= 1 && o->pc_sweeps <= 8, "solve: pc_sweeps out of range");
   HIPCHK(hipSetDevice(s->device));
   s->pc = o->pc;
@@ -1031,7 +1044,7 @@ static int pc_apply_t(tsx_solver *s, const double *v, double *z, int where) {
 
 extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps) {
   ARGCHK(s && v && z, "tsx_diff_pc_apply: null argument");
-  ARGCHK(pc == TSX_PC_COLUMN && pc_sweeps >= 1 && pc_sweeps <= 8, "tsx_diff_pc_apply: bad preconditioner");
+  ARGCHK((pc == TSX_PC_COLUMN || pc == TSX_PC_ZEBRA) && pc_sweeps >= 1 && pc_sweeps <= 8, "tsx_diff_pc_apply: bad preconditioner");
   if (!s->have_coeffs) {
     tsx_set_error("tsx_diff_pc_apply: call tsx_diff_set_coeffs first");
     return TSX_ERR_STATE;

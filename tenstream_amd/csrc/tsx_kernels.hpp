@@ -436,7 +436,10 @@ struct TsxSm {  // tiny dense helpers, fully unrolled
 template <int NTOP>
 __host__ __device__ constexpr int tsx_pc_ntmp() { return (NTOP / 2) * 2 * ((NTOP / 2) + 1); }
 
-template <int NTOP, int NSIDE, typename CT>
+// ROWS: 0 = every row; 1 / 2 = only rows with even / odd j (zebra line ordering).  GS: the right-hand side is
+// r + N_y z, the contribution of the +-y side streams of the neighbouring rows held in z (line Gauss-Seidel in y:
+// rows of one colour only see rows of the other colour, so all columns of a pass stay independent).
+template <int NTOP, int NSIDE, typename CT, int ROWS, bool GS>
 __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
                                                       const double *__restrict__ a11, const double *__restrict__ a12,
                                                       const double *__restrict__ albedo, const double *__restrict__ r,
@@ -446,10 +449,23 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
   constexpr int H = NTOP / 2;
   using SM = TsxSm<H>;
   if (done && *done) return;
-  const int col = blockIdx.x * 64 + threadIdx.x;
+  int col = blockIdx.x * 64 + threadIdx.x;
+  if (ROWS) {  // enumerate only the rows of this colour
+    const int nrows = ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2;
+    if (col >= nrows * g.xm) return;
+    col = (2 * (col / g.xm) + (ROWS - 1)) * g.xm + col % g.xm;
+  }
   if (col >= g.ncol) return;
   const long long Nc = g.Nc;
   const int Nz = g.Nz, ncol = g.ncol;
+  // neighbour rows for the y coupling (periodic wrap inside the rank; rank edges are block-Jacobi)
+  // (with an odd number of rows the two rows meeting at the periodic seam have the same colour: no coupling there)
+  const int jrow = col / g.xm;
+  const bool seam = g.wrap_y && (g.ym % 2 == 0);
+  const long long offN = (jrow + 1 < g.ym) ? (long long)g.xm : (seam ? -(long long)(g.ym - 1) * g.xm : 0);
+  const long long offS = (jrow > 0) ? -(long long)g.xm : (seam ? (long long)(g.ym - 1) * g.xm : 0);
+  (void)offN;
+  (void)offS;
   const double *__restrict__ rt = r + (size_t)D * Nc;
   double *__restrict__ zt = z + (size_t)D * Nc;
   double *__restrict__ tGw = tmp, *__restrict__ tGT = tmp + (size_t)H * Nc, *__restrict__ tA = tmp + (size_t)(H + H * H) * Nc,
@@ -493,6 +509,19 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
     for (int a = 0; a < H; ++a) {
       ru[a] = r[(size_t)(2 * a) * Nc + c];
       rd[a] = r[(size_t)(2 * a + 1) * Nc + c];
+    }
+    if (GS && !l1d[k]) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) {
+        const int sd = NTOP + NSIDE + q;
+        const long long off = tsx_inward(q) ? offS : offN;
+        const double zv = off ? z[(size_t)sd * Nc + c + off] : 0.0;
+#pragma unroll
+        for (int a = 0; a < H; ++a) {
+          ru[a] += (double)C[(size_t)((2 * a) * D + sd) * Nc + c] * zv;
+          rd[a] += (double)C[(size_t)((2 * a + 1) * D + sd) * Nc + c] * zv;
+        }
+      }
     }
     double RA[H][H], G[H][H], GT[H][H], w[H], Gw[H], AGw[H], TA[H][H], An[H][H], Bn[H];
     SM::matmul(Rdu, A, RA);
@@ -584,6 +613,14 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
 #pragma unroll
       for (int d = NTOP; d < D; ++d) z[(size_t)d * Nc + c] = r[(size_t)d * Nc + c];
     } else {
+      double zy[NSIDE];
+      if (GS) {
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) {
+          const long long off = tsx_inward(q) ? offS : offN;
+          zy[q] = off ? z[(size_t)(NTOP + NSIDE + q) * Nc + c + off] : 0.0;
+        }
+      }
 #pragma unroll
       for (int d = NTOP; d < D; ++d) {
         double acc = r[(size_t)d * Nc + c];
@@ -591,6 +628,10 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
         for (int a = 0; a < H; ++a) {
           acc += (double)C[(size_t)(d * D + 2 * a) * Nc + c] * Un[a];
           acc += (double)C[(size_t)(d * D + 2 * a + 1) * Nc + c] * V[a];
+        }
+        if (GS) {
+#pragma unroll
+          for (int q = 0; q < NSIDE; ++q) acc += (double)C[(size_t)(d * D + NTOP + NSIDE + q) * Nc + c] * zy[q];
         }
         z[(size_t)d * Nc + c] = acc;
       }
