@@ -382,37 +382,11 @@ static void launch_spmv_variant(tsx_solver *s, const double *x, double *y, const
                      w, s->partials, done);
 }
 
-// TSX_SPMV_MARCH=0 disables the marching kernel (A/B knob)
-static bool spmv_use_march(const tsx_solver *s) {
-  static int env = -1;
-  if (env < 0) {
-    const char *e = getenv("TSX_SPMV_MARCH");
-    env = e ? atoi(e) : 1;
-  }
-  return env != 0 && s->geo.ntop == 2 && (s->geo.xm % 2) == 0;
-}
-static int spmv_march_nblocks(const tsx_solver *s) {
-  const TsxGeo &g = s->geo;
-  const long long nt = (long long)((g.xm + 127) / 128) * ((g.ym + 3) / 4) * ((g.Nz + TSX_MARCH_KC - 1) / TSX_MARCH_KC);
-  return (int)(nt < TSX_MAX_PARTIAL_BLOCKS ? nt : TSX_MAX_PARTIAL_BLOCKS);
-}
-
 template <int NTOP, int NSIDE, int FUSE>
 static int launch_spmv(tsx_solver *s, const double *x, double *y, const double *w, bool in_solve) {
   int rc = halo_update<NTOP, NSIDE>(s, x, in_solve);
   if (rc) return rc;
   const int *done = in_solve ? &s->scal->done : nullptr;
-  if (NTOP == 2 && spmv_use_march(s)) {
-    const int nb = spmv_march_nblocks(s);
-    if (s->coef_bytes == 4)
-      hipLaunchKernelGGL((tsx_k_spmv_march<float, FUSE>), dim3(nb), dim3(256), 0, s->stream, s->geo, (const float *)s->coef,
-                         s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS, s->recvN, w, s->partials, done);
-    else
-      hipLaunchKernelGGL((tsx_k_spmv_march<double, FUSE>), dim3(nb), dim3(256), 0, s->stream, s->geo, (const double *)s->coef,
-                         s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS, s->recvN, w, s->partials, done);
-    HIPCHK(hipGetLastError());
-    return TSX_OK;
-  }
   const int cpt = spmv_cpt(s);
   if (s->coef_bytes == 4) {
     if (cpt == 4) launch_spmv_variant<NTOP, NSIDE, FUSE, float, 4>(s, x, y, w, done);
@@ -426,9 +400,7 @@ static int launch_spmv(tsx_solver *s, const double *x, double *y, const double *
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
-static inline int spmv_nblocks(const tsx_solver *s) {
-  return spmv_use_march(s) ? spmv_march_nblocks(s) : grid_for(s->geo.Nc / spmv_cpt(s), TSX_MAX_PARTIAL_BLOCKS);
-}
+static inline int spmv_nblocks(const tsx_solver *s) { return grid_for(s->geo.Nc / spmv_cpt(s), TSX_MAX_PARTIAL_BLOCKS); }
 
 // reduce partials -> (all-reduce) -> scalar algebra
 static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {

@@ -363,202 +363,6 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Marching variant of the operator (3_10): every vector element is fetched from HBM once.
-//   block = 4 waves = 4 consecutive rows (j) x 128 columns (64 lanes x 2 cells), marching over KC levels.
-//   * +-z neighbours (Edn from the cell above, Eup from the cell below) are the thread's own values of the
-//     previous / next step -> registers (the next step's planes are loaded one step ahead = software prefetch);
-//   * +-x neighbours come from the adjacent lane (__shfl) or the thread's second cell; only the two lanes at the
-//     ends of the 128-column segment load from memory;
-//   * +-y neighbours come from the adjacent wave through LDS (double-buffered, one barrier per level); only the
-//     first / last row of the tile loads its outer neighbour row from memory.
-// HBM traffic per cell: 400 B coefficients + 80 B x + 80 B y + ~12 B halo rows / chunk ends (was + 80 B re-read).
-#define TSX_MARCH_KC 8
-template <typename CT, int FUSE>
-__global__ __launch_bounds__(256) void tsx_k_spmv_march(
-    TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
-    const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ x,
-    double *__restrict__ y, const double *__restrict__ hW, const double *__restrict__ hE,
-    const double *__restrict__ hS, const double *__restrict__ hN, const double *__restrict__ w,
-    double *__restrict__ partials, const int *__restrict__ done) {
-  constexpr int NTOP = 2, NSIDE = 4, D = 10, KC = TSX_MARCH_KC;
-  __shared__ double lds[2][4][4][128];  // [buffer][y-side stream][row][column]
-  if (done && *done) return;
-  double sum[3] = {0.0, 0.0, 0.0};
-  const long long Nc = g.Nc;
-  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
-  const int ntx = (xm + 127) / 128, nty = (ym + 3) / 4, ntk = (Nz + KC - 1) / KC;
-  const long long ntiles = (long long)ntx * nty * ntk;
-  const double *__restrict__ xt = x + (size_t)D * Nc;
-  double *__restrict__ yt = y + (size_t)D * Nc;
-  const double *__restrict__ wt = (FUSE & 1) ? w + (size_t)D * Nc : nullptr;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-
-  for (long long base = 0; base < ntiles; base += gridDim.x) {
-    const long long nb = (ntiles - base) < (long long)gridDim.x ? (ntiles - base) : (long long)gridDim.x;
-    if ((long long)blockIdx.x >= nb) break;
-    const long long tile = base + tsx_swizzle(blockIdx.x, nb);
-    const int tx = (int)(tile % ntx);
-    const int ty = (int)((tile / ntx) % nty);
-    const int tk = (int)(tile / ((long long)ntx * nty));
-    const int i0 = tx * 128, j0 = ty * 4, k0 = tk * KC;
-    const int k1 = k0 + KC < Nz ? k0 + KC : Nz;
-    const int iend = i0 + 128 < xm ? i0 + 128 : xm;  // one past the last column of the segment
-    const int jend = j0 + 4 < ym ? j0 + 4 : ym;
-    const int i = i0 + 2 * lane, j = j0 + wv;
-    const bool valid = i < xm && j < ym;  // xm is even: a valid thread owns two valid cells
-    const bool edgeW = valid && lane == 0, edgeE = valid && i + 2 >= iend;
-    const bool rowS = j == j0, rowN = j == jend - 1;
-    const size_t col = valid ? (size_t)j * xm + i : 0;
-
-    double cur[D][2], nxt[D][2], prevdn[2];
-    if (valid) {
-      const size_t c = (size_t)k0 * ncol + col;
-#pragma unroll
-      for (int d = 0; d < D; ++d) TsxVec<2>::ld(x + (size_t)d * Nc + c, cur[d]);
-      if (k0 > 0) TsxVec<2>::ld(x + (size_t)1 * Nc + c - ncol, prevdn);
-      else TsxVec<2>::ld(xt + (size_t)1 * ncol + col, prevdn);
-    }
-    for (int k = k0; k < k1; ++k) {
-      const size_t c = (size_t)k * ncol + col;
-      const int buf = (k - k0) & 1;
-      // ---- prefetch the next level's own values (only Eup is needed from beyond the chunk)
-      if (valid) {
-        if (k + 1 < k1) {
-#pragma unroll
-          for (int d = 0; d < D; ++d) TsxVec<2>::ld(x + (size_t)d * Nc + c + ncol, nxt[d]);
-        } else if (k + 1 < Nz) {
-          TsxVec<2>::ld(x + c + ncol, nxt[0]);
-        } else {
-          TsxVec<2>::ld(xt + col, nxt[0]);
-        }
-        // publish my y-side streams for the neighbouring rows
-#pragma unroll
-        for (int q = 0; q < NSIDE; ++q) {
-          lds[buf][q][wv][2 * lane] = cur[NTOP + NSIDE + q][0];
-          lds[buf][q][wv][2 * lane + 1] = cur[NTOP + NSIDE + q][1];
-        }
-      }
-      __syncthreads();
-      if (valid) {
-        double xs[D][2];
-        xs[0][0] = nxt[0][0];  // Eup enters from the level below
-        xs[0][1] = nxt[0][1];
-        xs[1][0] = prevdn[0];  // Edn enters from the level above
-        xs[1][1] = prevdn[1];
-#pragma unroll
-        for (int q = 0; q < NSIDE; ++q) {
-          const int d = NTOP + q, slot = q >> 1;
-          if (tsx_inward(q)) {  // from the cell to the west
-            double e = __shfl_up(cur[d][1], 1, 64);
-            if (edgeW) {
-              if (i > 0) e = x[(size_t)d * Nc + c - 1];
-              else if (g.wrap_x) e = x[(size_t)d * Nc + c + (xm - 1)];
-              else e = hW[((size_t)slot * Nz + k) * ym + j];
-            }
-            xs[d][0] = e;
-            xs[d][1] = cur[d][0];
-          } else {  // from the cell to the east
-            double e = __shfl_down(cur[d][0], 1, 64);
-            if (edgeE) {
-              if (i + 2 < xm) e = x[(size_t)d * Nc + c + 2];
-              else if (g.wrap_x) e = x[(size_t)d * Nc + c + 2 - xm];
-              else e = hE[((size_t)slot * Nz + k) * ym + j];
-            }
-            xs[d][0] = cur[d][1];
-            xs[d][1] = e;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < NSIDE; ++q) {
-          const int d = NTOP + NSIDE + q, slot = q >> 1;
-          if (tsx_inward(q)) {  // from the row to the south
-            if (!rowS) {
-              xs[d][0] = lds[buf][q][wv - 1][2 * lane];
-              xs[d][1] = lds[buf][q][wv - 1][2 * lane + 1];
-            } else if (j > 0) TsxVec<2>::ld(x + (size_t)d * Nc + c - xm, xs[d]);
-            else if (g.wrap_y) TsxVec<2>::ld(x + (size_t)d * Nc + c + (size_t)(ym - 1) * xm, xs[d]);
-            else TsxVec<2>::ld(hS + ((size_t)slot * Nz + k) * xm + i, xs[d]);
-          } else {  // from the row to the north
-            if (!rowN) {
-              xs[d][0] = lds[buf][q][wv + 1][2 * lane];
-              xs[d][1] = lds[buf][q][wv + 1][2 * lane + 1];
-            } else if (j < ym - 1) TsxVec<2>::ld(x + (size_t)d * Nc + c + xm, xs[d]);
-            else if (g.wrap_y) TsxVec<2>::ld(x + (size_t)d * Nc + c - (size_t)(ym - 1) * xm, xs[d]);
-            else TsxVec<2>::ld(hN + ((size_t)slot * Nz + k) * xm + i, xs[d]);
-          }
-        }
-        const bool is1d = l1d[k] != 0;
-        double t11[2], t12[2];
-        if (is1d) {
-          TsxVec<2>::ld(a11 + c, t11);
-          TsxVec<2>::ld(a12 + c, t12);
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          double acc[2];
-          if (is1d) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-              acc[m] = d < NTOP ? cur[d][m] - t11[m] * xs[d][m] - t12[m] * xs[d < NTOP ? (d ^ 1) : d][m] : cur[d][m];
-          } else {
-            acc[0] = 0.0;
-            acc[1] = 0.0;
-#pragma unroll
-            for (int s = 0; s < D; ++s) {
-              double cf[2];
-              TsxVec<2>::ld(C + (size_t)(d * D + s) * Nc + c, cf);
-              acc[0] += cf[0] * xs[s][0];
-              acc[1] += cf[1] * xs[s][1];
-            }
-            acc[0] = cur[d][0] - acc[0];
-            acc[1] = cur[d][1] - acc[1];
-          }
-          TsxVec<2>::st(y + (size_t)d * Nc + c, acc);
-          if (FUSE & 1) {
-            double wv2[2];
-            TsxVec<2>::ld(w + (size_t)d * Nc + c, wv2);
-            sum[0] += wv2[0] * acc[0] + wv2[1] * acc[1];
-          }
-          if (FUSE & 2) sum[1] += cur[d][0] * acc[0] + cur[d][1] * acc[1];
-          if (FUSE & 4) sum[2] += acc[0] * acc[0] + acc[1] * acc[1];
-        }
-        if (k == Nz - 1) {  // tail rows of these two columns
-          double alb[2];
-          TsxVec<2>::ld(albedo + col, alb);
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            double xv[2], yv[2];
-            TsxVec<2>::ld(xt + (size_t)d * ncol + col, xv);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) yv[m] = d == 0 ? xv[m] - alb[m] * cur[1][m] : xv[m];
-            TsxVec<2>::st(yt + (size_t)d * ncol + col, yv);
-            if (FUSE & 1) {
-              double wv2[2];
-              TsxVec<2>::ld(wt + (size_t)d * ncol + col, wv2);
-              sum[0] += wv2[0] * yv[0] + wv2[1] * yv[1];
-            }
-            if (FUSE & 2) sum[1] += xv[0] * yv[0] + xv[1] * yv[1];
-            if (FUSE & 4) sum[2] += yv[0] * yv[0] + yv[1] * yv[1];
-          }
-        }
-        // rotate
-        prevdn[0] = cur[1][0];
-        prevdn[1] = cur[1][1];
-        if (k + 1 < k1) {
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            cur[d][0] = nxt[d][0];
-            cur[d][1] = nxt[d][1];
-          }
-        }
-      }
-    }
-    __syncthreads();  // the LDS buffers are reused by the next tile
-  }
-  if (FUSE) tsx_block_reduce_store<3>(sum, partials);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Column preconditioner  z = M^-1 r,  M = the column-diagonal blocks of A in dst-owned storage.
 // Inside one column only the top streams couple vertically (a cell's in-column sources are Eup(k+1) and
 // Edn(k)); the side streams leaving the column depend on those but nothing in the column depends on them.
