@@ -83,6 +83,8 @@ typedef struct {
   int32_t pc;                 /* TSX_PC_* */
   int32_t pc_sweeps;          /* sweeps of the preconditioner per application (>=1) */
   int32_t check_every;        /* host looks at the device convergence flag every n iterations */
+  int32_t fp32_directions;    /* 1 (default): preconditioned directions p-hat/s-hat and the shadow residual are stored in
+                                 fp32 -- flexible BiCGStab accepts any direction; x, r, p, s, v, t stay fp64.  0: all fp64 */
 } tsx_ksp_opts;
 
 /* what `solve` stores on the solution: Niter_diff, diff_ksp_residual_history(100)

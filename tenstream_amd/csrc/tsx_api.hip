@@ -10,6 +10,7 @@
 
 #include <mutex>
 #include <string>
+#include <type_traits>
 
 #include <stdlib.h>
 
@@ -161,6 +162,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->pc = TSX_PC_NONE;
   o->pc_sweeps = 1;
   o->check_every = 4;
+  o->fp32_directions = 1;
 }
 
 extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstrained_fraction, double *rtol,
@@ -351,12 +353,12 @@ static int face_exchange(tsx_solver *s) {
   return TSX_OK;
 }
 
-template <int NTOP, int NSIDE>
-static int halo_update(tsx_solver *s, const double *v, bool in_solve) {
+template <int NTOP, int NSIDE, typename XT = double>
+static int halo_update(tsx_solver *s, const XT *v, bool in_solve) {
   const TsxGeo &g = s->geo;
   if (g.wrap_x && g.wrap_y) return TSX_OK;
   const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
-  hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, v, s->sendW,
+  hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE, XT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, v, s->sendW,
                      s->sendE, s->sendS, s->sendN, in_solve ? &s->scal->done : (const int *)nullptr);
   return face_exchange(s);
 }
@@ -373,29 +375,29 @@ static int spmv_cpt(const tsx_solver *s) {
   return want;
 }
 
-template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT>
-static void launch_spmv_variant(tsx_solver *s, const double *x, double *y, const double *w, const int *done) {
+template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT>
+static void launch_spmv_variant(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done) {
   const TsxGeo &g = s->geo;
   const int nb = grid_for(g.Nc / CPT, TSX_MAX_PARTIAL_BLOCKS);
-  hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
+  hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT, XT, WT>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
                      (const CT *)s->coef, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS, s->recvN,
                      w, s->partials, done);
 }
 
-template <int NTOP, int NSIDE, int FUSE>
-static int launch_spmv(tsx_solver *s, const double *x, double *y, const double *w, bool in_solve) {
-  int rc = halo_update<NTOP, NSIDE>(s, x, in_solve);
+template <int NTOP, int NSIDE, int FUSE, typename XT = double, typename WT = double>
+static int launch_spmv(tsx_solver *s, const XT *x, double *y, const WT *w, bool in_solve) {
+  int rc = halo_update<NTOP, NSIDE, XT>(s, x, in_solve);
   if (rc) return rc;
   const int *done = in_solve ? &s->scal->done : nullptr;
   const int cpt = spmv_cpt(s);
   if (s->coef_bytes == 4) {
-    if (cpt == 4) launch_spmv_variant<NTOP, NSIDE, FUSE, float, 4>(s, x, y, w, done);
-    else if (cpt == 2) launch_spmv_variant<NTOP, NSIDE, FUSE, float, 2>(s, x, y, w, done);
-    else launch_spmv_variant<NTOP, NSIDE, FUSE, float, 1>(s, x, y, w, done);
+    if (cpt == 4) launch_spmv_variant<NTOP, NSIDE, FUSE, float, 4, XT, WT>(s, x, y, w, done);
+    else if (cpt == 2) launch_spmv_variant<NTOP, NSIDE, FUSE, float, 2, XT, WT>(s, x, y, w, done);
+    else launch_spmv_variant<NTOP, NSIDE, FUSE, float, 1, XT, WT>(s, x, y, w, done);
   } else {
-    if (cpt == 4) launch_spmv_variant<NTOP, NSIDE, FUSE, double, 4>(s, x, y, w, done);
-    else if (cpt == 2) launch_spmv_variant<NTOP, NSIDE, FUSE, double, 2>(s, x, y, w, done);
-    else launch_spmv_variant<NTOP, NSIDE, FUSE, double, 1>(s, x, y, w, done);
+    if (cpt == 4) launch_spmv_variant<NTOP, NSIDE, FUSE, double, 4, XT, WT>(s, x, y, w, done);
+    else if (cpt == 2) launch_spmv_variant<NTOP, NSIDE, FUSE, double, 2, XT, WT>(s, x, y, w, done);
+    else launch_spmv_variant<NTOP, NSIDE, FUSE, double, 1, XT, WT>(s, x, y, w, done);
   }
   HIPCHK(hipGetLastError());
   return TSX_OK;
@@ -762,7 +764,7 @@ static int diff_apply_t(tsx_solver *s, const double *x, double *y, int where) {
     yd = s->stage_b;
   }
   if ((rc = import_vec<NTOP, NSIDE>(s, xd, s->vp))) return rc;
-  if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, s->vp, s->vv, nullptr, false))) return rc;
+  if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vp, s->vv, (const double *)nullptr, false))) return rc;
   if ((rc = export_vec<NTOP, NSIDE>(s, s->vv, yd))) return rc;
   if (where == TSX_HOST) HIPCHK(hipMemcpyAsync(y, s->stage_b, nb, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
@@ -782,47 +784,50 @@ extern "C" int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int whe
 // ------------------------------------------------------------------------------------------------
 // z = M^-1 v with the column preconditioner; sweeps > 1 adds stationary refinement sweeps
 //   z <- z + M^-1 (v - A z)     (block-Jacobi iteration on column blocks)
-template <int NTOP, int NSIDE, int ROWS, bool GS>
-static int pc_column_launch(tsx_solver *s, const double *v, double *z, const int *done) {
+template <int NTOP, int NSIDE, int ROWS, bool GS, typename ZT>
+static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const int *done) {
   const TsxGeo &g = s->geo;
   const int ncols = ROWS == 0 ? g.ncol : (ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2) * g.xm;
   if (ncols == 0) return TSX_OK;
   const int nb = (ncols + 63) / 64;
   if (s->coef_bytes == 4)
-    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS>), dim3(nb), dim3(64), 0, s->stream, g,
+    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
                        (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
   else
-    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double, ROWS, GS>), dim3(nb), dim3(64), 0, s->stream, g,
+    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
                        (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
 
 // z = M^-1 v.
-//  TSX_PC_COLUMN: block-Jacobi over columns; sweeps > 1 adds stationary refinement  z <- z + M^-1 (v - A z)
+//  TSX_PC_COLUMN: block-Jacobi over columns; sweeps > 1 adds stationary refinement  z <- z + M^-1 (v - A z)  (fp64 only)
 //  TSX_PC_ZEBRA:  line Gauss-Seidel in y over the same column blocks: even rows, then odd rows with the even rows'
 //                 +-y streams on the right-hand side; sweeps = 2 adds a second pass over the even rows (symmetric)
-template <int NTOP, int NSIDE>
-static int apply_pc(tsx_solver *s, const double *v, double *z, bool in_solve) {
+// ZT = float stores the preconditioned direction in fp32 (legitimate in *flexible* BiCGStab, see tsx_k_spmv_w).
+template <int NTOP, int NSIDE, typename ZT>
+static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
   const TsxGeo &g = s->geo;
   const int *done = in_solve ? &s->scal->done : nullptr;
   int rc;
   if (s->pc == TSX_PC_ZEBRA) {
-    if ((rc = pc_column_launch<NTOP, NSIDE, 1, false>(s, v, z, done))) return rc;
-    if ((rc = pc_column_launch<NTOP, NSIDE, 2, true>(s, v, z, done))) return rc;
+    if ((rc = pc_column_launch<NTOP, NSIDE, 1, false, ZT>(s, v, z, done))) return rc;
+    if ((rc = pc_column_launch<NTOP, NSIDE, 2, true, ZT>(s, v, z, done))) return rc;
     if (s->pc_sweeps > 1)
-      if ((rc = pc_column_launch<NTOP, NSIDE, 1, true>(s, v, z, done))) return rc;
+      if ((rc = pc_column_launch<NTOP, NSIDE, 1, true, ZT>(s, v, z, done))) return rc;
     return TSX_OK;
   }
-  if ((rc = pc_column_launch<NTOP, NSIDE, 0, false>(s, v, z, done))) return rc;
-  const long long n2 = g.N / 2;
-  const int nbv = grid_for(n2);
-  for (int sw = 1; sw < s->pc_sweeps; ++sw) {
-    if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, z, s->vt, nullptr, in_solve))) return rc;
-    hipLaunchKernelGGL(tsx_k_sub, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)v, (const double2 *)s->vt,
-                       (double2 *)s->vt, done);
-    if ((rc = pc_column_launch<NTOP, NSIDE, 0, false>(s, s->vt, s->vw, done))) return rc;
-    hipLaunchKernelGGL(tsx_k_addto, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)s->vw, (double2 *)z, done);
+  if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, ZT>(s, v, z, done))) return rc;
+  if constexpr (std::is_same<ZT, double>::value) {
+    const long long n2 = g.N / 2;
+    const int nbv = grid_for(n2);
+    for (int sw = 1; sw < s->pc_sweeps; ++sw) {
+      if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)z, s->vt, (const double *)nullptr, in_solve))) return rc;
+      hipLaunchKernelGGL(tsx_k_sub, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)v, (const double2 *)s->vt,
+                         (double2 *)s->vt, done);
+      if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, double>(s, s->vt, s->vw, done))) return rc;
+      hipLaunchKernelGGL(tsx_k_addto, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)s->vw, (double2 *)z, done);
+    }
   }
   HIPCHK(hipGetLastError());
   return TSX_OK;
@@ -833,15 +838,19 @@ static int ensure_pc_buffers(tsx_solver *s) {
   const TsxGeo &g = s->geo;
   const size_t nb = (size_t)g.N * sizeof(double);
   if (!s->pc_tmp) HIPCHK(hipMalloc((void **)&s->pc_tmp, sizeof(double) * (size_t)tsx_pc_ntmp<NTOP>() * g.Nc));
-  if (s->vph == s->vp || !s->vph) HIPCHK(hipMalloc((void **)&s->vph, nb));
+  if (s->vph == s->vp || !s->vph) HIPCHK(hipMalloc((void **)&s->vph, nb));  // fp64-sized: also holds the fp32 form
   if (s->vsh == s->vs || !s->vsh) HIPCHK(hipMalloc((void **)&s->vsh, nb));
   if (!s->vw) HIPCHK(hipMalloc((void **)&s->vw, nb));
   return TSX_OK;
 }
 
 // One BiCGStab iteration on the stream (no host synchronisation).
-template <int NTOP, int NSIDE>
-static int enqueue_iteration(tsx_solver *s, bool first) {
+// One BiCGStab iteration on the stream (no host synchronisation).  MIX: preconditioned directions and the shadow
+// residual live in fp32 (s->mixed); x, r, p, s, v, t stay fp64.
+template <int NTOP, int NSIDE, bool MIX>
+static int enqueue_iteration_t(tsx_solver *s, bool first) {
+  using PT = typename std::conditional<MIX, float, double>::type;  // directions
+  using RT = PT;                                                    // shadow residual
   const TsxGeo &g = s->geo;
   const long long n2 = g.N / 2;
   const int nbv = grid_for(n2);
@@ -850,27 +859,37 @@ static int enqueue_iteration(tsx_solver *s, bool first) {
     hipLaunchKernelGGL(tsx_k_pupdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
                        (double2 *)s->vp, (const double2 *)s->vv);
   }
-  const double *ph = s->vp, *sh = s->vs;
+  const RT *rhat = (const RT *)s->vrhat;
   if (s->pc != TSX_PC_NONE) {
-    if ((rc = apply_pc<NTOP, NSIDE>(s, s->vp, s->vph, true))) return rc;
-    ph = s->vph;
+    PT *ph = (PT *)s->vph, *sh = (PT *)s->vsh;
+    if ((rc = apply_pc<NTOP, NSIDE, PT>(s, s->vp, ph, true))) return rc;
+    if ((rc = launch_spmv<NTOP, NSIDE, 1, PT, RT>(s, ph, s->vv, rhat, true))) return rc;
+    if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
+    hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
+                       (const double2 *)s->vv, (double2 *)s->vs);
+    if ((rc = apply_pc<NTOP, NSIDE, PT>(s, s->vs, sh, true))) return rc;
+    if ((rc = launch_spmv<NTOP, NSIDE, 5, PT, double>(s, sh, s->vt, s->vs, true))) return rc;
+    if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
+    hipLaunchKernelGGL((tsx_k_xrupdate<PT, RT>), dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (double2 *)s->vx, ph, sh,
+                       (const double2 *)s->vs, (const double2 *)s->vt, rhat, (double2 *)s->vr, s->partials);
+  } else {
+    if ((rc = launch_spmv<NTOP, NSIDE, 1, double, RT>(s, s->vp, s->vv, rhat, true))) return rc;
+    if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
+    hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
+                       (const double2 *)s->vv, (double2 *)s->vs);
+    if ((rc = launch_spmv<NTOP, NSIDE, 5, double, double>(s, s->vs, s->vt, s->vs, true))) return rc;
+    if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
+    hipLaunchKernelGGL((tsx_k_xrupdate<double, RT>), dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (double2 *)s->vx,
+                       (const double *)s->vp, (const double *)s->vs, (const double2 *)s->vs, (const double2 *)s->vt, rhat,
+                       (double2 *)s->vr, s->partials);
   }
-  if ((rc = launch_spmv<NTOP, NSIDE, 1>(s, ph, s->vv, s->vrhat, true))) return rc;
-  if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
-  hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
-                     (const double2 *)s->vv, (double2 *)s->vs);
-  if (s->pc != TSX_PC_NONE) {
-    if ((rc = apply_pc<NTOP, NSIDE>(s, s->vs, s->vsh, true))) return rc;
-    sh = s->vsh;
-  }
-  if ((rc = launch_spmv<NTOP, NSIDE, 5>(s, sh, s->vt, s->vs, true))) return rc;
-  if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
-  hipLaunchKernelGGL(tsx_k_xrupdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (double2 *)s->vx,
-                     (const double2 *)ph, (const double2 *)sh, (const double2 *)s->vs, (const double2 *)s->vt,
-                     (const double2 *)s->vrhat, (double2 *)s->vr, s->partials);
   if ((rc = scalar_stage(s, nbv, 2, TSX_STAGE_RHO))) return rc;
   HIPCHK(hipGetLastError());
   return TSX_OK;
+}
+template <int NTOP, int NSIDE>
+static int enqueue_iteration(tsx_solver *s, bool first) {
+  return s->mixed ? enqueue_iteration_t<NTOP, NSIDE, true>(s, first) : enqueue_iteration_t<NTOP, NSIDE, false>(s, first);
 }
 
 template <int NTOP, int NSIDE>
@@ -892,10 +911,14 @@ static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o, bool restart = fal
   }
   HIPCHK(hipMemcpyAsync(s->scal, s->scal_host, sizeof(TsxScalars), hipMemcpyHostToDevice, s->stream));
   // r = b - A x0 (nonzero initial guess, src/pprts.F90:4343); rhat = p = r
-  if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, s->vx, s->vt, nullptr, false))) return rc;
+  if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vx, s->vt, (const double *)nullptr, false))) return rc;
   const int nbv = grid_for(g.N);
-  hipLaunchKernelGGL(tsx_k_residual0, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr, s->vrhat,
-                     s->vp, s->partials);
+  if (s->mixed)
+    hipLaunchKernelGGL(tsx_k_residual0<float>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr,
+                       (float *)s->vrhat, s->vp, s->partials);
+  else
+    hipLaunchKernelGGL(tsx_k_residual0<double>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr, s->vrhat,
+                       s->vp, s->partials);
   if ((rc = scalar_stage(s, nbv, 1, TSX_STAGE_INIT))) return rc;
   return TSX_OK;
 }
@@ -998,6 +1021,8 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   HIPCHK(hipSetDevice(s->device));
   s->pc = o->pc;
   s->pc_sweeps = o->pc_sweeps;
+  // fp32 directions: default on; the multi-sweep Jacobi refinement works on fp64 directions only
+  s->mixed = o->fp32_directions != 0 && !(o->pc == TSX_PC_COLUMN && o->pc_sweeps > 1);
   if (o->pc != TSX_PC_NONE) {
     int rc = s->geo.ntop == 2 ? ensure_pc_buffers<2>(s) : ensure_pc_buffers<8>(s);
     if (rc) return rc;
@@ -1035,7 +1060,7 @@ static int pc_apply_t(tsx_solver *s, const double *v, double *z, int where) {
     zd = s->stage_b;
   }
   if ((rc = import_vec<NTOP, NSIDE>(s, vd, s->vp))) return rc;
-  if ((rc = apply_pc<NTOP, NSIDE>(s, s->vp, s->vph, false))) return rc;
+  if ((rc = apply_pc<NTOP, NSIDE, double>(s, s->vp, s->vph, false))) return rc;
   if ((rc = export_vec<NTOP, NSIDE>(s, s->vph, zd))) return rc;
   if (where == TSX_HOST) HIPCHK(hipMemcpyAsync(z, s->stage_b, nb, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
@@ -1077,10 +1102,10 @@ template <int NTOP, int NSIDE>
 static int bench_kernel_t(tsx_solver *s, int kernel, int reps, float *avg_ms) {
   int rc;
   if (kernel == 0) {
-    if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, s->vp, s->vv, nullptr, false))) return rc;  // warm
+    if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vp, s->vv, (const double *)nullptr, false))) return rc;  // warm
     HIPCHK(hipEventRecord(s->ev0, s->stream));
     for (int q = 0; q < reps; ++q)
-      if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, s->vp, s->vv, nullptr, false))) return rc;
+      if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vp, s->vv, (const double *)nullptr, false))) return rc;
     HIPCHK(hipEventRecord(s->ev1, s->stream));
   } else {
     // iterations on whatever state the vectors hold; scalars are neutralised so nothing diverges/stops

@@ -79,6 +79,7 @@ struct tsx_solver {
   double *vw;          // work vector of the multi-sweep preconditioner
   double *pc_tmp;      // column preconditioner: tsx_pc_ntmp planes of Nc doubles
   int pc, pc_sweeps;   // active preconditioner of the running solve
+  bool mixed;          // fp32 storage of preconditioned directions and shadow residual
   // staging in reference layout (for TSX_HOST callers and conversion)
   double *stage_a, *stage_b;
 

@@ -50,122 +50,16 @@ __device__ __forceinline__ long long tsx_swizzle(long long b, long long nb) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// y = (I - T) x.  Restates op_mat_mult_ediff (src/pprts_shell.F90:413-519) in dst-owned form: the
-// thread of cell (k,i,j) gathers the cell's D source streams and writes the D streams leaving it.
-// Surface row uses the assembled semantics (src/pprts.F90:5755-5794).
+// y = (I - T) x.  Restates op_mat_mult_ediff (src/pprts_shell.F90:413-519) in dst-owned form: the thread of
+// cell (k,i,j) gathers the cell's D source streams and writes the D streams leaving it.  Surface row uses the
+// assembled semantics (src/pprts.F90:5755-5794).
 // FUSE bit0 (1): partial slot0 += w.y   (BiCGStab (rhat, v) and (s, t))
 // FUSE bit1 (2): partial slot1 += x.y   (x = the operator's input at the same index)
 // FUSE bit2 (4): partial slot2 += y.y   (BiCGStab (t, t))
-template <int NTOP, int NSIDE, typename CT, int FUSE>
-__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv(
-    TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
-    const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ x,
-    double *__restrict__ y, const double *__restrict__ hW, const double *__restrict__ hE,
-    const double *__restrict__ hS, const double *__restrict__ hN, const double *__restrict__ w,
-    double *__restrict__ partials, const int *__restrict__ done) {
-  constexpr int D = NTOP + 2 * NSIDE;
-  if (done && *done) return;
-  double sum[3] = {0.0, 0.0, 0.0};
-  const long long Nc = g.Nc;
-  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
-  const long long nchunks = (Nc + TSX_BLOCK - 1) / TSX_BLOCK;
-  const double *__restrict__ xt = x + (size_t)D * Nc;
-  double *__restrict__ yt = y + (size_t)D * Nc;
-  const double *__restrict__ wt = (FUSE & 1) ? w + (size_t)D * Nc : nullptr;
-
-  for (long long base = 0; base < nchunks; base += gridDim.x) {
-    const long long nb = (nchunks - base) < (long long)gridDim.x ? (nchunks - base) : (long long)gridDim.x;
-    if ((long long)blockIdx.x >= nb) break;
-    const long long c = (base + tsx_swizzle(blockIdx.x, nb)) * TSX_BLOCK + threadIdx.x;
-    if (c >= Nc) continue;
-    const int i = (int)(c % xm);
-    const long long t = c / xm;
-    const int j = (int)(t % ym);
-    const int k = (int)(t / ym);
-    const int col = j * xm + i;
-
-    double xs[D], xo[D], acc[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) xo[d] = x[(size_t)d * Nc + c];
-#pragma unroll
-    for (int q = 0; q < NTOP; ++q) {
-      if (tsx_inward(q))
-        xs[q] = k > 0 ? x[(size_t)q * Nc + c - ncol] : xt[(size_t)q * ncol + col];
-      else
-        xs[q] = k + 1 < Nz ? x[(size_t)q * Nc + c + ncol] : xt[(size_t)q * ncol + col];
-    }
-#pragma unroll
-    for (int q = 0; q < NSIDE; ++q) {
-      const int d = NTOP + q, slot = q >> 1;
-      if (tsx_inward(q)) {  // +x moving, enters through face i, leaves cell i-1
-        if (i > 0) xs[d] = x[(size_t)d * Nc + c - 1];
-        else if (g.wrap_x) xs[d] = x[(size_t)d * Nc + c + (xm - 1)];
-        else xs[d] = hW[((size_t)slot * Nz + k) * ym + j];
-      } else {  // -x moving, enters through face i+1, leaves cell i+1
-        if (i < xm - 1) xs[d] = x[(size_t)d * Nc + c + 1];
-        else if (g.wrap_x) xs[d] = x[(size_t)d * Nc + c - (xm - 1)];
-        else xs[d] = hE[((size_t)slot * Nz + k) * ym + j];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NSIDE; ++q) {
-      const int d = NTOP + NSIDE + q, slot = q >> 1;
-      if (tsx_inward(q)) {
-        if (j > 0) xs[d] = x[(size_t)d * Nc + c - xm];
-        else if (g.wrap_y) xs[d] = x[(size_t)d * Nc + c + (size_t)(ym - 1) * xm];
-        else xs[d] = hS[((size_t)slot * Nz + k) * xm + i];
-      } else {
-        if (j < ym - 1) xs[d] = x[(size_t)d * Nc + c + xm];
-        else if (g.wrap_y) xs[d] = x[(size_t)d * Nc + c - (size_t)(ym - 1) * xm];
-        else xs[d] = hN[((size_t)slot * Nz + k) * xm + i];
-      }
-    }
-
-    if (l1d[k]) {  // 1-D (Eddington) layer: src/pprts_shell.F90:417-427; side rows are identity
-      const double t11 = a11[c], t12 = a12[c];
-#pragma unroll
-      for (int q = 0; q < NTOP; ++q) acc[q] = xo[q] - t11 * xs[q] - t12 * xs[q ^ 1];
-#pragma unroll
-      for (int d = NTOP; d < D; ++d) acc[d] = xo[d];
-    } else {
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        double a = 0.0;
-#pragma unroll
-        for (int s = 0; s < D; ++s) a += (double)C[(size_t)(d * D + s) * Nc + c] * xs[s];
-        acc[d] = xo[d] - a;
-      }
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      y[(size_t)d * Nc + c] = acc[d];
-      if (FUSE & 1) sum[0] += w[(size_t)d * Nc + c] * acc[d];
-      if (FUSE & 2) sum[1] += xo[d] * acc[d];
-      if (FUSE & 4) sum[2] += acc[d] * acc[d];
-    }
-    if (k == Nz - 1) {  // rows no cell writes: TOA Edn, surface Eup (albedo), bottom side dummies
-      const double alb = albedo[col] / (double)(NTOP / 2);
-      double down = 0.0;  // sum of inward top streams at level Nz == this cell's own inward outputs' inputs
-#pragma unroll
-      for (int q = 0; q < NTOP; ++q)
-        if (tsx_inward(q)) down += xo[q];
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const double xv = xt[(size_t)d * ncol + col];
-        double yv = xv;
-        if (d < NTOP && !tsx_inward(d)) yv = xv - alb * down;
-        yt[(size_t)d * ncol + col] = yv;
-        if (FUSE & 1) sum[0] += wt[(size_t)d * ncol + col] * yv;
-        if (FUSE & 2) sum[1] += xv * yv;
-        if (FUSE & 4) sum[2] += yv * yv;
-      }
-    }
-  }
-  if (FUSE) tsx_block_reduce_store<3>(sum, partials);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Wide variant: each thread owns CPT consecutive cells along x so that every plane is read with
+// XT / WT: storage type of the input x and of w.  With a preconditioner the input is the preconditioned direction
+// (p-hat, s-hat) which -- like the shadow residual rhat -- may be held in fp32: flexible BiCGStab (KSPFBCGS,
+// src/pprts.F90:4342) allows any direction as long as the same stored vector feeds both A*dir and x += a*dir.
+// Each thread owns CPT consecutive cells along x so that every plane is read with
 // 8/16-byte (fp32 coefficients) and 16/32-byte (fp64 vectors) loads per lane; the +-x neighbours inside
 // the group come from registers.  Requires xm % CPT == 0.
 template <int CPT> struct TsxVec;
@@ -204,12 +98,12 @@ template <> struct TsxVec<4> {
   }
 };
 
-template <int NTOP, int NSIDE, typename CT, int FUSE, int CPT>
+template <int NTOP, int NSIDE, typename CT, int FUSE, int CPT, typename XT, typename WT>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
     TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
-    const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ x,
+    const double *__restrict__ a12, const double *__restrict__ albedo, const XT *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ hW, const double *__restrict__ hE,
-    const double *__restrict__ hS, const double *__restrict__ hN, const double *__restrict__ w,
+    const double *__restrict__ hS, const double *__restrict__ hN, const WT *__restrict__ w,
     double *__restrict__ partials, const int *__restrict__ done) {
   constexpr int D = NTOP + 2 * NSIDE;
   using V = TsxVec<CPT>;
@@ -219,9 +113,9 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
   const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
   const long long ngroups = Nc / CPT;
   const long long nchunks = (ngroups + TSX_BLOCK - 1) / TSX_BLOCK;
-  const double *__restrict__ xt = x + (size_t)D * Nc;
+  const XT *__restrict__ xt = x + (size_t)D * Nc;
   double *__restrict__ yt = y + (size_t)D * Nc;
-  const double *__restrict__ wt = (FUSE & 1) ? w + (size_t)D * Nc : nullptr;
+  const WT *__restrict__ wt = (FUSE & 1) ? w + (size_t)D * Nc : nullptr;
 
   for (long long base = 0; base < nchunks; base += gridDim.x) {
     const long long nb = (nchunks - base) < (long long)gridDim.x ? (nchunks - base) : (long long)gridDim.x;
@@ -253,14 +147,14 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
       double own[CPT];
       V::ld(x + (size_t)d * Nc + c, own);
       if (tsx_inward(q)) {
-        if (i > 0) xs[d][0] = x[(size_t)d * Nc + c - 1];
-        else if (g.wrap_x) xs[d][0] = x[(size_t)d * Nc + c + (xm - 1)];
+        if (i > 0) xs[d][0] = (double)x[(size_t)d * Nc + c - 1];
+        else if (g.wrap_x) xs[d][0] = (double)x[(size_t)d * Nc + c + (xm - 1)];
         else xs[d][0] = hW[((size_t)slot * Nz + k) * ym + j];
 #pragma unroll
         for (int m = 1; m < CPT; ++m) xs[d][m] = own[m - 1];
       } else {
-        if (i + CPT < xm) xs[d][CPT - 1] = x[(size_t)d * Nc + c + CPT];
-        else if (g.wrap_x) xs[d][CPT - 1] = x[(size_t)d * Nc + c + CPT - xm];
+        if (i + CPT < xm) xs[d][CPT - 1] = (double)x[(size_t)d * Nc + c + CPT];
+        else if (g.wrap_x) xs[d][CPT - 1] = (double)x[(size_t)d * Nc + c + CPT - xm];
         else xs[d][CPT - 1] = hE[((size_t)slot * Nz + k) * ym + j];
 #pragma unroll
         for (int m = 0; m < CPT - 1; ++m) xs[d][m] = own[m + 1];
@@ -439,11 +333,11 @@ __host__ __device__ constexpr int tsx_pc_ntmp() { return (NTOP / 2) * 2 * ((NTOP
 // ROWS: 0 = every row; 1 / 2 = only rows with even / odd j (zebra line ordering).  GS: the right-hand side is
 // r + N_y z, the contribution of the +-y side streams of the neighbouring rows held in z (line Gauss-Seidel in y:
 // rows of one colour only see rows of the other colour, so all columns of a pass stay independent).
-template <int NTOP, int NSIDE, typename CT, int ROWS, bool GS>
+template <int NTOP, int NSIDE, typename CT, int ROWS, bool GS, typename ZT>
 __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
                                                       const double *__restrict__ a11, const double *__restrict__ a12,
                                                       const double *__restrict__ albedo, const double *__restrict__ r,
-                                                      double *__restrict__ z, double *__restrict__ tmp,
+                                                      ZT *__restrict__ z, double *__restrict__ tmp,
                                                       const int *__restrict__ done) {
   constexpr int D = NTOP + 2 * NSIDE;
   constexpr int H = NTOP / 2;
@@ -467,7 +361,7 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
   (void)offN;
   (void)offS;
   const double *__restrict__ rt = r + (size_t)D * Nc;
-  double *__restrict__ zt = z + (size_t)D * Nc;
+  ZT *__restrict__ zt = z + (size_t)D * Nc;
   double *__restrict__ tGw = tmp, *__restrict__ tGT = tmp + (size_t)H * Nc, *__restrict__ tA = tmp + (size_t)(H + H * H) * Nc,
                       *__restrict__ tB = tmp + (size_t)(H + 2 * H * H) * Nc;
 
@@ -515,7 +409,7 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
       for (int q = 0; q < NSIDE; ++q) {
         const int sd = NTOP + NSIDE + q;
         const long long off = tsx_inward(q) ? offS : offN;
-        const double zv = off ? z[(size_t)sd * Nc + c + off] : 0.0;
+        const double zv = off ? (double)z[(size_t)sd * Nc + c + off] : 0.0;
 #pragma unroll
         for (int a = 0; a < H; ++a) {
           ru[a] += (double)C[(size_t)((2 * a) * D + sd) * Nc + c] * zv;
@@ -558,7 +452,7 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
 #pragma unroll
   for (int a = 0; a < H; ++a) {
     V[a] = rt[(size_t)(2 * a + 1) * ncol + col];       // V_0 = rd_0 (TOA identity row)
-    zt[(size_t)(2 * a + 1) * ncol + col] = V[a];
+    zt[(size_t)(2 * a + 1) * ncol + col] = (ZT)V[a];
   }
   // U_0 = A_0 V_0 + B_0: A, B hold level 0 after the upward sweep
   double U[H];
@@ -599,26 +493,26 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
 #pragma unroll
       for (int a = 0; a < H; ++a) {
         Un[a] = rt[(size_t)(2 * a) * ncol + col] + alb * sv;
-        zt[(size_t)(2 * a) * ncol + col] = Un[a];
+        zt[(size_t)(2 * a) * ncol + col] = (ZT)Un[a];
       }
     }
     // outputs of cell k: up streams at level k, down streams at level k+1
 #pragma unroll
     for (int a = 0; a < H; ++a) {
-      z[(size_t)(2 * a) * Nc + c] = U[a];
-      z[(size_t)(2 * a + 1) * Nc + c] = Vn[a];
+      z[(size_t)(2 * a) * Nc + c] = (ZT)U[a];
+      z[(size_t)(2 * a + 1) * Nc + c] = (ZT)Vn[a];
     }
     // side streams leaving cell k: sources Eup(k+1) = Un, Edn(k) = V
     if (l1d[k]) {
 #pragma unroll
-      for (int d = NTOP; d < D; ++d) z[(size_t)d * Nc + c] = r[(size_t)d * Nc + c];
+      for (int d = NTOP; d < D; ++d) z[(size_t)d * Nc + c] = (ZT)r[(size_t)d * Nc + c];
     } else {
       double zy[NSIDE];
       if (GS) {
 #pragma unroll
         for (int q = 0; q < NSIDE; ++q) {
           const long long off = tsx_inward(q) ? offS : offN;
-          zy[q] = off ? z[(size_t)(NTOP + NSIDE + q) * Nc + c + off] : 0.0;
+          zy[q] = off ? (double)z[(size_t)(NTOP + NSIDE + q) * Nc + c + off] : 0.0;
         }
       }
 #pragma unroll
@@ -633,7 +527,7 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
 #pragma unroll
           for (int q = 0; q < NSIDE; ++q) acc += (double)C[(size_t)(d * D + NTOP + NSIDE + q) * Nc + c] * zy[q];
         }
-        z[(size_t)d * Nc + c] = acc;
+        z[(size_t)d * Nc + c] = (ZT)acc;
       }
     }
 #pragma unroll
@@ -644,7 +538,7 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
   }
   // bottom side dummies: identity rows
 #pragma unroll
-  for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = rt[(size_t)d * ncol + col];
+  for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (ZT)rt[(size_t)d * ncol + col];
 }
 
 // out = a - b   (second preconditioner sweep: residual of the first)
@@ -676,17 +570,18 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_addto(long long n2, const dou
 // BLAS-1 stages of the flexible BiCGStab (KSPFBCGS, selected at src/pprts.F90:4342), fused so that a
 // full iteration moves 19 N-vectors besides the two operator applications.
 // r = b - y (y = A x0); rhat = r; p = r; slot0 = (r,r)
+template <typename RT>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_residual0(long long n, const double *__restrict__ b,
                                                              const double *__restrict__ y, double *__restrict__ r,
-                                                             double *__restrict__ rhat, double *__restrict__ p,
+                                                             RT *__restrict__ rhat, double *__restrict__ p,
                                                              double *__restrict__ partials) {
   double sum[1] = {0.0};
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
     const double v = b[q] - y[q];
     r[q] = v;
-    rhat[q] = v;
+    rhat[q] = (RT)v;
     p[q] = v;
-    sum[0] += v * v;
+    sum[0] += (double)(RT)v * v;  // rho = (rhat, r) with the stored rhat
   }
   tsx_block_reduce_store<1>(sum, partials);
 }
@@ -721,25 +616,30 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_supdate(long long n2, const T
   }
 }
 
-// x += alpha ph + omega sh; r = s - omega t; slot0 = (rhat, r), slot1 = (r, r)
+// x += alpha ph + omega sh; r = s - omega t; slot0 = (rhat, r), slot1 = (r, r).  PT: storage of ph/sh, RT: of rhat
+template <typename PT, typename RT>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xrupdate(long long n2, const TsxScalars *__restrict__ sc,
-                                                            double2 *__restrict__ x, const double2 *__restrict__ ph,
-                                                            const double2 *__restrict__ sh, const double2 *__restrict__ s,
-                                                            const double2 *__restrict__ t, const double2 *__restrict__ rhat,
+                                                            double2 *__restrict__ x, const PT *__restrict__ ph,
+                                                            const PT *__restrict__ sh, const double2 *__restrict__ s,
+                                                            const double2 *__restrict__ t, const RT *__restrict__ rhat,
                                                             double2 *__restrict__ r, double *__restrict__ partials) {
   if (sc->done) return;
   const double alpha = sc->alpha, omega = sc->omega;
   double sum[2] = {0.0, 0.0};
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
-    const double2 xx = x[q], pp = ph[q], ss2 = sh[q], ss = s[q], tt = t[q], rh = rhat[q];
+    const double2 xx = x[q], ss = s[q], tt = t[q];
+    double pp[2], ss2[2], rh[2];
+    TsxVec<2>::ld(ph + 2 * q, pp);
+    TsxVec<2>::ld(sh + 2 * q, ss2);
+    TsxVec<2>::ld(rhat + 2 * q, rh);
     double2 xo, ro;
-    xo.x = xx.x + alpha * pp.x + omega * ss2.x;
-    xo.y = xx.y + alpha * pp.y + omega * ss2.y;
+    xo.x = xx.x + alpha * pp[0] + omega * ss2[0];
+    xo.y = xx.y + alpha * pp[1] + omega * ss2[1];
     ro.x = ss.x - omega * tt.x;
     ro.y = ss.y - omega * tt.y;
     x[q] = xo;
     r[q] = ro;
-    sum[0] += rh.x * ro.x + rh.y * ro.y;
+    sum[0] += rh[0] * ro.x + rh[1] * ro.y;
     sum[1] += ro.x * ro.x + ro.y * ro.y;
   }
   tsx_block_reduce_store<2>(sum, partials);
@@ -921,8 +821,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_import_unpack(TsxGeo g, doubl
 //   sendE = +x streams of my cells i = xm-1   (east rank reads them as its west halo)
 //   sendW = -x streams of my cells i = 0
 //   sendN = +y streams of my cells j = ym-1 ; sendS = -y streams of my cells j = 0
-template <int NTOP, int NSIDE>
-__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_halo_pack(TsxGeo g, const double *__restrict__ v,
+template <int NTOP, int NSIDE, typename XT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_halo_pack(TsxGeo g, const XT *__restrict__ v,
                                                              double *__restrict__ sendW, double *__restrict__ sendE,
                                                              double *__restrict__ sendS, double *__restrict__ sendN,
                                                              const int *__restrict__ done) {
@@ -937,8 +837,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_halo_pack(TsxGeo g, const dou
       const int slot = (int)(q / ((long long)ym * Nz));
       const size_t row = ((size_t)k * ym + j) * xm;
       if (!g.wrap_x) {
-        sendE[q] = v[(size_t)(NTOP + 2 * slot + 1) * Nc + row + (xm - 1)];
-        sendW[q] = v[(size_t)(NTOP + 2 * slot) * Nc + row];
+        sendE[q] = (double)v[(size_t)(NTOP + 2 * slot + 1) * Nc + row + (xm - 1)];
+        sendW[q] = (double)v[(size_t)(NTOP + 2 * slot) * Nc + row];
       }
     } else {
       const long long p = q - nx;
@@ -946,8 +846,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_halo_pack(TsxGeo g, const dou
       const int k = (int)((p / xm) % Nz);
       const int slot = (int)(p / ((long long)xm * Nz));
       if (!g.wrap_y) {
-        sendN[p] = v[(size_t)(NTOP + NSIDE + 2 * slot + 1) * Nc + ((size_t)k * ym + (ym - 1)) * xm + i];
-        sendS[p] = v[(size_t)(NTOP + NSIDE + 2 * slot) * Nc + (size_t)k * ym * xm + i];
+        sendN[p] = (double)v[(size_t)(NTOP + NSIDE + 2 * slot + 1) * Nc + ((size_t)k * ym + (ym - 1)) * xm + i];
+        sendS[p] = (double)v[(size_t)(NTOP + NSIDE + 2 * slot) * Nc + (size_t)k * ym * xm + i];
       }
     }
   }

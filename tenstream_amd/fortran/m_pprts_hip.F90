@@ -41,6 +41,7 @@ module m_pprts_hip
     integer(c_int32_t) :: pc
     integer(c_int32_t) :: pc_sweeps
     integer(c_int32_t) :: check_every
+    integer(c_int32_t) :: fp32_directions
   end type
 
   type, bind(C) :: t_tsx_ksp_result
