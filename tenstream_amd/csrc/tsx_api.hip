@@ -919,7 +919,7 @@ static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o, bool restart = fal
   else
     hipLaunchKernelGGL(tsx_k_residual0<double>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr, s->vrhat,
                        s->vp, s->partials);
-  if ((rc = scalar_stage(s, nbv, 1, TSX_STAGE_INIT))) return rc;
+  if ((rc = scalar_stage(s, nbv, 2, TSX_STAGE_INIT))) return rc;
   return TSX_OK;
 }
 

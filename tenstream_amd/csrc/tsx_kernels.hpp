@@ -575,15 +575,16 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_residual0(long long n, const 
                                                              const double *__restrict__ y, double *__restrict__ r,
                                                              RT *__restrict__ rhat, double *__restrict__ p,
                                                              double *__restrict__ partials) {
-  double sum[1] = {0.0};
+  double sum[2] = {0.0, 0.0};  // slot0 = (rhat, r) with rhat as stored, slot1 = (r, r)
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
     const double v = b[q] - y[q];
     r[q] = v;
     rhat[q] = (RT)v;
     p[q] = v;
-    sum[0] += (double)(RT)v * v;  // rho = (rhat, r) with the stored rhat
+    sum[0] += (double)(RT)v * v;
+    sum[1] += v * v;
   }
-  tsx_block_reduce_store<1>(sum, partials);
+  tsx_block_reduce_store<2>(sum, partials);
 }
 
 // p = r + beta (p - omega v)
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
   const double tiny = 2.2250738585072014e-308;
   switch (stage) {
     case TSX_STAGE_INIT: {
-      const double rn = sqrt(sc->red[0]);
+      const double rn = sqrt(sc->red[1]);
       sc->rnorm = rn;
       if (!sc->restart) {
         sc->rnorm0 = rn > tiny ? rn : tiny;  // n == 0: store initial norm, no test (:4455-4458)
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
       sc->omega = 1.0;
       sc->beta = 0.0;
       sc->reason = 0;
-      if (sc->red[0] == 0.0) {  // exact initial guess: nothing to do
+      if (sc->red[1] == 0.0) {  // exact initial guess: nothing to do
         sc->reason = 2;
         sc->done = 1;
       } else if (rn != rn) {
