@@ -790,6 +790,23 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const int *do
   const int ncols = ROWS == 0 ? g.ncol : (ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2) * g.xm;
   if (ncols == 0) return TSX_OK;
   const int nb = (ncols + 63) / 64;
+  static int use_h1 = -1;  // TSX_PC_PREFETCH=0 selects the generic kernel for 3_10 as well (A/B knob)
+  if (use_h1 < 0) {
+    const char *e = getenv("TSX_PC_PREFETCH");
+    use_h1 = e ? atoi(e) : 1;
+  }
+  if constexpr (NTOP == 2) {
+    if (use_h1) {
+      if (s->coef_bytes == 4)
+        hipLaunchKernelGGL((tsx_k_pc_column_h1<float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g, (const float *)s->coef,
+                           s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
+      else
+        hipLaunchKernelGGL((tsx_k_pc_column_h1<double, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
+                           (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
+      HIPCHK(hipGetLastError());
+      return TSX_OK;
+    }
+  }
   if (s->coef_bytes == 4)
     hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
                        (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);

@@ -541,6 +541,164 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
   for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (ZT)rt[(size_t)d * ncol + col];
 }
 
+// ---- 3_10 (H = 1) specialisation with explicit software prefetch: the loads of level k-1 (k+1) are issued before the
+// arithmetic of level k, so that the sequential sweep is paced by bandwidth, not by one memory latency per level.
+// Same mathematics as tsx_k_pc_column<2,4,...>; ROWS / GS as there.
+struct TsxUpIn {   // what one level of the upward sweep needs
+  double tuu, rud, rdu, tdd, ru, rd;
+};
+struct TsxDnIn {   // what one level of the downward sweep needs (besides U_{k+1} = A_{k+1} V_{k+1} + B_{k+1})
+  double gw, gt, an, bn;      // Gw, GT of cell k;  A, B of cell k+1 (or surface closure)
+  double rs[8];               // right-hand side of the 8 side streams (incl. y coupling)
+  float cu[8], cv[8];         // c(Eup -> side d), c(Edn -> side d)
+  bool is1d;
+};
+
+template <typename CT, int ROWS, bool GS, typename ZT>
+__global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
+                                                         const double *__restrict__ a11, const double *__restrict__ a12,
+                                                         const double *__restrict__ albedo, const double *__restrict__ r,
+                                                         ZT *__restrict__ z, double *__restrict__ tmp,
+                                                         const int *__restrict__ done) {
+  constexpr int D = 10, NTOP = 2, NSIDE = 4;
+  if (done && *done) return;
+  int col = blockIdx.x * 64 + threadIdx.x;
+  if (ROWS) {
+    const int nrows = ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2;
+    if (col >= nrows * g.xm) return;
+    col = (2 * (col / g.xm) + (ROWS - 1)) * g.xm + col % g.xm;
+  }
+  if (col >= g.ncol) return;
+  const long long Nc = g.Nc;
+  const int Nz = g.Nz, ncol = g.ncol;
+  const int jrow = col / g.xm;
+  const bool seam = g.wrap_y && (g.ym % 2 == 0);
+  const long long offN = (jrow + 1 < g.ym) ? (long long)g.xm : (seam ? -(long long)(g.ym - 1) * g.xm : 0);
+  const long long offS = (jrow > 0) ? -(long long)g.xm : (seam ? (long long)(g.ym - 1) * g.xm : 0);
+  const double *__restrict__ rt = r + (size_t)D * Nc;
+  ZT *__restrict__ zt = z + (size_t)D * Nc;
+  double *__restrict__ tGw = tmp, *__restrict__ tGT = tmp + Nc, *__restrict__ tA = tmp + 2 * Nc, *__restrict__ tB = tmp + 3 * Nc;
+
+  auto load_up = [&](int k) {
+    TsxUpIn u;
+    const size_t c = (size_t)k * ncol + col;
+    u.ru = r[c];
+    u.rd = r[(size_t)Nc + c];
+    if (l1d[k]) {
+      u.tuu = u.tdd = a11[c];
+      u.rud = u.rdu = a12[c];
+    } else {
+      u.tuu = (double)C[(size_t)0 * Nc + c];   // c(src 0 -> dst 0)
+      u.rud = (double)C[(size_t)1 * Nc + c];   // c(src 1 -> dst 0)
+      u.rdu = (double)C[(size_t)10 * Nc + c];  // c(src 0 -> dst 1)
+      u.tdd = (double)C[(size_t)11 * Nc + c];  // c(src 1 -> dst 1)
+      if (GS) {
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) {
+          const int sd = NTOP + NSIDE + q;
+          const long long off = tsx_inward(q) ? offS : offN;
+          const double zv = off ? (double)z[(size_t)sd * Nc + c + off] : 0.0;
+          u.ru += (double)C[(size_t)(0 * D + sd) * Nc + c] * zv;
+          u.rd += (double)C[(size_t)(1 * D + sd) * Nc + c] * zv;
+        }
+      }
+    }
+    return u;
+  };
+
+  // ---- upward sweep: U_k = A_k V_k + B_k
+  const double albc = albedo[col];
+  double A = albc, B = rt[col];
+  {
+    TsxUpIn cu = load_up(Nz - 1);
+    for (int k = Nz - 1; k >= 0; --k) {
+      TsxUpIn nx = cu;
+      if (k > 0) nx = load_up(k - 1);  // prefetch: independent of the recurrence
+      const size_t c = (size_t)k * ncol + col;
+      const double G = 1.0 / (1.0 - cu.rdu * A);
+      const double Gw = G * (cu.rd + cu.rdu * B);
+      const double GT = G * cu.tdd;
+      const double Bn = cu.ru + cu.tuu * (B + A * Gw);
+      const double An = cu.tuu * A * GT + cu.rud;
+      tGw[c] = Gw;
+      tGT[c] = GT;
+      tA[c] = An;
+      tB[c] = Bn;
+      A = An;
+      B = Bn;
+      cu = nx;
+    }
+  }
+
+  auto load_dn = [&](int k) {
+    TsxDnIn d;
+    const size_t c = (size_t)k * ncol + col;
+    d.gw = tGw[c];
+    d.gt = tGT[c];
+    if (k + 1 < Nz) {
+      d.an = tA[c + ncol];
+      d.bn = tB[c + ncol];
+    } else {
+      d.an = albc;       // U_Nz = albedo V_Nz + ru_Nz
+      d.bn = rt[col];
+    }
+    d.is1d = l1d[k] != 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+    if (!d.is1d) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        d.cu[q] = (float)C[(size_t)((NTOP + q) * D + 0) * Nc + c];
+        d.cv[q] = (float)C[(size_t)((NTOP + q) * D + 1) * Nc + c];
+      }
+      if (GS) {
+        double zy[NSIDE];
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) {
+          const long long off = tsx_inward(q) ? offS : offN;
+          zy[q] = off ? (double)z[(size_t)(NTOP + NSIDE + q) * Nc + c + off] : 0.0;
+        }
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+          for (int q = 0; q < NSIDE; ++q) d.rs[dd] += (double)C[(size_t)((NTOP + dd) * D + NTOP + NSIDE + q) * Nc + c] * zy[q];
+      }
+    }
+    return d;
+  };
+
+  // ---- downward sweep
+  double V = rt[(size_t)ncol + col];  // V_0 = rd_0 (TOA identity row)
+  zt[(size_t)ncol + col] = (ZT)V;
+  double U = A * V + B;               // A, B hold level 0
+  {
+    TsxDnIn cd = load_dn(0);
+    for (int k = 0; k < Nz; ++k) {
+      TsxDnIn nx = cd;
+      if (k + 1 < Nz) nx = load_dn(k + 1);
+      const size_t c = (size_t)k * ncol + col;
+      const double Vn = cd.gw + cd.gt * V;
+      const double Un = cd.an * Vn + cd.bn;
+      z[c] = (ZT)U;
+      z[(size_t)Nc + c] = (ZT)Vn;
+      if (cd.is1d) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) z[(size_t)(NTOP + q) * Nc + c] = (ZT)cd.rs[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          z[(size_t)(NTOP + q) * Nc + c] = (ZT)(cd.rs[q] + (double)cd.cu[q] * Un + (double)cd.cv[q] * V);
+      }
+      if (k + 1 == Nz) zt[col] = (ZT)Un;
+      V = Vn;
+      U = Un;
+      cd = nx;
+    }
+  }
+#pragma unroll
+  for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (ZT)rt[(size_t)d * ncol + col];
+}
+
 // out = a - b   (second preconditioner sweep: residual of the first)
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_sub(long long n2, const double2 *__restrict__ a, const double2 *__restrict__ b,
                                                        double2 *__restrict__ o, const int *__restrict__ done) {
