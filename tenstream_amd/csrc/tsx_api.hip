@@ -799,20 +799,20 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const int *do
     if (use_h1) {
       if (s->coef_bytes == 4)
         hipLaunchKernelGGL((tsx_k_pc_column_h1<float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g, (const float *)s->coef,
-                           s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
+                           s->l1d, s->a11, s->a12, s->albedo, v, z, (const ZT *)z, s->pc_tmp, done);
       else
         hipLaunchKernelGGL((tsx_k_pc_column_h1<double, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
+                           (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, (const ZT *)z, s->pc_tmp, done);
       HIPCHK(hipGetLastError());
       return TSX_OK;
     }
   }
   if (s->coef_bytes == 4)
     hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
-                       (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
+                       (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, (const ZT *)z, s->pc_tmp, done);
   else
     hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
-                       (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, s->pc_tmp, done);
+                       (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, (const ZT *)z, s->pc_tmp, done);
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }

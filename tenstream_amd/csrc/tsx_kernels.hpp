@@ -337,8 +337,11 @@ template <int NTOP, int NSIDE, typename CT, int ROWS, bool GS, typename ZT>
 __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
                                                       const double *__restrict__ a11, const double *__restrict__ a12,
                                                       const double *__restrict__ albedo, const double *__restrict__ r,
-                                                      ZT *__restrict__ z, double *__restrict__ tmp,
-                                                      const int *__restrict__ done) {
+                                                      ZT *__restrict__ z, const ZT *__restrict__ zc,
+                                                      double *__restrict__ tmp, const int *__restrict__ done) {
+  // zc aliases z but is only read at rows of the *other* colour, which this launch never writes: declaring it as a
+  // separate restrict pointer lets the compiler issue those loads ahead of the stores to z (otherwise every level
+  // waits for the previous level's stores to retire: vmcnt is in-order)
   constexpr int D = NTOP + 2 * NSIDE;
   constexpr int H = NTOP / 2;
   using SM = TsxSm<H>;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
       for (int q = 0; q < NSIDE; ++q) {
         const int sd = NTOP + NSIDE + q;
         const long long off = tsx_inward(q) ? offS : offN;
-        const double zv = off ? (double)z[(size_t)sd * Nc + c + off] : 0.0;
+        const double zv = off ? (double)zc[(size_t)sd * Nc + c + off] : 0.0;
 #pragma unroll
         for (int a = 0; a < H; ++a) {
           ru[a] += (double)C[(size_t)((2 * a) * D + sd) * Nc + c] * zv;
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
 #pragma unroll
         for (int q = 0; q < NSIDE; ++q) {
           const long long off = tsx_inward(q) ? offS : offN;
-          zy[q] = off ? (double)z[(size_t)(NTOP + NSIDE + q) * Nc + c + off] : 0.0;
+          zy[q] = off ? (double)zc[(size_t)(NTOP + NSIDE + q) * Nc + c + off] : 0.0;
         }
       }
 #pragma unroll
@@ -558,8 +561,8 @@ template <typename CT, int ROWS, bool GS, typename ZT>
 __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
                                                          const double *__restrict__ a11, const double *__restrict__ a12,
                                                          const double *__restrict__ albedo, const double *__restrict__ r,
-                                                         ZT *__restrict__ z, double *__restrict__ tmp,
-                                                         const int *__restrict__ done) {
+                                                         ZT *__restrict__ z, const ZT *__restrict__ zc,
+                                                         double *__restrict__ tmp, const int *__restrict__ done) {
   constexpr int D = 10, NTOP = 2, NSIDE = 4;
   if (done && *done) return;
   int col = blockIdx.x * 64 + threadIdx.x;
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__r
         for (int q = 0; q < NSIDE; ++q) {
           const int sd = NTOP + NSIDE + q;
           const long long off = tsx_inward(q) ? offS : offN;
-          const double zv = off ? (double)z[(size_t)sd * Nc + c + off] : 0.0;
+          const double zv = off ? (double)zc[(size_t)sd * Nc + c + off] : 0.0;
           u.ru += (double)C[(size_t)(0 * D + sd) * Nc + c] * zv;
           u.rd += (double)C[(size_t)(1 * D + sd) * Nc + c] * zv;
         }
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__r
 #pragma unroll
         for (int q = 0; q < NSIDE; ++q) {
           const long long off = tsx_inward(q) ? offS : offN;
-          zy[q] = off ? (double)z[(size_t)(NTOP + NSIDE + q) * Nc + c + off] : 0.0;
+          zy[q] = off ? (double)zc[(size_t)(NTOP + NSIDE + q) * Nc + c + off] : 0.0;
         }
 #pragma unroll
         for (int dd = 0; dd < 8; ++dd)
