@@ -797,12 +797,17 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const int *do
   }
   if constexpr (NTOP == 2) {
     if (use_h1) {
-      if (s->coef_bytes == 4)
-        hipLaunchKernelGGL((tsx_k_pc_column_h1<float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g, (const float *)s->coef,
-                           s->l1d, s->a11, s->a12, s->albedo, v, z, (const ZT *)z, s->pc_tmp, done);
-      else
-        hipLaunchKernelGGL((tsx_k_pc_column_h1<double, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, (const ZT *)z, s->pc_tmp, done);
+#define TSX_H1_LAUNCH(CTYPE, HAS)                                                                                            \
+  hipLaunchKernelGGL((tsx_k_pc_column_h1<CTYPE, ROWS, GS, ZT, HAS>), dim3(nb), dim3(64), 0, s->stream, g, (const CTYPE *)s->coef, \
+                     s->l1d, s->a11, s->a12, s->albedo, v, z, (const ZT *)z, s->pc_tmp, done)
+      if (s->coef_bytes == 4) {
+        if (s->any_l1d) TSX_H1_LAUNCH(float, true);
+        else TSX_H1_LAUNCH(float, false);
+      } else {
+        if (s->any_l1d) TSX_H1_LAUNCH(double, true);
+        else TSX_H1_LAUNCH(double, false);
+      }
+#undef TSX_H1_LAUNCH
       HIPCHK(hipGetLastError());
       return TSX_OK;
     }

@@ -412,7 +412,8 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
       for (int q = 0; q < NSIDE; ++q) {
         const int sd = NTOP + NSIDE + q;
         const long long off = tsx_inward(q) ? offS : offN;
-        const double zv = off ? (double)zc[(size_t)sd * Nc + c + off] : 0.0;
+        const double zl = (double)zc[(size_t)sd * Nc + c + off];  // unconditional load, then select: no branch, no wait
+        const double zv = off ? zl : 0.0;
 #pragma unroll
         for (int a = 0; a < H; ++a) {
           ru[a] += (double)C[(size_t)((2 * a) * D + sd) * Nc + c] * zv;
@@ -515,7 +516,8 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
 #pragma unroll
         for (int q = 0; q < NSIDE; ++q) {
           const long long off = tsx_inward(q) ? offS : offN;
-          zy[q] = off ? (double)zc[(size_t)(NTOP + NSIDE + q) * Nc + c + off] : 0.0;
+          const double zl = (double)zc[(size_t)(NTOP + NSIDE + q) * Nc + c + off];
+          zy[q] = off ? zl : 0.0;
         }
       }
 #pragma unroll
@@ -546,18 +548,19 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column(TsxGeo g, const CT *__rest
 
 // ---- 3_10 (H = 1) specialisation with explicit software prefetch: the loads of level k-1 (k+1) are issued before the
 // arithmetic of level k, so that the sequential sweep is paced by bandwidth, not by one memory latency per level.
-// Same mathematics as tsx_k_pc_column<2,4,...>; ROWS / GS as there.
+// The loop bodies are branch-free (unconditional loads + selects): a conditional load ends a basic block and costs a
+// full s_waitcnt vmcnt(0) per level.  Same mathematics as tsx_k_pc_column<2,4,...>; ROWS / GS as there; HAS1D = some
+// layer is 1-D (then a11/a12 are valid arrays).
 struct TsxUpIn {   // what one level of the upward sweep needs
   double tuu, rud, rdu, tdd, ru, rd;
 };
-struct TsxDnIn {   // what one level of the downward sweep needs (besides U_{k+1} = A_{k+1} V_{k+1} + B_{k+1})
-  double gw, gt, an, bn;      // Gw, GT of cell k;  A, B of cell k+1 (or surface closure)
+struct TsxDnIn {   // what one level of the downward sweep needs
+  double gw, gt, an, bn;      // Gw, GT of cell k;  A, B of cell k+1 (or the surface closure)
   double rs[8];               // right-hand side of the 8 side streams (incl. y coupling)
-  float cu[8], cv[8];         // c(Eup -> side d), c(Edn -> side d)
-  bool is1d;
+  float cu[8], cv[8];         // c(Eup -> side d), c(Edn -> side d); zero in 1-D layers
 };
 
-template <typename CT, int ROWS, bool GS, typename ZT>
+template <typename CT, int ROWS, bool GS, typename ZT, bool HAS1D>
 __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
                                                          const double *__restrict__ a11, const double *__restrict__ a12,
                                                          const double *__restrict__ albedo, const double *__restrict__ r,
@@ -578,45 +581,52 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__r
   const bool seam = g.wrap_y && (g.ym % 2 == 0);
   const long long offN = (jrow + 1 < g.ym) ? (long long)g.xm : (seam ? -(long long)(g.ym - 1) * g.xm : 0);
   const long long offS = (jrow > 0) ? -(long long)g.xm : (seam ? (long long)(g.ym - 1) * g.xm : 0);
+  const double facN = offN ? 1.0 : 0.0, facS = offS ? 1.0 : 0.0;
   const double *__restrict__ rt = r + (size_t)D * Nc;
   ZT *__restrict__ zt = z + (size_t)D * Nc;
   double *__restrict__ tGw = tmp, *__restrict__ tGT = tmp + Nc, *__restrict__ tA = tmp + 2 * Nc, *__restrict__ tB = tmp + 3 * Nc;
+  const double albc = albedo[col], rsurf = rt[col];
 
   auto load_up = [&](int k) {
     TsxUpIn u;
     const size_t c = (size_t)k * ncol + col;
     u.ru = r[c];
     u.rd = r[(size_t)Nc + c];
-    if (l1d[k]) {
-      u.tuu = u.tdd = a11[c];
-      u.rud = u.rdu = a12[c];
-    } else {
-      u.tuu = (double)C[(size_t)0 * Nc + c];   // c(src 0 -> dst 0)
-      u.rud = (double)C[(size_t)1 * Nc + c];   // c(src 1 -> dst 0)
-      u.rdu = (double)C[(size_t)10 * Nc + c];  // c(src 0 -> dst 1)
-      u.tdd = (double)C[(size_t)11 * Nc + c];  // c(src 1 -> dst 1)
-      if (GS) {
+    u.tuu = (double)C[(size_t)0 * Nc + c];   // c(src 0 -> dst 0)
+    u.rud = (double)C[(size_t)1 * Nc + c];   // c(src 1 -> dst 0)
+    u.rdu = (double)C[(size_t)10 * Nc + c];  // c(src 0 -> dst 1)
+    u.tdd = (double)C[(size_t)11 * Nc + c];  // c(src 1 -> dst 1)
+    double gu = 0.0, gd = 0.0;
+    if (GS) {
 #pragma unroll
-        for (int q = 0; q < NSIDE; ++q) {
-          const int sd = NTOP + NSIDE + q;
-          const long long off = tsx_inward(q) ? offS : offN;
-          const double zv = off ? (double)zc[(size_t)sd * Nc + c + off] : 0.0;
-          u.ru += (double)C[(size_t)(0 * D + sd) * Nc + c] * zv;
-          u.rd += (double)C[(size_t)(1 * D + sd) * Nc + c] * zv;
-        }
+      for (int q = 0; q < NSIDE; ++q) {
+        const int sd = NTOP + NSIDE + q;
+        const double zv = (double)zc[(size_t)sd * Nc + c + (tsx_inward(q) ? offS : offN)] * (tsx_inward(q) ? facS : facN);
+        gu += (double)C[(size_t)(0 * D + sd) * Nc + c] * zv;
+        gd += (double)C[(size_t)(1 * D + sd) * Nc + c] * zv;
       }
     }
+    if (HAS1D) {
+      const bool one = l1d[k] != 0;
+      const double t11 = a11[c], t12 = a12[c];
+      u.tuu = one ? t11 : u.tuu;
+      u.tdd = one ? t11 : u.tdd;
+      u.rud = one ? t12 : u.rud;
+      u.rdu = one ? t12 : u.rdu;
+      gu = one ? 0.0 : gu;
+      gd = one ? 0.0 : gd;
+    }
+    u.ru += gu;
+    u.rd += gd;
     return u;
   };
 
   // ---- upward sweep: U_k = A_k V_k + B_k
-  const double albc = albedo[col];
-  double A = albc, B = rt[col];
+  double A = albc, B = rsurf;
   {
     TsxUpIn cu = load_up(Nz - 1);
     for (int k = Nz - 1; k >= 0; --k) {
-      TsxUpIn nx = cu;
-      if (k > 0) nx = load_up(k - 1);  // prefetch: independent of the recurrence
+      const TsxUpIn nx = load_up(k > 0 ? k - 1 : 0);  // prefetch: independent of the recurrence
       const size_t c = (size_t)k * ncol + col;
       const double G = 1.0 / (1.0 - cu.rdu * A);
       const double Gw = G * (cu.rd + cu.rdu * B);
@@ -636,35 +646,33 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__r
   auto load_dn = [&](int k) {
     TsxDnIn d;
     const size_t c = (size_t)k * ncol + col;
+    const bool last = k + 1 >= Nz;
+    const size_t cn = last ? c : c + ncol;
     d.gw = tGw[c];
     d.gt = tGT[c];
-    if (k + 1 < Nz) {
-      d.an = tA[c + ncol];
-      d.bn = tB[c + ncol];
-    } else {
-      d.an = albc;       // U_Nz = albedo V_Nz + ru_Nz
-      d.bn = rt[col];
+    const double an = tA[cn], bn = tB[cn];
+    d.an = last ? albc : an;  // U_Nz = albedo V_Nz + ru_Nz
+    d.bn = last ? rsurf : bn;
+    bool one = false;
+    if (HAS1D) one = l1d[k] != 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+      const float fu = (float)C[(size_t)((NTOP + q) * D + 0) * Nc + c], fv = (float)C[(size_t)((NTOP + q) * D + 1) * Nc + c];
+      d.cu[q] = one ? 0.0f : fu;
+      d.cv[q] = one ? 0.0f : fv;
     }
-    d.is1d = l1d[k] != 0;
+    if (GS) {
+      double zy[NSIDE];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
-    if (!d.is1d) {
+      for (int q = 0; q < NSIDE; ++q)
+        zy[q] = (double)zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)] * (tsx_inward(q) ? facS : facN);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        d.cu[q] = (float)C[(size_t)((NTOP + q) * D + 0) * Nc + c];
-        d.cv[q] = (float)C[(size_t)((NTOP + q) * D + 1) * Nc + c];
-      }
-      if (GS) {
-        double zy[NSIDE];
+      for (int dd = 0; dd < 8; ++dd) {
+        double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < NSIDE; ++q) {
-          const long long off = tsx_inward(q) ? offS : offN;
-          zy[q] = off ? (double)zc[(size_t)(NTOP + NSIDE + q) * Nc + c + off] : 0.0;
-        }
-#pragma unroll
-        for (int dd = 0; dd < 8; ++dd)
-#pragma unroll
-          for (int q = 0; q < NSIDE; ++q) d.rs[dd] += (double)C[(size_t)((NTOP + dd) * D + NTOP + NSIDE + q) * Nc + c] * zy[q];
+        for (int q = 0; q < NSIDE; ++q) acc += (double)C[(size_t)((NTOP + dd) * D + NTOP + NSIDE + q) * Nc + c] * zy[q];
+        d.rs[dd] += one ? 0.0 : acc;
       }
     }
     return d;
@@ -677,27 +685,20 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__r
   {
     TsxDnIn cd = load_dn(0);
     for (int k = 0; k < Nz; ++k) {
-      TsxDnIn nx = cd;
-      if (k + 1 < Nz) nx = load_dn(k + 1);
+      const TsxDnIn nx = load_dn(k + 1 < Nz ? k + 1 : k);
       const size_t c = (size_t)k * ncol + col;
       const double Vn = cd.gw + cd.gt * V;
       const double Un = cd.an * Vn + cd.bn;
       z[c] = (ZT)U;
       z[(size_t)Nc + c] = (ZT)Vn;
-      if (cd.is1d) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) z[(size_t)(NTOP + q) * Nc + c] = (ZT)cd.rs[q];
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          z[(size_t)(NTOP + q) * Nc + c] = (ZT)(cd.rs[q] + (double)cd.cu[q] * Un + (double)cd.cv[q] * V);
-      }
-      if (k + 1 == Nz) zt[col] = (ZT)Un;
+      for (int q = 0; q < 8; ++q) z[(size_t)(NTOP + q) * Nc + c] = (ZT)(cd.rs[q] + (double)cd.cu[q] * Un + (double)cd.cv[q] * V);
       V = Vn;
       U = Un;
       cd = nx;
     }
   }
+  zt[col] = (ZT)U;  // U_Nz
 #pragma unroll
   for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (ZT)rt[(size_t)d * ncol + col];
 }
