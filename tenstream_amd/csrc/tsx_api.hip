@@ -363,7 +363,7 @@ static int halo_update(tsx_solver *s, const XT *v, bool in_solve) {
   return face_exchange(s);
 }
 
-// TSX_SPMV_CPT=1|2|4 selects cells per thread (experimentation knob; default picks the widest that divides xm)
+// TSX_SPMV_CPT=1|2 selects cells per thread (default 2 when xm is even)
 static int spmv_cpt(const tsx_solver *s) {
   static int env = -1;
   if (env < 0) {
@@ -371,17 +371,30 @@ static int spmv_cpt(const tsx_solver *s) {
     env = e ? atoi(e) : 0;
   }
   int want = env > 0 ? env : TSX_DEFAULT_CPT;
+  if (want > 2) want = 2;
   while (want > 1 && (s->geo.xm % want) != 0) want >>= 1;
   return want;
 }
 
-template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT>
+template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT, bool HALO, bool HAS1D>
 static void launch_spmv_variant(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done) {
   const TsxGeo &g = s->geo;
   const int nb = grid_for(g.Nc / CPT, TSX_MAX_PARTIAL_BLOCKS);
-  hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT, XT, WT>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
+  hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT, XT, WT, HALO, HAS1D>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
                      (const CT *)s->coef, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS, s->recvN,
                      w, s->partials, done);
+}
+
+template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT>
+static void launch_spmv_flags(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done) {
+  const bool halo = !(s->geo.wrap_x && s->geo.wrap_y), has1d = s->any_l1d;
+  if (halo) {
+    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, true>(s, x, y, w, done);
+    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, false>(s, x, y, w, done);
+  } else {
+    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, true>(s, x, y, w, done);
+    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, false>(s, x, y, w, done);
+  }
 }
 
 template <int NTOP, int NSIDE, int FUSE, typename XT = double, typename WT = double>
@@ -391,13 +404,11 @@ static int launch_spmv(tsx_solver *s, const XT *x, double *y, const WT *w, bool 
   const int *done = in_solve ? &s->scal->done : nullptr;
   const int cpt = spmv_cpt(s);
   if (s->coef_bytes == 4) {
-    if (cpt == 4) launch_spmv_variant<NTOP, NSIDE, FUSE, float, 4, XT, WT>(s, x, y, w, done);
-    else if (cpt == 2) launch_spmv_variant<NTOP, NSIDE, FUSE, float, 2, XT, WT>(s, x, y, w, done);
-    else launch_spmv_variant<NTOP, NSIDE, FUSE, float, 1, XT, WT>(s, x, y, w, done);
+    if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, float, 2, XT, WT>(s, x, y, w, done);
+    else launch_spmv_flags<NTOP, NSIDE, FUSE, float, 1, XT, WT>(s, x, y, w, done);
   } else {
-    if (cpt == 4) launch_spmv_variant<NTOP, NSIDE, FUSE, double, 4, XT, WT>(s, x, y, w, done);
-    else if (cpt == 2) launch_spmv_variant<NTOP, NSIDE, FUSE, double, 2, XT, WT>(s, x, y, w, done);
-    else launch_spmv_variant<NTOP, NSIDE, FUSE, double, 1, XT, WT>(s, x, y, w, done);
+    if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, double, 2, XT, WT>(s, x, y, w, done);
+    else launch_spmv_flags<NTOP, NSIDE, FUSE, double, 1, XT, WT>(s, x, y, w, done);
   }
   HIPCHK(hipGetLastError());
   return TSX_OK;

@@ -98,7 +98,10 @@ template <> struct TsxVec<4> {
   }
 };
 
-template <int NTOP, int NSIDE, typename CT, int FUSE, int CPT, typename XT, typename WT>
+// HALO: some face of the rank is not a periodic self-neighbour (edge threads then read the received face buffers);
+// HAS1D: some layer is 1-D.  Both are kernel-uniform and compiled out in the common case.  The gather is branch-free
+// (offset / pointer selects, unconditional loads): a conditional load ends a basic block and forces an s_waitcnt.
+template <int NTOP, int NSIDE, typename CT, int FUSE, int CPT, typename XT, typename WT, bool HALO, bool HAS1D>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
     TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
     const double *__restrict__ a12, const double *__restrict__ albedo, const XT *__restrict__ x,
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
   const XT *__restrict__ xt = x + (size_t)D * Nc;
   double *__restrict__ yt = y + (size_t)D * Nc;
   const WT *__restrict__ wt = (FUSE & 1) ? w + (size_t)D * Nc : nullptr;
+  const bool wrapx = g.wrap_x != 0, wrapy = g.wrap_y != 0;
 
   for (long long base = 0; base < nchunks; base += gridDim.x) {
     const long long nb = (nchunks - base) < (long long)gridDim.x ? (nchunks - base) : (long long)gridDim.x;
@@ -130,32 +134,39 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
     const int col = j * xm + i;
 
     double xs[D][CPT];
-    // ---- gather the D source streams of the CPT cells
+    // ---- gather the D source streams of the CPT cells (all loads unconditional)
 #pragma unroll
     for (int q = 0; q < NTOP; ++q) {
-      if (tsx_inward(q)) {
-        if (k > 0) V::ld(x + (size_t)q * Nc + c - ncol, xs[q]);
-        else V::ld(xt + (size_t)q * ncol + col, xs[q]);
-      } else {
-        if (k + 1 < Nz) V::ld(x + (size_t)q * Nc + c + ncol, xs[q]);
-        else V::ld(xt + (size_t)q * ncol + col, xs[q]);
-      }
+      const bool tail = tsx_inward(q) ? (k == 0) : (k + 1 >= Nz);
+      const XT *p = tail ? xt + (size_t)q * ncol + col
+                         : x + (size_t)q * Nc + c + (tsx_inward(q) ? -(long long)ncol : (long long)ncol);
+      V::ld(p, xs[q]);
     }
 #pragma unroll
     for (int q = 0; q < NSIDE; ++q) {
       const int d = NTOP + q, slot = q >> 1;
       double own[CPT];
       V::ld(x + (size_t)d * Nc + c, own);
-      if (tsx_inward(q)) {
-        if (i > 0) xs[d][0] = (double)x[(size_t)d * Nc + c - 1];
-        else if (g.wrap_x) xs[d][0] = (double)x[(size_t)d * Nc + c + (xm - 1)];
-        else xs[d][0] = hW[((size_t)slot * Nz + k) * ym + j];
+      if (tsx_inward(q)) {  // +x stream: leaves the cell to the west
+        const bool edge = i == 0;
+        const long long off = edge ? (wrapx ? (long long)(xm - 1) : 0) : -1;
+        double e = (double)x[(size_t)d * Nc + c + off];
+        if (HALO) {
+          const double h = hW[((size_t)slot * Nz + k) * ym + j];
+          e = (edge && !wrapx) ? h : e;
+        }
+        xs[d][0] = e;
 #pragma unroll
         for (int m = 1; m < CPT; ++m) xs[d][m] = own[m - 1];
-      } else {
-        if (i + CPT < xm) xs[d][CPT - 1] = (double)x[(size_t)d * Nc + c + CPT];
-        else if (g.wrap_x) xs[d][CPT - 1] = (double)x[(size_t)d * Nc + c + CPT - xm];
-        else xs[d][CPT - 1] = hE[((size_t)slot * Nz + k) * ym + j];
+      } else {  // -x stream: leaves the cell to the east
+        const bool edge = i + CPT >= xm;
+        const long long off = edge ? (wrapx ? (long long)CPT - xm : 0) : CPT;
+        double e = (double)x[(size_t)d * Nc + c + off];
+        if (HALO) {
+          const double h = hE[((size_t)slot * Nz + k) * ym + j];
+          e = (edge && !wrapx) ? h : e;
+        }
+        xs[d][CPT - 1] = e;
 #pragma unroll
         for (int m = 0; m < CPT - 1; ++m) xs[d][m] = own[m + 1];
       }
@@ -163,20 +174,22 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
 #pragma unroll
     for (int q = 0; q < NSIDE; ++q) {
       const int d = NTOP + NSIDE + q, slot = q >> 1;
-      if (tsx_inward(q)) {
-        if (j > 0) V::ld(x + (size_t)d * Nc + c - xm, xs[d]);
-        else if (g.wrap_y) V::ld(x + (size_t)d * Nc + c + (size_t)(ym - 1) * xm, xs[d]);
-        else V::ld(hS + ((size_t)slot * Nz + k) * xm + i, xs[d]);
-      } else {
-        if (j < ym - 1) V::ld(x + (size_t)d * Nc + c + xm, xs[d]);
-        else if (g.wrap_y) V::ld(x + (size_t)d * Nc + c - (size_t)(ym - 1) * xm, xs[d]);
-        else V::ld(hN + ((size_t)slot * Nz + k) * xm + i, xs[d]);
+      const bool edge = tsx_inward(q) ? (j == 0) : (j + 1 >= ym);
+      const long long wrapoff = tsx_inward(q) ? (long long)(ym - 1) * xm : -(long long)(ym - 1) * xm;
+      const long long off = edge ? (wrapy ? wrapoff : 0) : (tsx_inward(q) ? -(long long)xm : (long long)xm);
+      V::ld(x + (size_t)d * Nc + c + off, xs[d]);
+      if (HALO) {
+        double h[CPT];
+        V::ld((tsx_inward(q) ? hS : hN) + ((size_t)slot * Nz + k) * xm + i, h);
+#pragma unroll
+        for (int m = 0; m < CPT; ++m) xs[d][m] = (edge && !wrapy) ? h[m] : xs[d][m];
       }
     }
 
-    const bool is1d = l1d[k] != 0;
+    bool is1d = false;
     double t11[CPT], t12[CPT];
-    if (is1d) {
+    if (HAS1D) {
+      is1d = l1d[k] != 0;
       V::ld(a11 + c, t11);
       V::ld(a12 + c, t12);
     }
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
     for (int d = 0; d < D; ++d) {
       double xo[CPT], acc[CPT];
       V::ld(x + (size_t)d * Nc + c, xo);
-      if (is1d) {
+      if (HAS1D && is1d) {
 #pragma unroll
         for (int m = 0; m < CPT; ++m)
           acc[m] = d < NTOP ? xo[m] - t11[m] * xs[d][m] - t12[m] * xs[d < NTOP ? (d ^ 1) : d][m] : xo[m];
@@ -196,11 +209,11 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
 #pragma unroll
         for (int m = 0; m < CPT; ++m) acc[m] = 0.0;
 #pragma unroll
-        for (int s = 0; s < D; ++s) {
+        for (int s2 = 0; s2 < D; ++s2) {
           double cf[CPT];
-          V::ld(C + (size_t)(d * D + s) * Nc + c, cf);
+          V::ld(C + (size_t)(d * D + s2) * Nc + c, cf);
 #pragma unroll
-          for (int m = 0; m < CPT; ++m) acc[m] += cf[m] * xs[s][m];
+          for (int m = 0; m < CPT; ++m) acc[m] += cf[m] * xs[s2][m];
         }
 #pragma unroll
         for (int m = 0; m < CPT; ++m) acc[m] = xo[m] - acc[m];
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
         for (int m = 0; m < CPT; ++m) sum[2] += acc[m] * acc[m];
       }
     }
-    if (k == Nz - 1) {
+    if (k == Nz - 1) {  // rows no cell writes: TOA Edn, surface Eup (albedo), bottom side dummies
       double alb[CPT];
       V::ld(albedo + col, alb);
 #pragma unroll
