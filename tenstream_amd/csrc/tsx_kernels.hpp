@@ -98,6 +98,29 @@ template <> struct TsxVec<4> {
   }
 };
 
+// raw (unconverted) CPT-wide register images of a plane element group: lets loads be issued long before use
+template <typename T, int CPT> struct TsxRaw;
+template <> struct TsxRaw<float, 1> {
+  typedef float type;
+  static __device__ __forceinline__ type ld(const float *p) { return *p; }
+  static __device__ __forceinline__ void cvt(type v, double *o) { o[0] = (double)v; }
+};
+template <> struct TsxRaw<float, 2> {
+  typedef float2 type;
+  static __device__ __forceinline__ type ld(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+  static __device__ __forceinline__ void cvt(type v, double *o) { o[0] = (double)v.x; o[1] = (double)v.y; }
+};
+template <> struct TsxRaw<double, 1> {
+  typedef double type;
+  static __device__ __forceinline__ type ld(const double *p) { return *p; }
+  static __device__ __forceinline__ void cvt(type v, double *o) { o[0] = v; }
+};
+template <> struct TsxRaw<double, 2> {
+  typedef double2 type;
+  static __device__ __forceinline__ type ld(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+  static __device__ __forceinline__ void cvt(type v, double *o) { o[0] = v.x; o[1] = v.y; }
+};
+
 // HALO: some face of the rank is not a periodic self-neighbour (edge threads then read the received face buffers);
 // HAS1D: some layer is 1-D.  Both are kernel-uniform and compiled out in the common case.  The gather is branch-free
 // (offset / pointer selects, unconditional loads): a conditional load ends a basic block and forces an s_waitcnt.
@@ -196,11 +219,28 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
     double down[CPT];
 #pragma unroll
     for (int m = 0; m < CPT; ++m) down[m] = 0.0;
-    // ---- one destination stream at a time: keeps only xs live
+    // ---- one destination stream (coefficient row) at a time, software-pipelined: the D coefficient loads of row d+1
+    // (plus its diagonal / w operands) are issued before the FMAs of row d.  Without the explicit staging hipcc
+    // serialises load -> wait -> fma per coefficient (one memory latency each).
+    using CV = typename TsxRaw<CT, CPT>::type;
+    using XV = typename TsxRaw<XT, CPT>::type;
+    using WV = typename TsxRaw<WT, CPT>::type;
+    CV cfc[D], cfn[D];
+    XV xoc, xon;
+    WV wc, wn;
+    auto issue_row = [&](int d, CV(&cf)[D], XV &xo_, WV &w_) {
+#pragma unroll
+      for (int s2 = 0; s2 < D; ++s2) cf[s2] = TsxRaw<CT, CPT>::ld(C + (size_t)(d * D + s2) * Nc + c);
+      xo_ = TsxRaw<XT, CPT>::ld(x + (size_t)d * Nc + c);
+      if (FUSE & 1) w_ = TsxRaw<WT, CPT>::ld(w + (size_t)d * Nc + c);
+    };
+    issue_row(0, cfc, xoc, wc);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
+      if (d + 1 < D) issue_row(d + 1, cfn, xon, wn);
+      __builtin_amdgcn_sched_barrier(0);
       double xo[CPT], acc[CPT];
-      V::ld(x + (size_t)d * Nc + c, xo);
+      TsxRaw<XT, CPT>::cvt(xoc, xo);
       if (HAS1D && is1d) {
 #pragma unroll
         for (int m = 0; m < CPT; ++m)
@@ -211,7 +251,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
 #pragma unroll
         for (int s2 = 0; s2 < D; ++s2) {
           double cf[CPT];
-          V::ld(C + (size_t)(d * D + s2) * Nc + c, cf);
+          TsxRaw<CT, CPT>::cvt(cfc[s2], cf);
 #pragma unroll
           for (int m = 0; m < CPT; ++m) acc[m] += cf[m] * xs[s2][m];
         }
@@ -225,7 +265,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
       }
       if (FUSE & 1) {
         double wv[CPT];
-        V::ld(w + (size_t)d * Nc + c, wv);
+        TsxRaw<WT, CPT>::cvt(wc, wv);
 #pragma unroll
         for (int m = 0; m < CPT; ++m) sum[0] += wv[m] * acc[m];
       }
@@ -236,6 +276,12 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
       if (FUSE & 4) {
 #pragma unroll
         for (int m = 0; m < CPT; ++m) sum[2] += acc[m] * acc[m];
+      }
+      if (d + 1 < D) {
+#pragma unroll
+        for (int s2 = 0; s2 < D; ++s2) cfc[s2] = cfn[s2];
+        xoc = xon;
+        wc = wn;
       }
     }
     if (k == Nz - 1) {  // rows no cell writes: TOA Edn, surface Eup (albedo), bottom side dummies
