@@ -836,18 +836,20 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const int *do
 // z = M^-1 v.
 //  TSX_PC_COLUMN: block-Jacobi over columns; sweeps > 1 adds stationary refinement  z <- z + M^-1 (v - A z)  (fp64 only)
 //  TSX_PC_ZEBRA:  line Gauss-Seidel in y over the same column blocks: even rows, then odd rows with the even rows'
-//                 +-y streams on the right-hand side; sweeps = 2 adds a second pass over the even rows (symmetric)
+//                 +-y streams on the right-hand side, then even again, ...: pc_sweeps + 1 half-grid passes
 // ZT = float stores the preconditioned direction in fp32 (legitimate in *flexible* BiCGStab, see tsx_k_spmv_w).
 template <int NTOP, int NSIDE, typename ZT>
 static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
   const TsxGeo &g = s->geo;
   const int *done = in_solve ? &s->scal->done : nullptr;
   int rc;
-  if (s->pc == TSX_PC_ZEBRA) {
+  if (s->pc == TSX_PC_ZEBRA) {  // passes: even, odd, even, odd, ... (pc_sweeps + 1 of them)
     if ((rc = pc_column_launch<NTOP, NSIDE, 1, false, ZT>(s, v, z, done))) return rc;
-    if ((rc = pc_column_launch<NTOP, NSIDE, 2, true, ZT>(s, v, z, done))) return rc;
-    if (s->pc_sweeps > 1)
-      if ((rc = pc_column_launch<NTOP, NSIDE, 1, true, ZT>(s, v, z, done))) return rc;
+    for (int pass = 1; pass <= s->pc_sweeps; ++pass) {
+      if (pass & 1) rc = pc_column_launch<NTOP, NSIDE, 2, true, ZT>(s, v, z, done);
+      else rc = pc_column_launch<NTOP, NSIDE, 1, true, ZT>(s, v, z, done);
+      if (rc) return rc;
+    }
     return TSX_OK;
   }
   if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, ZT>(s, v, z, done))) return rc;

@@ -269,7 +269,7 @@ def test_breakdown_restart(gpu):
 
 
 @pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 9, 8, 6, 1), ("3_10", 6, 7, 5, 0), ("8_16", 5, 6, 4, 0)])
-@pytest.mark.parametrize("sweeps", [1, 2])
+@pytest.mark.parametrize("sweeps", [1, 2, 3])
 def test_zebra_preconditioner_is_line_gauss_seidel(gpu, solver, Nx, Ny, Nz, n1d, sweeps):
     """TSX_PC_ZEBRA = Gauss-Seidel in y over the column blocks: even rows, odd rows (+ even again), each pass an exact
     column-block solve with the other colour's +-y streams on the right-hand side."""
@@ -300,8 +300,10 @@ def test_zebra_preconditioner_is_line_gauss_seidel(gpu, solver, Nx, Ny, Nz, n1d,
     x = np.zeros(v.size)
     x[even] = lu.solve(v.ravel())[even]
     x[~even] = lu.solve(v.ravel() - Nyc @ x)[~even]
-    if sweeps == 2:
+    if sweeps >= 2:
         x[even] = lu.solve(v.ravel() - Nyc @ x)[even]
+    if sweeps >= 3:
+        x[~even] = lu.solve(v.ravel() - Nyc @ x)[~even]
     s = DiffuseSolver(solver, Nz, Nx, Ny)
     s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
     z = s.pc_apply(v, pc=2, sweeps=sweeps)
