@@ -795,8 +795,10 @@ extern "C" int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int whe
 // ------------------------------------------------------------------------------------------------
 // z = M^-1 v with the column preconditioner; sweeps > 1 adds stationary refinement sweeps
 //   z <- z + M^-1 (v - A z)     (block-Jacobi iteration on column blocks)
-template <int NTOP, int NSIDE, int ROWS, bool GS, typename ZT>
-static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const int *done) {
+// one pass of the column preconditioner: writes rows of colour ROWS into z; GS: +-y coupling from zy (other colour);
+// XL: lagged +-x coupling from zx (own colour, previous pass, a different buffer than z)
+template <int NTOP, int NSIDE, int ROWS, bool GS, bool XL, typename ZT>
+static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy, const ZT *zx, const int *done) {
   const TsxGeo &g = s->geo;
   const int ncols = ROWS == 0 ? g.ncol : (ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2) * g.xm;
   if (ncols == 0) return TSX_OK;
@@ -808,9 +810,9 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const int *do
   }
   if constexpr (NTOP == 2) {
     if (use_h1) {
-#define TSX_H1_LAUNCH(CTYPE, HAS)                                                                                            \
-  hipLaunchKernelGGL((tsx_k_pc_column_h1<CTYPE, ROWS, GS, ZT, HAS>), dim3(nb), dim3(64), 0, s->stream, g, (const CTYPE *)s->coef, \
-                     s->l1d, s->a11, s->a12, s->albedo, v, z, (const ZT *)z, s->pc_tmp, done)
+#define TSX_H1_LAUNCH(CTYPE, HAS)                                                                                              \
+  hipLaunchKernelGGL((tsx_k_pc_column_h1<CTYPE, ROWS, GS, ZT, HAS, XL>), dim3(nb), dim3(64), 0, s->stream, g,                     \
+                     (const CTYPE *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, s->pc_tmp, done)
       if (s->coef_bytes == 4) {
         if (s->any_l1d) TSX_H1_LAUNCH(float, true);
         else TSX_H1_LAUNCH(float, false);
@@ -823,36 +825,53 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const int *do
       return TSX_OK;
     }
   }
+  // generic kernel (8_16, or A/B): y coupling only
   if (s->coef_bytes == 4)
     hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
-                       (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, (const ZT *)z, s->pc_tmp, done);
+                       (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
   else
     hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
-                       (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, (const ZT *)z, s->pc_tmp, done);
+                       (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
 
 // z = M^-1 v.
 //  TSX_PC_COLUMN: block-Jacobi over columns; sweeps > 1 adds stationary refinement  z <- z + M^-1 (v - A z)  (fp64 only)
-//  TSX_PC_ZEBRA:  line Gauss-Seidel in y over the same column blocks: even rows, then odd rows with the even rows'
-//                 +-y streams on the right-hand side, then even again, ...: pc_sweeps + 1 half-grid passes
+//  TSX_PC_ZEBRA:  pc_sweeps + 1 half-grid passes over the column blocks, even rows / odd rows alternately.  From the
+//                 second pass on the +-y streams of the other colour (latest values) are on the right-hand side
+//                 (line Gauss-Seidel in y); from the third pass on also the +-x streams of the same rows with the
+//                 values of that colour's previous pass (Jacobi in x).  Each colour alternates between z and a
+//                 scratch buffer so that a pass never reads what it writes; the last pass of each colour lands in z.
 // ZT = float stores the preconditioned direction in fp32 (legitimate in *flexible* BiCGStab, see tsx_k_spmv_w).
 template <int NTOP, int NSIDE, typename ZT>
 static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
   const TsxGeo &g = s->geo;
   const int *done = in_solve ? &s->scal->done : nullptr;
   int rc;
-  if (s->pc == TSX_PC_ZEBRA) {  // passes: even, odd, even, odd, ... (pc_sweeps + 1 of them)
-    if ((rc = pc_column_launch<NTOP, NSIDE, 1, false, ZT>(s, v, z, done))) return rc;
-    for (int pass = 1; pass <= s->pc_sweeps; ++pass) {
-      if (pass & 1) rc = pc_column_launch<NTOP, NSIDE, 2, true, ZT>(s, v, z, done);
-      else rc = pc_column_launch<NTOP, NSIDE, 1, true, ZT>(s, v, z, done);
+  if (s->pc == TSX_PC_ZEBRA) {
+    const int P = s->pc_sweeps + 1;
+    ZT *alt = (ZT *)s->vw;
+    const bool xl = NTOP == 2 && g.ym >= 2;
+    auto buf = [&](int pass) {  // buffer a pass writes: its colour's last pass writes z, alternating backwards
+      const int last = ((P - 1) % 2 == pass % 2) ? P - 1 : P - 2;
+      return (((last - pass) / 2) % 2 == 0 || !xl) ? z : alt;
+    };
+    for (int pass = 0; pass < P; ++pass) {
+      ZT *out = buf(pass);
+      const ZT *zy = pass > 0 ? buf(pass - 1) : (const ZT *)out;
+      const ZT *zx = pass > 1 ? buf(pass - 2) : (const ZT *)out;
+      if (pass == 0) rc = pc_column_launch<NTOP, NSIDE, 1, false, false, ZT>(s, v, out, zy, zx, done);
+      else if (pass == 1) rc = pc_column_launch<NTOP, NSIDE, 2, true, false, ZT>(s, v, out, zy, zx, done);
+      else if (!xl) rc = (pass & 1) ? pc_column_launch<NTOP, NSIDE, 2, true, false, ZT>(s, v, out, zy, zx, done)
+                                    : pc_column_launch<NTOP, NSIDE, 1, true, false, ZT>(s, v, out, zy, zx, done);
+      else rc = (pass & 1) ? pc_column_launch<NTOP, NSIDE, 2, true, true, ZT>(s, v, out, zy, zx, done)
+                           : pc_column_launch<NTOP, NSIDE, 1, true, true, ZT>(s, v, out, zy, zx, done);
       if (rc) return rc;
     }
     return TSX_OK;
   }
-  if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, ZT>(s, v, z, done))) return rc;
+  if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, false, ZT>(s, v, z, (const ZT *)z, (const ZT *)z, done))) return rc;
   if constexpr (std::is_same<ZT, double>::value) {
     const long long n2 = g.N / 2;
     const int nbv = grid_for(n2);
@@ -860,7 +879,9 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
       if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)z, s->vt, (const double *)nullptr, in_solve))) return rc;
       hipLaunchKernelGGL(tsx_k_sub, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)v, (const double2 *)s->vt,
                          (double2 *)s->vt, done);
-      if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, double>(s, s->vt, s->vw, done))) return rc;
+      if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, false, double>(s, s->vt, s->vw, (const double *)s->vw,
+                                                                      (const double *)s->vw, done)))
+        return rc;
       hipLaunchKernelGGL(tsx_k_addto, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)s->vw, (double2 *)z, done);
     }
   }

@@ -269,7 +269,7 @@ def test_breakdown_restart(gpu):
 
 
 @pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 9, 8, 6, 1), ("3_10", 6, 7, 5, 0), ("8_16", 5, 6, 4, 0)])
-@pytest.mark.parametrize("sweeps", [1, 2, 3])
+@pytest.mark.parametrize("sweeps", [1, 2, 3, 4])
 def test_zebra_preconditioner_is_line_gauss_seidel(gpu, solver, Nx, Ny, Nz, n1d, sweeps):
     """TSX_PC_ZEBRA = Gauss-Seidel in y over the column blocks: even rows, odd rows (+ even again), each pass an exact
     column-block solve with the other colour's +-y streams on the right-hand side."""
@@ -293,17 +293,27 @@ def test_zebra_preconditioner_is_line_gauss_seidel(gpu, solver, Nx, Ny, Nz, n1d,
         seam = ((oj[Ac.row] == 0) & (oj[Ac.col] == Ny - 1)) | ((oj[Ac.row] == Ny - 1) & (oj[Ac.col] == 0))
         ydiff &= ~seam
     Nyc = sp.csr_matrix((Ac.data[ydiff], (Ac.row[ydiff], Ac.col[ydiff])), shape=A.shape)
+    # x coupling = off-column entries within the same row of columns (3_10 only: lagged Jacobi in x from pass 3 on)
+    qx = d - lay.ntop
+    mx = (qx >= 0) & (qx < lay.nside) & (qx % 2 == 1) & (k < Nz)
+    i_ = (idx // (D * L)) % Nx
+    oi = i_.copy()
+    oi[mx] = (i_[mx] - 1) % Nx
+    xdiff = (oj[Ac.row] == oj[Ac.col]) & (oi[Ac.row] != oi[Ac.col])
+    Nxc = sp.csr_matrix((Ac.data[xdiff], (Ac.row[xdiff], Ac.col[xdiff])), shape=A.shape)
     even = oj % 2 == 0
     lu = spla.splu(M.tocsc(), permc_spec="NATURAL")
     rng = np.random.default_rng(9)
     v = rng.standard_normal(P["b"].shape)
     x = np.zeros(v.size)
-    x[even] = lu.solve(v.ravel())[even]
-    x[~even] = lu.solve(v.ravel() - Nyc @ x)[~even]
-    if sweeps >= 2:
-        x[even] = lu.solve(v.ravel() - Nyc @ x)[even]
-    if sweeps >= 3:
-        x[~even] = lu.solve(v.ravel() - Nyc @ x)[~even]
+    for p_ in range(sweeps + 1):
+        mk = even if p_ % 2 == 0 else ~even
+        rhs = v.ravel().copy()
+        if p_ > 0:
+            rhs -= Nyc @ x
+        if p_ > 1 and solver == "3_10":
+            rhs -= Nxc @ x
+        x[mk] = lu.solve(rhs)[mk]
     s = DiffuseSolver(solver, Nz, Nx, Ny)
     s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
     z = s.pc_apply(v, pc=2, sweeps=sweeps)
