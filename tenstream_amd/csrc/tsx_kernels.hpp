@@ -622,7 +622,7 @@ struct TsxDnIn {   // what one level of the downward sweep needs
 // XL: additionally the +-x side streams of the same row enter the right-hand side with their values of this colour's
 // previous pass (zx, a different buffer than the one being written): Jacobi in x on top of Gauss-Seidel in y.
 template <typename CT, int ROWS, bool GS, typename ZT, bool HAS1D, bool XL>
-__global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void tsx_k_pc_column_h1(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
                                                          const double *__restrict__ a11, const double *__restrict__ a12,
                                                          const double *__restrict__ albedo, const double *__restrict__ r,
                                                          ZT *__restrict__ z, const ZT *__restrict__ zc,
@@ -643,11 +643,9 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__r
   const bool seam = g.wrap_y && (g.ym % 2 == 0);
   const long long offN = (jrow + 1 < g.ym) ? (long long)g.xm : (seam ? -(long long)(g.ym - 1) * g.xm : 0);
   const long long offS = (jrow > 0) ? -(long long)g.xm : (seam ? (long long)(g.ym - 1) * g.xm : 0);
-  const double facN = offN ? 1.0 : 0.0, facS = offS ? 1.0 : 0.0;
   const int icol = col % g.xm;
   const long long offE = (icol + 1 < g.xm) ? 1 : (g.wrap_x ? -(long long)(g.xm - 1) : 0);
   const long long offW = (icol > 0) ? -1 : (g.wrap_x ? (long long)(g.xm - 1) : 0);
-  const double facE = offE ? 1.0 : 0.0, facW = offW ? 1.0 : 0.0;
   const double *__restrict__ rt = r + (size_t)D * Nc;
   ZT *__restrict__ zt = z + (size_t)D * Nc;
   double *__restrict__ tGw = tmp, *__restrict__ tGT = tmp + Nc, *__restrict__ tA = tmp + 2 * Nc, *__restrict__ tB = tmp + 3 * Nc;
@@ -667,7 +665,8 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__r
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) {
         const int sd = NTOP + NSIDE + q;
-        const double zv = (double)zc[(size_t)sd * Nc + c + (tsx_inward(q) ? offS : offN)] * (tsx_inward(q) ? facS : facN);
+        const double zl = (double)zc[(size_t)sd * Nc + c + (tsx_inward(q) ? offS : offN)];
+        const double zv = (tsx_inward(q) ? offS : offN) ? zl : 0.0;  // select, not multiply: the unused slot may hold NaN
         gu += (double)C[(size_t)(0 * D + sd) * Nc + c] * zv;
         gd += (double)C[(size_t)(1 * D + sd) * Nc + c] * zv;
       }
@@ -676,7 +675,8 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__r
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) {
         const int sd = NTOP + q;
-        const double zv = (double)zx[(size_t)sd * Nc + c + (tsx_inward(q) ? offW : offE)] * (tsx_inward(q) ? facW : facE);
+        const double zl = (double)zx[(size_t)sd * Nc + c + (tsx_inward(q) ? offW : offE)];
+        const double zv = (tsx_inward(q) ? offW : offE) ? zl : 0.0;
         gu += (double)C[(size_t)(0 * D + sd) * Nc + c] * zv;
         gd += (double)C[(size_t)(1 * D + sd) * Nc + c] * zv;
       }
@@ -741,7 +741,10 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__r
       double zy[NSIDE];
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q)
-        zy[q] = (double)zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)] * (tsx_inward(q) ? facS : facN);
+      {
+        const double zl = (double)zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
+        zy[q] = (tsx_inward(q) ? offS : offN) ? zl : 0.0;
+      }
 #pragma unroll
       for (int dd = 0; dd < 8; ++dd) {
         double acc = 0.0;
@@ -754,7 +757,10 @@ __global__ __launch_bounds__(64) void tsx_k_pc_column_h1(TsxGeo g, const CT *__r
       double zq[NSIDE];
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q)
-        zq[q] = (double)zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)] * (tsx_inward(q) ? facW : facE);
+      {
+        const double zl = (double)zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
+        zq[q] = (tsx_inward(q) ? offW : offE) ? zl : 0.0;
+      }
 #pragma unroll
       for (int dd = 0; dd < 8; ++dd) {
         double acc = 0.0;
