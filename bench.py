@@ -141,6 +141,7 @@ def main():
 
     out = None
     if rank == 0:
+        traffic, traffic_src = pmc_traffic(f"{args.nx}x{args.ny}x{Nz}")
         out = {
             "metric": "pprts 3_10 diffuse-solve cells/s",
             "value": value,
@@ -179,7 +180,8 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "bytes_per_launch": bytes_spmv,
                 "ms_per_launch": spmv_ms,
             },
@@ -191,6 +193,27 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def pmc_traffic(key):
+    """HBM-side bytes per SpMV launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN/traffic_<key>.json, written by scripts/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 FETCH_SIZE x2 correction).  PMC passes cannot run inside the timed bench, so the figure is looked up;
+    None if no profile of this workload size is committed."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", f"traffic_{key}.json")), reverse=True):
+        try:
+            k = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+        # the variant tsx_bench_kernel(0) times: FUSE=0, fp64 x and y
+        spmv = [v for name, v in k.items() if name.startswith("tsx_k_spmv") and ",0,2,double,double" in name]
+        spmv = spmv or [v for name, v in k.items() if name.startswith("tsx_k_spmv") and v["launches"] > 0]
+        if spmv:
+            n = sum(v["launches"] for v in spmv)
+            return sum(v["traffic_bytes_per_launch"] * v["launches"] for v in spmv) / n, os.path.relpath(path, here)
+    return None, None
 
 
 def cpu_baseline(args, solver, dx, dz, albedo):
