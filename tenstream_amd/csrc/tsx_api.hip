@@ -163,6 +163,8 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->pc_sweeps = 1;
   o->check_every = 4;
   o->fp32_directions = 1;
+  o->pc_coeff_fp16 = 1;
+  o->reserved_ = 0;
 }
 
 extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstrained_fraction, double *rtol,
@@ -251,7 +253,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   if (!s) return TSX_OK;
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
-  void *ptrs[] = {s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
+  void *ptrs[] = {s->coef_h, s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
@@ -585,6 +587,7 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
   HIPCHK(hipStreamSynchronize(s->stream));
   if (tmp) HIPCHK(hipFree(tmp));
   s->have_coeffs = true;
+  s->coef_h_valid = false;
   return TSX_OK;
 }
 
@@ -728,6 +731,7 @@ extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const dou
   for (int q = 0; q < 4; ++q)
     if (tmp[q]) HIPCHK(hipFree(tmp[q]));
   s->have_coeffs = true;
+  s->coef_h_valid = false;
   return TSX_OK;
 }
 
@@ -812,8 +816,18 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
     if (use_h1) {
 #define TSX_H1_LAUNCH(CTYPE, HAS)                                                                                              \
   hipLaunchKernelGGL((tsx_k_pc_column_h1<CTYPE, ROWS, GS, ZT, HAS, XL>), dim3(nb), dim3(64), 0, s->stream, g,                     \
-                     (const CTYPE *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, s->pc_tmp, done)
-      if (s->coef_bytes == 4) {
+                     (const CTYPE *)cptr, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (void *)s->pc_tmp, done)
+      const void *cptr = s->coef;
+      if (std::is_same<ZT, float>::value && s->pc_half) {
+        if constexpr (std::is_same<ZT, float>::value) {
+          if (s->any_l1d)
+            hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
+                               (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+          else
+            hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
+                               (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+        }
+      } else if (s->coef_bytes == 4) {
         if (s->any_l1d) TSX_H1_LAUNCH(float, true);
         else TSX_H1_LAUNCH(float, false);
       } else {
@@ -1079,9 +1093,23 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   s->pc_sweeps = o->pc_sweeps;
   // fp32 directions: default on; the multi-sweep Jacobi refinement works on fp64 directions only
   s->mixed = o->fp32_directions != 0 && !(o->pc == TSX_PC_COLUMN && o->pc_sweeps > 1);
+  s->pc_half = false;
   if (o->pc != TSX_PC_NONE) {
     int rc = s->geo.ntop == 2 ? ensure_pc_buffers<2>(s) : ensure_pc_buffers<8>(s);
     if (rc) return rc;
+    if (o->pc_coeff_fp16 && s->mixed && s->geo.ntop == 2 && s->have_coeffs) {
+      const long long n = (long long)TSX_P16_GROUPS * s->geo.Nc;
+      if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
+      if (!s->coef_h_valid) {
+        if (s->coef_bytes == 4)
+          hipLaunchKernelGGL(tsx_k_pack_p16<float>, dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, s->geo.Nc, (const float *)s->coef, (tsx_h8 *)s->coef_h);
+        else
+          hipLaunchKernelGGL(tsx_k_pack_p16<double>, dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, s->geo.Nc, (const double *)s->coef, (tsx_h8 *)s->coef_h);
+        HIPCHK(hipGetLastError());
+        s->coef_h_valid = true;
+      }
+      s->pc_half = true;
+    }
   }
   return TSX_OK;
 }

@@ -66,6 +66,8 @@ struct tsx_solver {
   // operator
   void *coef;          // planes, float or double
   int coef_bytes;      // 4 or 8
+  void *coef_h;        // packed fp16 copy of the blocks for the preconditioner (tsx_k_pack_p16; built in prepare_ksp)
+  bool coef_h_valid, pc_half;
   uint8_t *l1d;        // [Nz]
   double *a11, *a12;   // [Nc] cell-indexed (only read where l1d)
   double *albedo;      // [ncol]

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                                                          const double *__restrict__ a11, const double *__restrict__ a12,
                                                          const double *__restrict__ albedo, const double *__restrict__ r,
                                                          ZT *__restrict__ z, const ZT *__restrict__ zc,
-                                                         const ZT *__restrict__ zx, double *__restrict__ tmp,
+                                                         const ZT *__restrict__ zx, void *__restrict__ tmp_,
                                                          const int *__restrict__ done) {
   constexpr int D = 10, NTOP = 2, NSIDE = 4;
   if (done && *done) return;
@@ -648,7 +648,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   const long long offW = (icol > 0) ? -1 : (g.wrap_x ? (long long)(g.xm - 1) : 0);
   const double *__restrict__ rt = r + (size_t)D * Nc;
   ZT *__restrict__ zt = z + (size_t)D * Nc;
-  double *__restrict__ tGw = tmp, *__restrict__ tGT = tmp + Nc, *__restrict__ tA = tmp + 2 * Nc, *__restrict__ tB = tmp + 3 * Nc;
+  // sweep temporaries in the precision of the output (fp32 for fp32 directions)
+  ZT *__restrict__ tmp = (ZT *)tmp_;
+  ZT *__restrict__ tGw = tmp, *__restrict__ tGT = tmp + Nc, *__restrict__ tA = tmp + 2 * Nc, *__restrict__ tB = tmp + 3 * Nc;
   const double albc = albedo[col], rsurf = rt[col];
 
   auto load_up = [&](int k) {
@@ -708,10 +710,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       const double GT = G * cu.tdd;
       const double Bn = cu.ru + cu.tuu * (B + A * Gw);
       const double An = cu.tuu * A * GT + cu.rud;
-      tGw[c] = Gw;
-      tGT[c] = GT;
-      tA[c] = An;
-      tB[c] = Bn;
+      tGw[c] = (ZT)Gw;
+      tGT[c] = (ZT)GT;
+      tA[c] = (ZT)An;
+      tB[c] = (ZT)Bn;
       A = An;
       B = Bn;
       cu = nx;
@@ -723,9 +725,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const size_t c = (size_t)k * ncol + col;
     const bool last = k + 1 >= Nz;
     const size_t cn = last ? c : c + ncol;
-    d.gw = tGw[c];
-    d.gt = tGT[c];
-    const double an = tA[cn], bn = tB[cn];
+    d.gw = (double)tGw[c];
+    d.gt = (double)tGT[c];
+    const double an = (double)tA[cn], bn = (double)tB[cn];
     d.an = last ? albc : an;  // U_Nz = albedo V_Nz + ru_Nz
     d.bn = last ? rsurf : bn;
     bool one = false;
@@ -795,6 +797,272 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   zt[col] = (ZT)U;  // U_Nz
 #pragma unroll
   for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (ZT)rt[(size_t)d * ncol + col];
+}
+
+// ---- 3_10 preconditioner on a *packed fp16* copy of the transport blocks (fp32 directions only) -------------------
+// The sweep above is paced by memory latency, not bytes: one wave can only track 63 outstanding vector-memory
+// operations (s_waitcnt vmcnt is 6 bits), and with one 4-byte load per coefficient a single level already needs > 100.
+// Here the 100 coefficients of a cell are regrouped into 13 records of 8 halves (16 B) in the order the two sweeps
+// consume them, P[(grp * Nc + cell)] as uint4: a level costs 3 (up) + 10 (down) coefficient loads of 16 B per lane, so
+// several levels fit under the counter and the sweeps are software-pipelined PU / PD levels deep.
+//   grp 0: tuu rud rdu tdd | c(y0->0) c(y0->1) c(y1->0) c(y1->1)          (y_q = src dof 6+q, x_q = src dof 2+q)
+//   grp 1: c(y2->0) c(y2->1) c(y3->0) c(y3->1) | c(x0->0) c(x0->1) c(x1->0) c(x1->1)
+//   grp 2: c(x2->0) c(x2->1) c(x3->0) c(x3->1) | pad
+//   grp 3: c(0 -> side d), d = 2..9          grp 4: c(1 -> side d)
+//   grp 5+m: c(y_q -> 2+2m), c(y_q -> 3+2m)  grp 9+m: c(x_q -> 2+2m), c(x_q -> 3+2m)      (m = 0..3, q = 0..3)
+typedef _Float16 tsx_h8 __attribute__((ext_vector_type(8)));
+constexpr int TSX_P16_GROUPS = 13;
+
+// plane index dst*10+src held by element e of group grp; -1 = padding
+__host__ __device__ constexpr int tsx_p16_plane(int grp, int e) {
+  if (grp == 0) {
+    if (e < 4) return (e >> 1) * 10 + (e & 1);
+    return (e & 1) * 10 + 6 + ((e - 4) >> 1);
+  }
+  if (grp == 1) {
+    if (e < 4) return (e & 1) * 10 + 8 + (e >> 1);
+    return (e & 1) * 10 + 2 + ((e - 4) >> 1);
+  }
+  if (grp == 2) return e < 4 ? (e & 1) * 10 + 4 + (e >> 1) : -1;
+  if (grp == 3) return (2 + e) * 10 + 0;
+  if (grp == 4) return (2 + e) * 10 + 1;
+  if (grp < 9) return (2 + 2 * (grp - 5) + (e >> 2)) * 10 + 6 + (e & 3);
+  return (2 + 2 * (grp - 9) + (e >> 2)) * 10 + 2 + (e & 3);
+}
+
+template <typename CT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pack_p16(long long Nc, const CT *__restrict__ C, tsx_h8 *__restrict__ P) {
+  const long long n = Nc * TSX_P16_GROUPS;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
+    const int grp = (int)(q / Nc);
+    const long long c = q - (long long)grp * Nc;
+    tsx_h8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int pl = tsx_p16_plane(grp, e);
+      v[e] = pl >= 0 ? (_Float16)C[(size_t)pl * Nc + c] : (_Float16)0;
+    }
+    P[q] = v;
+  }
+}
+
+struct TsxUpRaw {
+  tsx_h8 c0, c1, c2;
+  double ru, rd, t11, t12;
+  float zy[4], zx[4];
+};
+struct TsxDnRaw {
+  tsx_h8 cu, cv, cy[4], cx[4];
+  float4 t;        // Gw_k, GT_k, A_{k+1}, B_{k+1}
+  double rs[8];
+  float zy[4], zx[4];
+};
+
+template <int ROWS, bool GS, bool HAS1D, bool XL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void tsx_k_pc_column_p16(
+    TsxGeo g, const tsx_h8 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
+    const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ r, float *__restrict__ z,
+    const float *__restrict__ zc, const float *__restrict__ zx, float4 *__restrict__ tmp, const int *__restrict__ done) {
+  constexpr int D = 10, NTOP = 2, NSIDE = 4;
+  constexpr int PU = 4, PD = 2;  // prefetch depth of the upward / downward sweep (levels)
+  if (done && *done) return;
+  int col = blockIdx.x * 64 + threadIdx.x;
+  if (ROWS) {
+    const int nrows = ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2;
+    if (col >= nrows * g.xm) return;
+    col = (2 * (col / g.xm) + (ROWS - 1)) * g.xm + col % g.xm;
+  }
+  if (col >= g.ncol) return;
+  const long long Nc = g.Nc;
+  const int Nz = g.Nz, ncol = g.ncol;
+  const int jrow = col / g.xm;
+  const bool seam = g.wrap_y && (g.ym % 2 == 0);
+  const long long offN = (jrow + 1 < g.ym) ? (long long)g.xm : (seam ? -(long long)(g.ym - 1) * g.xm : 0);
+  const long long offS = (jrow > 0) ? -(long long)g.xm : (seam ? (long long)(g.ym - 1) * g.xm : 0);
+  const int icol = col % g.xm;
+  const long long offE = (icol + 1 < g.xm) ? 1 : (g.wrap_x ? -(long long)(g.xm - 1) : 0);
+  const long long offW = (icol > 0) ? -1 : (g.wrap_x ? (long long)(g.xm - 1) : 0);
+  const double *__restrict__ rt = r + (size_t)D * Nc;
+  float *__restrict__ zt = z + (size_t)D * Nc;
+  const double albc = albedo[col], rsurf = rt[col];
+
+  // loads only: nothing here depends on loaded data, so that the whole record of a level is in flight at once
+  auto load_up = [&](int k) {
+    TsxUpRaw u;
+    const size_t c = (size_t)k * ncol + col;
+    u.c0 = P[(size_t)0 * Nc + c];
+    if (GS) u.c1 = P[(size_t)1 * Nc + c];
+    if (XL) u.c2 = P[(size_t)2 * Nc + c];
+    u.ru = r[c];
+    u.rd = r[(size_t)Nc + c];
+    if (GS) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) u.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
+    }
+    if (XL) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) u.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
+    }
+    if (HAS1D) {
+      u.t11 = a11[c];
+      u.t12 = a12[c];
+    }
+    return u;
+  };
+
+  double A = albc, B = rsurf;
+  auto step_up = [&](int k, const TsxUpRaw &u) {
+    const size_t c = (size_t)k * ncol + col;
+    double tuu = (double)u.c0[0], rud = (double)u.c0[1], rdu = (double)u.c0[2], tdd = (double)u.c0[3];
+    double gu = 0.0, gd = 0.0;
+    if (GS) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) {
+        const double zv = (tsx_inward(q) ? offS : offN) ? (double)u.zy[q] : 0.0;  // select: the unused slot may hold NaN
+        const double c0 = q < 2 ? (double)u.c0[4 + 2 * q] : (double)u.c1[2 * (q - 2)];
+        const double c1 = q < 2 ? (double)u.c0[5 + 2 * q] : (double)u.c1[2 * (q - 2) + 1];
+        gu += c0 * zv;
+        gd += c1 * zv;
+      }
+    }
+    if (XL) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) {
+        const double zv = (tsx_inward(q) ? offW : offE) ? (double)u.zx[q] : 0.0;
+        const double c0 = q < 2 ? (double)u.c1[4 + 2 * q] : (double)u.c2[2 * (q - 2)];
+        const double c1 = q < 2 ? (double)u.c1[5 + 2 * q] : (double)u.c2[2 * (q - 2) + 1];
+        gu += c0 * zv;
+        gd += c1 * zv;
+      }
+    }
+    if (HAS1D) {
+      const bool one = l1d[k] != 0;
+      tuu = one ? u.t11 : tuu;
+      tdd = one ? u.t11 : tdd;
+      rud = one ? u.t12 : rud;
+      rdu = one ? u.t12 : rdu;
+      gu = one ? 0.0 : gu;
+      gd = one ? 0.0 : gd;
+    }
+    const double ru = u.ru + gu, rd = u.rd + gd;
+    const double G = 1.0 / (1.0 - rdu * A);
+    const double Gw = G * (rd + rdu * B);
+    const double GT = G * tdd;
+    tmp[c] = make_float4((float)Gw, (float)GT, (float)A, (float)B);
+    const double Bn = ru + tuu * (B + A * Gw);
+    const double An = tuu * A * GT + rud;
+    A = An;
+    B = Bn;
+  };
+
+  // ---- upward sweep: U_k = A_k V_k + B_k
+  {
+    int k = Nz - 1;
+    for (int rr = Nz % PU; rr > 0; --rr, --k) {
+      const TsxUpRaw u = load_up(k);
+      step_up(k, u);
+    }
+    if (k >= 0) {  // k + 1 is a multiple of PU
+      TsxUpRaw q[PU];
+#pragma unroll
+      for (int p = 0; p < PU; ++p) q[p] = load_up(k - p);
+      for (; k >= 0; k -= PU) {
+#pragma unroll
+        for (int p = 0; p < PU; ++p) {
+          const TsxUpRaw cu = q[p];
+          const int kn = k - p - PU;
+          q[p] = load_up(kn >= 0 ? kn : 0);
+          step_up(k - p, cu);
+        }
+      }
+    }
+  }
+
+  auto load_dn = [&](int k) {
+    TsxDnRaw d;
+    const size_t c = (size_t)k * ncol + col;
+    d.cu = P[(size_t)3 * Nc + c];
+    d.cv = P[(size_t)4 * Nc + c];
+    d.t = tmp[c];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+    if (GS) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) d.cy[m] = P[(size_t)(5 + m) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) d.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
+    }
+    if (XL) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) d.cx[m] = P[(size_t)(9 + m) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) d.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
+    }
+    return d;
+  };
+
+  double V = rt[(size_t)ncol + col];  // V_0 = rd_0 (TOA identity row)
+  zt[(size_t)ncol + col] = (float)V;
+  double U = A * V + B;               // A, B hold level 0
+  auto step_dn = [&](int k, const TsxDnRaw &d) {
+    const size_t c = (size_t)k * ncol + col;
+    bool one = false;
+    if (HAS1D) one = l1d[k] != 0;
+    const double Vn = (double)d.t.x + (double)d.t.y * V;
+    const double Un = (double)d.t.z * Vn + (double)d.t.w;
+    z[c] = (float)U;
+    z[(size_t)Nc + c] = (float)Vn;
+    double zy[NSIDE], zq[NSIDE];
+    if (GS) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) zy[q] = (tsx_inward(q) ? offS : offN) ? (double)d.zy[q] : 0.0;
+    }
+    if (XL) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) zq[q] = (tsx_inward(q) ? offW : offE) ? (double)d.zx[q] : 0.0;
+    }
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) {
+      double acc = (double)d.cu[dd] * Un + (double)d.cv[dd] * V;
+      if (GS) {
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) acc += (double)d.cy[dd >> 1][(dd & 1) * 4 + q] * zy[q];
+      }
+      if (XL) {
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) acc += (double)d.cx[dd >> 1][(dd & 1) * 4 + q] * zq[q];
+      }
+      z[(size_t)(NTOP + dd) * Nc + c] = (float)(d.rs[dd] + (one ? 0.0 : acc));
+    }
+    V = Vn;
+    U = Un;
+  };
+
+  // ---- downward sweep
+  {
+    int k = 0;
+    for (int rr = Nz % PD; rr > 0; --rr, ++k) {
+      const TsxDnRaw d = load_dn(k);
+      step_dn(k, d);
+    }
+    if (k < Nz) {
+      TsxDnRaw q[PD];
+#pragma unroll
+      for (int p = 0; p < PD; ++p) q[p] = load_dn(k + p);
+      for (; k < Nz; k += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+          const TsxDnRaw cd = q[p];
+          const int kn = k + p + PD;
+          q[p] = load_dn(kn < Nz ? kn : Nz - 1);
+          step_dn(k + p, cd);
+        }
+      }
+    }
+  }
+  zt[col] = (float)U;  // U_Nz
+#pragma unroll
+  for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (float)rt[(size_t)d * ncol + col];
 }
 
 // out = a - b   (second preconditioner sweep: residual of the first)

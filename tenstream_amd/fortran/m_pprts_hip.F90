@@ -42,6 +42,8 @@ module m_pprts_hip
     integer(c_int32_t) :: pc_sweeps
     integer(c_int32_t) :: check_every
     integer(c_int32_t) :: fp32_directions
+    integer(c_int32_t) :: pc_coeff_fp16
+    integer(c_int32_t) :: reserved_
   end type
 
   type, bind(C) :: t_tsx_ksp_result

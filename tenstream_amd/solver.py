@@ -250,7 +250,7 @@ class DiffuseSolver:
         return rtol.value, atol.value, maxit.value
 
     def solve(self, b, x, *, rtol=None, atol=None, maxit=None, dtol=None, pc=None, pc_sweeps=None,
-              check_every=None, fp32_directions=None) -> KspInfo:
+              check_every=None, fp32_directions=None, pc_coeff_fp16=None) -> KspInfo:
         """Solve in place: x holds the initial guess on entry (src/pprts.F90:4343) and the solution on exit."""
         if tuple(b.shape) != self.vec_shape or tuple(x.shape) != self.vec_shape:
             raise ValueError("b/x shape mismatch")
@@ -259,7 +259,8 @@ class DiffuseSolver:
         drt, dat, dmx = self.default_tolerances()
         o.rtol, o.atol, o.maxit = drt, dat, dmx
         for name, val in (("rtol", rtol), ("atol", atol), ("maxit", maxit), ("dtol", dtol), ("pc", pc),
-                          ("pc_sweeps", pc_sweeps), ("check_every", check_every), ("fp32_directions", fp32_directions)):
+                          ("pc_sweeps", pc_sweeps), ("check_every", check_every), ("fp32_directions", fp32_directions),
+                          ("pc_coeff_fp16", pc_coeff_fp16)):
             if val is not None:
                 setattr(o, name, val)
         bp, where = _ptr(b, np.float64)
