@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--nz", type=int, default=64)
     ap.add_argument("--solver", default="3_10")
     ap.add_argument("--pc", type=int, default=2, help="0 none, 1 column-block Jacobi, 2 zebra line-GS over column blocks")
-    ap.add_argument("--pc-sweeps", type=int, default=3)
+    ap.add_argument("--pc-sweeps", type=int, default=5)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=112, help="edge of the CPU-baseline sample tile (columns)")

@@ -216,6 +216,13 @@ extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
   s->own_stream = true;
   HIPCHK(hipEventCreate(&s->ev0));
   HIPCHK(hipEventCreate(&s->ev1));
+  HIPCHK(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&s->ev_pack, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
+  {
+    const char *e = getenv("TSX_OVERLAP");
+    s->overlap = e ? atoi(e) != 0 : true;
+  }
 
   const size_t nb = (size_t)g.N * sizeof(double);
   double **vecs[] = {&s->vx, &s->vb, &s->vr, &s->vrhat, &s->vp, &s->vv, &s->vs, &s->vt};
@@ -271,6 +278,9 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   if (s->comm_ready && g_rccl.CommDestroy) g_rccl.CommDestroy(s->nccl_comm);
   (void)hipEventDestroy(s->ev0);
   (void)hipEventDestroy(s->ev1);
+  (void)hipEventDestroy(s->ev_pack);
+  (void)hipEventDestroy(s->ev_recv);
+  (void)hipStreamDestroy(s->comm_stream);
   if (s->own_stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return TSX_OK;
@@ -296,7 +306,9 @@ extern "C" int tsx_set_stream(tsx_solver *s, void *hip_stream) {
 // sendW, recvS <- south's sendN, recvN <- north's sendS.  Point-to-point messages to one peer are
 // matched in issue order, so receives are posted E,W,N,S against sends W,E,S,N (matters when both
 // x-neighbours are the same rank, e.g. 2 ranks along a periodic axis).
-static int face_exchange(tsx_solver *s) {
+// st: the stream the transfers are issued on (the solver stream, or comm_stream when overlapping; the caller has made
+// st wait for the pack kernel)
+static int face_exchange(tsx_solver *s, hipStream_t st) {
   const TsxGeo &g = s->geo;
   const size_t bx = s->halo_x_elems, by = s->halo_y_elems;
   if (s->xchg_cb) {
@@ -309,15 +321,15 @@ static int face_exchange(tsx_solver *s) {
       const size_t cap = (q < 2 ? bx : by) * sizeof(double);
       if (!s->host_send[q]) HIPCHK(hipHostMalloc((void **)&s->host_send[q], cap, hipHostMallocDefault));
       if (!s->host_recv[q]) HIPCHK(hipHostMalloc((void **)&s->host_recv[q], cap, hipHostMallocDefault));
-      if (count[q]) HIPCHK(hipMemcpyAsync(s->host_send[q], dsend[q], count[q] * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+      if (count[q]) HIPCHK(hipMemcpyAsync(s->host_send[q], dsend[q], count[q] * sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipStreamSynchronize(st));
     if (s->xchg_cb(s->cb_ctx, (const double *const *)s->host_send, (double *const *)s->host_recv, count, peer)) {
       tsx_set_error("face_exchange: exchange callback failed");
       return TSX_ERR_COMM;
     }
     for (int q = 0; q < 4; ++q)
-      if (count[q]) HIPCHK(hipMemcpyAsync(drecv[q], s->host_recv[q], count[q] * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      if (count[q]) HIPCHK(hipMemcpyAsync(drecv[q], s->host_recv[q], count[q] * sizeof(double), hipMemcpyHostToDevice, st));
     return TSX_OK;
   }
   if (s->comm_ready) {
@@ -325,16 +337,16 @@ static int face_exchange(tsx_solver *s) {
     const tsx_grid &gr = s->grid;
     NCCLCHK(g_rccl.GroupStart());
     if (!g.wrap_x) {
-      NCCLCHK(g_rccl.Send(s->sendW, bx, TSX_NCCL_FLOAT64, gr.neigh_w, c, s->stream));
-      NCCLCHK(g_rccl.Send(s->sendE, bx, TSX_NCCL_FLOAT64, gr.neigh_e, c, s->stream));
-      NCCLCHK(g_rccl.Recv(s->recvE, bx, TSX_NCCL_FLOAT64, gr.neigh_e, c, s->stream));
-      NCCLCHK(g_rccl.Recv(s->recvW, bx, TSX_NCCL_FLOAT64, gr.neigh_w, c, s->stream));
+      NCCLCHK(g_rccl.Send(s->sendW, bx, TSX_NCCL_FLOAT64, gr.neigh_w, c, st));
+      NCCLCHK(g_rccl.Send(s->sendE, bx, TSX_NCCL_FLOAT64, gr.neigh_e, c, st));
+      NCCLCHK(g_rccl.Recv(s->recvE, bx, TSX_NCCL_FLOAT64, gr.neigh_e, c, st));
+      NCCLCHK(g_rccl.Recv(s->recvW, bx, TSX_NCCL_FLOAT64, gr.neigh_w, c, st));
     }
     if (!g.wrap_y) {
-      NCCLCHK(g_rccl.Send(s->sendS, by, TSX_NCCL_FLOAT64, gr.neigh_s, c, s->stream));
-      NCCLCHK(g_rccl.Send(s->sendN, by, TSX_NCCL_FLOAT64, gr.neigh_n, c, s->stream));
-      NCCLCHK(g_rccl.Recv(s->recvN, by, TSX_NCCL_FLOAT64, gr.neigh_n, c, s->stream));
-      NCCLCHK(g_rccl.Recv(s->recvS, by, TSX_NCCL_FLOAT64, gr.neigh_s, c, s->stream));
+      NCCLCHK(g_rccl.Send(s->sendS, by, TSX_NCCL_FLOAT64, gr.neigh_s, c, st));
+      NCCLCHK(g_rccl.Send(s->sendN, by, TSX_NCCL_FLOAT64, gr.neigh_n, c, st));
+      NCCLCHK(g_rccl.Recv(s->recvN, by, TSX_NCCL_FLOAT64, gr.neigh_n, c, st));
+      NCCLCHK(g_rccl.Recv(s->recvS, by, TSX_NCCL_FLOAT64, gr.neigh_s, c, st));
     }
     NCCLCHK(g_rccl.GroupEnd());
     return TSX_OK;
@@ -345,12 +357,12 @@ static int face_exchange(tsx_solver *s) {
   }
   // single rank with force_halo: every neighbour is this rank
   if (!g.wrap_x) {
-    HIPCHK(hipMemcpyAsync(s->recvE, s->sendW, bx * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->recvW, s->sendE, bx * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->recvE, s->sendW, bx * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->recvW, s->sendE, bx * sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   if (!g.wrap_y) {
-    HIPCHK(hipMemcpyAsync(s->recvN, s->sendS, by * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->recvS, s->sendN, by * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->recvN, s->sendS, by * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->recvS, s->sendN, by * sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   return TSX_OK;
 }
@@ -362,7 +374,7 @@ static int halo_update(tsx_solver *s, const XT *v, bool in_solve) {
   const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
   hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE, XT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, v, s->sendW,
                      s->sendE, s->sendS, s->sendN, in_solve ? &s->scal->done : (const int *)nullptr);
-  return face_exchange(s);
+  return face_exchange(s, s->stream);
 }
 
 // TSX_SPMV_CPT=1|2 selects cells per thread (default 2 when xm is even)
@@ -378,44 +390,81 @@ static int spmv_cpt(const tsx_solver *s) {
   return want;
 }
 
+#define TSX_FRAME_BLOCKS 256
+// groups of the frame (cells whose gather reads a received face), see tsx_k_spmv_w
+static long long frame_groups(const TsxGeo &g, int cpt) {
+  const int gx = g.xm / cpt;
+  const int nfull = g.wrap_y ? 0 : (g.ym >= 2 ? 2 : 1);
+  const int ex = g.wrap_x ? 0 : (gx >= 2 ? 2 : 1);
+  return (long long)g.Nz * (nfull * gx + (g.ym - nfull) * ex);
+}
+static inline bool spmv_split(const tsx_solver *s) { return s->overlap && !(s->geo.wrap_x && s->geo.wrap_y); }
+
+// part 0: whole grid; 1: interior (no halo reads); 2: frame, partial sums behind those of part 1
 template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT, bool HALO, bool HAS1D>
-static void launch_spmv_variant(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done) {
+static void launch_spmv_variant(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done, int part) {
   const TsxGeo &g = s->geo;
-  const int nb = grid_for(g.Nc / CPT, TSX_MAX_PARTIAL_BLOCKS);
+  const int nbmain = grid_for(g.Nc / CPT, TSX_MAX_PARTIAL_BLOCKS - TSX_FRAME_BLOCKS);
+  const int nb = part == 2 ? grid_for(frame_groups(g, CPT), TSX_FRAME_BLOCKS) : nbmain;
   hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT, XT, WT, HALO, HAS1D>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
                      (const CT *)s->coef, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS, s->recvN,
-                     w, s->partials, done);
+                     w, s->partials + (part == 2 ? nbmain : 0), done, part);
 }
 
 template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT>
-static void launch_spmv_flags(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done) {
-  const bool halo = !(s->geo.wrap_x && s->geo.wrap_y), has1d = s->any_l1d;
+static void launch_spmv_flags(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done, int part) {
+  const bool halo = !(s->geo.wrap_x && s->geo.wrap_y) && part != 1, has1d = s->any_l1d;
   if (halo) {
-    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, true>(s, x, y, w, done);
-    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, false>(s, x, y, w, done);
+    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, true>(s, x, y, w, done, part);
+    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, false>(s, x, y, w, done, part);
   } else {
-    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, true>(s, x, y, w, done);
-    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, false>(s, x, y, w, done);
+    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, true>(s, x, y, w, done, part);
+    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, false>(s, x, y, w, done, part);
   }
 }
 
 template <int NTOP, int NSIDE, int FUSE, typename XT = double, typename WT = double>
 static int launch_spmv(tsx_solver *s, const XT *x, double *y, const WT *w, bool in_solve) {
-  int rc = halo_update<NTOP, NSIDE, XT>(s, x, in_solve);
-  if (rc) return rc;
   const int *done = in_solve ? &s->scal->done : nullptr;
   const int cpt = spmv_cpt(s);
-  if (s->coef_bytes == 4) {
-    if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, float, 2, XT, WT>(s, x, y, w, done);
-    else launch_spmv_flags<NTOP, NSIDE, FUSE, float, 1, XT, WT>(s, x, y, w, done);
-  } else {
-    if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, double, 2, XT, WT>(s, x, y, w, done);
-    else launch_spmv_flags<NTOP, NSIDE, FUSE, double, 1, XT, WT>(s, x, y, w, done);
+  auto launch = [&](int part) {
+    if (s->coef_bytes == 4) {
+      if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, float, 2, XT, WT>(s, x, y, w, done, part);
+      else launch_spmv_flags<NTOP, NSIDE, FUSE, float, 1, XT, WT>(s, x, y, w, done, part);
+    } else {
+      if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, double, 2, XT, WT>(s, x, y, w, done, part);
+      else launch_spmv_flags<NTOP, NSIDE, FUSE, double, 1, XT, WT>(s, x, y, w, done, part);
+    }
+  };
+  if (!spmv_split(s)) {
+    int rc = halo_update<NTOP, NSIDE, XT>(s, x, in_solve);
+    if (rc) return rc;
+    launch(0);
+    HIPCHK(hipGetLastError());
+    return TSX_OK;
   }
+  // overlap: pack -> [exchange on comm_stream || interior cells on stream] -> frame cells
+  const TsxGeo &g = s->geo;
+  const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
+  hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE, XT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, x, s->sendW,
+                     s->sendE, s->sendS, s->sendN, done);
+  HIPCHK(hipEventRecord(s->ev_pack, s->stream));
+  HIPCHK(hipStreamWaitEvent(s->comm_stream, s->ev_pack, 0));
+  launch(1);  // queued before the (possibly host-synchronous) exchange so that it runs underneath it
+  HIPCHK(hipGetLastError());
+  int rc = face_exchange(s, s->comm_stream);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(s->ev_recv, s->comm_stream));
+  HIPCHK(hipStreamWaitEvent(s->stream, s->ev_recv, 0));
+  launch(2);
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
-static inline int spmv_nblocks(const tsx_solver *s) { return grid_for(s->geo.Nc / spmv_cpt(s), TSX_MAX_PARTIAL_BLOCKS); }
+static inline int spmv_nblocks(const tsx_solver *s) {
+  const int cpt = spmv_cpt(s);
+  const int nbmain = grid_for(s->geo.Nc / cpt, TSX_MAX_PARTIAL_BLOCKS - TSX_FRAME_BLOCKS);
+  return spmv_split(s) ? nbmain + grid_for(frame_groups(s->geo, cpt), TSX_FRAME_BLOCKS) : nbmain;
+}
 
 // reduce partials -> (all-reduce) -> scalar algebra
 static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {
@@ -454,7 +503,7 @@ static int import_vec(tsx_solver *s, const double *ref_dev, double *v) {
   HIPCHK(hipGetLastError());
   if (!(g.wrap_x && g.wrap_y)) {
     // only the W-ward / S-ward messages carry data; E/N-ward buffers travel as they are (ignored)
-    int rc = face_exchange(s);
+    int rc = face_exchange(s, s->stream);
     if (rc) return rc;
     const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
     // a direction that wraps in-kernel has nothing to unpack: pass through harmlessly by guarding in host

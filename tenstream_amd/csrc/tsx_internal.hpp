@@ -121,6 +121,9 @@ struct tsx_solver {
   double *host_send[4], *host_recv[4];  // pinned staging, order W,E,S,N
 
   hipEvent_t ev0, ev1;
+  hipStream_t comm_stream;   // face exchange runs here while the interior SpMV runs on `stream`
+  hipEvent_t ev_pack, ev_recv;
+  bool overlap;              // split SpMV into interior + frame launches around the exchange (TSX_OVERLAP=0 disables)
 };
 
 void tsx_set_error(const std::string &msg);

@@ -121,6 +121,9 @@ template <> struct TsxRaw<double, 2> {
   static __device__ __forceinline__ void cvt(type v, double *o) { o[0] = v.x; o[1] = v.y; }
 };
 
+// part: 0 = every cell; 1 = interior only (cells whose gather touches no received face: launched while the exchange is
+// in flight); 2 = frame only (the complement, enumerated directly: per level the first/last row and the first/last
+// group of every other row).  Partial sums of launch 2 go behind those of launch 1 (partials pointer is offset).
 // HALO: some face of the rank is not a periodic self-neighbour (edge threads then read the received face buffers);
 // HAS1D: some layer is 1-D.  Both are kernel-uniform and compiled out in the common case.  The gather is branch-free
 // (offset / pointer selects, unconditional loads): a conditional load ends a basic block and forces an s_waitcnt.
@@ -130,30 +133,56 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
     const double *__restrict__ a12, const double *__restrict__ albedo, const XT *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ hW, const double *__restrict__ hE,
     const double *__restrict__ hS, const double *__restrict__ hN, const WT *__restrict__ w,
-    double *__restrict__ partials, const int *__restrict__ done) {
+    double *__restrict__ partials, const int *__restrict__ done, int part) {
   constexpr int D = NTOP + 2 * NSIDE;
   using V = TsxVec<CPT>;
   if (done && *done) return;
   double sum[3] = {0.0, 0.0, 0.0};
   const long long Nc = g.Nc;
   const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
-  const long long ngroups = Nc / CPT;
+  const bool wrapx = g.wrap_x != 0, wrapy = g.wrap_y != 0;
+  const int gx = xm / CPT;                                   // groups per row
+  const int nfull = wrapy ? 0 : (ym >= 2 ? 2 : 1);           // frame: rows that belong to it entirely
+  const int ex = wrapx ? 0 : (gx >= 2 ? 2 : 1);              // frame: groups of every other row
+  const int nframe = nfull * gx + (ym - nfull) * ex;         // frame groups per level
+  const long long ngroups = part == 2 ? (long long)Nz * nframe : Nc / CPT;
   const long long nchunks = (ngroups + TSX_BLOCK - 1) / TSX_BLOCK;
   const XT *__restrict__ xt = x + (size_t)D * Nc;
   double *__restrict__ yt = y + (size_t)D * Nc;
   const WT *__restrict__ wt = (FUSE & 1) ? w + (size_t)D * Nc : nullptr;
-  const bool wrapx = g.wrap_x != 0, wrapy = g.wrap_y != 0;
 
   for (long long base = 0; base < nchunks; base += gridDim.x) {
     const long long nb = (nchunks - base) < (long long)gridDim.x ? (nchunks - base) : (long long)gridDim.x;
     if ((long long)blockIdx.x >= nb) break;
     const long long grp = (base + tsx_swizzle(blockIdx.x, nb)) * TSX_BLOCK + threadIdx.x;
     if (grp >= ngroups) continue;
-    const long long c = grp * CPT;
-    const int i = (int)(c % xm);
-    const long long t = c / xm;
-    const int j = (int)(t % ym);
-    const int k = (int)(t / ym);
+    long long c;
+    int i, j, k;
+    if (part == 2) {
+      k = (int)(grp / nframe);
+      const int f = (int)(grp - (long long)k * nframe);
+      int ig;
+      if (f < nfull * gx) {
+        j = (f / gx) == 0 ? 0 : ym - 1;
+        ig = f % gx;
+      } else {
+        const int f2 = f - nfull * gx, exs = ex > 0 ? ex : 1;
+        j = f2 / exs + (wrapy ? 0 : 1);
+        ig = (f2 % exs) == 0 ? 0 : gx - 1;
+      }
+      i = ig * CPT;
+      c = ((long long)k * ym + j) * xm + i;
+    } else {
+      c = grp * CPT;
+      i = (int)(c % xm);
+      const long long t = c / xm;
+      j = (int)(t % ym);
+      k = (int)(t / ym);
+      if (part == 1) {
+        const bool fr = (!wrapx && (i == 0 || i + CPT >= xm)) || (!wrapy && (j == 0 || j + 1 >= ym));
+        if (fr) continue;
+      }
+    }
     const int col = j * xm + i;
 
     double xs[D][CPT];

@@ -162,7 +162,7 @@ contains
     opts%atol = atol
     opts%maxit = maxit
     opts%pc = pc
-    if (pc .eq. TSX_PC_ZEBRA) opts%pc_sweeps = 3
+    if (pc .eq. TSX_PC_ZEBRA) opts%pc_sweeps = 5
     ierr = tsx_diff_solve(handle, c_loc(vb), c_loc(vediff), TSX_HOST, opts, res)
     niter = res%niter
     reason = res%reason

@@ -47,6 +47,28 @@ def test_apply_matches_oracle(gpu, solver, Nx, Ny, Nz, n1d, force_halo):
     s.close()
 
 
+@pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 20, 12, 9, 2), ("3_10", 3, 3, 4, 0), ("8_16", 6, 5, 4, 1)])
+def test_apply_split_launches_equal_single_launch(gpu, monkeypatch, solver, Nx, Ny, Nz, n1d):
+    """exchange/compute overlap: interior + frame launches (default) must give the bits of the one-launch SpMV"""
+    P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d, seed=5)
+    x = np.random.default_rng(2).standard_normal((Ny, Nx, Nz + 1, 10 if solver == "3_10" else 16))
+    ys = []
+    for ov in ("1", "0"):
+        monkeypatch.setenv("TSX_OVERLAP", ov)
+        s = DiffuseSolver(solver, Nz, Nx, Ny, force_halo=True)
+        s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+        assert x.shape == tuple(s.vec_shape)
+        ys.append(s.apply(x))
+        info_x = np.zeros_like(x)
+        info = s.solve(P["b"], info_x, pc=1)
+        ys.append(info_x)
+        ys.append(info.res_hist)
+        s.close()
+    assert np.array_equal(ys[0], ys[3])
+    np.testing.assert_allclose(ys[1], ys[4], rtol=1e-6, atol=1e-9 * np.abs(ys[4]).max())
+    assert abs(len(ys[2]) - len(ys[5])) <= 1
+
+
 def test_apply_fp64_coefficients_kept_when_lossy(gpu):
     """Blocks that are not fp32-representable must be stored as fp64 (results identical to the reference)."""
     P = synthetic.make_problem("3_10", Nx=8, Ny=6, Nz=5)
