@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--pc-sweeps", type=int, default=5)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=112, help="edge of the CPU-baseline sample tile (columns)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the CPU-baseline sample domain (columns); 0 = 256 with >= 32 threads, else 112")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads (= subdomains) of the CPU baseline; 0 = min(host cores, 64)")
     return ap.parse_args()
 
 
@@ -217,27 +218,32 @@ def pmc_traffic(key):
 
 
 def cpu_baseline(args, solver, dx, dz, albedo):
-    """The reference's default 1-rank path (assembled AIJ + KSPFBCGS + ILU(0), src/pprts.F90:4342-4360) as
-    restated by the oracle, timed on this box's host cores on a bounded tile of the same generator."""
+    """The reference's default CPU path as restated by the oracle, timed on this box's host cores on a bounded sample of
+    the same generator: assembled AIJ + KSPFBCGS + PCBJACOBI/ILU(0), one subdomain per core like one MPI rank per core
+    (src/pprts.F90:4342-4371, 4415-4425).  With one thread this is the 1-rank default (plain ILU(0))."""
     from oracle import oracle as O
     from tenstream_amd import synthetic as S
+    from tenstream_amd.coord import decompose
 
-    n = args.cpu_sample
+    cores = os.cpu_count() or 1
+    threads = args.cpu_threads if args.cpu_threads > 0 else min(cores, 64)
+    n = args.cpu_sample if args.cpu_sample > 0 else (256 if threads >= 32 else 112)
+    npx, npy = decompose(threads)
     P = S.make_problem(solver, Nx=n, Ny=n, Nz=args.nz, dx=dx, dz=dz, albedo=albedo)
     lay = O.layout(solver, args.nz, n, n)
     rt, at, mx = O.default_tolerances(n, n, args.nz + 1)
-    x, info = O.solve_ilu(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"], P["b"],
-                          rtol=rt, atol=at, maxit=mx)
+    x, info = O.solve_bjacobi_ilu_mt(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"],
+                                     P["b"], npx, npy, rtol=rt, atol=at, maxit=mx)
     cells = n * n * args.nz
     return {
         "value": cells / info["t_solve"],
         "unit": "cells/s",
-        "cores": 1,
+        "cores": threads,
         "kind": "port",
-        "sample": f"{n}x{n}x{args.nz} tile of the same generator; assembled CSR + FBCGS + ILU(0), "
-                  f"{info['niter']} its, solve {info['t_solve']:.2f}s (assembly {info['t_assemble']:.2f}s, "
-                  f"factor {info['t_factor']:.2f}s not counted)",
-        "host_cores_available": os.cpu_count(),
+        "sample": f"{n}x{n}x{args.nz} periodic domain of the same generator; assembled CSR + FBCGS + block-Jacobi/ILU(0) on "
+                  f"{npx}x{npy} subdomains (one thread each), {info['niter']} its, reason {info['reason']}, solve "
+                  f"{info['t_solve']:.2f}s (assembly {info['t_assemble']:.2f}s, factor {info['t_factor']:.2f}s not counted)",
+        "host_cores_available": cores,
     }
 
 

@@ -189,6 +189,25 @@ def solve_ilu(lay, coeff, l1d, a11, a12, albedo, b, x0=None, rtol=1e-5, atol=1e-
                    t_factor=tf.value, t_solve=ts.value)
 
 
+def solve_bjacobi_ilu_mt(lay, coeff, l1d, a11, a12, albedo, b, npx, npy, x0=None, rtol=1e-5, atol=1e-8, maxit=1000,
+                         dtol=1e4):
+    """The reference's default on npx*npy ranks (FBCGS + PCBJACOBI/ILU(0), pprts.F90:4415-4425), one host thread per
+    subdomain (pprts_oracle_mt.c)."""
+    coeff, l1d, a11, a12, albedo = _chk(lay, coeff, l1d, a11, a12, albedo)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64, order="C", copy=True)
+    tol = KspTol(rtol, atol, dtol, maxit)
+    nit = C.c_int()
+    hist = np.full(maxit + 2, -1.0)
+    ta, tf, ts = C.c_double(), C.c_double(), C.c_double()
+    reason = lib().orc_diff_solve_bjacobi_ilu_mt(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12),
+                                                 _p(albedo), _p(b), _p(x), C.byref(tol), int(npx), int(npy),
+                                                 C.byref(nit), _p(hist), len(hist), C.byref(ta), C.byref(tf),
+                                                 C.byref(ts))
+    return x, dict(reason=reason, niter=nit.value, res_hist=hist[: nit.value + 1], t_assemble=ta.value,
+                   t_factor=tf.value, t_solve=ts.value)
+
+
 def solve_sor(lay, coeff, l1d, a11, a12, albedo, b, x0=None, rtol=1e-5, atol=1e-8, maxit=10000, omega=1.0,
               adaptive=True):
     """The reference's PETSc-free explicit solver (pprts_explicit.F90:461-713)."""

@@ -1,0 +1,246 @@
+/*
+ * pprts_oracle_mt.c -- the reference's default *multi-rank* diffuse path restated for host threads.
+ * TEST / BASELINE INFRASTRUCTURE ONLY (see pprts_oracle.h): never linked into the product library.
+ *
+ * Reference: with more than one MPI rank the KSP is FBCGS + PCBJACOBI with one ILU(0) block per rank
+ * (src/pprts.F90:4350-4371, 4415-4425); ranks own x/y blocks of the DMDA, x fastest, xs = (xi*Nx)/npx
+ * (src/pprts_base.F90:747-790).  Here: one subdomain per thread, the subdomain's diagonal block of the assembled
+ * matrix in the subdomain's natural ordering, ILU(0) on it; MatMult and the BLAS-1 of FBCGS threaded over rows.
+ * This is SURVEY section 8(d) baseline B1.
+ */
+#include <math.h>
+#include <omp.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "pprts_oracle.h"
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+typedef struct {
+  int nsub;
+  orc_csr *A;      /* local diagonal blocks */
+  orc_ilu0 *F;
+  int64_t **l2g;   /* local -> global row */
+  double **bl, **xl;
+} bjacobi_t;
+
+static void bjacobi_free(bjacobi_t *B) {
+  for (int s = 0; s < B->nsub; ++s) {
+    if (B->F && B->F[s].lu) orc_ilu0_free(&B->F[s]);
+    if (B->A) orc_csr_free(&B->A[s]);
+    if (B->l2g) free(B->l2g[s]);
+    if (B->bl) free(B->bl[s]);
+    if (B->xl) free(B->xl[s]);
+  }
+  free(B->A); free(B->F); free(B->l2g); free(B->bl); free(B->xl);
+  memset(B, 0, sizeof(*B));
+}
+
+/* extract the diagonal block of subdomain (xi, yi) from the global matrix */
+static int extract_block(const orc_csr *G, int D, int L, int Nx, int xs, int xe, int ys, int ye, orc_csr *A, int64_t **l2g_out) {
+  const int xm = xe - xs, ym = ye - ys;
+  const int64_t nl = (int64_t)D * L * xm * ym;
+  int64_t *l2g = (int64_t *)malloc(sizeof(int64_t) * (size_t)nl);
+  int64_t *rowptr = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nl + 1));
+  if (!l2g || !rowptr) return 2;
+  int64_t q = 0;
+  for (int j = ys; j < ye; ++j)
+    for (int i = xs; i < xe; ++i)
+      for (int k = 0; k < L; ++k)
+        for (int d = 0; d < D; ++d) l2g[q++] = d + (int64_t)D * (k + (int64_t)L * (i + (int64_t)Nx * j));
+  const int64_t DL = (int64_t)D * L;
+  int64_t nnz = 0;
+  rowptr[0] = 0;
+  for (int64_t r = 0; r < nl; ++r) {
+    const int64_t g = l2g[r];
+    for (int64_t p = G->rowptr[g]; p < G->rowptr[g + 1]; ++p) {
+      const int64_t c = G->col[p], ij = c / DL;
+      const int i = (int)(ij % Nx), j = (int)(ij / Nx);
+      if (i >= xs && i < xe && j >= ys && j < ye) ++nnz;
+    }
+    rowptr[r + 1] = nnz;
+  }
+  int32_t *col = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+  double *val = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+  if (!col || !val) return 2;
+  nnz = 0;
+  for (int64_t r = 0; r < nl; ++r) {
+    const int64_t g = l2g[r];
+    for (int64_t p = G->rowptr[g]; p < G->rowptr[g + 1]; ++p) {
+      const int64_t c = G->col[p], ij = c / DL, dk = c % DL;
+      const int i = (int)(ij % Nx), j = (int)(ij / Nx);
+      if (i >= xs && i < xe && j >= ys && j < ye) {
+        col[nnz] = (int32_t)(dk + DL * ((i - xs) + (int64_t)xm * (j - ys)));
+        val[nnz] = G->val[p];
+        ++nnz;
+      }
+    }
+  }
+  A->n = nl;
+  A->nnz = nnz;
+  A->rowptr = rowptr;
+  A->col = col;
+  A->val = val;
+  *l2g_out = l2g;
+  return 0;
+}
+
+static double dot_mt(int64_t n, const double *a, const double *b) {
+  double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+  for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+
+static void matvec_mt(const orc_csr *A, const double *x, double *y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < A->n; ++r) {
+    double s = 0.0;
+    for (int64_t p = A->rowptr[r]; p < A->rowptr[r + 1]; ++p) s += A->val[p] * x[A->col[p]];
+    y[r] = s;
+  }
+}
+
+static void bjacobi_apply(bjacobi_t *B, const double *v, double *z) {
+#pragma omp parallel for schedule(static, 1)
+  for (int s = 0; s < B->nsub; ++s) {
+    const int64_t nl = B->A[s].n;
+    const int64_t *l2g = B->l2g[s];
+    double *bl = B->bl[s], *xl = B->xl[s];
+    for (int64_t q = 0; q < nl; ++q) bl[q] = v[l2g[q]];
+    orc_ilu0_solve(&B->F[s], bl, xl);
+    for (int64_t q = 0; q < nl; ++q) z[l2g[q]] = xl[q];
+  }
+}
+
+/* MyKSPConverged, src/pprts.F90:4437-4486 (same rule as the serial oracle) */
+static int converged(int n, double rnorm, double *initial, const orc_ksp_tol *tol) {
+  if (n == 0) {
+    *initial = rnorm > 2.2250738585072014e-308 ? rnorm : 2.2250738585072014e-308;
+    return 0;
+  }
+  if (rnorm != rnorm) return -9;
+  if (n > tol->maxit) return -3;
+  const double rel = rnorm / *initial;
+  if (rel <= tol->rtol) return 2;
+  if (rnorm <= tol->atol) return 3;
+  if (rel >= tol->dtol) return -4;
+  return 0;
+}
+
+/* the loop of orc_fbcgs (KSPFBCGS ordering), threaded */
+static int fbcgs_mt(const orc_csr *A, bjacobi_t *B, const double *b, double *x, const orc_ksp_tol *tol, int *niter,
+                    double *res_hist, int nhist) {
+  const int64_t n = A->n;
+  double *w = (double *)malloc(sizeof(double) * (size_t)n * 8);
+  if (!w) return -100;
+  double *r = w, *rp = r + n, *p = rp + n, *v = p + n, *s = v + n, *t = s + n, *p2 = t + n, *s2 = p2 + n;
+  int reason = 0, its = 0;
+  double initial = 0;
+  matvec_mt(A, x, s2);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    r[i] = b[i] - s2[i];
+    rp[i] = r[i];
+    p[i] = r[i];
+  }
+  double dp = sqrt(dot_mt(n, r, r));
+  if (res_hist && nhist > 0) res_hist[0] = dp;
+  reason = converged(0, dp, &initial, tol);
+  double rho = dot_mt(n, r, rp), rhoold, alpha, omega, beta;
+  if (!reason && rho == 0.0) reason = -5;
+  for (int i = 0; !reason && i < tol->maxit; ++i) {
+    bjacobi_apply(B, p, p2);
+    matvec_mt(A, p2, v);
+    rhoold = rho;
+    double d1 = dot_mt(n, v, rp);
+    if (d1 == 0.0) { reason = -5; break; }
+    alpha = rho / d1;
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < n; ++q) s[q] = r[q] - alpha * v[q];
+    bjacobi_apply(B, s, s2);
+    matvec_mt(A, s2, t);
+    d1 = dot_mt(n, s, t);
+    const double d2 = dot_mt(n, t, t);
+    if (d2 == 0.0) { reason = -5; break; }
+    omega = d1 / d2;
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < n; ++q) {
+      x[q] += alpha * p2[q] + omega * s2[q];
+      r[q] = s[q] - omega * t[q];
+    }
+    dp = sqrt(dot_mt(n, r, r));
+    rho = dot_mt(n, r, rp);
+    its++;
+    if (res_hist && its < nhist) res_hist[its] = dp;
+    reason = converged(i + 1, dp, &initial, tol);
+    if (reason) break;
+    if (rho == 0.0) { reason = -5; break; }
+    beta = (rho / rhoold) * (alpha / omega);
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < n; ++q) p[q] = r[q] - omega * beta * v[q] + beta * p[q];
+  }
+  if (!reason) reason = -3;
+  if (niter) *niter = its;
+  free(w);
+  return reason;
+}
+
+int orc_diff_solve_bjacobi_ilu_mt(const orc_layout *l, const double *diff2diff, const uint8_t *l1d, const double *a11,
+                                  const double *a12, const double *albedo, const double *b, double *x,
+                                  const orc_ksp_tol *tol, int npx, int npy, int *niter, double *res_hist, int nhist,
+                                  double *t_assemble, double *t_factor, double *t_solve) {
+  if (npx < 1 || npy < 1 || npx > l->xm || npy > l->ym) return -101;
+  const int D = l->ntop + 2 * l->nside, L = l->Nz + 1, Nx = l->xm, Ny = l->ym;
+  const int nsub = npx * npy;
+  const int saved = omp_get_max_threads();
+  omp_set_num_threads(nsub);
+  orc_csr G;
+  double t0 = now_s();
+  int rc = orc_diff_assemble_csr_1rank(l, diff2diff, l1d, a11, a12, albedo, &G);
+  if (rc) { omp_set_num_threads(saved); return -100 - rc; }
+  double t1 = now_s();
+  bjacobi_t B;
+  memset(&B, 0, sizeof(B));
+  B.nsub = nsub;
+  B.A = (orc_csr *)calloc((size_t)nsub, sizeof(orc_csr));
+  B.F = (orc_ilu0 *)calloc((size_t)nsub, sizeof(orc_ilu0));
+  B.l2g = (int64_t **)calloc((size_t)nsub, sizeof(int64_t *));
+  B.bl = (double **)calloc((size_t)nsub, sizeof(double *));
+  B.xl = (double **)calloc((size_t)nsub, sizeof(double *));
+  int err = 0;
+#pragma omp parallel for schedule(static, 1)
+  for (int s = 0; s < nsub; ++s) {
+    const int xi = s % npx, yi = s / npx; /* ranks x fastest */
+    const int xs = (int)(((int64_t)xi * Nx) / npx), xe = (int)(((int64_t)(xi + 1) * Nx) / npx);
+    const int ys = (int)(((int64_t)yi * Ny) / npy), ye = (int)(((int64_t)(yi + 1) * Ny) / npy);
+    int e = extract_block(&G, D, L, Nx, xs, xe, ys, ye, &B.A[s], &B.l2g[s]);
+    if (!e) e = orc_ilu0_factor(&B.A[s], &B.F[s]);
+    if (!e) {
+      B.bl[s] = (double *)malloc(sizeof(double) * (size_t)B.A[s].n);
+      B.xl[s] = (double *)malloc(sizeof(double) * (size_t)B.A[s].n);
+      if (!B.bl[s] || !B.xl[s]) e = 2;
+    }
+    if (e) {
+#pragma omp atomic write
+      err = e;
+    }
+  }
+  double t2 = now_s();
+  int reason = -200 - err;
+  if (!err) reason = fbcgs_mt(&G, &B, b, x, tol, niter, res_hist, nhist);
+  double t3 = now_s();
+  if (t_assemble) *t_assemble = t1 - t0;
+  if (t_factor) *t_factor = t2 - t1;
+  if (t_solve) *t_solve = t3 - t2;
+  bjacobi_free(&B);
+  orc_csr_free(&G);
+  omp_set_num_threads(saved);
+  return reason;
+}

@@ -49,6 +49,8 @@ def _ptr(a, dtype):
         want = {np.float64: torch.float64, np.float32: torch.float32, np.uint8: torch.uint8}[dtype]
         if a.dtype != want or not a.is_contiguous() or not a.is_cuda:
             raise TypeError("device arrays must be contiguous CUDA tensors of the right dtype")
+        # the library works on its own stream: whatever torch still has queued on this tensor must be done first
+        torch.cuda.current_stream(a.device).synchronize()
         return C.c_void_p(a.data_ptr()), TSX_DEVICE
     if a.dtype != dtype or not a.flags.c_contiguous:
         raise TypeError(f"host arrays must be C-contiguous {dtype}")

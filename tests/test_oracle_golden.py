@@ -129,6 +129,23 @@ def test_krylov_ilu_sor_share_the_fixed_point():
     assert np.abs(x1 - x2).max() < 1e-9 * scale and np.abs(x1 - x3).max() < 1e-7 * scale
 
 
+def test_threaded_block_jacobi_baseline_reduces_to_the_one_rank_default():
+    """bench.py's CPU baseline (FBCGS + PCBJACOBI/ILU(0), one thread per subdomain): 1x1 is the serial ILU path to the
+    bit; 2x3 subdomains converge to the same solution with at least as many iterations."""
+    from tenstream_amd import synthetic as S
+
+    P = S.make_problem("3_10", Nx=8, Ny=9, Nz=6, n1d=1)
+    lay = O.layout("3_10", 6, 8, 9)
+    args = (lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"], P["b"])
+    x1, i1 = O.solve_ilu(*args, rtol=1e-11, atol=1e-30)
+    x2, i2 = O.solve_bjacobi_ilu_mt(*args, 1, 1, rtol=1e-11, atol=1e-30)
+    x3, i3 = O.solve_bjacobi_ilu_mt(*args, 2, 3, rtol=1e-11, atol=1e-30)
+    assert i1["reason"] == i2["reason"] == i3["reason"] == 2
+    assert i1["niter"] == i2["niter"] and np.allclose(x1, x2, rtol=1e-12, atol=0)
+    assert i3["niter"] >= i1["niter"]
+    assert np.abs(x3 - x1).max() < 1e-8 * np.abs(x1).max()
+
+
 def test_default_tolerances():
     """determine_ksp_tolerances (src/pprts_base.F90:1126-1131)."""
     assert O.default_tolerances(4, 4, 21) == (1e-5, pytest.approx(1e-4 * 4 * 4 * 21), 1000)
