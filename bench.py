@@ -22,6 +22,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the CPU baseline's OpenMP threads: one per physical core, pinned, spread over the sockets (read when libgomp loads)
+os.environ.setdefault("OMP_PROC_BIND", "spread")
 
 import numpy as np  # noqa: E402
 
@@ -39,8 +41,8 @@ def parse():
     ap.add_argument("--pc-sweeps", type=int, default=5)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the CPU-baseline sample domain (columns); 0 = 256 with >= 32 threads, else 112")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads (= subdomains) of the CPU baseline; 0 = min(host cores, 64)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the CPU-baseline sample domain (columns); 0 = 256 with >= 16 threads, else 112")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads (= subdomains) of the CPU baseline; 0 = usable cores (affinity, cgroup quota), at most 128")
     return ap.parse_args()
 
 
@@ -217,6 +219,31 @@ def pmc_traffic(key):
     return None, None
 
 
+def usable_cores():
+    """CPUs this process may actually use: affinity mask and the cgroup CPU quota (the GPU boxes are slices of a node:
+    256 logical CPUs visible, cpu.max = 16 CPUs' worth of time), not just os.cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(args, solver, dx, dz, albedo):
     """The reference's default CPU path as restated by the oracle, timed on this box's host cores on a bounded sample of
     the same generator: assembled AIJ + KSPFBCGS + PCBJACOBI/ILU(0), one subdomain per core like one MPI rank per core
@@ -225,9 +252,9 @@ def cpu_baseline(args, solver, dx, dz, albedo):
     from tenstream_amd import synthetic as S
     from tenstream_amd.coord import decompose
 
-    cores = os.cpu_count() or 1
-    threads = args.cpu_threads if args.cpu_threads > 0 else min(cores, 64)
-    n = args.cpu_sample if args.cpu_sample > 0 else (256 if threads >= 32 else 112)
+    cores = usable_cores()
+    threads = args.cpu_threads if args.cpu_threads > 0 else min(cores, 128)
+    n = args.cpu_sample if args.cpu_sample > 0 else (256 if threads >= 16 else 112)
     npx, npy = decompose(threads)
     P = S.make_problem(solver, Nx=n, Ny=n, Nz=args.nz, dx=dx, dz=dz, albedo=albedo)
     lay = O.layout(solver, args.nz, n, n)
@@ -244,6 +271,7 @@ def cpu_baseline(args, solver, dx, dz, albedo):
                   f"{npx}x{npy} subdomains (one thread each), {info['niter']} its, reason {info['reason']}, solve "
                   f"{info['t_solve']:.2f}s (assembly {info['t_assemble']:.2f}s, factor {info['t_factor']:.2f}s not counted)",
         "host_cores_available": cores,
+        "host_cores_logical": os.cpu_count(),
     }
 
 

@@ -119,6 +119,33 @@ static void bjacobi_apply(bjacobi_t *B, const double *v, double *z) {
   }
 }
 
+/* NUMA placement: the assembly is serial, so its pages sit on one node.  Copy the matrix into arrays whose pages are
+ * first touched by the thread that will stream them in matvec_mt (same static row partition). */
+static int csr_rehome(orc_csr *G) {
+  const int64_t n = G->n;
+  int64_t *rowptr = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+  int32_t *col = (int32_t *)malloc(sizeof(int32_t) * (size_t)G->nnz);
+  double *val = (double *)malloc(sizeof(double) * (size_t)G->nnz);
+  if (!rowptr || !col || !val) {
+    free(rowptr); free(col); free(val);
+    return 2;
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n; ++r) {
+    rowptr[r] = G->rowptr[r];
+    for (int64_t p = G->rowptr[r]; p < G->rowptr[r + 1]; ++p) {
+      col[p] = G->col[p];
+      val[p] = G->val[p];
+    }
+  }
+  rowptr[n] = G->rowptr[n];
+  free(G->rowptr); free(G->col); free(G->val);
+  G->rowptr = rowptr;
+  G->col = col;
+  G->val = val;
+  return 0;
+}
+
 /* MyKSPConverged, src/pprts.F90:4437-4486 (same rule as the serial oracle) */
 static int converged(int n, double rnorm, double *initial, const orc_ksp_tol *tol) {
   if (n == 0) {
@@ -206,6 +233,7 @@ int orc_diff_solve_bjacobi_ilu_mt(const orc_layout *l, const double *diff2diff, 
   int rc = orc_diff_assemble_csr_1rank(l, diff2diff, l1d, a11, a12, albedo, &G);
   if (rc) { omp_set_num_threads(saved); return -100 - rc; }
   double t1 = now_s();
+  if (nsub > 1 && csr_rehome(&G)) { orc_csr_free(&G); omp_set_num_threads(saved); return -102; }
   bjacobi_t B;
   memset(&B, 0, sizeof(B));
   B.nsub = nsub;
