@@ -191,6 +191,14 @@ int tsx_lut_set_direct(tsx_solver *s, const float *Tdir, const float *Sdir, int6
 /* the same from `.mmap4` files (LUT_direct_3_10.<dims>.ds1000.nc.{Tdir,Sdir}.mmap4, src/optprop_LUT.F90:505, 1348);
  * axes = the LUT_3_10 preset unless a `<tdir_path>.axes` text sidecar (ndim, then "n v1..vn" per axis) exists */
 int tsx_lut_load_direct_mmap4(tsx_solver *s, const char *tdir_path, const char *sdir_path);
+/* set_optical_properties (src/pprts.F90:1764): raw kabs/ksca/g/dz (zs:ze-1, xs:xe, ys:ye) real64, albedo (xs:xe, ys:ye),
+ * planck (zs:ze, xs:xe, ys:ye) or NULL.  On the device: delta scaling with f = g**2 when ldelta_scaling (:1903-1917,
+ * src/helper_functions.fypp:1622-1666), 1-D layer detection dz/dx > twostr_ratio = 2 (:669-677), eddington_coeff_ec of the
+ * 1-D layers (:1962-1992, src/eddington.F90:173-241), diffuse coefficient lookup.  Needs tsx_pprts_set_angles and the
+ * diffuse LUT first. */
+int tsx_pprts_set_optical_properties(tsx_solver *s, const double *albedo, const double *kabs, const double *ksca,
+                                     const double *g, const double *dz, const double *planck, double dx, double dy,
+                                     int ldelta_scaling, int where);
 /* optical properties of one g-point, (zs:ze-1, xs:xe, ys:ye) real64, already delta-scaled; a11..a33 only read for
  * 1-D layers (eddington coefficients, src/pprts.F90:1962-1992); planck (zs:ze, xs:xe, ys:ye) or NULL for solar */
 int tsx_pprts_set_optprop(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz,

@@ -51,7 +51,7 @@ SYMBOLS = (
     "tsx_last_error", "tsx_version", "tsx_device_count", "tsx_create", "tsx_destroy", "tsx_default_ksp_opts",
     "tsx_determine_ksp_tolerances", "tsx_set_stream", "tsx_comm_unique_id", "tsx_comm_init", "tsx_comm_set_callbacks",
     "tsx_diff_set_coeffs", "tsx_lut_set_diffuse", "tsx_lut_load_diffuse_mmap4", "tsx_diff_set_optprop",
-    "tsx_diff_get_coeffs", "tsx_pprts_set_angles", "tsx_lut_set_direct", "tsx_lut_load_direct_mmap4", "tsx_pprts_set_optprop", "tsx_pprts_solve",
+    "tsx_diff_get_coeffs", "tsx_pprts_set_angles", "tsx_lut_set_direct", "tsx_lut_load_direct_mmap4", "tsx_pprts_set_optprop", "tsx_pprts_set_optical_properties", "tsx_pprts_solve",
     "tsx_pprts_zero_guess", "tsx_pprts_get_result", "tsx_pprts_get_field", "tsx_diff_apply", "tsx_diff_solve", "tsx_diff_pc_apply", "tsx_bench_kernel", "tsx_algorithmic_bytes",
     "tsx_probe_copy_bandwidth",
 )
@@ -91,6 +91,7 @@ def load():
     lib.tsx_lut_set_direct.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp, ip]
     lib.tsx_lut_load_direct_mmap4.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.tsx_pprts_set_optprop.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, ip]
+    lib.tsx_pprts_set_optical_properties.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, ip, ip]
     lib.tsx_pprts_solve.argtypes = [vp, C.c_double, ip, C.POINTER(KspOpts), C.POINTER(KspResult)]
     lib.tsx_pprts_zero_guess.argtypes = [vp]
     lib.tsx_pprts_get_result.argtypes = [vp, vp, vp, vp, vp, ip]

@@ -728,6 +728,34 @@ extern "C" int tsx_lut_load_diffuse_mmap4(tsx_solver *s, const char *path) {
   return rc;
 }
 
+// alloc_coeff_diff2diff on the device: kabs/ksca/g/dz are device pointers in the reference layout
+static void lut_diffuse_launch(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz, double dx) {
+  const TsxGeo &gm = s->geo;
+  TsxLutDev L;
+  memset(&L, 0, sizeof(L));
+  const TsxLutHost &H = s->lut_diff;
+  L.ndim = H.ndim;
+  L.nvec = H.nvec;
+  long long off = 1;
+  int aoff = 0;
+  for (int d = 0; d < H.ndim; ++d) {
+    L.n[d] = H.n[d];
+    L.axis_off[d] = aoff;
+    aoff += H.n[d];
+    L.offs[d] = off;
+    off *= H.n[d];
+  }
+  L.axes = H.d_axes;
+  L.table = H.d_table;
+  const int nbk = grid_for(gm.Nc, 8192);
+  if (gm.D == 10)
+    hipLaunchKernelGGL((tsx_k_lut_diff2diff<100>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, kabs, ksca, g, dz, dx,
+                       s->l1d, (float *)s->coef);
+  else
+    hipLaunchKernelGGL((tsx_k_lut_diff2diff<256>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, kabs, ksca, g, dz, dx,
+                       s->l1d, (float *)s->coef);
+}
+
 extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const double *ksca, const double *g,
                                     const double *dz, double dx, const uint8_t *l1d, const double *a11, const double *a12,
                                     const double *albedo, int where) {
@@ -752,29 +780,7 @@ extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const dou
       p[q] = tmp[q];
     }
   }
-  TsxLutDev L;
-  memset(&L, 0, sizeof(L));
-  const TsxLutHost &H = s->lut_diff;
-  L.ndim = H.ndim;
-  L.nvec = H.nvec;
-  long long off = 1;
-  int aoff = 0;
-  for (int d = 0; d < H.ndim; ++d) {
-    L.n[d] = H.n[d];
-    L.axis_off[d] = aoff;
-    aoff += H.n[d];
-    L.offs[d] = off;
-    off *= H.n[d];
-  }
-  L.axes = H.d_axes;
-  L.table = H.d_table;
-  const int nbk = grid_for(gm.Nc, 8192);
-  if (gm.D == 10)
-    hipLaunchKernelGGL((tsx_k_lut_diff2diff<100>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, p[0], p[1], p[2], p[3], dx,
-                       s->l1d, (float *)s->coef);
-  else
-    hipLaunchKernelGGL((tsx_k_lut_diff2diff<256>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, p[0], p[1], p[2], p[3], dx,
-                       s->l1d, (float *)s->coef);
+  lut_diffuse_launch(s, p[0], p[1], p[2], p[3], dx);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
   for (int q = 0; q < 4; ++q)

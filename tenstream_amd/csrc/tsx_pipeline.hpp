@@ -486,3 +486,90 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_get_result(TsxGeo g, TsxSun s
 }
 
 // scalar field in reference layout (k fastest) -> cell-indexed (i fastest) is tsx_k_import_cellfield (tsx_kernels.hpp)
+
+// ------------------------------------------------------------------------------------------------
+// set_optical_properties on the device (src/pprts.F90:1764-2000): delta scaling, 1-D layer detection, Eddington
+// coefficients of the 1-D layers.  Optical property fields are in the reference layout (z fastest).
+
+// delta_scale with f = g**2 (src/helper_functions.fypp:1622-1666), in place
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_delta_scale(long long n, double *__restrict__ kabs, double *__restrict__ ksca,
+                                                               double *__restrict__ g) {
+  const double eps = 2.220446049250313e-16;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double ka = kabs[q], ks = ksca[q], gq = g[q];
+    double tau = ka + ks;
+    if (tau < eps) continue;
+    double w0 = ks / tau, gn;
+    if (gq >= 1.0 - 10.0 * eps) {  // pure forward peak: everything scattered stays in the beam
+      tau *= 1.0 - w0;
+      w0 = 0.0;
+      gn = 0.0;
+    } else {
+      const double f = gq * gq;
+      tau *= 1.0 - w0 * f;
+      gn = (gq - f) / (1.0 - f);
+      w0 = w0 * (1.0 - f) / (1.0 - f * w0);
+    }
+    g[q] = gn;
+    kabs[q] = tau * (1.0 - w0);
+    ksca[q] = tau * w0;
+  }
+}
+
+// flags[k] = 1 if dz/dx > ratio anywhere in layer k (src/pprts.F90:669-677; the "and every layer above" part is host logic)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_flag_1d(long long n, int Nz, const double *__restrict__ dz, double dx, double ratio,
+                                                           int *__restrict__ flags) {
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK)
+    if (dz[q] / dx > ratio) atomicOr(&flags[(int)(q % Nz)], 1);
+}
+
+// eddington_coeff_ec (src/eddington.F90:173-241) for the cells of 1-D layers; inputs in the reference layout, outputs
+// in cell order.  a11 = t, a12 = r, a13 = rdir, a23 = sdir, a33 = tdir.
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_eddington(TsxGeo g, const double *__restrict__ kabs, const double *__restrict__ ksca,
+                                                             const double *__restrict__ gas, const double *__restrict__ dz, double mu0,
+                                                             const uint8_t *__restrict__ l1d, double *__restrict__ a11,
+                                                             double *__restrict__ a12, double *__restrict__ a13,
+                                                             double *__restrict__ a23, double *__restrict__ a33) {
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  const double eps = 2.220446049250313e-16, tiny = 2.2250738585072014e-308;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < g.Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int i = (int)(c % xm);
+    const long long t_ = c / xm;
+    const int j = (int)(t_ % ym), k = (int)(t_ / ym);
+    if (!l1d[k]) continue;
+    const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
+    const double ext = fmax(tiny, kabs[r] + ksca[r]);
+    const double dtau = dz[r] * ext, w0 = ksca[r] / ext, gg = gas[r];
+    const double f = 0.75 * gg;
+    const double g1 = 2.0 - w0 * (1.25 + f), g2 = w0 * (0.75 - f), g3 = 0.5 - mu0 * f;
+    const double slant = fmax(dtau / fmax(sqrt(tiny), mu0), 0.0);
+    double tt, rr, rdir, sdir, tdir;
+    if (slant > 1e-6) {
+      const double g4 = 1.0 - g3;
+      const double al1 = g1 * g4 + g2 * g3, al2 = g1 * g3 + g2 * g4;
+      const double A = sqrt(fmax((g1 - g2) * (g1 + g2), 1e-12));
+      double kmu = A * mu0;
+      if (kmu <= 1.0 + 10.0 * eps && kmu >= 1.0 - 10.0 * eps) kmu = 1.0 - 10.0 * eps;  // approx(), helper_functions.fypp:1272
+      const double kg3 = A * g3, kg4 = A * g4;
+      const double e0 = exp(-slant), e = exp(-A * dtau), e2 = e * e, k2e = 2.0 * A * e;
+      double beta = 1.0 / (A + g1 + (A - g1) * e2);
+      rr = g2 * (1.0 - e2) * beta;
+      tt = k2e * beta;
+      beta = w0 * beta / (1.0 - kmu * kmu);
+      sdir = beta * (k2e * (g4 + al1 * mu0) - e0 * ((1.0 + kmu) * (al1 + kg4) - (1.0 - kmu) * (al1 - kg4) * e2));
+      rdir = beta * ((1.0 - kmu) * (al2 + kg3) - (1.0 + kmu) * (al2 - kg3) * e2 - k2e * (g3 - al2 * mu0) * e0);
+      tdir = e0;
+    } else {
+      tt = 1.0 - g1 * dtau;
+      rr = g2 * dtau;
+      sdir = (1.0 - g3) * (w0 * dtau);
+      rdir = g3 * (w0 * dtau);
+      tdir = 1.0 - slant;
+    }
+    a11[c] = tt;
+    a12[c] = rr;
+    a13[c] = rdir;
+    a23[c] = sdir;
+    a33[c] = tdir;
+  }
+}

@@ -81,31 +81,54 @@ class PprtsSolver:
 
     # -- set_optical_properties ------------------------------------------------------------------------
     def set_optical_properties(self, albedo, kabs, ksca, g, dz, planck=None, ldelta_scaling=True):
-        """Fields (Ny, Nx, Nz) float64, k = 0 at TOA; albedo scalar or (Ny, Nx); planck (Ny, Nx, Nz+1) or None."""
-        kabs, ksca, g = (np.array(a, dtype=np.float64, copy=True) for a in (kabs, ksca, g))
-        if ldelta_scaling:
-            kabs, ksca, g = delta_scale(kabs, ksca, g)
-        dz = np.ascontiguousarray(np.broadcast_to(np.asarray(dz, dtype=np.float64), kabs.shape))
-        # 1-D layers: dz/dx > twostr_ratio anywhere in the layer, and then every layer above (src/pprts.F90:669-677)
+        """Fields (Ny, Nx, Nz) float64 (numpy, or CUDA tensors to stay on the device), k = 0 at TOA; albedo scalar or
+        (Ny, Nx); planck (Ny, Nx, Nz+1) or None.  Delta scaling, 1-D layer detection, Eddington coefficients and the
+        coefficient lookups all run on the device (tsx_pprts_set_optical_properties)."""
+        from .solver import _is_torch
+
+        on_dev = _is_torch(kabs)
+        shape = (self.Ny, self.Nx, self.Nz)
+        if on_dev:
+            import torch
+
+            f = lambda a, shp: (a if _is_torch(a) else torch.as_tensor(np.asarray(a, dtype=np.float64), device=kabs.device)
+                                ).to(torch.float64).expand(shp).contiguous()
+        else:
+            f = lambda a, shp: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), shp))
+        raw = dict(kabs=f(kabs, shape), ksca=f(ksca, shape), g=f(g, shape), dz=f(dz, shape),
+                   albedo=f(albedo, (self.Ny, self.Nx)),
+                   planck=None if planck is None else f(planck, (self.Ny, self.Nx, self.Nz + 1)))
+        self._raw, self._ldelta, self._fields = raw, bool(ldelta_scaling), None
+        ptr = lambda a: None if a is None else _ptr(a, np.float64)[0]
+        _lib.check(self.lib.tsx_pprts_set_optical_properties(
+            self.h, ptr(raw["albedo"]), ptr(raw["kabs"]), ptr(raw["ksca"]), ptr(raw["g"]), ptr(raw["dz"]),
+            ptr(raw["planck"]), self.dx, self.dy, int(self._ldelta), 1 if on_dev else 0))
+
+    @property
+    def fields(self):
+        """Host mirror of what the device derived (delta-scaled properties, Eddington coefficients): for tests and
+        diagnostics only, computed on demand from the raw inputs."""
+        if self._fields is None:
+            r = {k: (None if v is None else (v.cpu().numpy() if hasattr(v, "cpu") else v)) for k, v in self._raw.items()}
+            kabs, ksca, g = (np.array(r[k], dtype=np.float64, copy=True) for k in ("kabs", "ksca", "g"))
+            if self._ldelta:
+                kabs, ksca, g = delta_scale(kabs, ksca, g)
+            ext = np.maximum(np.finfo(np.float64).tiny, kabs + ksca)
+            a11, a12, a13, a23, a33 = eddington_coeff_ec(r["dz"] * ext, ksca / ext, g, self.mu0)
+            self._fields = dict(kabs=kabs, ksca=ksca, g=g, dz=r["dz"], a11=a11, a12=a12, a13=a13, a23=a23, a33=a33,
+                                albedo=r["albedo"], planck=r["planck"])
+        return self._fields
+
+    @property
+    def l1d(self):
+        """1-D layers: dz/dx > twostr_ratio anywhere in the layer, and then every layer above (src/pprts.F90:669-677)"""
+        dz = self._raw["dz"]
+        dz = dz.cpu().numpy() if hasattr(dz, "cpu") else dz
         l1d = np.zeros(self.Nz, dtype=np.uint8)
         big = np.nonzero((dz / self.dx > TWOSTR_RATIO).any(axis=(0, 1)))[0]
         if big.size:
             l1d[: big.max() + 1] = 1
-        tau = dz * np.maximum(np.finfo(np.float64).tiny, kabs + ksca)
-        w0 = ksca / np.maximum(np.finfo(np.float64).tiny, kabs + ksca)
-        a11, a12, a13, a23, a33 = eddington_coeff_ec(tau, w0, g, self.mu0)
-        alb = np.ascontiguousarray(np.broadcast_to(np.asarray(albedo, dtype=np.float64), (self.Ny, self.Nx)))
-        self.l1d = l1d
-        self.fields = dict(kabs=kabs, ksca=ksca, g=g, dz=dz, a11=a11, a12=a12, a13=a13, a23=a23, a33=a33, albedo=alb,
-                           planck=None if planck is None else np.ascontiguousarray(planck, dtype=np.float64))
-        args = [np.ascontiguousarray(a) for a in (kabs, ksca, g, dz)]
-        p = [_ptr(a, np.float64)[0] for a in args]
-        e = [np.ascontiguousarray(a) for a in (a11, a12, a13, a23, a33)]
-        pe = [_ptr(a, np.float64)[0] for a in e]
-        pp = None if planck is None else _ptr(self.fields["planck"], np.float64)[0]
-        _lib.check(self.lib.tsx_pprts_set_optprop(self.h, p[0], p[1], p[2], p[3], self.dx, self.dy, _ptr(alb, np.float64)[0],
-                                                  _ptr(l1d, np.uint8)[0], pe[0], pe[1], pe[2], pe[3], pe[4], pp, 0))
-        self._keep = (args, e, alb)
+        return l1d
 
     # -- solve_pprts -------------------------------------------------------------------------------------
     def solve(self, edirTOA, lsolar=None, zero_guess=False, **opts) -> KspInfo:
@@ -126,15 +149,21 @@ class PprtsSolver:
         return KspInfo(r.reason, r.niter, r.rnorm0, r.rnorm, np.array(r.res_hist[: r.nhist]), r.solve_ms, 0.0, 0.0)
 
     # -- pprts_get_result -----------------------------------------------------------------------------------
-    def get_result(self):
-        """edn, eup, edir (Ny, Nx, Nz+1) [W/m2] and abso (Ny, Nx, Nz) [W/m3]."""
+    def get_result(self, out=None):
+        """edn, eup, edir (Ny, Nx, Nz+1) [W/m2] and abso (Ny, Nx, Nz) [W/m3]; `out` = (edn, eup, abso, edir) CUDA tensors
+        keeps the result on the device."""
         L = self.Nz + 1
-        edn = np.empty((self.Ny, self.Nx, L))
-        eup = np.empty_like(edn)
-        edir = np.empty_like(edn)
-        abso = np.empty((self.Ny, self.Nx, self.Nz))
+        if out is None:
+            edn = np.empty((self.Ny, self.Nx, L))
+            eup = np.empty_like(edn)
+            edir = np.empty_like(edn)
+            abso = np.empty((self.Ny, self.Nx, self.Nz))
+            where = 0
+        else:
+            edn, eup, abso, edir = out
+            where = 1
         _lib.check(self.lib.tsx_pprts_get_result(self.h, _ptr(edn, np.float64)[0], _ptr(eup, np.float64)[0],
-                                                 _ptr(abso, np.float64)[0], _ptr(edir, np.float64)[0], 0))
+                                                 _ptr(abso, np.float64)[0], _ptr(edir, np.float64)[0], where))
         return edn, eup, abso, edir
 
     def get_field(self, which):

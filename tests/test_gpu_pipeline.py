@@ -205,3 +205,19 @@ def test_reference_c_abi_end_to_end(gpu, tmp_path):
     for got, want in zip(parts[4:7], (edn, eup, abso)):
         assert np.abs(got - want.ravel().astype(np.float32)).max() <= 2e-6 * np.abs(want).max()
     assert np.all(parts[7] == 0)  # thermal: edir = 0
+
+
+@pytest.mark.gpu
+def test_spectral_loop_script_runs(gpu):
+    """bench_specint.py (config 4: many g-points through the whole device pipeline) on a tiny domain"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench_specint.py"), "--sw", "3", "--lw", "3", "--nx", "16",
+                          "--ny", "12", "--nz", "8"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["rank0_gpoints"] == 6 and set(d["config"]["rank0_reasons"]) <= {2, 3}
+    assert d["config"]["toa_net_down_Wm2"] > 0
