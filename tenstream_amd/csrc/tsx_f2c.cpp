@@ -1,7 +1,6 @@
-// tsx_f2c.cpp -- c_wrapper/f2c_pprts.h served by libtsx (see include/tsx_f2c.h).  Host code only: the per-call
-// preparations the reference does in set_optical_properties (delta scaling src/pprts.F90:1903-1917, 1-D layer
-// detection :669-677 + :708-719, Eddington coefficients :1962-1992 / src/eddington.F90:173-241), then the device
-// pipeline tsx_pprts_*.
+// tsx_f2c.cpp -- c_wrapper/f2c_pprts.h served by libtsx (see include/tsx_f2c.h).  Host code only: argument
+// conversion (float32 -> ireals, minimal_dimension tiling, dz from hhl) around the device pipeline tsx_pprts_*; delta
+// scaling, 1-D layer detection and the Eddington coefficients run on the device (tsx_pprts_set_optical_properties).
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
@@ -19,7 +18,7 @@ namespace {
 struct F2cState {
   tsx_solver *h = nullptr;
   int solver_id = 0, Nz = 0, Nx = 0, Ny = 0, gNx = 0, gNy = 0;  // gN*: after minimal_dimension tiling (src/pprts.F90:205)
-  double dx = 0, dy = 0, phi0 = 0, theta0 = 0, mu0 = 0;
+  double dx = 0, dy = 0, phi0 = 0, theta0 = 0;
   std::vector<double> dz1d;
   bool have_planck = false;
 };
@@ -31,52 +30,6 @@ F2cState g_st;
 }
 void chk(int rc, const char *what) {
   if (rc) die(std::string(what) + ": " + tsx_last_error());
-}
-
-// eddington_coeff_ec, src/eddington.F90:173-241
-void eddington_ec(double dtau, double w0, double g, double mu0, double &t, double &r, double &rdir, double &sdir, double &tdir) {
-  const double f = 0.75 * g;
-  const double g1 = 2.0 - w0 * (1.25 + f), g2 = w0 * (0.75 - f), g3 = 0.5 - mu0 * f;
-  const double slant = fmax(dtau / fmax(sqrt(DBL_MIN), mu0), 0.0);
-  if (slant > 1e-6) {
-    const double g4 = 1.0 - g3, alpha1 = g1 * g4 + g2 * g3, alpha2 = g1 * g3 + g2 * g4;
-    const double A = sqrt(fmax((g1 - g2) * (g1 + g2), 1e-12));
-    double k_mu0 = A * mu0;
-    const double k_g3 = A * g3, k_g4 = A * g4, e0 = exp(-slant), e = exp(-A * dtau), e2 = e * e, k2e = 2 * A * e;
-    tdir = e0;
-    if (fabs(k_mu0 - 1.0) <= 10 * DBL_EPSILON) k_mu0 = 1 - 10 * DBL_EPSILON;
-    double beta = 1 / (A + g1 + (A - g1) * e2);
-    r = g2 * (1 - e2) * beta;
-    t = k2e * beta;
-    beta = w0 * beta / (1 - k_mu0 * k_mu0);
-    sdir = beta * (k2e * (g4 + alpha1 * mu0) - e0 * ((1 + k_mu0) * (alpha1 + k_g4) - (1 - k_mu0) * (alpha1 - k_g4) * e2));
-    rdir = beta * ((1 - k_mu0) * (alpha2 + k_g3) - (1 + k_mu0) * (alpha2 - k_g3) * e2 - k2e * (g3 - alpha2 * mu0) * e0);
-  } else {
-    t = 1.0 - g1 * dtau;
-    r = g2 * dtau;
-    sdir = (1.0 - g3) * (w0 * dtau);
-    rdir = g3 * (w0 * dtau);
-    tdir = 1.0 - slant;
-  }
-}
-
-// delta_scale with f = g**2, src/helper_functions.fypp:1622-1666
-void delta_scale(double &kabs, double &ksca, double &g) {
-  const double f = g * g;
-  double dtau = kabs + ksca;
-  if (dtau < DBL_EPSILON) return;
-  double w0 = ksca / dtau;
-  if (g >= 1.0 - DBL_EPSILON * 10) {
-    dtau *= (1.0 - w0);
-    w0 = 0;
-    g = 0;
-  } else {
-    dtau *= (1.0 - w0 * f);
-    g = (g - f) / (1.0 - f);
-    w0 = w0 * (1.0 - f) / (1.0 - f * w0);
-  }
-  kabs = dtau * (1.0 - w0);
-  ksca = dtau * w0;
 }
 
 bool file_exists(const std::string &p) {
@@ -111,7 +64,6 @@ extern "C" void pprts_f2c_init(int fcomm, int *solver_id, int *Nz, int *Nx, int 
   st.dy = *dy;
   st.phi0 = *phi0;
   st.theta0 = *theta0;
-  st.mu0 = st.theta0 >= 90.0 ? 0.0 : fmax(cos(st.theta0 * 3.14159265358979323846 / 180.0), 0.0);
   st.dz1d.resize(st.Nz);
   for (int k = 0; k < st.Nz; ++k) st.dz1d[k] = (double)hhl[k] - (double)hhl[k + 1];  // :231-234
   tsx_grid grid;
@@ -146,7 +98,7 @@ extern "C" void pprts_f2c_set_global_optical_properties(int Nz, int Nx, int Ny, 
   if (Nz != st.Nz || Nx != st.Nx || Ny != st.Ny) die("pprts_f2c_set_global_optical_properties: shape differs from init");
   const int gx = st.gNx, gy = st.gNy;
   const size_t nc = (size_t)Nz * gx * gy, nl = (size_t)(Nz + 1) * gx * gy;
-  std::vector<double> ka(nc), ks(nc), gg(nc), dz(nc), a11(nc), a12(nc), a13(nc), a23(nc), a33(nc), alb((size_t)gx * gy), pl;
+  std::vector<double> ka(nc), ks(nc), gg(nc), dz(nc), alb((size_t)gx * gy), pl;
   st.have_planck = false;
   if (planck)
     for (size_t q = 0; q < (size_t)(Nz + 1) * Nx * Ny; ++q) st.have_planck |= planck[q] > 0.0f;  // any(oplanck > 0), :303
@@ -162,35 +114,16 @@ extern "C" void pprts_f2c_set_global_optical_properties(int Nz, int Nx, int Ny, 
         ks[o] = ksca[q];
         gg[o] = g[q];
         dz[o] = st.dz1d[k];
-        delta_scale(ka[o], ks[o], gg[o]);  // -pprts_delta_scale default true
       }
       if (st.have_planck)
         for (int k = 0; k <= Nz; ++k)
           pl[(size_t)k + (size_t)(Nz + 1) * ((size_t)i + (size_t)gx * j)] =
               planck[(size_t)k + (size_t)(Nz + 1) * ((size_t)si + (size_t)Nx * sj)];
     }
-  // which layers are 1-D: src/pprts.F90:669-677, then the count is applied from the top (:708-719)
-  std::vector<uint8_t> l1d(Nz, 0);
-  const double twostr_ratio = 2.0;  // src/tenstream_options.F90
-  auto exceeds = [&](int k) { return st.dz1d[k] / st.dx > twostr_ratio; };
-  l1d[Nz - 1] = exceeds(Nz - 1);
-  for (int k = Nz - 2; k >= 0; --k)
-    if (exceeds(k)) {
-      for (int q = 0; q <= k; ++q) l1d[q] = 1;
-      break;
-    }
-  int n1d = 0;
-  for (int k = 0; k < Nz; ++k) n1d += l1d[k];
-  for (int k = 0; k < n1d; ++k) l1d[k] = 1;
-  for (size_t o = 0; o < nc; ++o) {
-    const int k = (int)(o % Nz);
-    if (!l1d[k]) continue;
-    const double ext = fmax(DBL_MIN, ka[o] + ks[o]);
-    eddington_ec(dz[o] * ext, ks[o] / ext, gg[o], st.mu0, a11[o], a12[o], a13[o], a23[o], a33[o]);
-  }
-  chk(tsx_pprts_set_optprop(st.h, ka.data(), ks.data(), gg.data(), dz.data(), st.dx, st.dy, alb.data(), l1d.data(), a11.data(),
-                            a12.data(), a13.data(), a23.data(), a33.data(), st.have_planck ? pl.data() : nullptr, TSX_HOST),
-      "tsx_pprts_set_optprop");
+  // delta scaling (-pprts_delta_scale default true), 1-D layers, Eddington coefficients, lookups: on the device
+  chk(tsx_pprts_set_optical_properties(st.h, alb.data(), ka.data(), ks.data(), gg.data(), dz.data(),
+                                       st.have_planck ? pl.data() : nullptr, st.dx, st.dy, 1, TSX_HOST),
+      "tsx_pprts_set_optical_properties");
 }
 
 extern "C" void pprts_f2c_solve(int fcomm, float edirTOA) {

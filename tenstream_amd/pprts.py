@@ -121,13 +121,16 @@ class PprtsSolver:
 
     @property
     def l1d(self):
-        """1-D layers: dz/dx > twostr_ratio anywhere in the layer, and then every layer above (src/pprts.F90:669-677)"""
+        """1-D layers as the reference flags them (src/pprts.F90:670-677, 708-719); host mirror of the device logic"""
         dz = self._raw["dz"]
         dz = dz.cpu().numpy() if hasattr(dz, "cpu") else dz
+        ex = (dz / self.dx > TWOSTR_RATIO).any(axis=(0, 1))
         l1d = np.zeros(self.Nz, dtype=np.uint8)
-        big = np.nonzero((dz / self.dx > TWOSTR_RATIO).any(axis=(0, 1)))[0]
-        if big.size:
-            l1d[: big.max() + 1] = 1
+        l1d[-1] = ex[-1]
+        upper = np.nonzero(ex[:-1])[0]
+        if upper.size:
+            l1d[: upper.max() + 1] = 1
+        l1d[: int(l1d.sum())] = 1  # the count of 1-D layers is applied from the top (:708-719)
         return l1d
 
     # -- solve_pprts -------------------------------------------------------------------------------------

@@ -2,6 +2,8 @@
 alloc_coeff_* -> explicit_edir -> setup_b -> diffuse solve -> calc_flx_div -> scale_flx -> pprts_get_result.
 Inputs are identical (same synthetic LUTs, same optical properties); coefficient lookups must be bit-exact,
 fluxes agree to solver tolerance."""
+import os
+
 import numpy as np
 import pytest
 
