@@ -219,7 +219,7 @@ int tsx_pprts_get_field(tsx_solver *s, int which, double *out, int where);
 
 /* ---- z = M^-1 v with the preconditioner the solve uses (exposed for parity tests: M is the column-block
  *      diagonal of the assembled matrix in the dst-owned numbering) */
-int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps);
+int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps, int mixed);
 
 /* ---- measurement helpers (bench.py): time `reps` launches of the dominant kernel with HIP events on
  *      the solver's stream.  kernel: 0 = SpMV (diffuse operator apply), 1 = one full BiCGStab iteration */

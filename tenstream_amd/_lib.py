@@ -98,7 +98,7 @@ def load():
     lib.tsx_pprts_get_field.argtypes = [vp, ip, vp, ip]
     lib.tsx_diff_apply.argtypes = [vp, vp, vp, ip]
     lib.tsx_diff_solve.argtypes = [vp, vp, vp, ip, C.POINTER(KspOpts), C.POINTER(KspResult)]
-    lib.tsx_diff_pc_apply.argtypes = [vp, vp, vp, ip, ip, ip]
+    lib.tsx_diff_pc_apply.argtypes = [vp, vp, vp, ip, ip, ip, ip]
     lib.tsx_bench_kernel.argtypes = [vp, ip, ip, C.POINTER(C.c_float)]
     lib.tsx_algorithmic_bytes.argtypes = [vp, ip, dp]
     lib.tsx_probe_copy_bandwidth.argtypes = [vp, C.c_size_t, ip, dp]

@@ -894,7 +894,19 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
       return TSX_OK;
     }
   }
-  // generic kernel (8_16, or A/B): y coupling only
+  if constexpr (NTOP == 8 && std::is_same<ZT, float>::value) {
+    if (s->pc_half) {
+      if (s->any_l1d)
+        hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
+                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+      else
+        hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
+                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+      HIPCHK(hipGetLastError());
+      return TSX_OK;
+    }
+  }
+  // generic kernel (8_16 exact path, or A/B): y coupling only
   if (s->coef_bytes == 4)
     hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
                        (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
@@ -921,7 +933,8 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
   if (s->pc == TSX_PC_ZEBRA) {
     const int P = s->pc_sweeps + 1;
     ZT *alt = (ZT *)s->vw;
-    const bool xl = NTOP == 2 && g.ym >= 2;
+    // lagged x coupling: 3_10 kernels and the packed 8_16 kernel; the generic (exact) 8_16 kernel couples in y only
+    const bool xl = g.ym >= 2 && (NTOP == 2 || (std::is_same<ZT, float>::value && s->pc_half));
     auto buf = [&](int pass) {  // buffer a pass writes: its colour's last pass writes z, alternating backwards
       const int last = ((P - 1) % 2 == pass % 2) ? P - 1 : P - 2;
       return (((last - pass) / 2) % 2 == 0 || !xl) ? z : alt;
@@ -1137,6 +1150,30 @@ static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, co
   return TSX_OK;
 }
 
+// packed fp16 copy of the blocks for the preconditioner (tsx_k_pack_p16), rebuilt when the coefficients changed
+static int ensure_pc_half(tsx_solver *s) {
+  const bool h1 = s->geo.ntop == 2;
+  const long long n = (long long)(h1 ? TSX_P16_GROUPS : TSX_P16H_GROUPS) * s->geo.Nc;
+  if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
+  if (!s->coef_h_valid) {
+#define TSX_PACK(CTYPE, NT)                                                                                        \
+  hipLaunchKernelGGL((tsx_k_pack_p16<CTYPE, NT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, s->geo.Nc,      \
+                     (const CTYPE *)s->coef, (tsx_h8 *)s->coef_h)
+    if (s->coef_bytes == 4) {
+      if (h1) TSX_PACK(float, 2);
+      else TSX_PACK(float, 8);
+    } else {
+      if (h1) TSX_PACK(double, 2);
+      else TSX_PACK(double, 8);
+    }
+#undef TSX_PACK
+    HIPCHK(hipGetLastError());
+    s->coef_h_valid = true;
+  }
+  s->pc_half = true;
+  return TSX_OK;
+}
+
 static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o) {
   if (opts) *o = *opts;
   else tsx_default_ksp_opts(o);
@@ -1152,18 +1189,8 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   if (o->pc != TSX_PC_NONE) {
     int rc = s->geo.ntop == 2 ? ensure_pc_buffers<2>(s) : ensure_pc_buffers<8>(s);
     if (rc) return rc;
-    if (o->pc_coeff_fp16 && s->mixed && s->geo.ntop == 2 && s->have_coeffs) {
-      const long long n = (long long)TSX_P16_GROUPS * s->geo.Nc;
-      if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
-      if (!s->coef_h_valid) {
-        if (s->coef_bytes == 4)
-          hipLaunchKernelGGL(tsx_k_pack_p16<float>, dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, s->geo.Nc, (const float *)s->coef, (tsx_h8 *)s->coef_h);
-        else
-          hipLaunchKernelGGL(tsx_k_pack_p16<double>, dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, s->geo.Nc, (const double *)s->coef, (tsx_h8 *)s->coef_h);
-        HIPCHK(hipGetLastError());
-        s->coef_h_valid = true;
-      }
-      s->pc_half = true;
+    if (o->pc_coeff_fp16 && s->mixed && s->have_coeffs) {
+      if ((rc = ensure_pc_half(s))) return rc;
     }
   }
   return TSX_OK;
@@ -1186,7 +1213,7 @@ extern "C" int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int whe
 
 // ------------------------------------------------------------------------------------------------
 template <int NTOP, int NSIDE>
-static int pc_apply_t(tsx_solver *s, const double *v, double *z, int where) {
+static int pc_apply_t(tsx_solver *s, const double *v, double *z, int where, bool mixed) {
   const TsxGeo &g = s->geo;
   const size_t nb = (size_t)g.N * sizeof(double);
   int rc = ensure_stage(s);
@@ -1199,14 +1226,19 @@ static int pc_apply_t(tsx_solver *s, const double *v, double *z, int where) {
     zd = s->stage_b;
   }
   if ((rc = import_vec<NTOP, NSIDE>(s, vd, s->vp))) return rc;
-  if ((rc = apply_pc<NTOP, NSIDE, double>(s, s->vp, s->vph, false))) return rc;
+  if (mixed) {  // the solver's default path: fp32 directions from the packed fp16 blocks, widened for the export
+    if ((rc = apply_pc<NTOP, NSIDE, float>(s, s->vp, (float *)s->vsh, false))) return rc;
+    hipLaunchKernelGGL(tsx_k_widen, dim3(grid_for(g.N)), dim3(TSX_BLOCK), 0, s->stream, g.N, (const float *)s->vsh, s->vph);
+  } else if ((rc = apply_pc<NTOP, NSIDE, double>(s, s->vp, s->vph, false))) {
+    return rc;
+  }
   if ((rc = export_vec<NTOP, NSIDE>(s, s->vph, zd))) return rc;
   if (where == TSX_HOST) HIPCHK(hipMemcpyAsync(z, s->stage_b, nb, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
   return TSX_OK;
 }
 
-extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps) {
+extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps, int mixed) {
   ARGCHK(s && v && z, "tsx_diff_pc_apply: null argument");
   ARGCHK((pc == TSX_PC_COLUMN || pc == TSX_PC_ZEBRA) && pc_sweeps >= 1 && pc_sweeps <= 8, "tsx_diff_pc_apply: bad preconditioner");
   if (!s->have_coeffs) {
@@ -1218,7 +1250,9 @@ extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int 
   s->pc_sweeps = pc_sweeps;
   int rc = s->geo.ntop == 2 ? ensure_pc_buffers<2>(s) : ensure_pc_buffers<8>(s);
   if (rc) return rc;
-  return s->geo.ntop == 2 ? pc_apply_t<2, 4>(s, v, z, where) : pc_apply_t<8, 4>(s, v, z, where);
+  s->pc_half = false;
+  if (mixed && (rc = ensure_pc_half(s))) return rc;
+  return s->geo.ntop == 2 ? pc_apply_t<2, 4>(s, v, z, where, mixed != 0) : pc_apply_t<8, 4>(s, v, z, where, mixed != 0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -859,16 +859,32 @@ __host__ __device__ constexpr int tsx_p16_plane(int grp, int e) {
   return (2 + 2 * (grp - 9) + (e >> 2)) * 10 + 2 + (e & 3);
 }
 
-template <typename CT>
+// 8_16 (D = 16): 32 records, no padding.  t = top dst 0..7, d = side dst 8..15, y_q = src 12+q, x_q = src 8+q.
+//   grp 0..7:   c(src 0..7 -> top dst t = grp)                       (Tuu/Rud/Rdu/Tdd interleaved by stream parity)
+//   grp 8+m:    c(y_q -> 2m), c(y_q -> 2m+1)        grp 12+m: c(x_q -> 2m), c(x_q -> 2m+1)
+//   grp 16+dd:  c(src 0..7 -> side dst 8+dd)
+//   grp 24+m:   c(y_q -> 8+2m), c(y_q -> 9+2m)      grp 28+m: c(x_q -> 8+2m), c(x_q -> 9+2m)
+constexpr int TSX_P16H_GROUPS = 32;
+__host__ __device__ constexpr int tsx_p16h_plane(int grp, int e) {
+  if (grp < 8) return grp * 16 + e;
+  if (grp < 12) return (2 * (grp - 8) + (e >> 2)) * 16 + 12 + (e & 3);
+  if (grp < 16) return (2 * (grp - 12) + (e >> 2)) * 16 + 8 + (e & 3);
+  if (grp < 24) return (8 + grp - 16) * 16 + e;
+  if (grp < 28) return (8 + 2 * (grp - 24) + (e >> 2)) * 16 + 12 + (e & 3);
+  return (8 + 2 * (grp - 28) + (e >> 2)) * 16 + 8 + (e & 3);
+}
+
+template <typename CT, int NTOP>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pack_p16(long long Nc, const CT *__restrict__ C, tsx_h8 *__restrict__ P) {
-  const long long n = Nc * TSX_P16_GROUPS;
+  constexpr int NG = NTOP == 2 ? TSX_P16_GROUPS : TSX_P16H_GROUPS;
+  const long long n = Nc * NG;
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
     const int grp = (int)(q / Nc);
     const long long c = q - (long long)grp * Nc;
     tsx_h8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int pl = tsx_p16_plane(grp, e);
+      const int pl = NTOP == 2 ? tsx_p16_plane(grp, e) : tsx_p16h_plane(grp, e);
       v[e] = pl >= 0 ? (_Float16)C[(size_t)pl * Nc + c] : (_Float16)0;
     }
     P[q] = v;
@@ -1092,6 +1108,280 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   zt[col] = (float)U;  // U_Nz
 #pragma unroll
   for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (float)rt[(size_t)d * ncol + col];
+}
+
+// ---- 8_16 (H = 4 up/down pairs) on the packed fp16 blocks: same mathematics as tsx_k_pc_column<8,4,...> (4x4 block
+// recurrences), same software pipeline as tsx_k_pc_column_p16.  Temporaries per cell: 10 float4 records
+// [Gw | GT rows 0..3 | A_{k+1} rows 0..3 | B_{k+1}].
+struct TsxUpRawH {
+  tsx_h8 row[8], cy[4], cx[4];
+  double r[8], t11, t12;
+  float zy[4], zx[4];
+};
+struct TsxDnRawH {
+  tsx_h8 row[8], cy[4], cx[4];
+  float4 t[10];
+  double rs[8];
+  float zy[4], zx[4];
+};
+
+template <int ROWS, bool GS, bool HAS1D, bool XL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void tsx_k_pc_column_p16h(
+    TsxGeo g, const tsx_h8 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
+    const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ r, float *__restrict__ z,
+    const float *__restrict__ zc, const float *__restrict__ zx, float4 *__restrict__ tmp, const int *__restrict__ done) {
+  constexpr int D = 16, NTOP = 8, NSIDE = 4, H = 4;
+  constexpr int PU = 2, PD = 1;
+  using SM = TsxSm<H>;
+  if (done && *done) return;
+  int col = blockIdx.x * 64 + threadIdx.x;
+  if (ROWS) {
+    const int nrows = ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2;
+    if (col >= nrows * g.xm) return;
+    col = (2 * (col / g.xm) + (ROWS - 1)) * g.xm + col % g.xm;
+  }
+  if (col >= g.ncol) return;
+  const long long Nc = g.Nc;
+  const int Nz = g.Nz, ncol = g.ncol;
+  const int jrow = col / g.xm;
+  const bool seam = g.wrap_y && (g.ym % 2 == 0);
+  const long long offN = (jrow + 1 < g.ym) ? (long long)g.xm : (seam ? -(long long)(g.ym - 1) * g.xm : 0);
+  const long long offS = (jrow > 0) ? -(long long)g.xm : (seam ? (long long)(g.ym - 1) * g.xm : 0);
+  const int icol = col % g.xm;
+  const long long offE = (icol + 1 < g.xm) ? 1 : (g.wrap_x ? -(long long)(g.xm - 1) : 0);
+  const long long offW = (icol > 0) ? -1 : (g.wrap_x ? (long long)(g.xm - 1) : 0);
+  const double *__restrict__ rt = r + (size_t)D * Nc;
+  float *__restrict__ zt = z + (size_t)D * Nc;
+  const double albh = albedo[col] / (double)H;  // assembled surface row: albedo/streams on every pair
+
+  auto load_up = [&](int k) {
+    TsxUpRawH u;
+    const size_t c = (size_t)k * ncol + col;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) u.row[t] = P[(size_t)t * Nc + c];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) u.r[t] = r[(size_t)t * Nc + c];
+    if (GS) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) u.cy[m] = P[(size_t)(8 + m) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) u.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
+    }
+    if (XL) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) u.cx[m] = P[(size_t)(12 + m) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) u.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
+    }
+    if (HAS1D) {
+      u.t11 = a11[c];
+      u.t12 = a12[c];
+    }
+    return u;
+  };
+
+  double A[H][H], B[H];
+#pragma unroll
+  for (int a = 0; a < H; ++a) {
+    B[a] = rt[(size_t)(2 * a) * ncol + col];
+#pragma unroll
+    for (int b = 0; b < H; ++b) A[a][b] = albh;
+  }
+  auto step_up = [&](int k, const TsxUpRawH &u) {
+    const size_t c = (size_t)k * ncol + col;
+    bool one = false;
+    if (HAS1D) one = l1d[k] != 0;
+    double Tuu[H][H], Rud[H][H], Rdu[H][H], Tdd[H][H], ru[H], rd[H];
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+#pragma unroll
+      for (int b = 0; b < H; ++b) {
+        const double dg = a == b ? 1.0 : 0.0;
+        Tuu[a][b] = one ? dg * u.t11 : (double)u.row[2 * a][2 * b];
+        Rud[a][b] = one ? dg * u.t12 : (double)u.row[2 * a][2 * b + 1];
+        Rdu[a][b] = one ? dg * u.t12 : (double)u.row[2 * a + 1][2 * b];
+        Tdd[a][b] = one ? dg * u.t11 : (double)u.row[2 * a + 1][2 * b + 1];
+      }
+      double gu = 0.0, gd = 0.0;
+      if (GS) {
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) {
+          const double zv = (tsx_inward(q) ? offS : offN) ? (double)u.zy[q] : 0.0;  // select: the unused slot may hold NaN
+          gu += (double)u.cy[a][q] * zv;
+          gd += (double)u.cy[a][4 + q] * zv;
+        }
+      }
+      if (XL) {
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) {
+          const double zv = (tsx_inward(q) ? offW : offE) ? (double)u.zx[q] : 0.0;
+          gu += (double)u.cx[a][q] * zv;
+          gd += (double)u.cx[a][4 + q] * zv;
+        }
+      }
+      ru[a] = u.r[2 * a] + (one ? 0.0 : gu);
+      rd[a] = u.r[2 * a + 1] + (one ? 0.0 : gd);
+    }
+    double RA[H][H], G[H][H], GT[H][H], w[H], Gw[H], AGw[H], TA[H][H], An[H][H], Bn[H];
+    SM::matmul(Rdu, A, RA);
+    SM::inv_i_minus(RA, G);
+    SM::matvec(Rdu, B, w);
+#pragma unroll
+    for (int a = 0; a < H; ++a) w[a] += rd[a];
+    SM::matvec(G, w, Gw);
+    SM::matmul(G, Tdd, GT);
+    tmp[(size_t)0 * Nc + c] = make_float4((float)Gw[0], (float)Gw[1], (float)Gw[2], (float)Gw[3]);
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      tmp[(size_t)(1 + a) * Nc + c] = make_float4((float)GT[a][0], (float)GT[a][1], (float)GT[a][2], (float)GT[a][3]);
+      tmp[(size_t)(5 + a) * Nc + c] = make_float4((float)A[a][0], (float)A[a][1], (float)A[a][2], (float)A[a][3]);
+    }
+    tmp[(size_t)9 * Nc + c] = make_float4((float)B[0], (float)B[1], (float)B[2], (float)B[3]);
+    SM::matvec(A, Gw, AGw);
+#pragma unroll
+    for (int a = 0; a < H; ++a) AGw[a] += B[a];
+    SM::matvec(Tuu, AGw, Bn);
+    SM::matmul(Tuu, A, TA);
+    SM::matmul(TA, GT, An);
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      B[a] = Bn[a] + ru[a];
+#pragma unroll
+      for (int b = 0; b < H; ++b) A[a][b] = An[a][b] + Rud[a][b];
+    }
+  };
+
+  // ---- upward sweep
+  {
+    int k = Nz - 1;
+    for (int rr = Nz % PU; rr > 0; --rr, --k) {
+      const TsxUpRawH u = load_up(k);
+      step_up(k, u);
+    }
+    if (k >= 0) {
+      TsxUpRawH q[PU];
+#pragma unroll
+      for (int p = 0; p < PU; ++p) q[p] = load_up(k - p);
+      for (; k >= 0; k -= PU) {
+#pragma unroll
+        for (int p = 0; p < PU; ++p) {
+          const TsxUpRawH cu = q[p];
+          const int kn = k - p - PU;
+          q[p] = load_up(kn >= 0 ? kn : 0);
+          step_up(k - p, cu);
+        }
+      }
+    }
+  }
+
+  auto load_dn = [&](int k) {
+    TsxDnRawH d;
+    const size_t c = (size_t)k * ncol + col;
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) d.row[dd] = P[(size_t)(16 + dd) * Nc + c];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) d.t[q] = tmp[(size_t)q * Nc + c];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+    if (GS) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) d.cy[m] = P[(size_t)(24 + m) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) d.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
+    }
+    if (XL) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) d.cx[m] = P[(size_t)(28 + m) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) d.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
+    }
+    return d;
+  };
+
+  double V[H], U[H];
+#pragma unroll
+  for (int a = 0; a < H; ++a) {
+    V[a] = rt[(size_t)(2 * a + 1) * ncol + col];  // V_0 = rd_0 (TOA identity rows)
+    zt[(size_t)(2 * a + 1) * ncol + col] = (float)V[a];
+  }
+  SM::matvec(A, V, U);  // A, B hold level 0
+#pragma unroll
+  for (int a = 0; a < H; ++a) U[a] += B[a];
+
+  auto f4 = [](const float4 &v, int i) { return (double)(i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w); };
+  auto step_dn = [&](int k, const TsxDnRawH &d) {
+    const size_t c = (size_t)k * ncol + col;
+    bool one = false;
+    if (HAS1D) one = l1d[k] != 0;
+    double Vn[H], Un[H];
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      double v = f4(d.t[0], a);
+#pragma unroll
+      for (int b = 0; b < H; ++b) v += f4(d.t[1 + a], b) * V[b];
+      Vn[a] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < H; ++a) {  // U_{k+1} = A_{k+1} V_{k+1} + B_{k+1} (the surface closure is what the sweep started from)
+      double v = f4(d.t[9], a);
+#pragma unroll
+      for (int b = 0; b < H; ++b) v += f4(d.t[5 + a], b) * Vn[b];
+      Un[a] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      z[(size_t)(2 * a) * Nc + c] = (float)U[a];
+      z[(size_t)(2 * a + 1) * Nc + c] = (float)Vn[a];
+    }
+    double zy[NSIDE], zq[NSIDE];
+    if (GS) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) zy[q] = (tsx_inward(q) ? offS : offN) ? (double)d.zy[q] : 0.0;
+    }
+    if (XL) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) zq[q] = (tsx_inward(q) ? offW : offE) ? (double)d.zx[q] : 0.0;
+    }
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) {
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < H; ++a) acc += (double)d.row[dd][2 * a] * Un[a] + (double)d.row[dd][2 * a + 1] * V[a];
+      if (GS) {
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) acc += (double)d.cy[dd >> 1][(dd & 1) * 4 + q] * zy[q];
+      }
+      if (XL) {
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) acc += (double)d.cx[dd >> 1][(dd & 1) * 4 + q] * zq[q];
+      }
+      z[(size_t)(NTOP + dd) * Nc + c] = (float)(d.rs[dd] + (one ? 0.0 : acc));
+    }
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      V[a] = Vn[a];
+      U[a] = Un[a];
+    }
+  };
+
+  // ---- downward sweep
+  {
+    TsxDnRawH cd = load_dn(0);
+    for (int k = 0; k < Nz; ++k) {
+      const TsxDnRawH nx = load_dn(k + 1 < Nz ? k + 1 : k);
+      step_dn(k, cd);
+      cd = nx;
+    }
+    (void)PD;
+  }
+#pragma unroll
+  for (int a = 0; a < H; ++a) zt[(size_t)(2 * a) * ncol + col] = (float)U[a];  // U_Nz
+#pragma unroll
+  for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (float)rt[(size_t)d * ncol + col];
+}
+
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_widen(long long n, const float *__restrict__ a, double *__restrict__ o) {
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) o[q] = (double)a[q];
 }
 
 // out = a - b   (second preconditioner sweep: residual of the first)

@@ -229,8 +229,9 @@ class DiffuseSolver:
         _lib.check(self.lib.tsx_diff_apply(self.h, xp, yp, where))
         return out
 
-    def pc_apply(self, v, pc=1, sweeps=1, out=None):
-        """z = M^-1 v with the solver's preconditioner (test hook)."""
+    def pc_apply(self, v, pc=1, sweeps=1, out=None, mixed=False):
+        """z = M^-1 v with the solver's preconditioner (test hook).  mixed: the path the solver uses by default (fp32
+        directions computed from the packed fp16 blocks) instead of the exact fp64 one."""
         if out is None:
             if _is_torch(v):
                 import torch
@@ -242,7 +243,7 @@ class DiffuseSolver:
         zp, w2 = _ptr(out, np.float64)
         if where != w2:
             raise TypeError("v and out must live on the same side")
-        _lib.check(self.lib.tsx_diff_pc_apply(self.h, vp_, zp, where, pc, sweeps))
+        _lib.check(self.lib.tsx_diff_pc_apply(self.h, vp_, zp, where, pc, sweeps, int(bool(mixed))))
         return out
 
     def default_tolerances(self, unconstrained_fraction=1.0):

@@ -290,7 +290,8 @@ def test_breakdown_restart(gpu):
         assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
 
 
-@pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 9, 8, 6, 1), ("3_10", 6, 7, 5, 0), ("8_16", 5, 6, 4, 0)])
+@pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 9, 8, 6, 1), ("3_10", 6, 7, 5, 0), ("8_16", 5, 6, 4, 0),
+                                                  ("8_16", 6, 6, 7, 2)])
 @pytest.mark.parametrize("sweeps", [1, 2, 3, 4])
 def test_zebra_preconditioner_is_line_gauss_seidel(gpu, solver, Nx, Ny, Nz, n1d, sweeps):
     """TSX_PC_ZEBRA = Gauss-Seidel in y over the column blocks: even rows, odd rows (+ even again), each pass an exact
@@ -327,19 +328,28 @@ def test_zebra_preconditioner_is_line_gauss_seidel(gpu, solver, Nx, Ny, Nz, n1d,
     lu = spla.splu(M.tocsc(), permc_spec="NATURAL")
     rng = np.random.default_rng(9)
     v = rng.standard_normal(P["b"].shape)
-    x = np.zeros(v.size)
-    for p_ in range(sweeps + 1):
-        mk = even if p_ % 2 == 0 else ~even
-        rhs = v.ravel().copy()
-        if p_ > 0:
-            rhs -= Nyc @ x
-        if p_ > 1 and solver == "3_10":
-            rhs -= Nxc @ x
-        x[mk] = lu.solve(rhs)[mk]
+    def model(with_x):
+        x = np.zeros(v.size)
+        for p_ in range(sweeps + 1):
+            mk = even if p_ % 2 == 0 else ~even
+            rhs = v.ravel().copy()
+            if p_ > 0:
+                rhs -= Nyc @ x
+            if p_ > 1 and with_x:
+                rhs -= Nxc @ x
+            x[mk] = lu.solve(rhs)[mk]
+        return x
+
+    x = model(solver == "3_10")  # exact fp64 path: the generic 8_16 kernel couples in y only
     s = DiffuseSolver(solver, Nz, Nx, Ny)
     s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
     z = s.pc_apply(v, pc=2, sweeps=sweeps)
     assert np.abs(z.ravel() - x).max() <= 1e-12 * np.abs(x).max()
+    # the path the solver takes by default: packed fp16 blocks, fp32 temporaries and output, x coupling for both
+    # solvers -- the same preconditioner up to that rounding (2^-11 per coefficient)
+    xm = model(True)
+    zm = s.pc_apply(v, pc=2, sweeps=sweeps, mixed=True)
+    assert np.abs(zm.ravel() - xm).max() <= 3e-3 * np.abs(xm).max()
     # and the zebra-preconditioned solve reaches the same solution in fewer iterations than block-Jacobi
     xs, xj = np.zeros(s.vec_shape), np.zeros(s.vec_shape)
     iz = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30, pc=2, pc_sweeps=sweeps)
