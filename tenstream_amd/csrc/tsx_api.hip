@@ -14,35 +14,15 @@
 
 #include <stdlib.h>
 
+#include "tsx_host.hpp"
 #include "tsx_kernels.hpp"
 #include "tsx_pipeline.hpp"
-
-#ifndef TSX_DEFAULT_CPT
-#define TSX_DEFAULT_CPT 2
-#endif
 
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 void tsx_set_error(const std::string &msg) { g_err = msg; }
 extern "C" const char *tsx_last_error(void) { return g_err.c_str(); }
 extern "C" int tsx_version(void) { return TSX_VERSION; }
-
-#define HIPCHK(call)                                                                      \
-  do {                                                                                    \
-    hipError_t e_ = (call);                                                               \
-    if (e_ != hipSuccess) {                                                               \
-      tsx_set_error(std::string(#call) + ": " + hipGetErrorString(e_) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); \
-      return e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? TSX_ERR_NO_DEVICE : TSX_ERR_HIP; \
-    }                                                                                     \
-  } while (0)
-
-#define ARGCHK(cond, msg)          \
-  do {                             \
-    if (!(cond)) {                 \
-      tsx_set_error(msg);          \
-      return TSX_ERR_ARG;          \
-    }                              \
-  } while (0)
 
 extern "C" int tsx_device_count(void) {
   int n = 0;
@@ -146,13 +126,6 @@ extern "C" int tsx_comm_set_callbacks(tsx_solver *s, tsx_exchange_fn exchange, t
 }
 
 // ------------------------------------------------------------------------------------------------
-static inline int grid_for(long long n, int cap = 2048) {
-  long long b = (n + TSX_BLOCK - 1) / TSX_BLOCK;
-  if (b < 1) b = 1;
-  if (b > cap) b = cap;
-  return (int)b;
-}
-
 extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   if (!o) return;
   o->rtol = 1e-5;   // determine_ksp_tolerances, src/pprts_base.F90:1128
@@ -308,7 +281,7 @@ extern "C" int tsx_set_stream(tsx_solver *s, void *hip_stream) {
 // x-neighbours are the same rank, e.g. 2 ranks along a periodic axis).
 // st: the stream the transfers are issued on (the solver stream, or comm_stream when overlapping; the caller has made
 // st wait for the pack kernel)
-static int face_exchange(tsx_solver *s, hipStream_t st) {
+int tsx_face_exchange(tsx_solver *s, hipStream_t st) {
   const TsxGeo &g = s->geo;
   const size_t bx = s->halo_x_elems, by = s->halo_y_elems;
   if (s->xchg_cb) {
@@ -367,105 +340,6 @@ static int face_exchange(tsx_solver *s, hipStream_t st) {
   return TSX_OK;
 }
 
-template <int NTOP, int NSIDE, typename XT = double>
-static int halo_update(tsx_solver *s, const XT *v, bool in_solve) {
-  const TsxGeo &g = s->geo;
-  if (g.wrap_x && g.wrap_y) return TSX_OK;
-  const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
-  hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE, XT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, v, s->sendW,
-                     s->sendE, s->sendS, s->sendN, in_solve ? &s->scal->done : (const int *)nullptr);
-  return face_exchange(s, s->stream);
-}
-
-// TSX_SPMV_CPT=1|2 selects cells per thread (default 2 when xm is even)
-static int spmv_cpt(const tsx_solver *s) {
-  static int env = -1;
-  if (env < 0) {
-    const char *e = getenv("TSX_SPMV_CPT");
-    env = e ? atoi(e) : 0;
-  }
-  int want = env > 0 ? env : TSX_DEFAULT_CPT;
-  if (want > 2) want = 2;
-  while (want > 1 && (s->geo.xm % want) != 0) want >>= 1;
-  return want;
-}
-
-#define TSX_FRAME_BLOCKS 256
-// groups of the frame (cells whose gather reads a received face), see tsx_k_spmv_w
-static long long frame_groups(const TsxGeo &g, int cpt) {
-  const int gx = g.xm / cpt;
-  const int nfull = g.wrap_y ? 0 : (g.ym >= 2 ? 2 : 1);
-  const int ex = g.wrap_x ? 0 : (gx >= 2 ? 2 : 1);
-  return (long long)g.Nz * (nfull * gx + (g.ym - nfull) * ex);
-}
-static inline bool spmv_split(const tsx_solver *s) { return s->overlap && !(s->geo.wrap_x && s->geo.wrap_y); }
-
-// part 0: whole grid; 1: interior (no halo reads); 2: frame, partial sums behind those of part 1
-template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT, bool HALO, bool HAS1D>
-static void launch_spmv_variant(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done, int part) {
-  const TsxGeo &g = s->geo;
-  const int nbmain = grid_for(g.Nc / CPT, TSX_MAX_PARTIAL_BLOCKS - TSX_FRAME_BLOCKS);
-  const int nb = part == 2 ? grid_for(frame_groups(g, CPT), TSX_FRAME_BLOCKS) : nbmain;
-  hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT, XT, WT, HALO, HAS1D>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
-                     (const CT *)s->coef, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS, s->recvN,
-                     w, s->partials + (part == 2 ? nbmain : 0), done, part);
-}
-
-template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT>
-static void launch_spmv_flags(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done, int part) {
-  const bool halo = !(s->geo.wrap_x && s->geo.wrap_y) && part != 1, has1d = s->any_l1d;
-  if (halo) {
-    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, true>(s, x, y, w, done, part);
-    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, false>(s, x, y, w, done, part);
-  } else {
-    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, true>(s, x, y, w, done, part);
-    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, false>(s, x, y, w, done, part);
-  }
-}
-
-template <int NTOP, int NSIDE, int FUSE, typename XT = double, typename WT = double>
-static int launch_spmv(tsx_solver *s, const XT *x, double *y, const WT *w, bool in_solve) {
-  const int *done = in_solve ? &s->scal->done : nullptr;
-  const int cpt = spmv_cpt(s);
-  auto launch = [&](int part) {
-    if (s->coef_bytes == 4) {
-      if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, float, 2, XT, WT>(s, x, y, w, done, part);
-      else launch_spmv_flags<NTOP, NSIDE, FUSE, float, 1, XT, WT>(s, x, y, w, done, part);
-    } else {
-      if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, double, 2, XT, WT>(s, x, y, w, done, part);
-      else launch_spmv_flags<NTOP, NSIDE, FUSE, double, 1, XT, WT>(s, x, y, w, done, part);
-    }
-  };
-  if (!spmv_split(s)) {
-    int rc = halo_update<NTOP, NSIDE, XT>(s, x, in_solve);
-    if (rc) return rc;
-    launch(0);
-    HIPCHK(hipGetLastError());
-    return TSX_OK;
-  }
-  // overlap: pack -> [exchange on comm_stream || interior cells on stream] -> frame cells
-  const TsxGeo &g = s->geo;
-  const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
-  hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE, XT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, x, s->sendW,
-                     s->sendE, s->sendS, s->sendN, done);
-  HIPCHK(hipEventRecord(s->ev_pack, s->stream));
-  HIPCHK(hipStreamWaitEvent(s->comm_stream, s->ev_pack, 0));
-  launch(1);  // queued before the (possibly host-synchronous) exchange so that it runs underneath it
-  HIPCHK(hipGetLastError());
-  int rc = face_exchange(s, s->comm_stream);
-  if (rc) return rc;
-  HIPCHK(hipEventRecord(s->ev_recv, s->comm_stream));
-  HIPCHK(hipStreamWaitEvent(s->stream, s->ev_recv, 0));
-  launch(2);
-  HIPCHK(hipGetLastError());
-  return TSX_OK;
-}
-static inline int spmv_nblocks(const tsx_solver *s) {
-  const int cpt = spmv_cpt(s);
-  const int nbmain = grid_for(s->geo.Nc / cpt, TSX_MAX_PARTIAL_BLOCKS - TSX_FRAME_BLOCKS);
-  return spmv_split(s) ? nbmain + grid_for(frame_groups(s->geo, cpt), TSX_FRAME_BLOCKS) : nbmain;
-}
-
 // reduce partials -> (all-reduce) -> scalar algebra
 static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {
   if (s->allred_cb) {
@@ -503,7 +377,7 @@ static int import_vec(tsx_solver *s, const double *ref_dev, double *v) {
   HIPCHK(hipGetLastError());
   if (!(g.wrap_x && g.wrap_y)) {
     // only the W-ward / S-ward messages carry data; E/N-ward buffers travel as they are (ignored)
-    int rc = face_exchange(s, s->stream);
+    int rc = tsx_face_exchange(s, s->stream);
     if (rc) return rc;
     const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
     // a direction that wraps in-kernel has nothing to unpack: pass through harmlessly by guarding in host
@@ -851,137 +725,6 @@ extern "C" int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int whe
   return s->geo.ntop == 2 ? diff_apply_t<2, 4>(s, x, y, where) : diff_apply_t<8, 4>(s, x, y, where);
 }
 
-// ------------------------------------------------------------------------------------------------
-// z = M^-1 v with the column preconditioner; sweeps > 1 adds stationary refinement sweeps
-//   z <- z + M^-1 (v - A z)     (block-Jacobi iteration on column blocks)
-// one pass of the column preconditioner: writes rows of colour ROWS into z; GS: +-y coupling from zy (other colour);
-// XL: lagged +-x coupling from zx (own colour, previous pass, a different buffer than z)
-template <int NTOP, int NSIDE, int ROWS, bool GS, bool XL, typename ZT>
-static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy, const ZT *zx, const int *done) {
-  const TsxGeo &g = s->geo;
-  const int ncols = ROWS == 0 ? g.ncol : (ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2) * g.xm;
-  if (ncols == 0) return TSX_OK;
-  const int nb = (ncols + 63) / 64;
-  static int use_h1 = -1;  // TSX_PC_PREFETCH=0 selects the generic kernel for 3_10 as well (A/B knob)
-  if (use_h1 < 0) {
-    const char *e = getenv("TSX_PC_PREFETCH");
-    use_h1 = e ? atoi(e) : 1;
-  }
-  if constexpr (NTOP == 2) {
-    if (use_h1) {
-#define TSX_H1_LAUNCH(CTYPE, HAS)                                                                                              \
-  hipLaunchKernelGGL((tsx_k_pc_column_h1<CTYPE, ROWS, GS, ZT, HAS, XL>), dim3(nb), dim3(64), 0, s->stream, g,                     \
-                     (const CTYPE *)cptr, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (void *)s->pc_tmp, done)
-      const void *cptr = s->coef;
-      if (std::is_same<ZT, float>::value && s->pc_half) {
-        if constexpr (std::is_same<ZT, float>::value) {
-          if (s->any_l1d)
-            hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                               (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
-          else
-            hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                               (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
-        }
-      } else if (s->coef_bytes == 4) {
-        if (s->any_l1d) TSX_H1_LAUNCH(float, true);
-        else TSX_H1_LAUNCH(float, false);
-      } else {
-        if (s->any_l1d) TSX_H1_LAUNCH(double, true);
-        else TSX_H1_LAUNCH(double, false);
-      }
-#undef TSX_H1_LAUNCH
-      HIPCHK(hipGetLastError());
-      return TSX_OK;
-    }
-  }
-  if constexpr (NTOP == 8 && std::is_same<ZT, float>::value) {
-    if (s->pc_half) {
-      if (s->any_l1d)
-        hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
-      else
-        hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
-      HIPCHK(hipGetLastError());
-      return TSX_OK;
-    }
-  }
-  // generic kernel (8_16 exact path, or A/B): y coupling only
-  if (s->coef_bytes == 4)
-    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
-                       (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
-  else
-    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
-                       (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
-  HIPCHK(hipGetLastError());
-  return TSX_OK;
-}
-
-// z = M^-1 v.
-//  TSX_PC_COLUMN: block-Jacobi over columns; sweeps > 1 adds stationary refinement  z <- z + M^-1 (v - A z)  (fp64 only)
-//  TSX_PC_ZEBRA:  pc_sweeps + 1 half-grid passes over the column blocks, even rows / odd rows alternately.  From the
-//                 second pass on the +-y streams of the other colour (latest values) are on the right-hand side
-//                 (line Gauss-Seidel in y); from the third pass on also the +-x streams of the same rows with the
-//                 values of that colour's previous pass (Jacobi in x).  Each colour alternates between z and a
-//                 scratch buffer so that a pass never reads what it writes; the last pass of each colour lands in z.
-// ZT = float stores the preconditioned direction in fp32 (legitimate in *flexible* BiCGStab, see tsx_k_spmv_w).
-template <int NTOP, int NSIDE, typename ZT>
-static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
-  const TsxGeo &g = s->geo;
-  const int *done = in_solve ? &s->scal->done : nullptr;
-  int rc;
-  if (s->pc == TSX_PC_ZEBRA) {
-    const int P = s->pc_sweeps + 1;
-    ZT *alt = (ZT *)s->vw;
-    // lagged x coupling: 3_10 kernels and the packed 8_16 kernel; the generic (exact) 8_16 kernel couples in y only
-    const bool xl = g.ym >= 2 && (NTOP == 2 || (std::is_same<ZT, float>::value && s->pc_half));
-    auto buf = [&](int pass) {  // buffer a pass writes: its colour's last pass writes z, alternating backwards
-      const int last = ((P - 1) % 2 == pass % 2) ? P - 1 : P - 2;
-      return (((last - pass) / 2) % 2 == 0 || !xl) ? z : alt;
-    };
-    for (int pass = 0; pass < P; ++pass) {
-      ZT *out = buf(pass);
-      const ZT *zy = pass > 0 ? buf(pass - 1) : (const ZT *)out;
-      const ZT *zx = pass > 1 ? buf(pass - 2) : (const ZT *)out;
-      if (pass == 0) rc = pc_column_launch<NTOP, NSIDE, 1, false, false, ZT>(s, v, out, zy, zx, done);
-      else if (pass == 1) rc = pc_column_launch<NTOP, NSIDE, 2, true, false, ZT>(s, v, out, zy, zx, done);
-      else if (!xl) rc = (pass & 1) ? pc_column_launch<NTOP, NSIDE, 2, true, false, ZT>(s, v, out, zy, zx, done)
-                                    : pc_column_launch<NTOP, NSIDE, 1, true, false, ZT>(s, v, out, zy, zx, done);
-      else rc = (pass & 1) ? pc_column_launch<NTOP, NSIDE, 2, true, true, ZT>(s, v, out, zy, zx, done)
-                           : pc_column_launch<NTOP, NSIDE, 1, true, true, ZT>(s, v, out, zy, zx, done);
-      if (rc) return rc;
-    }
-    return TSX_OK;
-  }
-  if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, false, ZT>(s, v, z, (const ZT *)z, (const ZT *)z, done))) return rc;
-  if constexpr (std::is_same<ZT, double>::value) {
-    const long long n2 = g.N / 2;
-    const int nbv = grid_for(n2);
-    for (int sw = 1; sw < s->pc_sweeps; ++sw) {
-      if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)z, s->vt, (const double *)nullptr, in_solve))) return rc;
-      hipLaunchKernelGGL(tsx_k_sub, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)v, (const double2 *)s->vt,
-                         (double2 *)s->vt, done);
-      if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, false, double>(s, s->vt, s->vw, (const double *)s->vw,
-                                                                      (const double *)s->vw, done)))
-        return rc;
-      hipLaunchKernelGGL(tsx_k_addto, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)s->vw, (double2 *)z, done);
-    }
-  }
-  HIPCHK(hipGetLastError());
-  return TSX_OK;
-}
-
-template <int NTOP>
-static int ensure_pc_buffers(tsx_solver *s) {
-  const TsxGeo &g = s->geo;
-  const size_t nb = (size_t)g.N * sizeof(double);
-  if (!s->pc_tmp) HIPCHK(hipMalloc((void **)&s->pc_tmp, sizeof(double) * (size_t)tsx_pc_ntmp<NTOP>() * g.Nc));
-  if (s->vph == s->vp || !s->vph) HIPCHK(hipMalloc((void **)&s->vph, nb));  // fp64-sized: also holds the fp32 form
-  if (s->vsh == s->vs || !s->vsh) HIPCHK(hipMalloc((void **)&s->vsh, nb));
-  if (!s->vw) HIPCHK(hipMalloc((void **)&s->vw, nb));
-  return TSX_OK;
-}
-
 // One BiCGStab iteration on the stream (no host synchronisation).
 // One BiCGStab iteration on the stream (no host synchronisation).  MIX: preconditioned directions and the shadow
 // residual live in fp32 (s->mixed); x, r, p, s, v, t stay fp64.
@@ -1000,12 +743,12 @@ static int enqueue_iteration_t(tsx_solver *s, bool first) {
   const RT *rhat = (const RT *)s->vrhat;
   if (s->pc != TSX_PC_NONE) {
     PT *ph = (PT *)s->vph, *sh = (PT *)s->vsh;
-    if ((rc = apply_pc<NTOP, NSIDE, PT>(s, s->vp, ph, true))) return rc;
+    if ((rc = tsx_pc_apply(s, s->vp, ph, std::is_same<PT, float>::value, true))) return rc;
     if ((rc = launch_spmv<NTOP, NSIDE, 1, PT, RT>(s, ph, s->vv, rhat, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
     hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
                        (const double2 *)s->vv, (double2 *)s->vs);
-    if ((rc = apply_pc<NTOP, NSIDE, PT>(s, s->vs, sh, true))) return rc;
+    if ((rc = tsx_pc_apply(s, s->vs, sh, std::is_same<PT, float>::value, true))) return rc;
     if ((rc = launch_spmv<NTOP, NSIDE, 5, PT, double>(s, sh, s->vt, s->vs, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
     hipLaunchKernelGGL((tsx_k_xrupdate<PT, RT>), dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (double2 *)s->vx, ph, sh,
@@ -1150,30 +893,6 @@ static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, co
   return TSX_OK;
 }
 
-// packed fp16 copy of the blocks for the preconditioner (tsx_k_pack_p16), rebuilt when the coefficients changed
-static int ensure_pc_half(tsx_solver *s) {
-  const bool h1 = s->geo.ntop == 2;
-  const long long n = (long long)(h1 ? TSX_P16_GROUPS : TSX_P16H_GROUPS) * s->geo.Nc;
-  if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
-  if (!s->coef_h_valid) {
-#define TSX_PACK(CTYPE, NT)                                                                                        \
-  hipLaunchKernelGGL((tsx_k_pack_p16<CTYPE, NT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, s->geo.Nc,      \
-                     (const CTYPE *)s->coef, (tsx_h8 *)s->coef_h)
-    if (s->coef_bytes == 4) {
-      if (h1) TSX_PACK(float, 2);
-      else TSX_PACK(float, 8);
-    } else {
-      if (h1) TSX_PACK(double, 2);
-      else TSX_PACK(double, 8);
-    }
-#undef TSX_PACK
-    HIPCHK(hipGetLastError());
-    s->coef_h_valid = true;
-  }
-  s->pc_half = true;
-  return TSX_OK;
-}
-
 static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o) {
   if (opts) *o = *opts;
   else tsx_default_ksp_opts(o);
@@ -1187,10 +906,10 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   s->mixed = o->fp32_directions != 0 && !(o->pc == TSX_PC_COLUMN && o->pc_sweeps > 1);
   s->pc_half = false;
   if (o->pc != TSX_PC_NONE) {
-    int rc = s->geo.ntop == 2 ? ensure_pc_buffers<2>(s) : ensure_pc_buffers<8>(s);
+    int rc = tsx_pc_ensure_buffers(s);
     if (rc) return rc;
     if (o->pc_coeff_fp16 && s->mixed && s->have_coeffs) {
-      if ((rc = ensure_pc_half(s))) return rc;
+      if ((rc = tsx_pc_ensure_half(s))) return rc;
     }
   }
   return TSX_OK;
@@ -1227,9 +946,9 @@ static int pc_apply_t(tsx_solver *s, const double *v, double *z, int where, bool
   }
   if ((rc = import_vec<NTOP, NSIDE>(s, vd, s->vp))) return rc;
   if (mixed) {  // the solver's default path: fp32 directions from the packed fp16 blocks, widened for the export
-    if ((rc = apply_pc<NTOP, NSIDE, float>(s, s->vp, (float *)s->vsh, false))) return rc;
-    hipLaunchKernelGGL(tsx_k_widen, dim3(grid_for(g.N)), dim3(TSX_BLOCK), 0, s->stream, g.N, (const float *)s->vsh, s->vph);
-  } else if ((rc = apply_pc<NTOP, NSIDE, double>(s, s->vp, s->vph, false))) {
+    if ((rc = tsx_pc_apply(s, s->vp, s->vsh, true, false))) return rc;
+    if ((rc = tsx_pc_widen(s, (const float *)s->vsh, s->vph))) return rc;
+  } else if ((rc = tsx_pc_apply(s, s->vp, s->vph, false, false))) {
     return rc;
   }
   if ((rc = export_vec<NTOP, NSIDE>(s, s->vph, zd))) return rc;
@@ -1248,10 +967,10 @@ extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int 
   HIPCHK(hipSetDevice(s->device));
   s->pc = pc;
   s->pc_sweeps = pc_sweeps;
-  int rc = s->geo.ntop == 2 ? ensure_pc_buffers<2>(s) : ensure_pc_buffers<8>(s);
+  int rc = tsx_pc_ensure_buffers(s);
   if (rc) return rc;
   s->pc_half = false;
-  if (mixed && (rc = ensure_pc_half(s))) return rc;
+  if (mixed && (rc = tsx_pc_ensure_half(s))) return rc;
   return s->geo.ntop == 2 ? pc_apply_t<2, 4>(s, v, z, where, mixed != 0) : pc_apply_t<8, 4>(s, v, z, where, mixed != 0);
 }
 

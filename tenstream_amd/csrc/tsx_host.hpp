@@ -1,0 +1,100 @@
+// tsx_host.hpp -- host-side helpers shared by the translation units of libtsx (tsx_api.hip, tsx_spmv_*.hip, tsx_pc.hip)
+#pragma once
+#include <stdlib.h>
+
+#include <string>
+#include <type_traits>
+
+#include "tsx_dev.hpp"
+
+#ifndef TSX_DEFAULT_CPT
+#define TSX_DEFAULT_CPT 2
+#endif
+
+#define HIPCHK(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      tsx_set_error(std::string(#call) + ": " + hipGetErrorString(e_) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); \
+      return e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? TSX_ERR_NO_DEVICE : TSX_ERR_HIP; \
+    }                                                                                     \
+  } while (0)
+
+#define ARGCHK(cond, msg)          \
+  do {                             \
+    if (!(cond)) {                 \
+      tsx_set_error(msg);          \
+      return TSX_ERR_ARG;          \
+    }                              \
+  } while (0)
+
+static inline int grid_for(long long n, int cap = 2048) {
+  long long b = (n + TSX_BLOCK - 1) / TSX_BLOCK;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+// TSX_SPMV_CPT=1|2 selects cells per thread (default 2 when xm is even)
+static inline int spmv_cpt(const tsx_solver *s) {
+  static int env = -1;
+  if (env < 0) {
+    const char *e = getenv("TSX_SPMV_CPT");
+    env = e ? atoi(e) : 0;
+  }
+  int want = env > 0 ? env : TSX_DEFAULT_CPT;
+  if (want > 2) want = 2;
+  while (want > 1 && (s->geo.xm % want) != 0) want >>= 1;
+  return want;
+}
+
+#define TSX_FRAME_BLOCKS 256
+// groups of the frame (cells whose gather reads a received face), see tsx_k_spmv_w
+static inline long long frame_groups(const TsxGeo &g, int cpt) {
+  const int gx = g.xm / cpt;
+  const int nfull = g.wrap_y ? 0 : (g.ym >= 2 ? 2 : 1);
+  const int ex = g.wrap_x ? 0 : (gx >= 2 ? 2 : 1);
+  return (long long)g.Nz * (nfull * gx + (g.ym - nfull) * ex);
+}
+static inline bool spmv_split(const tsx_solver *s) { return s->overlap && !(s->geo.wrap_x && s->geo.wrap_y); }
+
+static inline int spmv_nblocks(const tsx_solver *s) {
+  const int cpt = spmv_cpt(s);
+  const int nbmain = grid_for(s->geo.Nc / cpt, TSX_MAX_PARTIAL_BLOCKS - TSX_FRAME_BLOCKS);
+  return spmv_split(s) ? nbmain + grid_for(frame_groups(s->geo, cpt), TSX_FRAME_BLOCKS) : nbmain;
+}
+
+// ---- cross-unit entry points --------------------------------------------------------------------
+// face exchange on stream st (RCCL / host-staged callbacks / self copies), tsx_api.hip
+int tsx_face_exchange(tsx_solver *s, hipStream_t st);
+
+// operator apply: one translation unit per stream configuration (tsx_spmv_3_10.hip, tsx_spmv_8_16.hip).
+// combo = (fused dots, type of x, type of w): the variants the Krylov loop uses
+enum TsxSpmvCombo { TSX_SPMV_0DD = 0, TSX_SPMV_1FF, TSX_SPMV_5FD, TSX_SPMV_1DF, TSX_SPMV_1DD, TSX_SPMV_5DD };
+int tsx_spmv_launch_310(tsx_solver *s, int combo, const void *x, double *y, const void *w, bool in_solve);
+int tsx_spmv_launch_816(tsx_solver *s, int combo, const void *x, double *y, const void *w, bool in_solve);
+int tsx_halo_update_310(tsx_solver *s, const double *v, bool in_solve);
+int tsx_halo_update_816(tsx_solver *s, const double *v, bool in_solve);
+
+template <int FUSE, typename XT, typename WT>
+constexpr int tsx_spmv_combo() {
+  constexpr bool xf = std::is_same<XT, float>::value, wf = std::is_same<WT, float>::value;
+  static_assert(FUSE == 0 || FUSE == 1 || FUSE == 5, "unsupported fused-dot set");
+  static_assert(!(FUSE == 0 && (xf || wf)) && !(FUSE == 5 && wf) && !(FUSE == 1 && xf && !wf), "variant not instantiated");
+  return FUSE == 0 ? TSX_SPMV_0DD : FUSE == 1 ? (xf ? TSX_SPMV_1FF : (wf ? TSX_SPMV_1DF : TSX_SPMV_1DD)) : (xf ? TSX_SPMV_5FD : TSX_SPMV_5DD);
+}
+template <int NTOP, int NSIDE, int FUSE, typename XT = double, typename WT = double>
+static inline int launch_spmv(tsx_solver *s, const XT *x, double *y, const WT *w, bool in_solve) {
+  constexpr int combo = tsx_spmv_combo<FUSE, XT, WT>();
+  return NTOP == 2 ? tsx_spmv_launch_310(s, combo, x, y, w, in_solve) : tsx_spmv_launch_816(s, combo, x, y, w, in_solve);
+}
+template <int NTOP, int NSIDE>
+static inline int halo_update(tsx_solver *s, const double *v, bool in_solve) {
+  return NTOP == 2 ? tsx_halo_update_310(s, v, in_solve) : tsx_halo_update_816(s, v, in_solve);
+}
+
+// preconditioner (tsx_pc.hip): z = M^-1 v, z fp32 (the solver's fp32 directions, packed fp16 blocks) or fp64 (exact)
+int tsx_pc_apply(tsx_solver *s, const double *v, void *z, bool z_is_float, bool in_solve);
+int tsx_pc_ensure_buffers(tsx_solver *s);
+int tsx_pc_ensure_half(tsx_solver *s);
+int tsx_pc_widen(tsx_solver *s, const float *a, double *o);  // o = (double) a over the N unknowns

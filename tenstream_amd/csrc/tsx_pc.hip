@@ -1,0 +1,174 @@
+// tsx_pc.hip -- host side of the column-block preconditioner (kernels: tsx_kernels_pc.hpp).  Its own translation unit so
+// that the sweep kernels compile next to the operator's.
+#include "tsx_host.hpp"
+#include "tsx_kernels_pc.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// z = M^-1 v with the column preconditioner; sweeps > 1 adds stationary refinement sweeps
+//   z <- z + M^-1 (v - A z)     (block-Jacobi iteration on column blocks)
+// one pass of the column preconditioner: writes rows of colour ROWS into z; GS: +-y coupling from zy (other colour);
+// XL: lagged +-x coupling from zx (own colour, previous pass, a different buffer than z)
+template <int NTOP, int NSIDE, int ROWS, bool GS, bool XL, typename ZT>
+static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy, const ZT *zx, const int *done) {
+  const TsxGeo &g = s->geo;
+  const int ncols = ROWS == 0 ? g.ncol : (ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2) * g.xm;
+  if (ncols == 0) return TSX_OK;
+  const int nb = (ncols + 63) / 64;
+  static int use_h1 = -1;  // TSX_PC_PREFETCH=0 selects the generic kernel for 3_10 as well (A/B knob)
+  if (use_h1 < 0) {
+    const char *e = getenv("TSX_PC_PREFETCH");
+    use_h1 = e ? atoi(e) : 1;
+  }
+  if constexpr (NTOP == 2) {
+    if (use_h1) {
+#define TSX_H1_LAUNCH(CTYPE, HAS)                                                                                              \
+  hipLaunchKernelGGL((tsx_k_pc_column_h1<CTYPE, ROWS, GS, ZT, HAS, XL>), dim3(nb), dim3(64), 0, s->stream, g,                     \
+                     (const CTYPE *)cptr, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (void *)s->pc_tmp, done)
+      const void *cptr = s->coef;
+      if (std::is_same<ZT, float>::value && s->pc_half) {
+        if constexpr (std::is_same<ZT, float>::value) {
+          if (s->any_l1d)
+            hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
+                               (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+          else
+            hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
+                               (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+        }
+      } else if (s->coef_bytes == 4) {
+        if (s->any_l1d) TSX_H1_LAUNCH(float, true);
+        else TSX_H1_LAUNCH(float, false);
+      } else {
+        if (s->any_l1d) TSX_H1_LAUNCH(double, true);
+        else TSX_H1_LAUNCH(double, false);
+      }
+#undef TSX_H1_LAUNCH
+      HIPCHK(hipGetLastError());
+      return TSX_OK;
+    }
+  }
+  if constexpr (NTOP == 8 && std::is_same<ZT, float>::value) {
+    if (s->pc_half) {
+      if (s->any_l1d)
+        hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
+                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+      else
+        hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
+                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+      HIPCHK(hipGetLastError());
+      return TSX_OK;
+    }
+  }
+  // generic kernel (8_16 exact path, or A/B): y coupling only
+  if (s->coef_bytes == 4)
+    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
+                       (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
+  else
+    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
+                       (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+// z = M^-1 v.
+//  TSX_PC_COLUMN: block-Jacobi over columns; sweeps > 1 adds stationary refinement  z <- z + M^-1 (v - A z)  (fp64 only)
+//  TSX_PC_ZEBRA:  pc_sweeps + 1 half-grid passes over the column blocks, even rows / odd rows alternately.  From the
+//                 second pass on the +-y streams of the other colour (latest values) are on the right-hand side
+//                 (line Gauss-Seidel in y); from the third pass on also the +-x streams of the same rows with the
+//                 values of that colour's previous pass (Jacobi in x).  Each colour alternates between z and a
+//                 scratch buffer so that a pass never reads what it writes; the last pass of each colour lands in z.
+// ZT = float stores the preconditioned direction in fp32 (legitimate in *flexible* BiCGStab, see tsx_k_spmv_w).
+template <int NTOP, int NSIDE, typename ZT>
+static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
+  const TsxGeo &g = s->geo;
+  const int *done = in_solve ? &s->scal->done : nullptr;
+  int rc;
+  if (s->pc == TSX_PC_ZEBRA) {
+    const int P = s->pc_sweeps + 1;
+    ZT *alt = (ZT *)s->vw;
+    // lagged x coupling: 3_10 kernels and the packed 8_16 kernel; the generic (exact) 8_16 kernel couples in y only
+    const bool xl = g.ym >= 2 && (NTOP == 2 || (std::is_same<ZT, float>::value && s->pc_half));
+    auto buf = [&](int pass) {  // buffer a pass writes: its colour's last pass writes z, alternating backwards
+      const int last = ((P - 1) % 2 == pass % 2) ? P - 1 : P - 2;
+      return (((last - pass) / 2) % 2 == 0 || !xl) ? z : alt;
+    };
+    for (int pass = 0; pass < P; ++pass) {
+      ZT *out = buf(pass);
+      const ZT *zy = pass > 0 ? buf(pass - 1) : (const ZT *)out;
+      const ZT *zx = pass > 1 ? buf(pass - 2) : (const ZT *)out;
+      if (pass == 0) rc = pc_column_launch<NTOP, NSIDE, 1, false, false, ZT>(s, v, out, zy, zx, done);
+      else if (pass == 1) rc = pc_column_launch<NTOP, NSIDE, 2, true, false, ZT>(s, v, out, zy, zx, done);
+      else if (!xl) rc = (pass & 1) ? pc_column_launch<NTOP, NSIDE, 2, true, false, ZT>(s, v, out, zy, zx, done)
+                                    : pc_column_launch<NTOP, NSIDE, 1, true, false, ZT>(s, v, out, zy, zx, done);
+      else rc = (pass & 1) ? pc_column_launch<NTOP, NSIDE, 2, true, true, ZT>(s, v, out, zy, zx, done)
+                           : pc_column_launch<NTOP, NSIDE, 1, true, true, ZT>(s, v, out, zy, zx, done);
+      if (rc) return rc;
+    }
+    return TSX_OK;
+  }
+  if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, false, ZT>(s, v, z, (const ZT *)z, (const ZT *)z, done))) return rc;
+  if constexpr (std::is_same<ZT, double>::value) {
+    const long long n2 = g.N / 2;
+    const int nbv = grid_for(n2);
+    for (int sw = 1; sw < s->pc_sweeps; ++sw) {
+      if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)z, s->vt, (const double *)nullptr, in_solve))) return rc;
+      hipLaunchKernelGGL(tsx_k_sub, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)v, (const double2 *)s->vt,
+                         (double2 *)s->vt, done);
+      if ((rc = pc_column_launch<NTOP, NSIDE, 0, false, false, double>(s, s->vt, s->vw, (const double *)s->vw,
+                                                                      (const double *)s->vw, done)))
+        return rc;
+      hipLaunchKernelGGL(tsx_k_addto, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, (const double2 *)s->vw, (double2 *)z, done);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+template <int NTOP>
+static int ensure_pc_buffers_t(tsx_solver *s) {
+  const TsxGeo &g = s->geo;
+  const size_t nb = (size_t)g.N * sizeof(double);
+  if (!s->pc_tmp) HIPCHK(hipMalloc((void **)&s->pc_tmp, sizeof(double) * (size_t)tsx_pc_ntmp<NTOP>() * g.Nc));
+  if (s->vph == s->vp || !s->vph) HIPCHK(hipMalloc((void **)&s->vph, nb));  // fp64-sized: also holds the fp32 form
+  if (s->vsh == s->vs || !s->vsh) HIPCHK(hipMalloc((void **)&s->vsh, nb));
+  if (!s->vw) HIPCHK(hipMalloc((void **)&s->vw, nb));
+  return TSX_OK;
+}
+
+// packed fp16 copy of the blocks for the preconditioner (tsx_k_pack_p16), rebuilt when the coefficients changed
+int tsx_pc_ensure_half(tsx_solver *s) {
+  const bool h1 = s->geo.ntop == 2;
+  const long long n = (long long)(h1 ? TSX_P16_GROUPS : TSX_P16H_GROUPS) * s->geo.Nc;
+  if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
+  if (!s->coef_h_valid) {
+#define TSX_PACK(CTYPE, NT)                                                                                        \
+  hipLaunchKernelGGL((tsx_k_pack_p16<CTYPE, NT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, s->geo.Nc,      \
+                     (const CTYPE *)s->coef, (tsx_h8 *)s->coef_h)
+    if (s->coef_bytes == 4) {
+      if (h1) TSX_PACK(float, 2);
+      else TSX_PACK(float, 8);
+    } else {
+      if (h1) TSX_PACK(double, 2);
+      else TSX_PACK(double, 8);
+    }
+#undef TSX_PACK
+    HIPCHK(hipGetLastError());
+    s->coef_h_valid = true;
+  }
+  s->pc_half = true;
+  return TSX_OK;
+}
+
+
+int tsx_pc_ensure_buffers(tsx_solver *s) { return s->geo.ntop == 2 ? ensure_pc_buffers_t<2>(s) : ensure_pc_buffers_t<8>(s); }
+
+int tsx_pc_apply(tsx_solver *s, const double *v, void *z, bool z_is_float, bool in_solve) {
+  if (s->geo.ntop == 2)
+    return z_is_float ? apply_pc<2, 4, float>(s, v, (float *)z, in_solve) : apply_pc<2, 4, double>(s, v, (double *)z, in_solve);
+  return z_is_float ? apply_pc<8, 4, float>(s, v, (float *)z, in_solve) : apply_pc<8, 4, double>(s, v, (double *)z, in_solve);
+}
+
+int tsx_pc_widen(tsx_solver *s, const float *a, double *o) {
+  hipLaunchKernelGGL(tsx_k_widen, dim3(grid_for(s->geo.N)), dim3(TSX_BLOCK), 0, s->stream, s->geo.N, a, o);
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}

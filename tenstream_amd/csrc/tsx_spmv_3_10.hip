@@ -1,0 +1,4 @@
+// operator apply, 3_10 (2 top + 4 side streams per direction pair): see tsx_spmv_impl.hpp
+#define TSX_SPMV_NTOP 2
+#define TSX_SPMV_TAG 310
+#include "tsx_spmv_impl.hpp"

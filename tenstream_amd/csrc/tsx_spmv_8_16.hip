@@ -1,0 +1,4 @@
+// operator apply, 8_16 (8 top + 4 side streams per direction pair): see tsx_spmv_impl.hpp
+#define TSX_SPMV_NTOP 8
+#define TSX_SPMV_TAG 816
+#include "tsx_spmv_impl.hpp"
