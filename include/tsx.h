@@ -180,8 +180,9 @@ int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int where, const t
  *   explicit_edir (src/pprts_explicit.F90:60-459)   -> column-marching sweeps iterated to the same stop rule
  *   setup_b (:4641-4987)                            -> written directly in dst-owned storage
  *   calc_flx_div (:5152-5504), scale_flx (:3682-3988), pprts_get_result (:5799-5888) -> tsx_pprts_get_result
- * Round 1: one rank (periodic wrap in-kernel), solver 3_10; nranks > 1 returns TSX_ERR_UNSUPPORTED here (the
- * diffuse seam above is multi-rank). */
+ * Solver 3_10.  On several ranks the direct sweep exchanges one face per sweep with the upwind / downwind neighbours
+ * (exchange_direct_boundary, src/pprts_explicit.F90:1076-1140), its residual is the mean over ranks of the local norms
+ * (:184), setup_b needs no exchange in dst-owned storage, and the flux divergence reads one halo update of the solution. */
 /* set_angles (src/pprts.F90:1100-1183): sun azimuth phi0 / zenith theta0 in degrees as pprts_f2c_init takes them */
 int tsx_pprts_set_angles(tsx_solver *s, double phi0, double theta0);
 /* direct tables Tdir (S*S per entry) and Sdir (S*D per entry), 6 axes [tau, w0, aspect_zx, g, phi, theta]

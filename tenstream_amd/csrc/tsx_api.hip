@@ -233,7 +233,8 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   if (!s) return TSX_OK;
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
-  void *ptrs[] = {s->coef_h, s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
+  void *ptrs[] = {s->dsend[0], s->dsend[1], s->dsend[2], s->dsend[3], s->drecv[0], s->drecv[1], s->drecv[2], s->drecv[3],
+                  s->coef_h, s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
@@ -279,22 +280,26 @@ extern "C" int tsx_set_stream(tsx_solver *s, void *hip_stream) {
 // sendW, recvS <- south's sendN, recvN <- north's sendS.  Point-to-point messages to one peer are
 // matched in issue order, so receives are posted E,W,N,S against sends W,E,S,N (matters when both
 // x-neighbours are the same rank, e.g. 2 ranks along a periodic axis).
-// st: the stream the transfers are issued on (the solver stream, or comm_stream when overlapping; the caller has made
-// st wait for the pack kernel)
-int tsx_face_exchange(tsx_solver *s, hipStream_t st) {
+// Exchange of four face buffers with the W, E, S, N neighbours (what I send W-ward lands in my west neighbour's
+// east buffer ...).  st: the stream the transfers are issued on (the solver stream, or comm_stream when overlapping;
+// the caller has made st wait for the pack kernel).  send/recv: device buffers in the order W, E, S, N; cx / cy:
+// doubles per x / y face message.  Used for the diffuse halo (tsx_face_exchange) and the direct beam's.
+int tsx_face_exchange_bufs(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy) {
   const TsxGeo &g = s->geo;
-  const size_t bx = s->halo_x_elems, by = s->halo_y_elems;
+  const size_t bx = cx, by = cy;
   if (s->xchg_cb) {
     const tsx_grid &gr = s->grid;
-    double *dsend[4] = {s->sendW, s->sendE, s->sendS, s->sendN};
-    double *drecv[4] = {s->recvW, s->recvE, s->recvS, s->recvN};
     const size_t count[4] = {g.wrap_x ? 0 : bx, g.wrap_x ? 0 : bx, g.wrap_y ? 0 : by, g.wrap_y ? 0 : by};
     const int peer[4] = {gr.neigh_w, gr.neigh_e, gr.neigh_s, gr.neigh_n};
     for (int q = 0; q < 4; ++q) {
-      const size_t cap = (q < 2 ? bx : by) * sizeof(double);
+      const size_t cap = (q < 2 ? s->halo_x_elems : s->halo_y_elems) * sizeof(double);
+      if (count[q] * sizeof(double) > cap) {
+        tsx_set_error("face_exchange: message larger than the staging buffers");
+        return TSX_ERR_ARG;
+      }
       if (!s->host_send[q]) HIPCHK(hipHostMalloc((void **)&s->host_send[q], cap, hipHostMallocDefault));
       if (!s->host_recv[q]) HIPCHK(hipHostMalloc((void **)&s->host_recv[q], cap, hipHostMallocDefault));
-      if (count[q]) HIPCHK(hipMemcpyAsync(s->host_send[q], dsend[q], count[q] * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (count[q]) HIPCHK(hipMemcpyAsync(s->host_send[q], send[q], count[q] * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipStreamSynchronize(st));
     if (s->xchg_cb(s->cb_ctx, (const double *const *)s->host_send, (double *const *)s->host_recv, count, peer)) {
@@ -302,7 +307,7 @@ int tsx_face_exchange(tsx_solver *s, hipStream_t st) {
       return TSX_ERR_COMM;
     }
     for (int q = 0; q < 4; ++q)
-      if (count[q]) HIPCHK(hipMemcpyAsync(drecv[q], s->host_recv[q], count[q] * sizeof(double), hipMemcpyHostToDevice, st));
+      if (count[q]) HIPCHK(hipMemcpyAsync(recv[q], s->host_recv[q], count[q] * sizeof(double), hipMemcpyHostToDevice, st));
     return TSX_OK;
   }
   if (s->comm_ready) {
@@ -310,16 +315,16 @@ int tsx_face_exchange(tsx_solver *s, hipStream_t st) {
     const tsx_grid &gr = s->grid;
     NCCLCHK(g_rccl.GroupStart());
     if (!g.wrap_x) {
-      NCCLCHK(g_rccl.Send(s->sendW, bx, TSX_NCCL_FLOAT64, gr.neigh_w, c, st));
-      NCCLCHK(g_rccl.Send(s->sendE, bx, TSX_NCCL_FLOAT64, gr.neigh_e, c, st));
-      NCCLCHK(g_rccl.Recv(s->recvE, bx, TSX_NCCL_FLOAT64, gr.neigh_e, c, st));
-      NCCLCHK(g_rccl.Recv(s->recvW, bx, TSX_NCCL_FLOAT64, gr.neigh_w, c, st));
+      NCCLCHK(g_rccl.Send(send[0], bx, TSX_NCCL_FLOAT64, gr.neigh_w, c, st));
+      NCCLCHK(g_rccl.Send(send[1], bx, TSX_NCCL_FLOAT64, gr.neigh_e, c, st));
+      NCCLCHK(g_rccl.Recv(recv[1], bx, TSX_NCCL_FLOAT64, gr.neigh_e, c, st));
+      NCCLCHK(g_rccl.Recv(recv[0], bx, TSX_NCCL_FLOAT64, gr.neigh_w, c, st));
     }
     if (!g.wrap_y) {
-      NCCLCHK(g_rccl.Send(s->sendS, by, TSX_NCCL_FLOAT64, gr.neigh_s, c, st));
-      NCCLCHK(g_rccl.Send(s->sendN, by, TSX_NCCL_FLOAT64, gr.neigh_n, c, st));
-      NCCLCHK(g_rccl.Recv(s->recvN, by, TSX_NCCL_FLOAT64, gr.neigh_n, c, st));
-      NCCLCHK(g_rccl.Recv(s->recvS, by, TSX_NCCL_FLOAT64, gr.neigh_s, c, st));
+      NCCLCHK(g_rccl.Send(send[2], by, TSX_NCCL_FLOAT64, gr.neigh_s, c, st));
+      NCCLCHK(g_rccl.Send(send[3], by, TSX_NCCL_FLOAT64, gr.neigh_n, c, st));
+      NCCLCHK(g_rccl.Recv(recv[3], by, TSX_NCCL_FLOAT64, gr.neigh_n, c, st));
+      NCCLCHK(g_rccl.Recv(recv[2], by, TSX_NCCL_FLOAT64, gr.neigh_s, c, st));
     }
     NCCLCHK(g_rccl.GroupEnd());
     return TSX_OK;
@@ -330,14 +335,21 @@ int tsx_face_exchange(tsx_solver *s, hipStream_t st) {
   }
   // single rank with force_halo: every neighbour is this rank
   if (!g.wrap_x) {
-    HIPCHK(hipMemcpyAsync(s->recvE, s->sendW, bx * sizeof(double), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(s->recvW, s->sendE, bx * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(recv[1], send[0], bx * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(recv[0], send[1], bx * sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   if (!g.wrap_y) {
-    HIPCHK(hipMemcpyAsync(s->recvN, s->sendS, by * sizeof(double), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(s->recvS, s->sendN, by * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(recv[3], send[2], by * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(recv[2], send[3], by * sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   return TSX_OK;
+}
+
+// the diffuse halo: entering side streams (exchange_diffuse_boundary's traffic)
+int tsx_face_exchange(tsx_solver *s, hipStream_t st) {
+  double *const send[4] = {s->sendW, s->sendE, s->sendS, s->sendN};
+  double *const recv[4] = {s->recvW, s->recvE, s->recvS, s->recvN};
+  return tsx_face_exchange_bufs(s, st, send, recv, s->halo_x_elems, s->halo_y_elems);
 }
 
 // reduce partials -> (all-reduce) -> scalar algebra

@@ -67,6 +67,7 @@ static inline int spmv_nblocks(const tsx_solver *s) {
 // ---- cross-unit entry points --------------------------------------------------------------------
 // face exchange on stream st (RCCL / host-staged callbacks / self copies), tsx_api.hip
 int tsx_face_exchange(tsx_solver *s, hipStream_t st);
+int tsx_face_exchange_bufs(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy);
 
 // operator apply: one translation unit per stream configuration (tsx_spmv_3_10.hip, tsx_spmv_8_16.hip).
 // combo = (fused dots, type of x, type of w): the variants the Krylov loop uses

@@ -107,6 +107,7 @@ struct tsx_solver {
   double *a13, *a23, *a33;       // cell-indexed, 1-D layers only
   double *planck;                // (L, xm, ym) reference layout
   double *edir_a, *edir_b;       // direct streams, current / scratch
+  double *dsend[4], *drecv[4];   // direct-beam face buffers W, E, S, N (several ranks)
   void *dsc, *dsc_host;          // TsxDirScalars device / pinned
   double *abso;                  // (Nz, xm, ym) reference layout
   int last_lsolar;

@@ -76,6 +76,12 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_dir(TsxGeo g, TsxLutDev L
   }
 }
 
+// face buffers of the direct beam on several ranks (W, E, S, N); all null on one periodic rank
+struct TsxDirHalo {
+  double *sendW, *sendE, *sendS, *sendN;
+  const double *recvW, *recvE, *recvS, *recvN;
+};
+
 // ---- K6: one sweep of the direct beam (explicit_edir_forward_sweep, src/pprts_explicit.F90:330-459): the thread of a
 //      column marches down in k (fresh top stream), side streams of the neighbouring columns come from the previous
 //      sweep.  Same fixed point as the reference's lexicographic sweep; iterated until ||x_new - x_old|| converges
@@ -84,9 +90,15 @@ template <int DTOP, int DSIDE>
 __global__ __launch_bounds__(64) void tsx_k_edir_sweep(TsxGeo g, TsxSun sun, const float *__restrict__ T,
                                                        const uint8_t *__restrict__ l1d, const double *__restrict__ a33,
                                                        double inc_solar, const double *__restrict__ xo, double *__restrict__ xn,
-                                                       double *__restrict__ partials, const int *__restrict__ done) {
+                                                       double *__restrict__ partials, const int *__restrict__ done,
+                                                       TsxDirHalo hb) {
+  // Several ranks (g.wrap_x / g.wrap_y false): the one x (y) face per row that is off-rank is either my downwind output
+  // (sun moving +x: cell xm-1 writes it -> send buffer, the east rank stores it as its face 0 in tsx_k_edir_unpack) or my
+  // upwind source (sun moving -x: cell xm-1 reads face xm = the east rank's face 0 -> received buffer), i.e. exactly
+  // exchange_direct_boundary (src/pprts_explicit.F90:1076-1140).  Buffers: [q][k][j] resp. [q][k][i].
   constexpr int S = DTOP + 2 * DSIDE;
   if (done && *done) return;
+  const bool offx = g.wrap_x == 0, offy = g.wrap_y == 0;
   const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
   const long long Nc = g.Nc, Ncl = (long long)(Nz + 1) * ncol;
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -125,8 +137,11 @@ __global__ __launch_bounds__(64) void tsx_k_edir_sweep(TsxGeo g, TsxSun sun, con
         for (int q = 0; q < DTOP; ++q) src[q] = top[q];
 #pragma unroll
         for (int q = 0; q < DSIDE; ++q) {
-          src[DTOP + q] = xo[(size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + iu];
-          src[DTOP + DSIDE + q] = xo[(size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)ju * xm + i];
+          src[DTOP + q] = (offx && !sun.xinc && i + 1 == xm) ? hb.recvE[((size_t)q * Nz + k) * ym + j]
+                                                             : xo[(size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + iu];
+          src[DTOP + DSIDE + q] = (offy && !sun.yinc && j + 1 == ym)
+                                      ? hb.recvN[((size_t)q * Nz + k) * xm + i]
+                                      : xo[(size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)ju * xm + i];
         }
         double out[S];
 #pragma unroll
@@ -142,10 +157,22 @@ __global__ __launch_bounds__(64) void tsx_k_edir_sweep(TsxGeo g, TsxSun sun, con
         for (int q = 0; q < DSIDE; ++q) {
           const size_t ox = (size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + id;
           const size_t oy = (size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)jd * xm + i;
-          const double dx_ = out[DTOP + q] - xo[ox], dy_ = out[DTOP + DSIDE + q] - xo[oy];
-          xn[ox] = out[DTOP + q];
-          xn[oy] = out[DTOP + DSIDE + q];
-          sum[0] += dx_ * dx_ + dy_ * dy_;
+          if (offx && sun.xinc && i + 1 == xm) {
+            hb.sendE[((size_t)q * Nz + k) * ym + j] = out[DTOP + q];  // lands on the east rank's face 0
+          } else {
+            const double dx_ = out[DTOP + q] - xo[ox];
+            xn[ox] = out[DTOP + q];
+            sum[0] += dx_ * dx_;
+            if (offx && !sun.xinc && i == 0) hb.sendW[((size_t)q * Nz + k) * ym + j] = out[DTOP + q];  // the west rank's face xm
+          }
+          if (offy && sun.yinc && j + 1 == ym) {
+            hb.sendN[((size_t)q * Nz + k) * xm + i] = out[DTOP + DSIDE + q];
+          } else {
+            const double dy_ = out[DTOP + DSIDE + q] - xo[oy];
+            xn[oy] = out[DTOP + DSIDE + q];
+            sum[0] += dy_ * dy_;
+            if (offy && !sun.yinc && j == 0) hb.sendS[((size_t)q * Nz + k) * xm + i] = out[DTOP + DSIDE + q];
+          }
         }
       }
 #pragma unroll
@@ -168,29 +195,76 @@ __global__ __launch_bounds__(64) void tsx_k_edir_sweep(TsxGeo g, TsxSun sun, con
   if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }
 
-// scalar stage of the direct iteration: residual(iter) = max(tiny, sqrt(sum)); stop rule src/pprts_explicit.F90:175-208
+// After the exchange: the faces received from the upwind rank become my face 0 (sun moving +x: recvW -> faces i = 0;
+// +y: recvS -> faces j = 0); their change enters my residual like any owned entry (the reference's norm runs over
+// owned entries after exchange_direct_boundary).  1-D layers carry no side streams.
+template <int DTOP, int DSIDE>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_edir_unpack(TsxGeo g, TsxSun sun, const uint8_t *__restrict__ l1d,
+                                                               const double *__restrict__ xo, double *__restrict__ xn,
+                                                               TsxDirHalo hb, double *__restrict__ partial,
+                                                               const int *__restrict__ done) {
+  if (done && *done) return;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
+  const long long Ncl = (long long)(Nz + 1) * ncol;
+  const bool ux = g.wrap_x == 0 && sun.xinc, uy = g.wrap_y == 0 && sun.yinc;
+  const long long nx = ux ? (long long)DSIDE * Nz * ym : 0, ny = uy ? (long long)DSIDE * Nz * xm : 0;
+  double sum[1] = {0.0};
+  for (long long t = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; t < nx + ny; t += (long long)gridDim.x * TSX_BLOCK) {
+    size_t o;
+    double v;
+    int k;
+    if (t < nx) {
+      const int j = (int)(t % ym);
+      k = (int)((t / ym) % Nz);
+      const int q = (int)(t / ((long long)ym * Nz));
+      o = (size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm;
+      v = hb.recvW[t];
+    } else {
+      const long long u = t - nx;
+      const int i = (int)(u % xm);
+      k = (int)((u / xm) % Nz);
+      const int q = (int)(u / ((long long)xm * Nz));
+      o = (size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + i;
+      v = hb.recvS[u];
+    }
+    if (l1d[k]) continue;
+    const double d = v - xo[o];
+    xn[o] = v;
+    sum[0] += d * d;
+  }
+  tsx_block_reduce_store<1>(sum, partial);
+}
+
+// scalar stage of the direct iteration: residual(iter) = max(tiny, sqrt(sum)); stop rule src/pprts_explicit.F90:175-208.
+// mode 1: local residual (norm2 over what this rank owns) -> sc->res; mode 2: stop rule on sc->res (after the mean over
+// ranks, imp_allreduce_mean :184); mode 3: both (one rank)
 struct TsxDirScalars {
   double res1, res, rtol, atol;
   int iter, maxit, done, converged;
 };
 __global__ __launch_bounds__(1024) void tsx_k_edir_scalar(TsxDirScalars *__restrict__ sc, const double *__restrict__ partials,
-                                                          int nblocks) {
+                                                          int nblocks, int mode, double scale) {
   __shared__ double sm[16];
   if (sc->done) return;
-  double v = 0.0;
-  for (int q = threadIdx.x; q < nblocks; q += 1024) v += partials[q];
-  v = tsx_wave_sum(v);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  double t = 0.0;
-  for (int q = 0; q < 16; ++q) t += sm[q];
   const double tiny = 2.2250738585072014e-308;
-  double res = sqrt(t);
-  res = res > tiny ? res : tiny;
+  if (mode & 1) {
+    double v = 0.0;
+    for (int q = threadIdx.x; q < nblocks; q += 1024) v += partials[q];
+    v = tsx_wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int q = 0; q < 16; ++q) t += sm[q];
+      const double res = sqrt(t);
+      sc->res = res > tiny ? res : tiny;
+    }
+  }
+  if (!(mode & 2) || threadIdx.x != 0) return;
+  const double res = sc->res * scale;  // scale = 1/nranks after the sum over ranks
+  sc->res = res;
   sc->iter += 1;
   if (sc->iter == 1) sc->res1 = res;
-  sc->res = res;
   const double rel = sc->res1 <= 1.4916681462400413e-154 ? 0.0 : res / sc->res1;
   if (res < sc->atol || rel < sc->rtol) {
     sc->converged = 1;
@@ -206,8 +280,10 @@ template <int NTOP, int NSIDE, int DTOP, int DSIDE>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_setup_b_solar(TsxGeo g, TsxSun sun, const float *__restrict__ Sd,
                                                                  const uint8_t *__restrict__ l1d, const double *__restrict__ a13,
                                                                  const double *__restrict__ a23, const double *__restrict__ albedo,
-                                                                 const double *__restrict__ E, double *__restrict__ b) {
+                                                                 const double *__restrict__ E, double *__restrict__ b,
+                                                                 TsxDirHalo hb) {
   constexpr int D = NTOP + 2 * NSIDE, S = DTOP + 2 * DSIDE;
+  const bool gx = g.wrap_x == 0 && !sun.xinc, gy = g.wrap_y == 0 && !sun.yinc;  // upwind face of the last cell is off-rank
   const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
   const long long Nc = g.Nc, Ncl = (long long)(Nz + 1) * ncol;
   const double streams = (double)(NTOP / 2);
@@ -231,8 +307,10 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_setup_b_solar(TsxGeo g, TsxSu
     for (int q = 0; q < DTOP; ++q) src[q] = own[q];
 #pragma unroll
     for (int q = 0; q < DSIDE; ++q) {
-      src[DTOP + q] = E[(size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + iu];
-      src[DTOP + DSIDE + q] = E[(size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)ju * xm + i];
+      src[DTOP + q] = (gx && i + 1 == xm) ? hb.recvE[((size_t)q * Nz + k) * ym + j]
+                                          : E[(size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + iu];
+      src[DTOP + DSIDE + q] = (gy && j + 1 == ym) ? hb.recvN[((size_t)q * Nz + k) * xm + i]
+                                                  : E[(size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)ju * xm + i];
     }
     double out[D];
 #pragma unroll
@@ -357,8 +435,13 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_flx_div(TsxGeo g, TsxSun sun,
                                                            const double *__restrict__ kabs, const double *__restrict__ dz,
                                                            double dx, double dy, const double *__restrict__ E,
                                                            const double *__restrict__ x, const double *__restrict__ bsrc,
-                                                           double *__restrict__ abso) {
+                                                           double *__restrict__ abso, TsxDirHalo hb,
+                                                           const double *__restrict__ hW, const double *__restrict__ hE,
+                                                           const double *__restrict__ hS, const double *__restrict__ hN) {
+  // hb: direct-beam faces from the upwind ranks; hW..hN: the diffuse halo of x (entering side streams, as the operator
+  // reads them: [slot][k][j] / [slot][k][i]); only dereferenced where the rank does not wrap onto itself
   constexpr int D = NTOP + 2 * NSIDE, S = DTOP + 2 * DSIDE;
+  const bool offx = g.wrap_x == 0, offy = g.wrap_y == 0;
   const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
   const long long Nc = g.Nc, Ncl = (long long)(Nz + 1) * ncol;
   const double *__restrict__ xt = x + (size_t)D * Nc;
@@ -384,8 +467,11 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_flx_div(TsxGeo g, TsxSun sun,
         for (int q = 0; q < DTOP; ++q) src[q] = E[(size_t)q * Ncl + (size_t)k * ncol + col];
 #pragma unroll
         for (int q = 0; q < DSIDE; ++q) {
-          src[DTOP + q] = E[(size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + iu];
-          src[DTOP + DSIDE + q] = E[(size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)ju * xm + i];
+          src[DTOP + q] = (offx && !sun.xinc && i + 1 == xm) ? hb.recvE[((size_t)q * Nz + k) * ym + j]
+                                                             : E[(size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + iu];
+          src[DTOP + DSIDE + q] = (offy && !sun.yinc && j + 1 == ym)
+                                      ? hb.recvN[((size_t)q * Nz + k) * xm + i]
+                                      : E[(size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)ju * xm + i];
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -408,15 +494,19 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_flx_div(TsxGeo g, TsxSun sun,
     if (!is1d) {
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) {
-        const int d = NTOP + q;
-        if (tsx_inward(q)) xs[d] = x[(size_t)d * Nc + c + (i > 0 ? -1 : xm - 1)];
-        else xs[d] = x[(size_t)d * Nc + c + (i < xm - 1 ? 1 : -(xm - 1))];
+        const int d = NTOP + q, slot = q >> 1;
+        if (tsx_inward(q)) xs[d] = (offx && i == 0) ? hW[((size_t)slot * Nz + k) * ym + j] : x[(size_t)d * Nc + c + (i > 0 ? -1 : xm - 1)];
+        else xs[d] = (offx && i == xm - 1) ? hE[((size_t)slot * Nz + k) * ym + j] : x[(size_t)d * Nc + c + (i < xm - 1 ? 1 : -(xm - 1))];
       }
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) {
-        const int d = NTOP + NSIDE + q;
-        if (tsx_inward(q)) xs[d] = x[(size_t)d * Nc + c + (j > 0 ? -(long long)xm : (long long)(ym - 1) * xm)];
-        else xs[d] = x[(size_t)d * Nc + c + (j < ym - 1 ? (long long)xm : -(long long)(ym - 1) * xm)];
+        const int d = NTOP + NSIDE + q, slot = q >> 1;
+        if (tsx_inward(q))
+          xs[d] = (offy && j == 0) ? hS[((size_t)slot * Nz + k) * xm + i]
+                                   : x[(size_t)d * Nc + c + (j > 0 ? -(long long)xm : (long long)(ym - 1) * xm)];
+        else
+          xs[d] = (offy && j == ym - 1) ? hN[((size_t)slot * Nz + k) * xm + i]
+                                        : x[(size_t)d * Nc + c + (j < ym - 1 ? (long long)xm : -(long long)(ym - 1) * xm)];
       }
 #pragma unroll
       for (int s = 0; s < D; ++s) {

@@ -58,9 +58,12 @@ def eddington_coeff_ec(dtau, w0, g, mu0):
 class PprtsSolver:
     """One pprts solver (3_10) on one GPU, driven like the reference's Fortran/C API."""
 
-    def __init__(self, Nz, Nx, Ny, dx, dy, phi0, theta0, solver="3_10", device=-1):
+    def __init__(self, Nz, Nx, Ny, dx, dy, phi0, theta0, solver="3_10", device=-1, **decomposition):
+        """Nx, Ny: the columns this rank owns; decomposition: xs, ys, glob_xm, glob_ym, rank, nranks, neighbors (W, E, S, N)
+        as DiffuseSolver takes them (several ranks: call core.comm_init / core.comm_set_callbacks before the first
+        set_optical_properties), force_halo for tests."""
         self.Nz, self.Nx, self.Ny, self.dx, self.dy = int(Nz), int(Nx), int(Ny), float(dx), float(dy)
-        self.core = DiffuseSolver(solver, Nz, Nx, Ny, device=device)
+        self.core = DiffuseSolver(solver, Nz, Nx, Ny, device=device, **decomposition)
         self.lib = self.core.lib
         self.h = self.core.h
         self.phi0, self.theta0 = float(phi0), float(theta0)

@@ -114,3 +114,122 @@ def test_sharded_hip_solve_equals_global_oracle(gpu, world, solver, Nx, Ny):
         for e_apply, e_solve, reason, niter, r0, bn in ret.values():
             assert e_apply < 1e-13 and reason == 2 and e_solve < 1e-8
             assert abs(r0 - bn) <= 1e-12 * bn  # the initial residual is the *global* norm of b
+
+
+# ---- the whole g-point pipeline on several ranks ------------------------------------------------------------------
+def _pipeline_worker(rank, world, port, Nx, Ny, Nz, phi0, theta0, tall_top, ret):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from tenstream_amd import coord, lut, synthetic
+    from tenstream_amd.pprts import PprtsSolver
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=5)
+        kabs *= 20.0
+        dz = np.full((Ny, Nx, Nz), 50.0)
+        if tall_top:
+            dz[:, :, :tall_top] = 400.0
+        planck = np.linspace(2.0, 6.0, Nz + 1)[None, None, :] * (1 + 0.05 * np.random.default_rng(0).random((Ny, Nx, 1)))
+        dax = lut.direct_axes()
+        Tdir, Sdir = lut.synthetic_direct_tables(dax)
+
+        def make(nx, ny, **kw):
+            P = PprtsSolver(Nz, nx, ny, 100.0, 100.0, phi0, theta0, device=0, **kw)
+            P.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
+            P.set_lut_direct(Tdir, Sdir, dax)
+            return P
+
+        co = coord.coord(rank, world, Nx, Ny)
+        sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
+        P = make(co.xm, co.ym, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank, nranks=world,
+                 neighbors=(co.west, co.east, co.south, co.north))
+
+        def exchange(send, recv, peers):
+            want_tag = [1, 0, 3, 2]
+            reqs, keep = [], []
+            for q in range(4):
+                if len(recv[q]) == 0 or peers[q] == rank:
+                    continue
+                t = torch.from_numpy(recv[q])
+                keep.append(t)
+                reqs.append(dist.irecv(t, src=peers[q], tag=want_tag[q]))
+            for q in range(4):
+                if len(send[q]) == 0 or peers[q] == rank:
+                    continue
+                t = torch.from_numpy(np.array(send[q], copy=True))
+                keep.append(t)
+                reqs.append(dist.isend(t, dst=peers[q], tag=q))
+            for q in range(4):
+                if len(recv[q]) and peers[q] == rank:
+                    recv[q][...] = send[q ^ 1]
+            for r in reqs:
+                r.wait()
+
+        def allreduce(buf):
+            dist.all_reduce(torch.from_numpy(buf))
+
+        P.core.comm_set_callbacks(exchange, allreduce)
+        loc = lambda a: np.ascontiguousarray(a[sl])
+        out = {}
+        for kind in ("solar", "thermal"):
+            lsolar = kind == "solar"
+            P.set_optical_properties(0.15, loc(kabs), loc(ksca), loc(g), loc(dz), planck=None if lsolar else loc(planck))
+            info = P.solve(1000.0 if lsolar else 0.0, rtol=1e-10, atol=1e-30, maxit=3000)
+            out[kind] = (info.reason, info.niter) + tuple(P.get_result())
+        # the same problem on one periodic rank (rank 0 only; same process, same GPU)
+        errs = {}
+        if rank == 0:
+            G = make(Nx, Ny)
+        ref = {}
+        for kind in ("solar", "thermal"):
+            lsolar = kind == "solar"
+            if rank == 0:
+                G.set_optical_properties(0.15, kabs, ksca, g, dz, planck=None if lsolar else planck)
+                gi = G.solve(1000.0 if lsolar else 0.0, rtol=1e-10, atol=1e-30, maxit=3000)
+                ref[kind] = [np.ascontiguousarray(a) for a in G.get_result()]
+            objs = [ref.get(kind)]
+            dist.broadcast_object_list(objs, src=0)
+            full = objs[0]
+            e = []
+            for got, want in zip(out[kind][2:], full):
+                scale = max(np.abs(want).max(), 1e-30)
+                e.append(float(np.abs(got - want[sl]).max() / scale))
+            errs[kind] = (out[kind][0], out[kind][1], e)
+        ret[rank] = errs
+        P.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,Nx,Ny,phi0,theta0,tall_top", [(2, 10, 12, 200.0, 40.0, 0), (4, 12, 10, 30.0, 55.0, 1),
+                                                               (4, 10, 12, 300.0, 20.0, 0)])
+def test_sharded_pipeline_equals_one_rank_pipeline(gpu, world, Nx, Ny, phi0, theta0, tall_top):
+    """set_optical_properties -> direct sweep (face exchange per sweep) -> setup_b -> solve -> flux divergence on 2/4
+    ranks against the same g-point on one periodic rank."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        ret = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, Nx, Ny, 8, phi0, theta0, tall_top, ret))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+        for p in procs:
+            assert p.exitcode == 0
+        assert len(ret) == world
+        for errs in ret.values():
+            reason, _, e = errs["solar"]
+            assert reason == 2
+            # edn, eup, abso, edir: the direct sweep stops at rtol 1e-5 on both decompositions (different iterates)
+            assert max(e) < 3e-4, e
+            reason, _, e = errs["thermal"]
+            assert reason == 2 and max(e) < 1e-7, e

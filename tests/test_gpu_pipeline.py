@@ -13,14 +13,14 @@ from tenstream_amd.pprts import PprtsSolver, eddington_coeff_ec
 
 
 
-def _setup(Nx, Ny, Nz, phi0, theta0, tall_top=0, seed=5):
+def _setup(Nx, Ny, Nz, phi0, theta0, tall_top=0, seed=5, **kw):
     dx = dy = 100.0
     kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=seed)
     kabs *= 20.0  # some real absorption so that abso is not tiny
     dz = np.full((Ny, Nx, Nz), 50.0)
     if tall_top:
         dz[:, :, :tall_top] = 400.0  # dz/dx > twostr_ratio -> 1-D layers at the top (src/pprts.F90:669-677)
-    P = PprtsSolver(Nz, Nx, Ny, dx, dy, phi0, theta0)
+    P = PprtsSolver(Nz, Nx, Ny, dx, dy, phi0, theta0, **kw)
     P.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
     dax = lut.direct_axes()
     Tdir, Sdir = lut.synthetic_direct_tables(dax)
@@ -61,10 +61,11 @@ def _oracle_pipeline(P, I, albedo, edirTOA, lsolar, planck=None, rtol=1e-10):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("force_halo", [False, True])  # True: rank faces go through the exchange buffers (self neighbours)
 @pytest.mark.parametrize("phi0,theta0,tall_top", [(180.0, 40.0, 0), (10.0, 60.0, 2), (250.0, 20.0, 0), (300.0, 0.0, 1)])
-def test_solar_pipeline_matches_oracle(gpu, phi0, theta0, tall_top):
+def test_solar_pipeline_matches_oracle(gpu, phi0, theta0, tall_top, force_halo):
     Nx, Ny, Nz = 10, 8, 12
-    P, I = _setup(Nx, Ny, Nz, phi0, theta0, tall_top)
+    P, I = _setup(Nx, Ny, Nz, phi0, theta0, tall_top, force_halo=force_halo)
     P.set_optical_properties(0.15, I["kabs"], I["ksca"], I["g"], I["dz"])
     assert P.l1d.sum() == tall_top
     info = P.solve(1000.0, rtol=1e-10, atol=1e-30, maxit=3000)
