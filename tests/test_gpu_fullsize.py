@@ -1,0 +1,119 @@
+"""Size-independent properties at BASELINE.json's full sizes (the oracle is too slow there): linearity of the operator,
+a checksum of checksums against column sums computed on the host, true residual and linearity of the solve, and the
+energy balance of a whole solar g-point.  Configs: (2) 128x128x64 and the metric domain 256x256x64 for 3_10, (5) 8_16
+on 256x256x64."""
+import numpy as np
+import pytest
+
+from tenstream_amd import DiffuseSolver, lut, synthetic
+
+pytestmark = pytest.mark.gpu
+DX, DZ, ALB = 100.0, 50.0, 0.1
+
+
+def _solver(solver, Nx, Ny, Nz):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=20240611)
+    kabs, ksca, g = synthetic.delta_scale(kabs, ksca, g)
+    s = DiffuseSolver(solver, Nz, Nx, Ny)
+    s.set_lut_diffuse(lut.synthetic_diffuse_table(solver), lut.diffuse_axes(solver))
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    z = torch.zeros((Ny, Nx, Nz), dtype=torch.float64, device=dev)
+    s.set_optprop(t(kabs), t(ksca), t(g), torch.full((Ny, Nx, Nz), DZ, dtype=torch.float64, device=dev), DX,
+                  torch.zeros(Nz, dtype=torch.uint8, device=dev), z, z, torch.full((Ny, Nx), ALB, dtype=torch.float64, device=dev))
+    b = torch.tensor(synthetic.solar_source(solver, kabs, ksca, g, DZ, DX, np.full((Ny, Nx), ALB)), device=dev)
+    return s, b, dev
+
+
+@pytest.mark.parametrize("solver,Nx,Ny,Nz", [("3_10", 128, 128, 64), ("3_10", 256, 256, 64), ("8_16", 256, 256, 64)])
+def test_operator_linearity_and_solve_residual_full_size(gpu, solver, Nx, Ny, Nz):
+    import torch
+
+    s, b, dev = _solver(solver, Nx, Ny, Nz)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(b.shape, dtype=torch.float64, device=dev, generator=gen)
+    y = torch.randn(b.shape, dtype=torch.float64, device=dev, generator=gen)
+    Ax, Ay = s.apply(x), s.apply(y)
+    lin = s.apply(0.75 * x - 2.5 * y) - (0.75 * Ax - 2.5 * Ay)
+    assert float(lin.abs().max()) <= 1e-13 * float(Ax.abs().max())
+    # the returned solution satisfies the stop rule on the *true* residual, computed with an independent apply
+    sol = torch.zeros_like(b)
+    info = s.solve(b, sol)  # reference default tolerances
+    assert info.reason in (2, 3)
+    r = b - s.apply(sol)
+    rn, bn = float(torch.linalg.vector_norm(r)), float(torch.linalg.vector_norm(b))
+    assert abs(info.rnorm0 - bn) <= 1e-12 * bn
+    assert abs(rn - info.rnorm) <= 1e-6 * bn  # recurrence residual == true residual
+    rt, at, _ = s.default_tolerances()
+    assert rn / bn <= rt or rn <= at
+    # solution map is linear: tight solves of b and -3b
+    x1, x2 = torch.zeros_like(b), torch.zeros_like(b)
+    i1 = s.solve(b, x1, rtol=1e-9, atol=1e-30)
+    i2 = s.solve(-3.0 * b, x2, rtol=1e-9, atol=1e-30)
+    assert i1.reason == 2 and i2.reason == 2
+    assert float((x2 + 3.0 * x1).abs().max()) <= 1e-6 * float(x1.abs().max())
+    assert float(x1.min()) > -1e-9 * float(x1.max())  # fluxes are non-negative
+    s.close()
+
+
+@pytest.mark.parametrize("Nx,Ny,Nz", [(256, 256, 64)])
+def test_operator_checksum_against_host_column_sums(gpu, Nx, Ny, Nz):
+    """1^T (A x) = sum_u x_u (1 - sum_dst c(u -> dst)): every unknown enters exactly one cell, whose block column sums
+    are computed on the host from the exported blocks (the albedo row adds albedo * Edn at the surface)."""
+    import torch
+
+    s, b, dev = _solver("3_10", Nx, Ny, Nz)
+    D = 10
+    coeff = s.get_coeffs()  # (Ny, Nx, Nz, D*D), index dst*D + src, float64
+    colsum = coeff.reshape(Ny, Nx, Nz, D, D).sum(axis=3)  # sum over dst for each src: (Ny, Nx, Nz, src)
+    del coeff
+    x = torch.rand(b.shape, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    total = float(s.apply(x).sum())
+    xh = x.cpu().numpy()
+    # unknown (j, i, level/layer k, dof) is the src of: Eup (dof 0) at level k+1 -> cell k; Edn (dof 1) at level k -> cell k;
+    # side dofs: -x (2,4) at face i+1, +x (3,5) at face i, -y (6,8) at face j+1, +y (7,9) at face j -> cell (k, i, j)
+    want = xh.sum()
+    want -= (xh[:, :, 1:, 0] * colsum[:, :, :, 0]).sum() + (xh[:, :, :-1, 1] * colsum[:, :, :, 1]).sum()
+    for d in (2, 4):
+        want -= (np.roll(xh[:, :, :-1, d], -1, axis=1) * colsum[:, :, :, d]).sum()
+    for d in (3, 5):
+        want -= (xh[:, :, :-1, d] * colsum[:, :, :, d]).sum()
+    for d in (6, 8):
+        want -= (np.roll(xh[:, :, :-1, d], -1, axis=0) * colsum[:, :, :, d]).sum()
+    for d in (7, 9):
+        want -= (xh[:, :, :-1, d] * colsum[:, :, :, d]).sum()
+    want -= ALB * xh[:, :, -1, 1].sum()  # surface row: Eup(Nz) - albedo * Edn(Nz)
+    assert abs(total - want) <= 1e-11 * abs(want)
+    s.close()
+
+
+def test_solar_gpoint_energy_balance_full_size(gpu):
+    """Whole pipeline on the metric domain: what enters at TOA leaves at TOA, is absorbed by the surface or by the
+    atmosphere (flux divergence), to the accuracy the solves are stopped at."""
+    from tenstream_amd.pprts import PprtsSolver
+
+    Nx = Ny = 256
+    Nz = 64
+    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=20240611)
+    kabs = kabs * 50.0  # make the atmosphere absorb a visible share
+    P = PprtsSolver(Nz, Nx, Ny, DX, DX, 180.0, 40.0)
+    P.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
+    dax = lut.direct_axes()
+    P.set_lut_direct(*lut.synthetic_direct_tables(dax), dax)
+    P.set_optical_properties(ALB, kabs, ksca, g, np.full((Ny, Nx, Nz), DZ))
+    info = P.solve(1000.0, rtol=1e-8, atol=1e-30)
+    assert info.reason == 2
+    edn, eup, abso, edir = P.get_result()
+    mu0 = np.cos(np.deg2rad(40.0))
+    incoming = 1000.0 * mu0 * Nx * Ny
+    assert np.allclose(edir[:, :, 0], 1000.0 * mu0, rtol=1e-12) and np.abs(edn[:, :, 0]).max() < 1e-9
+    out_toa = eup[:, :, 0].sum()
+    srf = ((edn[:, :, -1] + edir[:, :, -1]) * (1.0 - ALB)).sum()
+    atm = (abso * DZ).sum()
+    assert abso.min() > -1e-6 * abso.max()
+    # the surrogate LUTs conserve energy by construction (rows sum to exp(-tau_abs)); direct sweep stops at rtol 1e-5
+    assert abs(out_toa + srf + atm - incoming) <= 2e-4 * incoming
+    assert atm > 0.01 * incoming and out_toa > 0.01 * incoming
+    P.close()
