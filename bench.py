@@ -22,8 +22,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# the CPU baseline's OpenMP threads: one per physical core, pinned, spread over the sockets (read when libgomp loads)
-os.environ.setdefault("OMP_PROC_BIND", "spread")
+try:  # taken before any OpenMP runtime gets a chance to bind this thread to a single place
+    _AFFINITY = len(os.sched_getaffinity(0))
+except AttributeError:
+    _AFFINITY = os.cpu_count() or 1
 
 import numpy as np  # noqa: E402
 
@@ -74,15 +76,18 @@ def main():
     dx, dz, albedo = 100.0, 50.0, 0.1
     solver = args.solver
 
-    # ---- synthetic optical properties for the owned block (same seed on all ranks -> one global field)
+    # ---- synthetic optical properties for the owned block (same seed on all ranks -> one global field).  Only the cloud
+    # mask is generated globally; delta scaling and the source term are evaluated on the owned block plus one periodic
+    # halo column/row (the source of a side stream comes from the neighbouring column), so set-up cost does not grow with N
     kabs, ksca, g = S.cloud_field(Nx, Ny, Nz, seed=20240611)
+    jj = np.arange(co.ys - 1, co.ys + co.ym + 1) % Ny
+    ii = np.arange(co.xs - 1, co.xs + co.xm + 1) % Nx
+    kabs, ksca, g = (np.ascontiguousarray(a[np.ix_(jj, ii)]) for a in (kabs, ksca, g))
     kabs, ksca, g = S.delta_scale(kabs, ksca, g)
-    sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
-    alb_full = np.full((Ny, Nx), albedo)
-    b_full = S.solar_source(solver, kabs, ksca, g, dz, dx, alb_full)
-    kabs_l, ksca_l, g_l = (np.ascontiguousarray(a[sl]) for a in (kabs, ksca, g))
-    b = torch.tensor(np.ascontiguousarray(b_full[sl]), device=dev)
-    del b_full
+    b_slab = S.solar_source(solver, kabs, ksca, g, dz, dx, np.full((co.ym + 2, co.xm + 2), albedo))
+    kabs_l, ksca_l, g_l = (np.ascontiguousarray(a[1:-1, 1:-1]) for a in (kabs, ksca, g))
+    b = torch.tensor(np.ascontiguousarray(b_slab[1:-1, 1:-1]), device=dev)
+    del b_slab, kabs, ksca, g
     l1d = torch.zeros(Nz, dtype=torch.uint8, device=dev)
     a11 = torch.zeros((co.ym, co.xm, Nz), dtype=torch.float64, device=dev)
     a12 = torch.zeros_like(a11)
@@ -222,11 +227,7 @@ def pmc_traffic(key):
 def usable_cores():
     """CPUs this process may actually use: affinity mask and the cgroup CPU quota (the GPU boxes are slices of a node:
     256 logical CPUs visible, cpu.max = 16 CPUs' worth of time), not just os.cpu_count()."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
+    n = min(os.cpu_count() or 1, _AFFINITY)
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
             txt = open(path).read().split()
