@@ -224,3 +224,60 @@ def test_spectral_loop_script_runs(gpu):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["rank0_gpoints"] == 6 and set(d["config"]["rank0_reasons"]) <= {2, 3}
     assert d["config"]["toa_net_down_Wm2"] > 0
+
+
+def _abso_by_flux_divergence(P, edir, ediff, lsolar):
+    """The reference's other absorption formula (compute_absorption_by_flx_divergence, src/pprts.F90:5400-5474): net flux
+    through the faces of every cell, fluxes in W, reference layout (Ny, Nx, L, dof); periodic neighbours; returns W/m3."""
+    Ny, Nx, Nz = P.Ny, P.Nx, P.Nz
+    O_sun = O.suninfo(P.phi0, P.theta0)
+    xinc, yinc = int(O_sun.xinc), int(O_sun.yinc)
+    l1d = P.l1d
+    a = np.zeros((Ny, Nx, Nz))
+    at = lambda f, d, k, di=0, dj=0: np.roll(f[:, :, k, d], (-dj, -di), axis=(0, 1))  # f(d, k, i+di, j+dj)
+    for k in range(Nz):
+        if lsolar:
+            a[:, :, k] += at(edir, 0, k) - at(edir, 0, k + 1)
+            if not l1d[k]:
+                a[:, :, k] += at(edir, 1, k, di=1 - xinc) - at(edir, 1, k, di=xinc)
+                a[:, :, k] += at(edir, 2, k, dj=1 - yinc) - at(edir, 2, k, dj=yinc)
+        # difftop: dof 0 = Eup (not inward), dof 1 = Edn (inward)
+        a[:, :, k] += at(ediff, 0, k + 1) - at(ediff, 0, k)
+        a[:, :, k] += at(ediff, 1, k) - at(ediff, 1, k + 1)
+        if not l1d[k]:
+            for q in range(4):  # x-side dofs 2..5, is_inward = [F, T, F, T]
+                d = 2 + q
+                a[:, :, k] += (at(ediff, d, k) - at(ediff, d, k, di=1)) * (1 if q % 2 else -1)
+            for q in range(4):
+                d = 6 + q
+                a[:, :, k] += (at(ediff, d, k) - at(ediff, d, k, dj=1)) * (1 if q % 2 else -1)
+    dz = P.fields["dz"]
+    return a / (P.dx * P.dy * dz)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lsolar", [True, False])
+def test_absorption_by_flux_divergence_equals_coeff_divergence(gpu, lsolar):
+    """tests/test_pprts_absorption_by_coeff_divergence of the reference (3x3x4 columns, dtau 1 per layer, a scattering cloud in
+    layers 2-3, albedo 0.1, thermal and solar): both absorption formulas must agree -- there to 1 % of max, here (converged
+    solve, same fluxes) to rounding of the solver tolerance."""
+    Nx = Ny = 3
+    Nz = 4
+    dxy, dz = 100.0, 100.0  # the reference uses dx = dy = dz = 1; only the aspect ratio enters the coefficients
+    P = PprtsSolver(Nz, Nx, Ny, dxy, dxy, 180.0, 0.0)
+    P.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
+    dax = lut.direct_axes()
+    P.set_lut_direct(*lut.synthetic_direct_tables(dax), dax)
+    kext = np.full((Ny, Nx, Nz), 1.0 / dz)  # dtau = 1
+    w0 = np.zeros((Ny, Nx, Nz))
+    g = np.zeros((Ny, Nx, Nz))
+    w0[:, :, 1:3] = 0.2
+    g[:, :, 1:3] = 0.2
+    planck = None if lsolar else np.full((Ny, Nx, Nz + 1), 100.0 / np.pi)
+    P.set_optical_properties(0.1, kext * (1 - w0), kext * w0, g, np.full((Ny, Nx, Nz), dz), planck=planck)
+    info = P.solve(1.0 if lsolar else 0.0, lsolar=lsolar, rtol=1e-12, atol=1e-30, maxit=2000)
+    assert info.reason == 2
+    edn, eup, abso, edir = P.get_result()
+    fd = _abso_by_flux_divergence(P, P.get_field("edir") if lsolar else None, P.get_field("ediff"), lsolar)
+    assert np.abs(abso).max() > 0
+    assert np.abs(fd - abso).max() <= 1e-6 * np.abs(abso).max()
