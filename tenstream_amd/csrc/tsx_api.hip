@@ -183,6 +183,8 @@ extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
   const bool self_x = grid->nranks == 1 || (grid->neigh_w == grid->rank && grid->neigh_e == grid->rank);
   const bool self_y = grid->nranks == 1 || (grid->neigh_s == grid->rank && grid->neigh_n == grid->rank);
   g.wrap_x = self_x && !grid->force_halo;
+  g.pc_tile_x = g.pc_tile_y = 0;
+  if (const char *e = getenv("TSX_PC_TILE")) sscanf(e, "%d,%d", &g.pc_tile_x, &g.pc_tile_y);
   g.wrap_y = self_y && !grid->force_halo;
 
   HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));

@@ -30,6 +30,8 @@ struct TsxGeo {
   long long N;     // D*(Nc+ncol)
   int D, ntop, nside;
   int wrap_x, wrap_y;  // 1: neighbour in that direction is this rank itself and faces wrap in-kernel
+  int pc_tile_x, pc_tile_y;  // analysis knob (TSX_PC_TILE=tx,ty): the preconditioner drops couplings across tile edges as
+                             // it does across rank faces, to study rank-local preconditioning on one GPU; 0 = off
 };
 
 // device-resident scalars of the Krylov loop (one instance per solver)

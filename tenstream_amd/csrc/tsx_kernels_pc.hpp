@@ -580,11 +580,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   const int Nz = g.Nz, ncol = g.ncol;
   const int jrow = col / g.xm;
   const bool seam = g.wrap_y && (g.ym % 2 == 0);
-  const long long offN = (jrow + 1 < g.ym) ? (long long)g.xm : (seam ? -(long long)(g.ym - 1) * g.xm : 0);
-  const long long offS = (jrow > 0) ? -(long long)g.xm : (seam ? (long long)(g.ym - 1) * g.xm : 0);
+  long long offN = (jrow + 1 < g.ym) ? (long long)g.xm : (seam ? -(long long)(g.ym - 1) * g.xm : 0);
+  long long offS = (jrow > 0) ? -(long long)g.xm : (seam ? (long long)(g.ym - 1) * g.xm : 0);
   const int icol = col % g.xm;
-  const long long offE = (icol + 1 < g.xm) ? 1 : (g.wrap_x ? -(long long)(g.xm - 1) : 0);
-  const long long offW = (icol > 0) ? -1 : (g.wrap_x ? (long long)(g.xm - 1) : 0);
+  long long offE = (icol + 1 < g.xm) ? 1 : (g.wrap_x ? -(long long)(g.xm - 1) : 0);
+  long long offW = (icol > 0) ? -1 : (g.wrap_x ? (long long)(g.xm - 1) : 0);
+  if (g.pc_tile_x > 0) {  // analysis knob: behave like a rank of pc_tile_x x pc_tile_y columns
+    if ((icol + 1) % g.pc_tile_x == 0) offE = 0;
+    if (icol % g.pc_tile_x == 0) offW = 0;
+  }
+  if (g.pc_tile_y > 0) {
+    if ((jrow + 1) % g.pc_tile_y == 0) offN = 0;
+    if (jrow % g.pc_tile_y == 0) offS = 0;
+  }
   const double *__restrict__ rt = r + (size_t)D * Nc;
   float *__restrict__ zt = z + (size_t)D * Nc;
   const double albc = albedo[col], rsurf = rt[col];
