@@ -170,3 +170,40 @@ def test_B_eff_limits():
     """src/schwarzschild.F90:36-67: thin limit is the mean, thick limit tends to the near value."""
     assert O.B_eff(2.0, 4.0, 1e-6) == pytest.approx(3.0, rel=1e-12)
     assert O.B_eff(2.0, 4.0, 1e3) == pytest.approx(4.0, rel=1e-2)
+
+
+def test_B_eff_like_the_reference_test():
+    """tests/test_schwarzschild/test_schwarzschild.F90:13-55 restated: Planck levels 5.67e-8 (280+k)^4 / pi, k = 1..11;
+    tau = 1000 -> the near value (abs 0.1); tau = 0 -> the mean (abs 0.1); for tau = 10^(-10 .. 4) and both orderings the
+    result lies between the two level values."""
+    Blev = [5.67e-8 * float(280 + k) ** 4 / np.pi for k in range(1, 12)]
+    between = lambda v, a, b: min(a, b) <= v <= max(a, b)
+    for k in range(10):
+        B = O.B_eff(Blev[k], Blev[k + 1], 1000.0)
+        assert abs(B - Blev[k + 1]) <= 0.1 and between(B, Blev[k], Blev[k + 1])
+        B = O.B_eff(Blev[k], Blev[k + 1], 0.0)
+        assert abs(B - 0.5 * (Blev[k] + Blev[k + 1])) <= 0.1 and between(B, Blev[k], Blev[k + 1])
+    for itau in range(-100, 41):
+        tau = 10.0 ** (itau / 10.0)
+        for k in range(10):
+            assert between(O.B_eff(Blev[k], Blev[k + 1], tau), Blev[k], Blev[k + 1]), (tau, k)
+            assert between(O.B_eff(Blev[k + 1], Blev[k], tau), Blev[k], Blev[k + 1]), (tau, k)
+
+
+def test_flux_scaling_round_trip_like_the_reference_test():
+    """tests/test_pprts_solution_vecscale (:55-100) restated for 3_10: a solution of ones in W/m2, scaled to W and back
+    (gen_scale_*_flx_vec_arr, src/pprts.F90:3901-3987), keeps its norm; first layer 10x as thick like there."""
+    nv, nx, ny, dx = 3, 3, 3, 100.0
+    lay, dlay = O.layout("3_10", nv, nx, ny), O.dir_layout_3_10()
+    dz = np.full((ny, nx, nv), dx)
+    dz[:, :, 0] = 10 * dx
+    ediff = np.ones((ny, nx, nv + 1, 10))
+    edir = np.ones((ny, nx, nv + 1, 3))
+    w_diff = O.scale_diff(lay, dz, dx, dx, False, ediff)
+    w_dir = O.scale_dir(lay, dlay, dz, dx, dx, False, edir)
+    assert np.allclose(w_diff[:, :, :, :2], dx * dx) and np.allclose(w_dir[:, :, :, 0], dx * dx)
+    assert np.allclose(w_diff[:, :, 0, 2:], dx * 10 * dx) and np.allclose(w_dir[:, :, 1, 1:], dx * dx)  # side faces: dx * dz(k)
+    back_diff = O.scale_diff(lay, dz, dx, dx, True, w_diff)
+    back_dir = O.scale_dir(lay, dlay, dz, dx, dx, True, w_dir)
+    assert np.linalg.norm(back_diff) == pytest.approx(np.linalg.norm(ediff), rel=1e-14)
+    assert np.linalg.norm(back_dir) == pytest.approx(np.linalg.norm(edir), rel=1e-14)
