@@ -132,8 +132,8 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->atol = 1e-8;
   o->dtol = 1e4;    // PETSc KSP default divergence tolerance
   o->maxit = 1000;  // src/pprts_base.F90:1118
-  o->pc = TSX_PC_NONE;
-  o->pc_sweeps = 1;
+  o->pc = TSX_PC_ZEBRA;  // this back-end's default preconditioner: 6 half-grid passes
+  o->pc_sweeps = 5;
   o->check_every = 4;
   o->fp32_directions = 1;
   o->pc_coeff_fp16 = 1;

@@ -85,7 +85,7 @@ def _worker(rank, world, port, solver, Nx, Ny, Nz, ret):
         A = O.assemble_csr(layg, c64, P["l1d"], P["a11"], P["a12"], P["albedo"])
         x_ref = spla.spsolve(A.tocsc(), P["b"].ravel()).reshape(P["b"].shape)
         x = np.zeros(s.vec_shape)
-        info = s.solve(np.ascontiguousarray(P["b"][sl]), x, rtol=1e-10, atol=1e-30, pc=1)
+        info = s.solve(np.ascontiguousarray(P["b"][sl]), x, rtol=1e-10, atol=1e-30, pc=1, pc_sweeps=1)
         e_solve = float(np.abs(x - x_ref[sl]).max() / np.abs(x_ref).max())
         ret[rank] = (e_apply, e_solve, info.reason, info.niter, float(info.res_hist[0]), float(np.linalg.norm(P["b"])))
         s.close()

@@ -60,7 +60,7 @@ def test_apply_split_launches_equal_single_launch(gpu, monkeypatch, solver, Nx, 
         assert x.shape == tuple(s.vec_shape)
         ys.append(s.apply(x))
         info_x = np.zeros_like(x)
-        info = s.solve(P["b"], info_x, pc=1)
+        info = s.solve(P["b"], info_x, pc=1, pc_sweeps=1)
         ys.append(info_x)
         ys.append(info.res_hist)
         s.close()
@@ -85,14 +85,15 @@ def test_apply_fp64_coefficients_kept_when_lossy(gpu):
 
 @pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 12, 10, 8, 2), ("3_10", 33, 17, 20, 0), ("8_16", 8, 6, 6, 0)])
 @pytest.mark.parametrize("force_halo", [False, True])
-def test_solve_matches_oracle(gpu, solver, Nx, Ny, Nz, n1d, force_halo):
+@pytest.mark.parametrize("pc", [0, 2])  # bare operator / the default preconditioner
+def test_solve_matches_oracle(gpu, solver, Nx, Ny, Nz, n1d, force_halo, pc):
     P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
     s = DiffuseSolver(solver, Nz, Nx, Ny, force_halo=force_halo)
     s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
     lay = O.layout(solver, Nz, Nx, Ny)
     c64 = P["coeff"].astype(np.float64)
     x = np.zeros(s.vec_shape)
-    info = s.solve(P["b"], x, rtol=1e-10, atol=1e-30, maxit=2000)
+    info = s.solve(P["b"], x, rtol=1e-10, atol=1e-30, maxit=2000, pc=pc)
     assert info.reason == 2, info
     if solver == "3_10":
         x_ref, ri = O.solve_matfree(lay, c64, P["l1d"], P["a11"], P["a12"], P["albedo"], P["b"], rtol=1e-12,
@@ -180,7 +181,7 @@ def test_preconditioned_solve_same_fixed_point(gpu, solver, Nx, Ny, Nz, n1d, swe
     s = DiffuseSolver(solver, Nz, Nx, Ny)
     s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
     x0 = np.zeros(s.vec_shape)
-    plain = s.solve(P["b"], x0, rtol=1e-10, atol=1e-30)
+    plain = s.solve(P["b"], x0, rtol=1e-10, atol=1e-30, pc=0)
     x = np.zeros(s.vec_shape)
     info = s.solve(P["b"], x, rtol=1e-10, atol=1e-30, pc=1, pc_sweeps=sweeps)
     assert info.reason == 2 and info.niter < plain.niter
@@ -204,7 +205,7 @@ def test_rccl_transport_with_one_rank_communicator(gpu):
     y_ref = O.diff_apply(lay, c64, P["l1d"], P["a11"], P["a12"], P["albedo"], x)
     assert np.abs(y - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
     xs = np.zeros(s.vec_shape)
-    info = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30, pc=1)
+    info = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30, pc=1, pc_sweeps=1)
     x_ref, _ = O.solve_matfree(lay, c64, P["l1d"], P["a11"], P["a12"], P["albedo"], P["b"], rtol=1e-12, atol=1e-30)
     assert info.reason == 2 and np.abs(xs - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
 
@@ -285,7 +286,7 @@ def test_breakdown_restart(gpu):
     assert oi["reason"] == -5
     for pc in (0, 1):
         x = np.zeros(s.vec_shape)
-        info = s.solve(b, x, rtol=1e-10, atol=1e-30, pc=pc)
+        info = s.solve(b, x, rtol=1e-10, atol=1e-30, pc=pc, pc_sweeps=1)
         assert info.reason == 2, (pc, info)
         assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
 
@@ -353,6 +354,6 @@ def test_zebra_preconditioner_is_line_gauss_seidel(gpu, solver, Nx, Ny, Nz, n1d,
     # and the zebra-preconditioned solve reaches the same solution in fewer iterations than block-Jacobi
     xs, xj = np.zeros(s.vec_shape), np.zeros(s.vec_shape)
     iz = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30, pc=2, pc_sweeps=sweeps)
-    ij = s.solve(P["b"], xj, rtol=1e-10, atol=1e-30, pc=1)
+    ij = s.solve(P["b"], xj, rtol=1e-10, atol=1e-30, pc=1, pc_sweeps=1)
     assert iz.reason == 2 and iz.niter <= ij.niter
     assert np.abs(xs - xj).max() <= 1e-8 * np.abs(xj).max()
