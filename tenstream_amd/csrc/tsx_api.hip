@@ -192,6 +192,7 @@ extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
   HIPCHK(hipEventCreate(&s->ev0));
   HIPCHK(hipEventCreate(&s->ev1));
   HIPCHK(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+  HIPCHK(hipDeviceGetAttribute(&s->max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, s->device));
   HIPCHK(hipEventCreateWithFlags(&s->ev_pack, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
   {

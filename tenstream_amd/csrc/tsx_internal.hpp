@@ -126,6 +126,7 @@ struct tsx_solver {
   hipEvent_t ev0, ev1;
   hipStream_t comm_stream;   // face exchange runs here while the interior SpMV runs on `stream`
   hipEvent_t ev_pack, ev_recv;
+  int max_lds;               // hipDeviceAttributeMaxSharedMemoryPerBlock
   bool overlap;              // split SpMV into interior + frame launches around the exchange (TSX_OVERLAP=0 disables)
 };
 

@@ -561,13 +561,16 @@ struct TsxDnRaw {
   float zy[4], zx[4];
 };
 
-template <int ROWS, bool GS, bool HAS1D, bool XL>
+// LDST: the sweep temporaries (16 B per level and column) live in LDS instead of global memory -- a lane only ever touches
+// its own column's slots, so no barrier is needed; 64 columns x Nz levels x 16 B (64 KiB at Nz = 64).
+template <int ROWS, bool GS, bool HAS1D, bool XL, bool LDST>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void tsx_k_pc_column_p16(
     TsxGeo g, const tsx_h8 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
     const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ r, float *__restrict__ z,
     const float *__restrict__ zc, const float *__restrict__ zx, float4 *__restrict__ tmp, const int *__restrict__ done) {
   constexpr int D = 10, NTOP = 2, NSIDE = 4;
   constexpr int PU = 4, PD = 2;  // prefetch depth of the upward / downward sweep (levels)
+  extern __shared__ float4 tsx_pc_lds[];
   if (done && *done) return;
   int col = blockIdx.x * 64 + threadIdx.x;
   if (ROWS) {
@@ -659,7 +662,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const double G = 1.0 / (1.0 - rdu * A);
     const double Gw = G * (rd + rdu * B);
     const double GT = G * tdd;
-    tmp[c] = make_float4((float)Gw, (float)GT, (float)A, (float)B);
+    if (LDST) tsx_pc_lds[k * 64 + threadIdx.x] = make_float4((float)Gw, (float)GT, (float)A, (float)B);
+    else tmp[c] = make_float4((float)Gw, (float)GT, (float)A, (float)B);
     const double Bn = ru + tuu * (B + A * Gw);
     const double An = tuu * A * GT + rud;
     A = An;
@@ -694,7 +698,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const size_t c = (size_t)k * ncol + col;
     d.cu = P[(size_t)3 * Nc + c];
     d.cv = P[(size_t)4 * Nc + c];
-    d.t = tmp[c];
+    d.t = LDST ? tsx_pc_lds[k * 64 + threadIdx.x] : tmp[c];  // prefetched with the rest of the level: off the recurrence
 #pragma unroll
     for (int q = 0; q < 8; ++q) d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
     if (GS) {
@@ -719,8 +723,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const size_t c = (size_t)k * ncol + col;
     bool one = false;
     if (HAS1D) one = l1d[k] != 0;
-    const double Vn = (double)d.t.x + (double)d.t.y * V;
-    const double Un = (double)d.t.z * Vn + (double)d.t.w;
+    const float4 t = d.t;
+    const double Vn = (double)t.x + (double)t.y * V;
+    const double Un = (double)t.z * Vn + (double)t.w;
     z[c] = (float)U;
     z[(size_t)Nc + c] = (float)Vn;
     double zy[NSIDE], zq[NSIDE];

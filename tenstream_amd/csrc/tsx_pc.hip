@@ -27,12 +27,24 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
       const void *cptr = s->coef;
       if (std::is_same<ZT, float>::value && s->pc_half) {
         if constexpr (std::is_same<ZT, float>::value) {
-          if (s->any_l1d)
-            hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                               (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
-          else
-            hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                               (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+          // sweep temporaries in LDS when a block's share (Nz x 64 columns x 16 B) fits the per-block limit
+          const size_t lds = (size_t)g.Nz * 64 * sizeof(float4);
+          static int use_lds = -1;  // TSX_PC_LDS=0: keep them in global memory (A/B knob)
+          if (use_lds < 0) {
+            const char *e = getenv("TSX_PC_LDS");
+            use_lds = e ? atoi(e) : 1;
+          }
+#define TSX_P16_LAUNCH(HAS, LDST, BYTES)                                                                                        \
+  hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, HAS, XL, LDST>), dim3(nb), dim3(64), BYTES, s->stream, g,                    \
+                     (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done)
+          if (use_lds && lds <= (size_t)s->max_lds) {
+            if (s->any_l1d) TSX_P16_LAUNCH(true, true, lds);
+            else TSX_P16_LAUNCH(false, true, lds);
+          } else {
+            if (s->any_l1d) TSX_P16_LAUNCH(true, false, 0);
+            else TSX_P16_LAUNCH(false, false, 0);
+          }
+#undef TSX_P16_LAUNCH
         }
       } else if (s->coef_bytes == 4) {
         if (s->any_l1d) TSX_H1_LAUNCH(float, true);
