@@ -486,35 +486,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (ZT)rt[(size_t)d * ncol + col];
 }
 
-// ---- 3_10 preconditioner on a *packed fp16* copy of the transport blocks (fp32 directions only) -------------------
+// ---- 3_10 preconditioner on a *packed* reduced-precision copy of the transport blocks (fp32 directions only) -----
 // The sweep above is paced by memory latency, not bytes: one wave can only track 63 outstanding vector-memory
 // operations (s_waitcnt vmcnt is 6 bits), and with one 4-byte load per coefficient a single level already needs > 100.
-// Here the 100 coefficients of a cell are regrouped into 13 records of 8 halves (16 B) in the order the two sweeps
-// consume them, P[(grp * Nc + cell)] as uint4: a level costs 3 (up) + 10 (down) coefficient loads of 16 B per lane, so
-// several levels fit under the counter and the sweeps are software-pipelined PU / PD levels deep.
-//   grp 0: tuu rud rdu tdd | c(y0->0) c(y0->1) c(y1->0) c(y1->1)          (y_q = src dof 6+q, x_q = src dof 2+q)
-//   grp 1: c(y2->0) c(y2->1) c(y3->0) c(y3->1) | c(x0->0) c(x0->1) c(x1->0) c(x1->1)
-//   grp 2: c(x2->0) c(x2->1) c(x3->0) c(x3->1) | pad
-//   grp 3: c(0 -> side d), d = 2..9          grp 4: c(1 -> side d)
-//   grp 5+m: c(y_q -> 2+2m), c(y_q -> 3+2m)  grp 9+m: c(x_q -> 2+2m), c(x_q -> 3+2m)      (m = 0..3, q = 0..3)
+// Here the 100 coefficients of a cell are regrouped into 8 records of 16 B in the order the two sweeps consume them,
+// P[(grp * Nc + cell)] as uint4: a level costs 2 (up) + 6 (down) coefficient loads of 16 B per lane, so several levels fit
+// under the counter and the sweeps are software-pipelined PU / PD levels deep.  The 20 coefficients of the column block
+// itself (the exact part of M) are fp16; the 80 couplings to neighbouring columns -- which only enter the right-hand side
+// with lagged / Gauss-Seidel values -- are OCP fp8 e4m3 scaled by 64 (measured: same iteration counts as fp16).
+//   grp 0: tuu rud rdu tdd (fp16) | c(y_q->0) c(y_q->1), q = 0..3 (fp8)       (y_q = src dof 6+q, x_q = src dof 2+q)
+//   grp 1: c(x_q->0) c(x_q->1), q = 0..3 (fp8) | pad
+//   grp 2: c(0 -> side d), d = 2..9 (fp16)        grp 3: c(1 -> side d) (fp16)
+//   grp 4, 5: c(y_q -> side 2+dd), byte 4 dd + q (fp8)       grp 6, 7: c(x_q -> side 2+dd) (fp8)
 typedef _Float16 tsx_h8 __attribute__((ext_vector_type(8)));
-constexpr int TSX_P16_GROUPS = 13;
+typedef _Float16 tsx_h4 __attribute__((ext_vector_type(4)));
+constexpr int TSX_P16_GROUPS = 8;
+constexpr float TSX_FP8_SCALE = 64.0f;
 
-// plane index dst*10+src held by element e of group grp; -1 = padding
-__host__ __device__ constexpr int tsx_p16_plane(int grp, int e) {
-  if (grp == 0) {
-    if (e < 4) return (e >> 1) * 10 + (e & 1);
-    return (e & 1) * 10 + 6 + ((e - 4) >> 1);
-  }
-  if (grp == 1) {
-    if (e < 4) return (e & 1) * 10 + 8 + (e >> 1);
-    return (e & 1) * 10 + 2 + ((e - 4) >> 1);
-  }
-  if (grp == 2) return e < 4 ? (e & 1) * 10 + 4 + (e >> 1) : -1;
-  if (grp == 3) return (2 + e) * 10 + 0;
-  if (grp == 4) return (2 + e) * 10 + 1;
-  if (grp < 9) return (2 + 2 * (grp - 5) + (e >> 2)) * 10 + 6 + (e & 3);
-  return (2 + 2 * (grp - 9) + (e >> 2)) * 10 + 2 + (e & 3);
+// four fp8 e4m3 bytes of one word -> floats (still scaled by TSX_FP8_SCALE)
+__device__ __forceinline__ void tsx_fp8x4(unsigned w, float (&o)[4]) {
+  const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
+  const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+  o[0] = lo[0];
+  o[1] = lo[1];
+  o[2] = hi[0];
+  o[3] = hi[1];
+}
+__device__ __forceinline__ unsigned tsx_to_fp8x4(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a * TSX_FP8_SCALE, b * TSX_FP8_SCALE, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c * TSX_FP8_SCALE, d * TSX_FP8_SCALE, w, true);
+  return (unsigned)w;
+}
+__device__ __forceinline__ unsigned tsx_to_h2(float a, float b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  h2 v;
+  v[0] = (_Float16)a;
+  v[1] = (_Float16)b;
+  return __builtin_bit_cast(unsigned, v);
 }
 
 // 8_16 (D = 16): 32 records, no padding.  t = top dst 0..7, d = side dst 8..15, y_q = src 12+q, x_q = src 8+q.
@@ -533,29 +541,54 @@ __host__ __device__ constexpr int tsx_p16h_plane(int grp, int e) {
 }
 
 template <typename CT, int NTOP>
-__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pack_p16(long long Nc, const CT *__restrict__ C, tsx_h8 *__restrict__ P) {
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pack_p16(long long Nc, const CT *__restrict__ C, uint4 *__restrict__ P) {
   constexpr int NG = NTOP == 2 ? TSX_P16_GROUPS : TSX_P16H_GROUPS;
   const long long n = Nc * NG;
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
     const int grp = (int)(q / Nc);
     const long long c = q - (long long)grp * Nc;
-    tsx_h8 v;
+    auto cf = [&](int dst, int src) { return (float)C[(size_t)(dst * (NTOP + 8) + src) * Nc + c]; };
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (NTOP == 2) {
+      if (grp == 0) {
+        v.x = tsx_to_h2(cf(0, 0), cf(0, 1));
+        v.y = tsx_to_h2(cf(1, 0), cf(1, 1));
+        v.z = tsx_to_fp8x4(cf(0, 6), cf(1, 6), cf(0, 7), cf(1, 7));
+        v.w = tsx_to_fp8x4(cf(0, 8), cf(1, 8), cf(0, 9), cf(1, 9));
+      } else if (grp == 1) {
+        v.x = tsx_to_fp8x4(cf(0, 2), cf(1, 2), cf(0, 3), cf(1, 3));
+        v.y = tsx_to_fp8x4(cf(0, 4), cf(1, 4), cf(0, 5), cf(1, 5));
+      } else if (grp == 2 || grp == 3) {
+        const int s = grp - 2;
+        v.x = tsx_to_h2(cf(2, s), cf(3, s));
+        v.y = tsx_to_h2(cf(4, s), cf(5, s));
+        v.z = tsx_to_h2(cf(6, s), cf(7, s));
+        v.w = tsx_to_h2(cf(8, s), cf(9, s));
+      } else {
+        const int s0 = grp < 6 ? 6 : 2, d0 = 2 + 4 * ((grp - 4) & 1);  // y sources 6..9 / x sources 2..5; side dst d0..d0+3
+        v.x = tsx_to_fp8x4(cf(d0 + 0, s0), cf(d0 + 0, s0 + 1), cf(d0 + 0, s0 + 2), cf(d0 + 0, s0 + 3));
+        v.y = tsx_to_fp8x4(cf(d0 + 1, s0), cf(d0 + 1, s0 + 1), cf(d0 + 1, s0 + 2), cf(d0 + 1, s0 + 3));
+        v.z = tsx_to_fp8x4(cf(d0 + 2, s0), cf(d0 + 2, s0 + 1), cf(d0 + 2, s0 + 2), cf(d0 + 2, s0 + 3));
+        v.w = tsx_to_fp8x4(cf(d0 + 3, s0), cf(d0 + 3, s0 + 1), cf(d0 + 3, s0 + 2), cf(d0 + 3, s0 + 3));
+      }
+    } else {
+      tsx_h8 h;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int pl = NTOP == 2 ? tsx_p16_plane(grp, e) : tsx_p16h_plane(grp, e);
-      v[e] = pl >= 0 ? (_Float16)C[(size_t)pl * Nc + c] : (_Float16)0;
+      for (int e = 0; e < 8; ++e) h[e] = (_Float16)C[(size_t)tsx_p16h_plane(grp, e) * Nc + c];
+      v = __builtin_bit_cast(uint4, h);
     }
     P[q] = v;
   }
 }
 
 struct TsxUpRaw {
-  tsx_h8 c0, c1, c2;
+  uint4 c0;        // grp 0
+  uint2 c1;        // grp 1 (first 8 bytes)
   double ru, rd, t11, t12;
   float zy[4], zx[4];
 };
 struct TsxDnRaw {
-  tsx_h8 cu, cv, cy[4], cx[4];
+  uint4 cu, cv, cy[2], cx[2];
   float4 t;        // Gw_k, GT_k, A_{k+1}, B_{k+1}
   double rs[8];
   float zy[4], zx[4];
@@ -565,7 +598,7 @@ struct TsxDnRaw {
 // its own column's slots, so no barrier is needed; 64 columns x Nz levels x 16 B (64 KiB at Nz = 64).
 template <int ROWS, bool GS, bool HAS1D, bool XL, bool LDST>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void tsx_k_pc_column_p16(
-    TsxGeo g, const tsx_h8 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
+    TsxGeo g, const uint4 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
     const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ r, float *__restrict__ z,
     const float *__restrict__ zc, const float *__restrict__ zx, float4 *__restrict__ tmp, const int *__restrict__ done) {
   constexpr int D = 10, NTOP = 2, NSIDE = 4;
@@ -605,8 +638,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     TsxUpRaw u;
     const size_t c = (size_t)k * ncol + col;
     u.c0 = P[(size_t)0 * Nc + c];
-    if (GS) u.c1 = P[(size_t)1 * Nc + c];
-    if (XL) u.c2 = P[(size_t)2 * Nc + c];
+    if (XL) u.c1 = *reinterpret_cast<const uint2 *>(P + (size_t)1 * Nc + c);
     u.ru = r[c];
     u.rd = r[(size_t)Nc + c];
     if (GS) {
@@ -627,28 +659,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   double A = albc, B = rsurf;
   auto step_up = [&](int k, const TsxUpRaw &u) {
     const size_t c = (size_t)k * ncol + col;
-    double tuu = (double)u.c0[0], rud = (double)u.c0[1], rdu = (double)u.c0[2], tdd = (double)u.c0[3];
-    double gu = 0.0, gd = 0.0;
+    const tsx_h4 tt = __builtin_bit_cast(tsx_h4, make_uint2(u.c0.x, u.c0.y));
+    double tuu = (double)tt[0], rud = (double)tt[1], rdu = (double)tt[2], tdd = (double)tt[3];
+    float gu8 = 0.0f, gd8 = 0.0f;  // coupling sums in fp8 units (x TSX_FP8_SCALE), fp32 accumulation
     if (GS) {
+      float ca[4], cb[4];  // [c(y0->0) c(y0->1) c(y1->0) c(y1->1)], [y2, y3]
+      tsx_fp8x4(u.c0.z, ca);
+      tsx_fp8x4(u.c0.w, cb);
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) {
-        const double zv = (tsx_inward(q) ? offS : offN) ? (double)u.zy[q] : 0.0;  // select: the unused slot may hold NaN
-        const double c0 = q < 2 ? (double)u.c0[4 + 2 * q] : (double)u.c1[2 * (q - 2)];
-        const double c1 = q < 2 ? (double)u.c0[5 + 2 * q] : (double)u.c1[2 * (q - 2) + 1];
-        gu += c0 * zv;
-        gd += c1 * zv;
+        const float zv = (tsx_inward(q) ? offS : offN) ? u.zy[q] : 0.0f;  // select: the unused slot may hold NaN
+        gu8 += (q < 2 ? ca[2 * q] : cb[2 * (q - 2)]) * zv;
+        gd8 += (q < 2 ? ca[2 * q + 1] : cb[2 * (q - 2) + 1]) * zv;
       }
     }
     if (XL) {
+      float ca[4], cb[4];
+      tsx_fp8x4(u.c1.x, ca);
+      tsx_fp8x4(u.c1.y, cb);
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) {
-        const double zv = (tsx_inward(q) ? offW : offE) ? (double)u.zx[q] : 0.0;
-        const double c0 = q < 2 ? (double)u.c1[4 + 2 * q] : (double)u.c2[2 * (q - 2)];
-        const double c1 = q < 2 ? (double)u.c1[5 + 2 * q] : (double)u.c2[2 * (q - 2) + 1];
-        gu += c0 * zv;
-        gd += c1 * zv;
+        const float zv = (tsx_inward(q) ? offW : offE) ? u.zx[q] : 0.0f;
+        gu8 += (q < 2 ? ca[2 * q] : cb[2 * (q - 2)]) * zv;
+        gd8 += (q < 2 ? ca[2 * q + 1] : cb[2 * (q - 2) + 1]) * zv;
       }
     }
+    double gu = (double)gu8 * (1.0 / TSX_FP8_SCALE), gd = (double)gd8 * (1.0 / TSX_FP8_SCALE);
     if (HAS1D) {
       const bool one = l1d[k] != 0;
       tuu = one ? u.t11 : tuu;
@@ -696,20 +732,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   auto load_dn = [&](int k) {
     TsxDnRaw d;
     const size_t c = (size_t)k * ncol + col;
-    d.cu = P[(size_t)3 * Nc + c];
-    d.cv = P[(size_t)4 * Nc + c];
+    d.cu = P[(size_t)2 * Nc + c];
+    d.cv = P[(size_t)3 * Nc + c];
     d.t = LDST ? tsx_pc_lds[k * 64 + threadIdx.x] : tmp[c];  // prefetched with the rest of the level: off the recurrence
 #pragma unroll
     for (int q = 0; q < 8; ++q) d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
     if (GS) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) d.cy[m] = P[(size_t)(5 + m) * Nc + c];
+      for (int m = 0; m < 2; ++m) d.cy[m] = P[(size_t)(4 + m) * Nc + c];
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) d.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
     }
     if (XL) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) d.cx[m] = P[(size_t)(9 + m) * Nc + c];
+      for (int m = 0; m < 2; ++m) d.cx[m] = P[(size_t)(6 + m) * Nc + c];
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) d.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
     }
@@ -728,26 +764,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const double Un = (double)t.z * Vn + (double)t.w;
     z[c] = (float)U;
     z[(size_t)Nc + c] = (float)Vn;
-    double zy[NSIDE], zq[NSIDE];
+    float zy[NSIDE], zq[NSIDE];
     if (GS) {
 #pragma unroll
-      for (int q = 0; q < NSIDE; ++q) zy[q] = (tsx_inward(q) ? offS : offN) ? (double)d.zy[q] : 0.0;
+      for (int q = 0; q < NSIDE; ++q) zy[q] = (tsx_inward(q) ? offS : offN) ? d.zy[q] : 0.0f;
     }
     if (XL) {
 #pragma unroll
-      for (int q = 0; q < NSIDE; ++q) zq[q] = (tsx_inward(q) ? offW : offE) ? (double)d.zx[q] : 0.0;
+      for (int q = 0; q < NSIDE; ++q) zq[q] = (tsx_inward(q) ? offW : offE) ? d.zx[q] : 0.0f;
     }
+    const tsx_h8 hcu = __builtin_bit_cast(tsx_h8, d.cu), hcv = __builtin_bit_cast(tsx_h8, d.cv);
+    const unsigned wy[8] = {d.cy[0].x, d.cy[0].y, d.cy[0].z, d.cy[0].w, d.cy[1].x, d.cy[1].y, d.cy[1].z, d.cy[1].w};
+    const unsigned wx[8] = {d.cx[0].x, d.cx[0].y, d.cx[0].z, d.cx[0].w, d.cx[1].x, d.cx[1].y, d.cx[1].z, d.cx[1].w};
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd) {
-      double acc = (double)d.cu[dd] * Un + (double)d.cv[dd] * V;
+      double acc = (double)hcu[dd] * Un + (double)hcv[dd] * V;
+      float a8 = 0.0f;  // couplings: fp8 units, fp32 accumulation
       if (GS) {
+        float cq[4];
+        tsx_fp8x4(wy[dd], cq);
 #pragma unroll
-        for (int q = 0; q < NSIDE; ++q) acc += (double)d.cy[dd >> 1][(dd & 1) * 4 + q] * zy[q];
+        for (int q = 0; q < NSIDE; ++q) a8 += cq[q] * zy[q];
       }
       if (XL) {
+        float cq[4];
+        tsx_fp8x4(wx[dd], cq);
 #pragma unroll
-        for (int q = 0; q < NSIDE; ++q) acc += (double)d.cx[dd >> 1][(dd & 1) * 4 + q] * zq[q];
+        for (int q = 0; q < NSIDE; ++q) a8 += cq[q] * zq[q];
       }
+      acc += (double)a8 * (1.0 / TSX_FP8_SCALE);
       z[(size_t)(NTOP + dd) * Nc + c] = (float)(d.rs[dd] + (one ? 0.0 : acc));
     }
     V = Vn;

@@ -36,7 +36,7 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
           }
 #define TSX_P16_LAUNCH(HAS, LDST, BYTES)                                                                                        \
   hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, HAS, XL, LDST>), dim3(nb), dim3(64), BYTES, s->stream, g,                    \
-                     (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done)
+                     (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done)
           if (use_lds && lds <= (size_t)s->max_lds) {
             if (s->any_l1d) TSX_P16_LAUNCH(true, true, lds);
             else TSX_P16_LAUNCH(false, true, lds);
@@ -154,7 +154,7 @@ int tsx_pc_ensure_half(tsx_solver *s) {
   if (!s->coef_h_valid) {
 #define TSX_PACK(CTYPE, NT)                                                                                        \
   hipLaunchKernelGGL((tsx_k_pack_p16<CTYPE, NT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, s->geo.Nc,      \
-                     (const CTYPE *)s->coef, (tsx_h8 *)s->coef_h)
+                     (const CTYPE *)s->coef, (uint4 *)s->coef_h)
     if (s->coef_bytes == 4) {
       if (h1) TSX_PACK(float, 2);
       else TSX_PACK(float, 8);
