@@ -94,8 +94,11 @@ static inline int halo_update(tsx_solver *s, const double *v, bool in_solve) {
   return NTOP == 2 ? tsx_halo_update_310(s, v, in_solve) : tsx_halo_update_816(s, v, in_solve);
 }
 
-// preconditioner (tsx_pc.hip): z = M^-1 v, z fp32 (the solver's fp32 directions, packed fp16 blocks) or fp64 (exact)
+// preconditioner (tsx_pc.hip): z = M^-1 v, z fp64 (exact blocks, reads v) or fp32 (the solver's fp32 directions on the
+// packed reduced-precision blocks; reads the fp32 copy s->v32 of v that tsx_k_pupdate / supdate / residual0 -- or
+// tsx_pc_narrow -- left there)
 int tsx_pc_apply(tsx_solver *s, const double *v, void *z, bool z_is_float, bool in_solve);
 int tsx_pc_ensure_buffers(tsx_solver *s);
 int tsx_pc_ensure_half(tsx_solver *s);
+int tsx_pc_narrow(tsx_solver *s, const double *a);
 int tsx_pc_widen(tsx_solver *s, const float *a, double *o);  // o = (double) a over the N unknowns

@@ -108,6 +108,7 @@ struct tsx_solver {
   bool have_optprop;
   double *a13, *a23, *a33;       // cell-indexed, 1-D layers only
   double *planck;                // (L, xm, ym) reference layout
+  float *v32;                    // fp32 copy of the preconditioner's right-hand side (mixed path)
   double *edir_a, *edir_b;       // direct streams, current / scratch
   double *dsend[4], *drecv[4];   // direct-beam face buffers W, E, S, N (several ranks)
   void *dsc, *dsc_host;          // TsxDirScalars device / pinned

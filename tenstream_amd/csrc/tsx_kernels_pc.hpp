@@ -584,13 +584,14 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pack_p16(long long Nc, const 
 struct TsxUpRaw {
   uint4 c0;        // grp 0
   uint2 c1;        // grp 1 (first 8 bytes)
-  double ru, rd, t11, t12;
+  float ru, rd;
+  double t11, t12;
   float zy[4], zx[4];
 };
 struct TsxDnRaw {
   uint4 cu, cv, cy[2], cx[2];
   float4 t;        // Gw_k, GT_k, A_{k+1}, B_{k+1}
-  double rs[8];
+  float rs[8];
   float zy[4], zx[4];
 };
 
@@ -599,7 +600,7 @@ struct TsxDnRaw {
 template <int ROWS, bool GS, bool HAS1D, bool XL, bool LDST>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void tsx_k_pc_column_p16(
     TsxGeo g, const uint4 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
-    const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ r, float *__restrict__ z,
+    const double *__restrict__ a12, const double *__restrict__ albedo, const float *__restrict__ r, float *__restrict__ z,
     const float *__restrict__ zc, const float *__restrict__ zx, float4 *__restrict__ tmp, const int *__restrict__ done) {
   constexpr int D = 10, NTOP = 2, NSIDE = 4;
   constexpr int PU = 4, PD = 2;  // prefetch depth of the upward / downward sweep (levels)
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     if ((jrow + 1) % g.pc_tile_y == 0) offN = 0;
     if (jrow % g.pc_tile_y == 0) offS = 0;
   }
-  const double *__restrict__ rt = r + (size_t)D * Nc;
+  const float *__restrict__ rt = r + (size_t)D * Nc;
   float *__restrict__ zt = z + (size_t)D * Nc;
   const double albc = albedo[col], rsurf = rt[col];
 
@@ -831,20 +832,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // [Gw | GT rows 0..3 | A_{k+1} rows 0..3 | B_{k+1}].
 struct TsxUpRawH {
   tsx_h8 row[8], cy[4], cx[4];
-  double r[8], t11, t12;
+  float r[8];
+  double t11, t12;
   float zy[4], zx[4];
 };
 struct TsxDnRawH {
   tsx_h8 row[8], cy[4], cx[4];
   float4 t[10];
-  double rs[8];
+  float rs[8];
   float zy[4], zx[4];
 };
 
 template <int ROWS, bool GS, bool HAS1D, bool XL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void tsx_k_pc_column_p16h(
     TsxGeo g, const tsx_h8 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
-    const double *__restrict__ a12, const double *__restrict__ albedo, const double *__restrict__ r, float *__restrict__ z,
+    const double *__restrict__ a12, const double *__restrict__ albedo, const float *__restrict__ r, float *__restrict__ z,
     const float *__restrict__ zc, const float *__restrict__ zx, float4 *__restrict__ tmp, const int *__restrict__ done) {
   constexpr int D = 16, NTOP = 8, NSIDE = 4, H = 4;
   constexpr int PU = 2, PD = 1;
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const int icol = col % g.xm;
   const long long offE = (icol + 1 < g.xm) ? 1 : (g.wrap_x ? -(long long)(g.xm - 1) : 0);
   const long long offW = (icol > 0) ? -1 : (g.wrap_x ? (long long)(g.xm - 1) : 0);
-  const double *__restrict__ rt = r + (size_t)D * Nc;
+  const float *__restrict__ rt = r + (size_t)D * Nc;
   float *__restrict__ zt = z + (size_t)D * Nc;
   const double albh = albedo[col] / (double)H;  // assembled surface row: albedo/streams on every pair
 
@@ -1096,6 +1098,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (float)rt[(size_t)d * ncol + col];
 }
 
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_narrow(long long n, const double *__restrict__ a, float *__restrict__ o) {
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) o[q] = (float)a[q];
+}
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_widen(long long n, const float *__restrict__ a, double *__restrict__ o) {
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) o[q] = (double)a[q];
 }

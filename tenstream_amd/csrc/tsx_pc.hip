@@ -36,7 +36,8 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
           }
 #define TSX_P16_LAUNCH(HAS, LDST, BYTES)                                                                                        \
   hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, HAS, XL, LDST>), dim3(nb), dim3(64), BYTES, s->stream, g,                    \
-                     (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done)
+                     (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,             \
+                     (float4 *)s->pc_tmp, done)
           if (use_lds && lds <= (size_t)s->max_lds) {
             if (s->any_l1d) TSX_P16_LAUNCH(true, true, lds);
             else TSX_P16_LAUNCH(false, true, lds);
@@ -62,10 +63,10 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
     if (s->pc_half) {
       if (s->any_l1d)
         hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx, (float4 *)s->pc_tmp, done);
       else
         hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (float4 *)s->pc_tmp, done);
+                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx, (float4 *)s->pc_tmp, done);
       HIPCHK(hipGetLastError());
       return TSX_OK;
     }
@@ -143,6 +144,7 @@ static int ensure_pc_buffers_t(tsx_solver *s) {
   if (s->vph == s->vp || !s->vph) HIPCHK(hipMalloc((void **)&s->vph, nb));  // fp64-sized: also holds the fp32 form
   if (s->vsh == s->vs || !s->vsh) HIPCHK(hipMalloc((void **)&s->vsh, nb));
   if (!s->vw) HIPCHK(hipMalloc((void **)&s->vw, nb));
+  if (!s->v32) HIPCHK(hipMalloc((void **)&s->v32, (size_t)g.N * sizeof(float)));  // fp32 right-hand side of the mixed path
   return TSX_OK;
 }
 
@@ -177,6 +179,12 @@ int tsx_pc_apply(tsx_solver *s, const double *v, void *z, bool z_is_float, bool 
   if (s->geo.ntop == 2)
     return z_is_float ? apply_pc<2, 4, float>(s, v, (float *)z, in_solve) : apply_pc<2, 4, double>(s, v, (double *)z, in_solve);
   return z_is_float ? apply_pc<8, 4, float>(s, v, (float *)z, in_solve) : apply_pc<8, 4, double>(s, v, (double *)z, in_solve);
+}
+
+int tsx_pc_narrow(tsx_solver *s, const double *a) {  // s->v32 = (float) a: the mixed path's right-hand side
+  hipLaunchKernelGGL(tsx_k_narrow, dim3(grid_for(s->geo.N)), dim3(TSX_BLOCK), 0, s->stream, s->geo.N, a, s->v32);
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
 }
 
 int tsx_pc_widen(tsx_solver *s, const float *a, double *o) {
