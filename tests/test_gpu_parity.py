@@ -127,6 +127,27 @@ def test_solve_default_tolerances_and_warm_start(gpu):
     assert info2.niter < info.niter and info2.reason in (2, 3)
 
 
+def test_stop_rule_reason_codes_like_MyKSPConverged(gpu):
+    """Diverged reasons of MyKSPConverged (src/pprts.F90:4437-4486): -3 iteration limit, -9 NaN; the oracle's restatement
+    of KSPFBCGS gives the same reason and iteration count for the bare operator."""
+    P = synthetic.make_problem("3_10", Nx=12, Ny=10, Nz=8)
+    s = DiffuseSolver("3_10", 8, 12, 10)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    lay = O.layout("3_10", 8, 12, 10)
+    x = np.zeros(s.vec_shape)
+    info = s.solve(P["b"], x, rtol=1e-14, atol=1e-300, maxit=5, pc=0, fp32_directions=0)
+    _, oi = O.solve_matfree(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"], P["b"],
+                            rtol=1e-14, atol=1e-300, maxit=5)
+    assert info.reason == -3 == oi["reason"] and info.niter == oi["niter"] == 5
+    np.testing.assert_allclose(info.res_hist, oi["res_hist"][: len(info.res_hist)], rtol=1e-9)  # same iterates in fp64
+    b = P["b"].copy()
+    b[0, 0, 0, 0] = np.nan
+    x = np.zeros(s.vec_shape)
+    info = s.solve(b, x, pc=2)
+    assert info.reason == -9
+    s.close()
+
+
 def _column_block_matrix(P, lay):
     """M = entries of the assembled matrix whose row and column unknowns leave the same cell column
     (dst-owned numbering): the matrix the column preconditioner inverts exactly."""
