@@ -85,9 +85,10 @@ typedef struct {
   int32_t check_every;        /* host looks at the device convergence flag every n iterations */
   int32_t fp32_directions;    /* 1 (default): preconditioned directions p-hat/s-hat and the shadow residual are stored in
                                  fp32 -- flexible BiCGStab accepts any direction; x, r, p, s, v, t stay fp64.  0: all fp64 */
-  int32_t pc_coeff_fp16;      /* 1 (default): with fp32 directions the 3_10 preconditioner reads an fp16 copy of the
-                                 transport blocks and keeps its sweep temporaries in fp32 (the preconditioner is an
-                                 approximation anyway; the operator itself always uses the exact blocks).  0: exact blocks */
+  int32_t pc_coeff_fp16;      /* 1 (default): with fp32 directions the preconditioner reads a packed reduced-precision copy
+                                 of the transport blocks (fp16; for 3_10 the couplings to neighbouring columns fp8 e4m3) and
+                                 keeps its sweep temporaries in fp32 -- the preconditioner is an approximation anyway; the
+                                 operator itself always uses the exact blocks.  0: exact blocks in the preconditioner too */
   int32_t reserved_;
 } tsx_ksp_opts;
 
