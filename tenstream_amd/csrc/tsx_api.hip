@@ -917,15 +917,15 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   HIPCHK(hipSetDevice(s->device));
   s->pc = o->pc;
   s->pc_sweeps = o->pc_sweeps;
-  // fp32 directions: default on; the multi-sweep Jacobi refinement works on fp64 directions only
-  s->mixed = o->fp32_directions != 0 && !(o->pc == TSX_PC_COLUMN && o->pc_sweeps > 1);
+  // fp32 directions (default on) always come with the packed reduced-precision preconditioner blocks; the multi-sweep
+  // Jacobi refinement and pc_coeff_fp16 = 0 work on fp64 directions and the exact blocks
+  s->mixed = o->fp32_directions != 0 && !(o->pc == TSX_PC_COLUMN && o->pc_sweeps > 1) &&
+             (o->pc == TSX_PC_NONE || o->pc_coeff_fp16 != 0);
   s->pc_half = false;
   if (o->pc != TSX_PC_NONE) {
     int rc = tsx_pc_ensure_buffers(s);
     if (rc) return rc;
-    if (o->pc_coeff_fp16 && s->mixed && s->have_coeffs) {
-      if ((rc = tsx_pc_ensure_half(s))) return rc;
-    }
+    if (s->mixed && (rc = tsx_pc_ensure_half(s))) return rc;
   }
   return TSX_OK;
 }

@@ -14,72 +14,78 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
   const int ncols = ROWS == 0 ? g.ncol : (ROWS == 1 ? (g.ym + 1) / 2 : g.ym / 2) * g.xm;
   if (ncols == 0) return TSX_OK;
   const int nb = (ncols + 63) / 64;
-  static int use_h1 = -1;  // TSX_PC_PREFETCH=0 selects the generic kernel for 3_10 as well (A/B knob)
-  if (use_h1 < 0) {
-    const char *e = getenv("TSX_PC_PREFETCH");
-    use_h1 = e ? atoi(e) : 1;
-  }
-  if constexpr (NTOP == 2) {
-    if (use_h1) {
-#define TSX_H1_LAUNCH(CTYPE, HAS)                                                                                              \
-  hipLaunchKernelGGL((tsx_k_pc_column_h1<CTYPE, ROWS, GS, ZT, HAS, XL>), dim3(nb), dim3(64), 0, s->stream, g,                     \
-                     (const CTYPE *)cptr, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (void *)s->pc_tmp, done)
-      const void *cptr = s->coef;
-      if (std::is_same<ZT, float>::value && s->pc_half) {
-        if constexpr (std::is_same<ZT, float>::value) {
-          // sweep temporaries in LDS when a block's share (Nz x 64 columns x 16 B) fits the per-block limit
-          const size_t lds = (size_t)g.Nz * 64 * sizeof(float4);
-          static int use_lds = -1;  // TSX_PC_LDS=0: keep them in global memory (A/B knob)
-          if (use_lds < 0) {
-            const char *e = getenv("TSX_PC_LDS");
-            use_lds = e ? atoi(e) : 1;
-          }
+  if constexpr (std::is_same<ZT, float>::value) {
+    // fp32 directions: always the packed reduced-precision blocks (tsx_pc_ensure_half) and the fp32 right-hand side s->v32
+    if (!s->pc_half || !s->v32) {
+      tsx_set_error("preconditioner: fp32 directions need the packed blocks (internal state error)");
+      return TSX_ERR_STATE;
+    }
+    if constexpr (NTOP == 2) {
+      // sweep temporaries in LDS when a block's share (Nz x 64 columns x 16 B) fits the per-block limit
+      const size_t lds = (size_t)g.Nz * 64 * sizeof(float4);
+      static int use_lds = -1;  // TSX_PC_LDS=0: keep them in global memory (A/B knob)
+      if (use_lds < 0) {
+        const char *e = getenv("TSX_PC_LDS");
+        use_lds = e ? atoi(e) : 1;
+      }
 #define TSX_P16_LAUNCH(HAS, LDST, BYTES)                                                                                        \
   hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, HAS, XL, LDST>), dim3(nb), dim3(64), BYTES, s->stream, g,                    \
                      (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,             \
                      (float4 *)s->pc_tmp, done)
-          if (use_lds && lds <= (size_t)s->max_lds) {
-            if (s->any_l1d) TSX_P16_LAUNCH(true, true, lds);
-            else TSX_P16_LAUNCH(false, true, lds);
-          } else {
-            if (s->any_l1d) TSX_P16_LAUNCH(true, false, 0);
-            else TSX_P16_LAUNCH(false, false, 0);
-          }
-#undef TSX_P16_LAUNCH
-        }
-      } else if (s->coef_bytes == 4) {
-        if (s->any_l1d) TSX_H1_LAUNCH(float, true);
-        else TSX_H1_LAUNCH(float, false);
+      if (use_lds && lds <= (size_t)s->max_lds) {
+        if (s->any_l1d) TSX_P16_LAUNCH(true, true, lds);
+        else TSX_P16_LAUNCH(false, true, lds);
       } else {
-        if (s->any_l1d) TSX_H1_LAUNCH(double, true);
-        else TSX_H1_LAUNCH(double, false);
+        if (s->any_l1d) TSX_P16_LAUNCH(true, false, 0);
+        else TSX_P16_LAUNCH(false, false, 0);
       }
-#undef TSX_H1_LAUNCH
-      HIPCHK(hipGetLastError());
-      return TSX_OK;
-    }
-  }
-  if constexpr (NTOP == 8 && std::is_same<ZT, float>::value) {
-    if (s->pc_half) {
+#undef TSX_P16_LAUNCH
+    } else {
       if (s->any_l1d)
         hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx, (float4 *)s->pc_tmp, done);
+                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,
+                           (float4 *)s->pc_tmp, done);
       else
         hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx, (float4 *)s->pc_tmp, done);
-      HIPCHK(hipGetLastError());
-      return TSX_OK;
+                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,
+                           (float4 *)s->pc_tmp, done);
     }
+    HIPCHK(hipGetLastError());
+    return TSX_OK;
+  } else {
+    // fp64 directions: the exact blocks
+    static int use_h1 = -1;  // TSX_PC_PREFETCH=0 selects the generic kernel for 3_10 as well (A/B knob)
+    if (use_h1 < 0) {
+      const char *e = getenv("TSX_PC_PREFETCH");
+      use_h1 = e ? atoi(e) : 1;
+    }
+    if constexpr (NTOP == 2) {
+      if (use_h1) {
+#define TSX_H1_LAUNCH(CTYPE, HAS)                                                                                              \
+  hipLaunchKernelGGL((tsx_k_pc_column_h1<CTYPE, ROWS, GS, ZT, HAS, XL>), dim3(nb), dim3(64), 0, s->stream, g,                     \
+                     (const CTYPE *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, zx, (void *)s->pc_tmp, done)
+        if (s->coef_bytes == 4) {
+          if (s->any_l1d) TSX_H1_LAUNCH(float, true);
+          else TSX_H1_LAUNCH(float, false);
+        } else {
+          if (s->any_l1d) TSX_H1_LAUNCH(double, true);
+          else TSX_H1_LAUNCH(double, false);
+        }
+#undef TSX_H1_LAUNCH
+        HIPCHK(hipGetLastError());
+        return TSX_OK;
+      }
+    }
+    // generic kernel (8_16, or A/B): y coupling only
+    if (s->coef_bytes == 4)
+      hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
+                         (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
+    else
+      hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
+                         (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
+    HIPCHK(hipGetLastError());
+    return TSX_OK;
   }
-  // generic kernel (8_16 exact path, or A/B): y coupling only
-  if (s->coef_bytes == 4)
-    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, float, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
-                       (const float *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
-  else
-    hipLaunchKernelGGL((tsx_k_pc_column<NTOP, NSIDE, double, ROWS, GS, ZT>), dim3(nb), dim3(64), 0, s->stream, g,
-                       (const double *)s->coef, s->l1d, s->a11, s->a12, s->albedo, v, z, zy, s->pc_tmp, done);
-  HIPCHK(hipGetLastError());
-  return TSX_OK;
 }
 
 // z = M^-1 v.
@@ -99,7 +105,7 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
     const int P = s->pc_sweeps + 1;
     ZT *alt = (ZT *)s->vw;
     // lagged x coupling: 3_10 kernels and the packed 8_16 kernel; the generic (exact) 8_16 kernel couples in y only
-    const bool xl = g.ym >= 2 && (NTOP == 2 || (std::is_same<ZT, float>::value && s->pc_half));
+    const bool xl = g.ym >= 2 && (NTOP == 2 || std::is_same<ZT, float>::value);
     auto buf = [&](int pass) {  // buffer a pass writes: its colour's last pass writes z, alternating backwards
       const int last = ((P - 1) % 2 == pass % 2) ? P - 1 : P - 2;
       return (((last - pass) / 2) % 2 == 0 || !xl) ? z : alt;
