@@ -525,20 +525,12 @@ __device__ __forceinline__ unsigned tsx_to_h2(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-// 8_16 (D = 16): 32 records, no padding.  t = top dst 0..7, d = side dst 8..15, y_q = src 12+q, x_q = src 8+q.
-//   grp 0..7:   c(src 0..7 -> top dst t = grp)                       (Tuu/Rud/Rdu/Tdd interleaved by stream parity)
-//   grp 8+m:    c(y_q -> 2m), c(y_q -> 2m+1)        grp 12+m: c(x_q -> 2m), c(x_q -> 2m+1)
-//   grp 16+dd:  c(src 0..7 -> side dst 8+dd)
-//   grp 24+m:   c(y_q -> 8+2m), c(y_q -> 9+2m)      grp 28+m: c(x_q -> 8+2m), c(x_q -> 9+2m)
-constexpr int TSX_P16H_GROUPS = 32;
-__host__ __device__ constexpr int tsx_p16h_plane(int grp, int e) {
-  if (grp < 8) return grp * 16 + e;
-  if (grp < 12) return (2 * (grp - 8) + (e >> 2)) * 16 + 12 + (e & 3);
-  if (grp < 16) return (2 * (grp - 12) + (e >> 2)) * 16 + 8 + (e & 3);
-  if (grp < 24) return (8 + grp - 16) * 16 + e;
-  if (grp < 28) return (8 + 2 * (grp - 24) + (e >> 2)) * 16 + 12 + (e & 3);
-  return (8 + 2 * (grp - 28) + (e >> 2)) * 16 + 8 + (e & 3);
-}
+// 8_16 (D = 16): 24 records.  t = top dst 0..7, d = side dst 8..15, y_q = src 12+q, x_q = src 8+q.
+//   grp 0..7:    c(src 0..7 -> top dst t = grp), fp16                (Tuu/Rud/Rdu/Tdd interleaved by stream parity)
+//   grp 8, 9:    c(y_q -> t), byte 4 t + q, fp8        grp 10, 11: c(x_q -> t), fp8
+//   grp 12..19:  c(src 0..7 -> side dst 8 + dd), fp16
+//   grp 20, 21:  c(y_q -> 8 + dd), byte 4 dd + q, fp8  grp 22, 23: c(x_q -> 8 + dd), fp8
+constexpr int TSX_P16H_GROUPS = 24;
 
 template <typename CT, int NTOP>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pack_p16(long long Nc, const CT *__restrict__ C, uint4 *__restrict__ P) {
@@ -572,10 +564,20 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pack_p16(long long Nc, const 
         v.w = tsx_to_fp8x4(cf(d0 + 3, s0), cf(d0 + 3, s0 + 1), cf(d0 + 3, s0 + 2), cf(d0 + 3, s0 + 3));
       }
     } else {
-      tsx_h8 h;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) h[e] = (_Float16)C[(size_t)tsx_p16h_plane(grp, e) * Nc + c];
-      v = __builtin_bit_cast(uint4, h);
+      const bool up = grp < 12;
+      const int g2 = up ? grp : grp - 12, d0 = up ? 0 : 8;  // the two halves of the layout are built alike
+      if (g2 < 8) {
+        v.x = tsx_to_h2(cf(d0 + g2, 0), cf(d0 + g2, 1));
+        v.y = tsx_to_h2(cf(d0 + g2, 2), cf(d0 + g2, 3));
+        v.z = tsx_to_h2(cf(d0 + g2, 4), cf(d0 + g2, 5));
+        v.w = tsx_to_h2(cf(d0 + g2, 6), cf(d0 + g2, 7));
+      } else {
+        const int s0 = g2 < 10 ? 12 : 8, t0 = d0 + 4 * ((g2 - 8) & 1);
+        v.x = tsx_to_fp8x4(cf(t0 + 0, s0), cf(t0 + 0, s0 + 1), cf(t0 + 0, s0 + 2), cf(t0 + 0, s0 + 3));
+        v.y = tsx_to_fp8x4(cf(t0 + 1, s0), cf(t0 + 1, s0 + 1), cf(t0 + 1, s0 + 2), cf(t0 + 1, s0 + 3));
+        v.z = tsx_to_fp8x4(cf(t0 + 2, s0), cf(t0 + 2, s0 + 1), cf(t0 + 2, s0 + 2), cf(t0 + 2, s0 + 3));
+        v.w = tsx_to_fp8x4(cf(t0 + 3, s0), cf(t0 + 3, s0 + 1), cf(t0 + 3, s0 + 2), cf(t0 + 3, s0 + 3));
+      }
     }
     P[q] = v;
   }
@@ -827,28 +829,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (float)rt[(size_t)d * ncol + col];
 }
 
-// ---- 8_16 (H = 4 up/down pairs) on the packed fp16 blocks: same mathematics as tsx_k_pc_column<8,4,...> (4x4 block
-// recurrences), same software pipeline as tsx_k_pc_column_p16.  Temporaries per cell: 10 float4 records
-// [Gw | GT rows 0..3 | A_{k+1} rows 0..3 | B_{k+1}].
+// ---- 8_16 (H = 4 up/down pairs) on the packed blocks: same mathematics as tsx_k_pc_column<8,4,...> (4x4 block
+// recurrences), same software pipeline as tsx_k_pc_column_p16.  Temporaries per cell: 6 records of 16 B
+// [Gw fp32 | GT rows 0..3 fp16 (2 records) | A_{k+1} rows 0..3 fp16 (2 records) | B_{k+1} fp32]: GT and A are products of
+// transfer coefficients in [0, 1], Gw and B carry flux magnitudes.
 struct TsxUpRawH {
-  tsx_h8 row[8], cy[4], cx[4];
+  tsx_h8 row[8];
+  uint4 cy[2], cx[2];
   float r[8];
   double t11, t12;
   float zy[4], zx[4];
 };
 struct TsxDnRawH {
-  tsx_h8 row[8], cy[4], cx[4];
-  float4 t[10];
+  tsx_h8 row[8];
+  uint4 cy[2], cx[2];
+  uint4 t[6];
   float rs[8];
   float zy[4], zx[4];
 };
 
 template <int ROWS, bool GS, bool HAS1D, bool XL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void tsx_k_pc_column_p16h(
-    TsxGeo g, const tsx_h8 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
+    TsxGeo g, const uint4 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
     const double *__restrict__ a12, const double *__restrict__ albedo, const float *__restrict__ r, float *__restrict__ z,
-    const float *__restrict__ zc, const float *__restrict__ zx, float4 *__restrict__ tmp, const int *__restrict__ done) {
+    const float *__restrict__ zc, const float *__restrict__ zx, float4 *__restrict__ tmp_, const int *__restrict__ done) {
   constexpr int D = 16, NTOP = 8, NSIDE = 4, H = 4;
+  uint4 *__restrict__ tmp = reinterpret_cast<uint4 *>(tmp_);
   constexpr int PU = 2, PD = 1;
   using SM = TsxSm<H>;
   if (done && *done) return;
@@ -876,18 +882,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     TsxUpRawH u;
     const size_t c = (size_t)k * ncol + col;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) u.row[t] = P[(size_t)t * Nc + c];
+    for (int t = 0; t < 8; ++t) u.row[t] = __builtin_bit_cast(tsx_h8, P[(size_t)t * Nc + c]);
 #pragma unroll
     for (int t = 0; t < 8; ++t) u.r[t] = r[(size_t)t * Nc + c];
     if (GS) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) u.cy[m] = P[(size_t)(8 + m) * Nc + c];
+      for (int m = 0; m < 2; ++m) u.cy[m] = P[(size_t)(8 + m) * Nc + c];
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) u.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
     }
     if (XL) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) u.cx[m] = P[(size_t)(12 + m) * Nc + c];
+      for (int m = 0; m < 2; ++m) u.cx[m] = P[(size_t)(10 + m) * Nc + c];
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) u.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
     }
@@ -920,25 +926,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         Rdu[a][b] = one ? dg * u.t12 : (double)u.row[2 * a + 1][2 * b];
         Tdd[a][b] = one ? dg * u.t11 : (double)u.row[2 * a + 1][2 * b + 1];
       }
-      double gu = 0.0, gd = 0.0;
+      float gu8 = 0.0f, gd8 = 0.0f;  // coupling sums in fp8 units (x TSX_FP8_SCALE)
       if (GS) {
+        const unsigned wu = a < 2 ? (a == 0 ? u.cy[0].x : u.cy[0].z) : (a == 2 ? u.cy[1].x : u.cy[1].z);  // dst 2a
+        const unsigned wd = a < 2 ? (a == 0 ? u.cy[0].y : u.cy[0].w) : (a == 2 ? u.cy[1].y : u.cy[1].w);  // dst 2a+1
+        float cu4[4], cd4[4];
+        tsx_fp8x4(wu, cu4);
+        tsx_fp8x4(wd, cd4);
 #pragma unroll
         for (int q = 0; q < NSIDE; ++q) {
-          const double zv = (tsx_inward(q) ? offS : offN) ? (double)u.zy[q] : 0.0;  // select: the unused slot may hold NaN
-          gu += (double)u.cy[a][q] * zv;
-          gd += (double)u.cy[a][4 + q] * zv;
+          const float zv = (tsx_inward(q) ? offS : offN) ? u.zy[q] : 0.0f;  // select: the unused slot may hold NaN
+          gu8 += cu4[q] * zv;
+          gd8 += cd4[q] * zv;
         }
       }
       if (XL) {
+        const unsigned wu = a < 2 ? (a == 0 ? u.cx[0].x : u.cx[0].z) : (a == 2 ? u.cx[1].x : u.cx[1].z);
+        const unsigned wd = a < 2 ? (a == 0 ? u.cx[0].y : u.cx[0].w) : (a == 2 ? u.cx[1].y : u.cx[1].w);
+        float cu4[4], cd4[4];
+        tsx_fp8x4(wu, cu4);
+        tsx_fp8x4(wd, cd4);
 #pragma unroll
         for (int q = 0; q < NSIDE; ++q) {
-          const double zv = (tsx_inward(q) ? offW : offE) ? (double)u.zx[q] : 0.0;
-          gu += (double)u.cx[a][q] * zv;
-          gd += (double)u.cx[a][4 + q] * zv;
+          const float zv = (tsx_inward(q) ? offW : offE) ? u.zx[q] : 0.0f;
+          gu8 += cu4[q] * zv;
+          gd8 += cd4[q] * zv;
         }
       }
-      ru[a] = u.r[2 * a] + (one ? 0.0 : gu);
-      rd[a] = u.r[2 * a + 1] + (one ? 0.0 : gd);
+      ru[a] = (double)u.r[2 * a] + (one ? 0.0 : (double)gu8 * (1.0 / TSX_FP8_SCALE));
+      rd[a] = (double)u.r[2 * a + 1] + (one ? 0.0 : (double)gd8 * (1.0 / TSX_FP8_SCALE));
     }
     double RA[H][H], G[H][H], GT[H][H], w[H], Gw[H], AGw[H], TA[H][H], An[H][H], Bn[H];
     SM::matmul(Rdu, A, RA);
@@ -948,13 +964,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int a = 0; a < H; ++a) w[a] += rd[a];
     SM::matvec(G, w, Gw);
     SM::matmul(G, Tdd, GT);
-    tmp[(size_t)0 * Nc + c] = make_float4((float)Gw[0], (float)Gw[1], (float)Gw[2], (float)Gw[3]);
+    tmp[(size_t)0 * Nc + c] = __builtin_bit_cast(uint4, make_float4((float)Gw[0], (float)Gw[1], (float)Gw[2], (float)Gw[3]));
 #pragma unroll
-    for (int a = 0; a < H; ++a) {
-      tmp[(size_t)(1 + a) * Nc + c] = make_float4((float)GT[a][0], (float)GT[a][1], (float)GT[a][2], (float)GT[a][3]);
-      tmp[(size_t)(5 + a) * Nc + c] = make_float4((float)A[a][0], (float)A[a][1], (float)A[a][2], (float)A[a][3]);
+    for (int a2 = 0; a2 < 2; ++a2) {  // two matrix rows per record
+      tmp[(size_t)(1 + a2) * Nc + c] =
+          make_uint4(tsx_to_h2((float)GT[2 * a2][0], (float)GT[2 * a2][1]), tsx_to_h2((float)GT[2 * a2][2], (float)GT[2 * a2][3]),
+                     tsx_to_h2((float)GT[2 * a2 + 1][0], (float)GT[2 * a2 + 1][1]), tsx_to_h2((float)GT[2 * a2 + 1][2], (float)GT[2 * a2 + 1][3]));
+      tmp[(size_t)(3 + a2) * Nc + c] =
+          make_uint4(tsx_to_h2((float)A[2 * a2][0], (float)A[2 * a2][1]), tsx_to_h2((float)A[2 * a2][2], (float)A[2 * a2][3]),
+                     tsx_to_h2((float)A[2 * a2 + 1][0], (float)A[2 * a2 + 1][1]), tsx_to_h2((float)A[2 * a2 + 1][2], (float)A[2 * a2 + 1][3]));
     }
-    tmp[(size_t)9 * Nc + c] = make_float4((float)B[0], (float)B[1], (float)B[2], (float)B[3]);
+    tmp[(size_t)5 * Nc + c] = __builtin_bit_cast(uint4, make_float4((float)B[0], (float)B[1], (float)B[2], (float)B[3]));
     SM::matvec(A, Gw, AGw);
 #pragma unroll
     for (int a = 0; a < H; ++a) AGw[a] += B[a];
@@ -996,20 +1016,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     TsxDnRawH d;
     const size_t c = (size_t)k * ncol + col;
 #pragma unroll
-    for (int dd = 0; dd < 8; ++dd) d.row[dd] = P[(size_t)(16 + dd) * Nc + c];
+    for (int dd = 0; dd < 8; ++dd) d.row[dd] = __builtin_bit_cast(tsx_h8, P[(size_t)(12 + dd) * Nc + c]);
 #pragma unroll
-    for (int q = 0; q < 10; ++q) d.t[q] = tmp[(size_t)q * Nc + c];
+    for (int q = 0; q < 6; ++q) d.t[q] = tmp[(size_t)q * Nc + c];
 #pragma unroll
     for (int q = 0; q < 8; ++q) d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
     if (GS) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) d.cy[m] = P[(size_t)(24 + m) * Nc + c];
+      for (int m = 0; m < 2; ++m) d.cy[m] = P[(size_t)(20 + m) * Nc + c];
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) d.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
     }
     if (XL) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) d.cx[m] = P[(size_t)(28 + m) * Nc + c];
+      for (int m = 0; m < 2; ++m) d.cx[m] = P[(size_t)(22 + m) * Nc + c];
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) d.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
     }
@@ -1026,7 +1046,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
   for (int a = 0; a < H; ++a) U[a] += B[a];
 
-  auto f4 = [](const float4 &v, int i) { return (double)(i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w); };
+  auto f4 = [](const uint4 &u, int i) {  // element i of a record of 4 floats
+    const float4 v = __builtin_bit_cast(float4, u);
+    return (double)(i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w);
+  };
+  auto h8 = [](const uint4 &u, int i) { return (double)__builtin_bit_cast(tsx_h8, u)[i]; };  // element i of 8 halves
   auto step_dn = [&](int k, const TsxDnRawH &d) {
     const size_t c = (size_t)k * ncol + col;
     bool one = false;
@@ -1036,14 +1060,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int a = 0; a < H; ++a) {
       double v = f4(d.t[0], a);
 #pragma unroll
-      for (int b = 0; b < H; ++b) v += f4(d.t[1 + a], b) * V[b];
+      for (int b = 0; b < H; ++b) v += h8(d.t[1 + (a >> 1)], (a & 1) * 4 + b) * V[b];
       Vn[a] = v;
     }
 #pragma unroll
     for (int a = 0; a < H; ++a) {  // U_{k+1} = A_{k+1} V_{k+1} + B_{k+1} (the surface closure is what the sweep started from)
-      double v = f4(d.t[9], a);
+      double v = f4(d.t[5], a);
 #pragma unroll
-      for (int b = 0; b < H; ++b) v += f4(d.t[5 + a], b) * Vn[b];
+      for (int b = 0; b < H; ++b) v += h8(d.t[3 + (a >> 1)], (a & 1) * 4 + b) * Vn[b];
       Un[a] = v;
     }
 #pragma unroll
@@ -1051,28 +1075,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       z[(size_t)(2 * a) * Nc + c] = (float)U[a];
       z[(size_t)(2 * a + 1) * Nc + c] = (float)Vn[a];
     }
-    double zy[NSIDE], zq[NSIDE];
+    float zy[NSIDE], zq[NSIDE];
     if (GS) {
 #pragma unroll
-      for (int q = 0; q < NSIDE; ++q) zy[q] = (tsx_inward(q) ? offS : offN) ? (double)d.zy[q] : 0.0;
+      for (int q = 0; q < NSIDE; ++q) zy[q] = (tsx_inward(q) ? offS : offN) ? d.zy[q] : 0.0f;
     }
     if (XL) {
 #pragma unroll
-      for (int q = 0; q < NSIDE; ++q) zq[q] = (tsx_inward(q) ? offW : offE) ? (double)d.zx[q] : 0.0;
+      for (int q = 0; q < NSIDE; ++q) zq[q] = (tsx_inward(q) ? offW : offE) ? d.zx[q] : 0.0f;
     }
+    const unsigned wy[8] = {d.cy[0].x, d.cy[0].y, d.cy[0].z, d.cy[0].w, d.cy[1].x, d.cy[1].y, d.cy[1].z, d.cy[1].w};
+    const unsigned wx[8] = {d.cx[0].x, d.cx[0].y, d.cx[0].z, d.cx[0].w, d.cx[1].x, d.cx[1].y, d.cx[1].z, d.cx[1].w};
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd) {
       double acc = 0.0;
 #pragma unroll
       for (int a = 0; a < H; ++a) acc += (double)d.row[dd][2 * a] * Un[a] + (double)d.row[dd][2 * a + 1] * V[a];
+      float a8 = 0.0f;
       if (GS) {
+        float cq[4];
+        tsx_fp8x4(wy[dd], cq);
 #pragma unroll
-        for (int q = 0; q < NSIDE; ++q) acc += (double)d.cy[dd >> 1][(dd & 1) * 4 + q] * zy[q];
+        for (int q = 0; q < NSIDE; ++q) a8 += cq[q] * zy[q];
       }
       if (XL) {
+        float cq[4];
+        tsx_fp8x4(wx[dd], cq);
 #pragma unroll
-        for (int q = 0; q < NSIDE; ++q) acc += (double)d.cx[dd >> 1][(dd & 1) * 4 + q] * zq[q];
+        for (int q = 0; q < NSIDE; ++q) a8 += cq[q] * zq[q];
       }
+      acc += (double)a8 * (1.0 / TSX_FP8_SCALE);
       z[(size_t)(NTOP + dd) * Nc + c] = (float)(d.rs[dd] + (one ? 0.0 : acc));
     }
 #pragma unroll

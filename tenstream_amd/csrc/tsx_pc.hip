@@ -43,11 +43,11 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
     } else {
       if (s->any_l1d)
         hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,
+                           (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,
                            (float4 *)s->pc_tmp, done);
       else
         hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const tsx_h8 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,
+                           (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,
                            (float4 *)s->pc_tmp, done);
     }
     HIPCHK(hipGetLastError());
