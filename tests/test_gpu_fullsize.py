@@ -11,19 +11,30 @@ pytestmark = pytest.mark.gpu
 DX, DZ, ALB = 100.0, 50.0, 0.1
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=2)
+def _fields(solver, Nx, Ny, Nz):
+    """host-side generation is the slow part on a busy box: do it once per configuration"""
+    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=20240611)
+    kabs, ksca, g = synthetic.delta_scale(kabs, ksca, g)
+    b = synthetic.solar_source(solver, kabs, ksca, g, DZ, DX, np.full((Ny, Nx), ALB))
+    return kabs, ksca, g, b
+
+
 def _solver(solver, Nx, Ny, Nz):
     import torch
 
     dev = torch.device("cuda", 0)
-    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=20240611)
-    kabs, ksca, g = synthetic.delta_scale(kabs, ksca, g)
+    kabs, ksca, g, b_host = _fields(solver, Nx, Ny, Nz)
     s = DiffuseSolver(solver, Nz, Nx, Ny)
     s.set_lut_diffuse(lut.synthetic_diffuse_table(solver), lut.diffuse_axes(solver))
     t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
     z = torch.zeros((Ny, Nx, Nz), dtype=torch.float64, device=dev)
     s.set_optprop(t(kabs), t(ksca), t(g), torch.full((Ny, Nx, Nz), DZ, dtype=torch.float64, device=dev), DX,
                   torch.zeros(Nz, dtype=torch.uint8, device=dev), z, z, torch.full((Ny, Nx), ALB, dtype=torch.float64, device=dev))
-    b = torch.tensor(synthetic.solar_source(solver, kabs, ksca, g, DZ, DX, np.full((Ny, Nx), ALB)), device=dev)
+    b = torch.tensor(b_host, device=dev)
     return s, b, dev
 
 
