@@ -446,11 +446,14 @@ static int set_aux(tsx_solver *s, const uint8_t *l1d, const double *a11, const d
   if (s->any_l1d) {
     if (!s->a11) HIPCHK(hipMalloc((void **)&s->a11, sizeof(double) * g.Nc));
     if (!s->a12) HIPCHK(hipMalloc((void **)&s->a12, sizeof(double) * g.Nc));
+    TsxDevTmp g11, g12;
     double *t11 = nullptr, *t12 = nullptr;
     const double *p11 = a11, *p12 = a12;
     if (where == TSX_HOST) {
-      HIPCHK(hipMalloc((void **)&t11, sizeof(double) * g.Nc));
-      HIPCHK(hipMalloc((void **)&t12, sizeof(double) * g.Nc));
+      HIPCHK(g11.alloc(sizeof(double) * g.Nc));
+      HIPCHK(g12.alloc(sizeof(double) * g.Nc));
+      t11 = g11.as<double>();
+      t12 = g12.as<double>();
       HIPCHK(hipMemcpyAsync(t11, a11, sizeof(double) * g.Nc, hipMemcpyHostToDevice, s->stream));
       HIPCHK(hipMemcpyAsync(t12, a12, sizeof(double) * g.Nc, hipMemcpyHostToDevice, s->stream));
       p11 = t11;
@@ -459,8 +462,6 @@ static int set_aux(tsx_solver *s, const uint8_t *l1d, const double *a11, const d
     hipLaunchKernelGGL(tsx_k_import_cellfield, dim3(grid_for(g.Nc)), dim3(TSX_BLOCK), 0, s->stream, g, p11, s->a11);
     hipLaunchKernelGGL(tsx_k_import_cellfield, dim3(grid_for(g.Nc)), dim3(TSX_BLOCK), 0, s->stream, g, p12, s->a12);
     HIPCHK(hipStreamSynchronize(s->stream));
-    if (t11) HIPCHK(hipFree(t11));
-    if (t12) HIPCHK(hipFree(t12));
   }
   HIPCHK(hipStreamSynchronize(s->stream));
   return TSX_OK;
@@ -523,7 +524,6 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
                        (const float *)src_dev, (float *)s->coef);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
-  if (tmp) HIPCHK(hipFree(tmp));
   s->have_coeffs = true;
   s->coef_h_valid = false;
   return TSX_OK;
@@ -661,19 +661,17 @@ extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const dou
   if ((rc = ensure_coef_storage(s, 4))) return rc;
   const size_t nb = sizeof(double) * gm.Nc;
   const double *p[4] = {kabs, ksca, g, dz};
-  double *tmp[4] = {nullptr, nullptr, nullptr, nullptr};
+  TsxDevTmp tmp[4];
   if (where == TSX_HOST) {
     for (int q = 0; q < 4; ++q) {
-      HIPCHK(hipMalloc((void **)&tmp[q], nb));
-      HIPCHK(hipMemcpyAsync(tmp[q], p[q], nb, hipMemcpyHostToDevice, s->stream));
-      p[q] = tmp[q];
+      HIPCHK(tmp[q].alloc(nb));
+      HIPCHK(hipMemcpyAsync(tmp[q].p, p[q], nb, hipMemcpyHostToDevice, s->stream));
+      p[q] = tmp[q].as<double>();
     }
   }
   lut_diffuse_launch(s, p[0], p[1], p[2], p[3], dx);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
-  for (int q = 0; q < 4; ++q)
-    if (tmp[q]) HIPCHK(hipFree(tmp[q]));
   s->have_coeffs = true;
   s->coef_h_valid = false;
   return TSX_OK;
@@ -690,9 +688,11 @@ extern "C" int tsx_diff_get_coeffs(tsx_solver *s, double *diff2diff, int where) 
   const int DD = g.D * g.D;
   const size_t ncoef = (size_t)DD * g.Nc;
   double *out = diff2diff;
+  TsxDevTmp tmp_guard;
   double *tmp = nullptr;
   if (where == TSX_HOST) {
-    HIPCHK(hipMalloc((void **)&tmp, ncoef * sizeof(double)));
+    HIPCHK(tmp_guard.alloc(ncoef * sizeof(double)));
+    tmp = tmp_guard.as<double>();
     out = tmp;
   }
   if (s->coef_bytes == 4)
@@ -704,7 +704,6 @@ extern "C" int tsx_diff_get_coeffs(tsx_solver *s, double *diff2diff, int where) 
   HIPCHK(hipGetLastError());
   if (where == TSX_HOST) HIPCHK(hipMemcpyAsync(diff2diff, tmp, ncoef * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
-  if (tmp) HIPCHK(hipFree(tmp));
   return TSX_OK;
 }
 

@@ -64,6 +64,19 @@ static inline int spmv_nblocks(const tsx_solver *s) {
   return spmv_split(s) ? nbmain + grid_for(frame_groups(s->geo, cpt), TSX_FRAME_BLOCKS) : nbmain;
 }
 
+// scratch device buffer that is released on every exit path (the HIPCHK / ARGCHK macros return early)
+struct TsxDevTmp {
+  void *p = nullptr;
+  TsxDevTmp() = default;
+  TsxDevTmp(const TsxDevTmp &) = delete;
+  TsxDevTmp &operator=(const TsxDevTmp &) = delete;
+  ~TsxDevTmp() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
 // ---- cross-unit entry points --------------------------------------------------------------------
 // face exchange on stream st (RCCL / host-staged callbacks / self copies), tsx_api.hip
 int tsx_face_exchange(tsx_solver *s, hipStream_t st);
