@@ -39,8 +39,9 @@ def parse():
     ap.add_argument("--ny", type=int, default=256, help="columns per GPU in y")
     ap.add_argument("--nz", type=int, default=64)
     ap.add_argument("--solver", default="3_10")
-    ap.add_argument("--pc", type=int, default=2, help="0 none, 1 column-block Jacobi, 2 zebra line-GS over column blocks")
-    ap.add_argument("--pc-sweeps", type=int, default=5)
+    ap.add_argument("--pc", type=int, default=3,
+                    help="0 none, 1 column-block Jacobi, 2 zebra line-GS over column blocks, 3 red-black GS over column blocks")
+    ap.add_argument("--pc-sweeps", type=int, default=9)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the CPU-baseline sample domain (columns); 0 = 256 with >= 16 threads, else 112")
@@ -175,7 +176,8 @@ def main():
                 "coeff_storage": "fp32 blocks (lossless), fp64 vectors",
                 "coeff_source": "device N-linear LUT interpolation (tsx_diff_set_optprop), synthetic table",
                 "coeff_setup_ms": t_setup * 1e3,
-                "preconditioner": {0: "none", 1: "column-jacobi", 2: f"column-zebra({args.pc_sweeps + 1} passes)"}.get(args.pc, str(args.pc)),
+                "preconditioner": {0: "none", 1: "column-jacobi", 2: f"column-zebra({args.pc_sweeps + 1} passes)",
+                                   3: f"column-red-black({args.pc_sweeps + 1} passes)"}.get(args.pc, str(args.pc)),
                 "iterations": info.niter,
                 "reason": info.reason,
                 "rel_residual": info.rnorm / info.rnorm0,

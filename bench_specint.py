@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--nx", type=int, default=256)
     ap.add_argument("--ny", type=int, default=256)
     ap.add_argument("--nz", type=int, default=64)
+    ap.add_argument("--pc-sweeps", type=int, default=0, help="0 = library default")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -85,7 +86,8 @@ def main():
         f = float(factors[q])
         lsolar = q < args.sw
         P.set_optical_properties(alb, kabs0 * f, ksca0 * f, g0, dz_d, planck=None if lsolar else planck0 * weights[q])
-        info = P.solve(1361.0 * weights[q] if lsolar else 0.0, lsolar=lsolar)
+        kw = dict(pc_sweeps=args.pc_sweeps) if args.pc_sweeps > 0 else {}
+        info = P.solve(1361.0 * weights[q] if lsolar else 0.0, lsolar=lsolar, **kw)
         P.get_result(out=tmp)
         for a, t in zip(acc, tmp):
             a += t

@@ -56,7 +56,10 @@ enum { TSX_SOLVER_3_10 = 310, TSX_SOLVER_8_16 = 816 };
 
 /* preconditioners for the flexible BiCGStab (reference default: PCILU / PCBJACOBI+ILU(0),
  * src/pprts.F90:4350-4371, 4415-4425; here GPU-native equivalents) */
-enum { TSX_PC_NONE = 0, TSX_PC_COLUMN = 1, TSX_PC_ZEBRA = 2 };
+/* NONE: bare operator.  COLUMN: exact column-block solves, block-Jacobi over the columns.  ZEBRA: the same blocks in
+ * Gauss-Seidel order over even / odd rows (+ lagged x coupling).  REDBLACK (default): checkerboard order, every pass a
+ * Gauss-Seidel step in x and y; 3_10 with fp32 directions and an even number of columns per row, else ZEBRA is used. */
+enum { TSX_PC_NONE = 0, TSX_PC_COLUMN = 1, TSX_PC_ZEBRA = 2, TSX_PC_REDBLACK = 3 };
 
 typedef struct tsx_solver tsx_solver; /* opaque */
 
@@ -81,7 +84,7 @@ typedef struct {
   double rtol, atol, dtol;
   int32_t maxit;
   int32_t pc;                 /* TSX_PC_* */
-  int32_t pc_sweeps;          /* sweeps of the preconditioner per application (>=1) */
+  int32_t pc_sweeps;          /* ZEBRA / REDBLACK: pc_sweeps + 1 half-grid passes per application; COLUMN: Jacobi sweeps (1..16) */
   int32_t check_every;        /* host looks at the device convergence flag every n iterations */
   int32_t fp32_directions;    /* 1 (default): preconditioned directions p-hat/s-hat and the shadow residual are stored in
                                  fp32 -- flexible BiCGStab accepts any direction; x, r, p, s, v, t stay fp64.  0: all fp64 */

@@ -14,7 +14,7 @@ t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
 s.set_optprop(t(kabs), t(ksca), t(g), torch.full((Ny, Nx, Nz), 50.0, dtype=torch.float64, device=dev), 100.0,
               torch.zeros(Nz, dtype=torch.uint8, device=dev), t(np.zeros_like(kabs)), t(np.zeros_like(kabs)), t(alb))
 x = torch.zeros_like(b)
-for pc, sw, mixed, h in ((2, 3, 1, 1), (2, 4, 1, 1), (2, 5, 1, 1), (2, 6, 1, 1), (2, 7, 1, 1), (2, 8, 1, 1)):
+for pc, sw, mixed, h in ((3, 5, 1, 1), (3, 7, 1, 1), (3, 8, 1, 1), (3, 9, 1, 1), (3, 10, 1, 1), (3, 11, 1, 1), (3, 13, 1, 1)):
     best = 1e9
     for rep in range(3):
         x.zero_(); info = s.solve(b, x, pc=pc, pc_sweeps=sw, fp32_directions=mixed, pc_coeff_fp16=h)

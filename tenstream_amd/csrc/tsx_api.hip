@@ -132,8 +132,8 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->atol = 1e-8;
   o->dtol = 1e4;    // PETSc KSP default divergence tolerance
   o->maxit = 1000;  // src/pprts_base.F90:1118
-  o->pc = TSX_PC_ZEBRA;  // this back-end's default preconditioner: 6 half-grid passes
-  o->pc_sweeps = 5;
+  o->pc = TSX_PC_REDBLACK;  // this back-end's default preconditioner: 10 half-grid passes
+  o->pc_sweeps = 9;
   o->check_every = 4;
   o->fp32_directions = 1;
   o->pc_coeff_fp16 = 1;
@@ -752,7 +752,7 @@ static int enqueue_iteration_t(tsx_solver *s, bool first) {
   int rc;
   if (!first) {
     hipLaunchKernelGGL(tsx_k_pupdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
-                       (double2 *)s->vp, (const double2 *)s->vv, (MIX && s->pc != TSX_PC_NONE) ? (float2 *)s->v32 : (float2 *)nullptr);
+                       (double2 *)s->vp, (const double2 *)s->vv, (MIX && s->pc != TSX_PC_NONE) ? (float2 *)s->v32 : (float2 *)nullptr, g, (int)s->pc_split);
   }
   const RT *rhat = (const RT *)s->vrhat;
   if (s->pc != TSX_PC_NONE) {
@@ -761,7 +761,7 @@ static int enqueue_iteration_t(tsx_solver *s, bool first) {
     if ((rc = launch_spmv<NTOP, NSIDE, 1, PT, RT>(s, ph, s->vv, rhat, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
     hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
-                       (const double2 *)s->vv, (double2 *)s->vs, MIX ? (float2 *)s->v32 : (float2 *)nullptr);
+                       (const double2 *)s->vv, (double2 *)s->vs, MIX ? (float2 *)s->v32 : (float2 *)nullptr, g, (int)s->pc_split);
     if ((rc = tsx_pc_apply(s, s->vs, sh, std::is_same<PT, float>::value, true))) return rc;
     if ((rc = launch_spmv<NTOP, NSIDE, 5, PT, double>(s, sh, s->vt, s->vs, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
@@ -771,7 +771,7 @@ static int enqueue_iteration_t(tsx_solver *s, bool first) {
     if ((rc = launch_spmv<NTOP, NSIDE, 1, double, RT>(s, s->vp, s->vv, rhat, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
     hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
-                       (const double2 *)s->vv, (double2 *)s->vs, (float2 *)nullptr);
+                       (const double2 *)s->vv, (double2 *)s->vs, (float2 *)nullptr, g, 0);
     if ((rc = launch_spmv<NTOP, NSIDE, 5, double, double>(s, s->vs, s->vt, s->vs, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
     hipLaunchKernelGGL((tsx_k_xrupdate<double, RT>), dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (double2 *)s->vx,
@@ -810,10 +810,10 @@ static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o, bool restart = fal
   const int nbv = grid_for(g.N);
   if (s->mixed)
     hipLaunchKernelGGL(tsx_k_residual0<float>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr,
-                       (float *)s->vrhat, s->vp, s->pc != TSX_PC_NONE ? s->v32 : (float *)nullptr, s->partials);
+                       (float *)s->vrhat, s->vp, s->pc != TSX_PC_NONE ? s->v32 : (float *)nullptr, s->partials, g, (int)s->pc_split);
   else
     hipLaunchKernelGGL(tsx_k_residual0<double>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr, s->vrhat,
-                       s->vp, (float *)nullptr, s->partials);
+                       s->vp, (float *)nullptr, s->partials, g, 0);
   if ((rc = scalar_stage(s, nbv, 2, TSX_STAGE_INIT))) return rc;
   return TSX_OK;
 }
@@ -911,8 +911,8 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   if (opts) *o = *opts;
   else tsx_default_ksp_opts(o);
   ARGCHK(o->maxit >= 1, "solve: maxit < 1");
-  ARGCHK(o->pc == TSX_PC_NONE || o->pc == TSX_PC_COLUMN || o->pc == TSX_PC_ZEBRA, "solve: unsupported preconditioner");
-  ARGCHK(o->pc_sweeps >= 1 && o->pc_sweeps <= 8, "solve: pc_sweeps out of range");
+  ARGCHK(o->pc >= TSX_PC_NONE && o->pc <= TSX_PC_REDBLACK, "solve: unsupported preconditioner");
+  ARGCHK(o->pc_sweeps >= 1 && o->pc_sweeps <= 16, "solve: pc_sweeps out of range");
   HIPCHK(hipSetDevice(s->device));
   s->pc = o->pc;
   s->pc_sweeps = o->pc_sweeps;
@@ -920,6 +920,14 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   // Jacobi refinement and pc_coeff_fp16 = 0 work on fp64 directions and the exact blocks
   s->mixed = o->fp32_directions != 0 && !(o->pc == TSX_PC_COLUMN && o->pc_sweeps > 1) &&
              (o->pc == TSX_PC_NONE || o->pc_coeff_fp16 != 0);
+  // red-black ordering exists for 3_10 on the packed path; it needs an even number of columns per row, and an even
+  // number of rows where the rank wraps onto itself in y (a periodic seam between equal colours) -- else zebra rows
+  if (s->pc == TSX_PC_REDBLACK) {
+    const TsxGeo &g = s->geo;
+    const bool ok = s->mixed && g.ntop == 2 && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0);
+    if (!ok) s->pc = TSX_PC_ZEBRA;
+  }
+  s->pc_split = s->pc == TSX_PC_REDBLACK;
   s->pc_half = false;
   if (o->pc != TSX_PC_NONE) {
     int rc = tsx_pc_ensure_buffers(s);
@@ -974,7 +982,7 @@ static int pc_apply_t(tsx_solver *s, const double *v, double *z, int where, bool
 
 extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps, int mixed) {
   ARGCHK(s && v && z, "tsx_diff_pc_apply: null argument");
-  ARGCHK((pc == TSX_PC_COLUMN || pc == TSX_PC_ZEBRA) && pc_sweeps >= 1 && pc_sweeps <= 8, "tsx_diff_pc_apply: bad preconditioner");
+  ARGCHK(pc >= TSX_PC_COLUMN && pc <= TSX_PC_REDBLACK && pc_sweeps >= 1 && pc_sweeps <= 16, "tsx_diff_pc_apply: bad preconditioner");
   if (!s->have_coeffs) {
     tsx_set_error("tsx_diff_pc_apply: call tsx_diff_set_coeffs first");
     return TSX_ERR_STATE;
@@ -982,6 +990,11 @@ extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int 
   HIPCHK(hipSetDevice(s->device));
   s->pc = pc;
   s->pc_sweeps = pc_sweeps;
+  if (s->pc == TSX_PC_REDBLACK) {  // same eligibility rule as prepare_ksp
+    const TsxGeo &g = s->geo;
+    if (!(mixed && g.ntop == 2 && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0))) s->pc = TSX_PC_ZEBRA;
+  }
+  s->pc_split = s->pc == TSX_PC_REDBLACK;
   int rc = tsx_pc_ensure_buffers(s);
   if (rc) return rc;
   s->pc_half = false;

@@ -120,3 +120,23 @@ template <> struct TsxRaw<double, 2> {
   static __device__ __forceinline__ type ld(const double *p) { return *reinterpret_cast<const double2 *>(p); }
   static __device__ __forceinline__ void cvt(type v, double *o) { o[0] = v.x; o[1] = v.y; }
 };
+
+// ---- colour-split order of the red-black preconditioner's private arrays: within a row of columns the xm/2 columns of
+// colour (i + j) & 1 == 0 first, then colour 1, so that a pass over one colour streams contiguous memory
+__host__ __device__ __forceinline__ long long tsx_split_col(int i, int j, int xm) {
+  return (long long)j * xm + (long long)((i + j) & 1) * (xm >> 1) + (i >> 1);
+}
+// position of element idx of an N-vector (D planes of Nc cells + D tail rows of ncol columns) in that order
+__device__ __forceinline__ long long tsx_split_pos(long long idx, const TsxGeo &g) {
+  const long long body = (long long)g.D * g.Nc;
+  if (idx < body) {
+    const long long d = idx / g.Nc, c = idx - d * g.Nc;
+    const int i = (int)(c % g.xm);
+    const long long t = c / g.xm;
+    const int j = (int)(t % g.ym);
+    return d * g.Nc + (t / g.ym) * g.ncol + tsx_split_col(i, j, g.xm);
+  }
+  const long long t = idx - body, d = t / g.ncol;
+  const int col = (int)(t - d * g.ncol);
+  return body + d * g.ncol + tsx_split_col(col % g.xm, col / g.xm, g.xm);
+}

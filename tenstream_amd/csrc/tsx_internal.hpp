@@ -70,6 +70,8 @@ struct tsx_solver {
   int coef_bytes;      // 4 or 8
   void *coef_h;        // packed fp16 copy of the blocks for the preconditioner (tsx_k_pack_p16; built in prepare_ksp)
   bool coef_h_valid, pc_half;
+  bool coef_h_split;   // layout of the packed copy: colour-split (red-black preconditioner) or natural
+  bool pc_split;       // the preconditioner's private arrays (packed blocks, fp32 rhs) are in colour-split order
   uint8_t *l1d;        // [Nz]
   double *a11, *a12;   // [Nc] cell-indexed (only read where l1d)
   double *albedo;      // [ncol]

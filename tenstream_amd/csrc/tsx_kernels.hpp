@@ -11,14 +11,15 @@ template <typename RT>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_residual0(long long n, const double *__restrict__ b,
                                                              const double *__restrict__ y, double *__restrict__ r,
                                                              RT *__restrict__ rhat, double *__restrict__ p,
-                                                             float *__restrict__ p32, double *__restrict__ partials) {
+                                                             float *__restrict__ p32, double *__restrict__ partials, TsxGeo g,
+                                                             int split) {
   double sum[2] = {0.0, 0.0};  // slot0 = (rhat, r) with rhat as stored, slot1 = (r, r)
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
     const double v = b[q] - y[q];
     r[q] = v;
     rhat[q] = (RT)v;
     p[q] = v;
-    if (p32) p32[q] = (float)v;  // what the fp32-direction preconditioner reads (see tsx_k_pupdate)
+    if (p32) p32[split ? tsx_split_pos(q, g) : q] = (float)v;  // what the fp32-direction preconditioner reads (see tsx_k_pupdate)
     sum[0] += (double)(RT)v * v;
     sum[1] += v * v;
   }
@@ -29,7 +30,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_residual0(long long n, const 
 // times per colour -- the preconditioner is an approximation anyway, the Krylov recurrence keeps the fp64 p
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pupdate(long long n2, const TsxScalars *__restrict__ sc,
                                                            const double2 *__restrict__ r, double2 *__restrict__ p,
-                                                           const double2 *__restrict__ v, float2 *__restrict__ p32) {
+                                                           const double2 *__restrict__ v, float2 *__restrict__ p32, TsxGeo g,
+                                                           int split) {
   if (sc->done) return;
   const double beta = sc->beta, omega = sc->omega;
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
@@ -38,14 +40,23 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pupdate(long long n2, const T
     o.x = rr.x + beta * (pp.x - omega * vv.x);
     o.y = rr.y + beta * (pp.y - omega * vv.y);
     p[q] = o;
-    if (p32) p32[q] = make_float2((float)o.x, (float)o.y);
+    if (p32) {
+      if (split) {  // colour-split order of the red-black preconditioner
+        float *f = reinterpret_cast<float *>(p32);
+        f[tsx_split_pos(2 * q, g)] = (float)o.x;
+        f[tsx_split_pos(2 * q + 1, g)] = (float)o.y;
+      } else {
+        p32[q] = make_float2((float)o.x, (float)o.y);
+      }
+    }
   }
 }
 
 // s = r - alpha v
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_supdate(long long n2, const TsxScalars *__restrict__ sc,
                                                            const double2 *__restrict__ r, const double2 *__restrict__ v,
-                                                           double2 *__restrict__ s, float2 *__restrict__ s32) {
+                                                           double2 *__restrict__ s, float2 *__restrict__ s32, TsxGeo g,
+                                                           int split) {
   if (sc->done) return;
   const double alpha = sc->alpha;
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
@@ -54,7 +65,15 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_supdate(long long n2, const T
     o.x = rr.x - alpha * vv.x;
     o.y = rr.y - alpha * vv.y;
     s[q] = o;
-    if (s32) s32[q] = make_float2((float)o.x, (float)o.y);
+    if (s32) {
+      if (split) {
+        float *f = reinterpret_cast<float *>(s32);
+        f[tsx_split_pos(2 * q, g)] = (float)o.x;
+        f[tsx_split_pos(2 * q + 1, g)] = (float)o.y;
+      } else {
+        s32[q] = make_float2((float)o.x, (float)o.y);
+      }
+    }
   }
 }
 

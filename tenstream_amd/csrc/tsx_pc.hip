@@ -101,6 +101,55 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
   const TsxGeo &g = s->geo;
   const int *done = in_solve ? &s->scal->done : nullptr;
   int rc;
+  if constexpr (NTOP == 2 && std::is_same<ZT, float>::value) {
+    if (s->pc == TSX_PC_REDBLACK) {
+      // pc_sweeps + 1 passes, colours alternately; the iterate lives colour-split in s->vw; the last pass of each colour
+      // also writes the Krylov-layout result z
+      if (!s->pc_half || !s->v32 || !s->coef_h_split) {
+        tsx_set_error("preconditioner: red-black ordering needs the colour-split packed blocks (internal state error)");
+        return TSX_ERR_STATE;
+      }
+      const int P = s->pc_sweeps + 1;
+      float *zs = (float *)s->vw;
+      const int nb = (g.ym * (g.xm / 2) + 63) / 64;
+      const size_t lds = (size_t)g.Nz * 64 * sizeof(float4);
+      static int use_lds = -1;
+      if (use_lds < 0) {
+        const char *e = getenv("TSX_PC_LDS");
+        use_lds = e ? atoi(e) : 1;
+      }
+      const bool ld = use_lds && lds <= (size_t)s->max_lds;
+#define TSX_RB_LAUNCH(GSV, HAS, LDSV, FIN)                                                                                      \
+  hipLaunchKernelGGL((tsx_k_pc_column_rb<GSV, HAS, LDSV, FIN>), dim3(nb), dim3(64), LDSV ? lds : 0, s->stream, g,                \
+                     (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, zs,                    \
+                     (const float *)zs, (float *)z, (float4 *)s->pc_tmp, done, pass & 1)
+#define TSX_RB_L2(GSV, HAS, FIN)                                                                                                \
+  do {                                                                                                                          \
+    if (ld) TSX_RB_LAUNCH(GSV, HAS, true, FIN);                                                                                 \
+    else TSX_RB_LAUNCH(GSV, HAS, false, FIN);                                                                                   \
+  } while (0)
+#define TSX_RB_L1(GSV, FIN)                                                                                                     \
+  do {                                                                                                                          \
+    if (s->any_l1d) TSX_RB_L2(GSV, true, FIN);                                                                                  \
+    else TSX_RB_L2(GSV, false, FIN);                                                                                            \
+  } while (0)
+      for (int pass = 0; pass < P; ++pass) {
+        const bool fin = pass >= P - 2;
+        if (pass == 0) {
+          if (fin) TSX_RB_L1(false, true);
+          else TSX_RB_L1(false, false);
+        } else {
+          if (fin) TSX_RB_L1(true, true);
+          else TSX_RB_L1(true, false);
+        }
+      }
+#undef TSX_RB_L1
+#undef TSX_RB_L2
+#undef TSX_RB_LAUNCH
+      HIPCHK(hipGetLastError());
+      return TSX_OK;
+    }
+  }
   if (s->pc == TSX_PC_ZEBRA) {
     const int P = s->pc_sweeps + 1;
     ZT *alt = (ZT *)s->vw;
@@ -159,10 +208,11 @@ int tsx_pc_ensure_half(tsx_solver *s) {
   const bool h1 = s->geo.ntop == 2;
   const long long n = (long long)(h1 ? TSX_P16_GROUPS : TSX_P16H_GROUPS) * s->geo.Nc;
   if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
-  if (!s->coef_h_valid) {
+  if (!s->coef_h_valid || s->coef_h_split != s->pc_split) {
+    const int sx = s->pc_split ? s->geo.xm : 0, sy = s->pc_split ? s->geo.ym : 0;
 #define TSX_PACK(CTYPE, NT)                                                                                        \
   hipLaunchKernelGGL((tsx_k_pack_p16<CTYPE, NT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, s->geo.Nc,      \
-                     (const CTYPE *)s->coef, (uint4 *)s->coef_h)
+                     (const CTYPE *)s->coef, (uint4 *)s->coef_h, sx, sy)
     if (s->coef_bytes == 4) {
       if (h1) TSX_PACK(float, 2);
       else TSX_PACK(float, 8);
@@ -173,6 +223,7 @@ int tsx_pc_ensure_half(tsx_solver *s) {
 #undef TSX_PACK
     HIPCHK(hipGetLastError());
     s->coef_h_valid = true;
+    s->coef_h_split = s->pc_split;
   }
   s->pc_half = true;
   return TSX_OK;
@@ -188,7 +239,7 @@ int tsx_pc_apply(tsx_solver *s, const double *v, void *z, bool z_is_float, bool 
 }
 
 int tsx_pc_narrow(tsx_solver *s, const double *a) {  // s->v32 = (float) a: the mixed path's right-hand side
-  hipLaunchKernelGGL(tsx_k_narrow, dim3(grid_for(s->geo.N)), dim3(TSX_BLOCK), 0, s->stream, s->geo.N, a, s->v32);
+  hipLaunchKernelGGL(tsx_k_narrow, dim3(grid_for(s->geo.N)), dim3(TSX_BLOCK), 0, s->stream, s->geo, (int)s->pc_split, a, s->v32);
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }

@@ -16,10 +16,10 @@ module m_pprts_hip
   private
   public :: t_tsx_grid, t_tsx_ksp_opts, t_tsx_ksp_result, &
     & hip_diff_create, hip_diff_destroy, hip_diff_set_coeffs, hip_ediff, hip_diff_apply, hip_last_error, &
-    & TSX_HOST, TSX_DEVICE, TSX_PC_NONE, TSX_PC_COLUMN, TSX_PC_ZEBRA
+    & TSX_HOST, TSX_DEVICE, TSX_PC_NONE, TSX_PC_COLUMN, TSX_PC_ZEBRA, TSX_PC_REDBLACK
 
   integer(c_int), parameter :: TSX_HOST = 0, TSX_DEVICE = 1
-  integer(c_int), parameter :: TSX_PC_NONE = 0, TSX_PC_COLUMN = 1, TSX_PC_ZEBRA = 2
+  integer(c_int), parameter :: TSX_PC_NONE = 0, TSX_PC_COLUMN = 1, TSX_PC_ZEBRA = 2, TSX_PC_REDBLACK = 3
 
   ! mirrors tsx_grid (include/tsx.h) == the fields of t_coord the back-end needs (src/pprts_base.F90:92-109)
   type, bind(C) :: t_tsx_grid
@@ -163,6 +163,7 @@ contains
     opts%maxit = maxit
     opts%pc = pc
     if (pc .eq. TSX_PC_ZEBRA) opts%pc_sweeps = 5
+    if (pc .eq. TSX_PC_REDBLACK) opts%pc_sweeps = 9
     ierr = tsx_diff_solve(handle, c_loc(vb), c_loc(vediff), TSX_HOST, opts, res)
     niter = res%niter
     reason = res%reason

@@ -36,7 +36,7 @@ program test_shim
   b = 0.01_c_double; b(2, 1, :, :) = 1._c_double   ! diffuse light entering at TOA (Edn at level 0) + weak sources
   b(3:, Nz + 1, :, :) = 0; b(3:, 1:2, :, :) = 0     ! identity rows (bottom side dummies, 1-D layers) carry no source
   x = 0; hist = -1
-  call hip_ediff(h, b, x, 1e-10_c_double, 1e-30_c_double, 1000_c_int, TSX_PC_ZEBRA, niter, hist, reason, ierr)
+  call hip_ediff(h, b, x, 1e-10_c_double, 1e-30_c_double, 1000_c_int, TSX_PC_REDBLACK, niter, hist, reason, ierr)
   if (ierr .ne. 0) then
     print *, 'solve failed ierr=', ierr, ' reason=', reason, ' ', hip_last_error()
     stop 4

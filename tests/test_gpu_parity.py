@@ -127,6 +127,50 @@ def test_solve_default_tolerances_and_warm_start(gpu):
     assert info2.niter < info.niter and info2.reason in (2, 3)
 
 
+@pytest.mark.parametrize("Nx,Ny,Nz,n1d", [(8, 6, 6, 1), (6, 8, 5, 0), (12, 4, 7, 0)])
+@pytest.mark.parametrize("sweeps", [1, 2, 3, 5])
+def test_red_black_preconditioner_is_checkerboard_gauss_seidel(gpu, Nx, Ny, Nz, n1d, sweeps):
+    """TSX_PC_REDBLACK = Gauss-Seidel over the column blocks in checkerboard order: colour (i + j) & 1 == 0, then 1, ...;
+    each pass an exact column-block solve with *all* couplings to the other colour (x and y) on the right-hand side.
+    Only the reduced-precision path exists (fp16 block, fp8 couplings, fp32 iterate): compared at 6 % of max."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
+    lay = O.layout("3_10", Nz, Nx, Ny)
+    M, A = _column_block_matrix(P, lay)
+    D, L = lay.D, Nz + 1
+    idx = np.arange(A.shape[0])
+    d, k = idx % D, (idx // D) % L
+    i, j = (idx // (D * L)) % Nx, idx // (D * L * Nx)
+    oi, oj = i.copy(), j.copy()
+    qx, qy = d - lay.ntop, d - lay.ntop - lay.nside
+    mx = (qx >= 0) & (qx < lay.nside) & (qx % 2 == 1) & (k < Nz)
+    my = (qy >= 0) & (qy < lay.nside) & (qy % 2 == 1) & (k < Nz)
+    oi[mx] = (i[mx] - 1) % Nx
+    oj[my] = (j[my] - 1) % Ny
+    colour = (oi + oj) % 2
+    Noff = (A - M.tocsr()).tocsr()
+    lu = spla.splu(M.tocsc(), permc_spec="NATURAL")
+    v = np.random.default_rng(4).standard_normal(P["b"].shape)
+    x = np.zeros(v.size)
+    for p_ in range(sweeps + 1):
+        rhs = v.ravel() - (Noff @ x if p_ > 0 else 0.0)
+        mk = colour == (p_ % 2)
+        x[mk] = lu.solve(rhs)[mk]
+    s = DiffuseSolver("3_10", Nz, Nx, Ny)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    z = s.pc_apply(v, pc=3, sweeps=sweeps, mixed=True)
+    assert np.abs(z.ravel() - x).max() <= 6e-2 * np.abs(x).max()
+    # and it preconditions the solve to the same fixed point, in no more iterations than zebra rows
+    xs, xz = np.zeros(s.vec_shape), np.zeros(s.vec_shape)
+    ir = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30, pc=3, pc_sweeps=sweeps)
+    iz = s.solve(P["b"], xz, rtol=1e-10, atol=1e-30, pc=2, pc_sweeps=sweeps)
+    assert ir.reason == 2 and ir.niter <= iz.niter + 1
+    assert np.abs(xs - xz).max() <= 1e-8 * np.abs(xz).max()
+    s.close()
+
+
 def test_stop_rule_reason_codes_like_MyKSPConverged(gpu):
     """Diverged reasons of MyKSPConverged (src/pprts.F90:4437-4486): -3 iteration limit, -9 NaN; the oracle's restatement
     of KSPFBCGS gives the same reason and iteration count for the bare operator."""
