@@ -77,3 +77,39 @@ for name, col, order in (
     if VARIANTS and not any(v in name for v in VARIANTS.split(",")):
         continue
     print(f"{name:22s} its {fbcgs(gs_passes(col, order))}", flush=True)
+
+
+# ---- which outer iteration makes best use of one preconditioner application? ---------------------------------
+def richardson(Minv, rtol=1e-5, maxit=200):
+    x = np.zeros(n); r = b.copy(); r0 = np.linalg.norm(r)
+    for it in range(1, maxit + 1):
+        x += Minv(r); r = b - A @ x
+        if np.linalg.norm(r) / r0 <= rtol:
+            return it
+    return maxit
+
+
+def fgmres(Minv, rtol=1e-5, maxit=200, m=30):
+    x = np.zeros(n); r = b.copy(); r0 = np.linalg.norm(r); apps = 0
+    while apps < maxit:
+        beta = np.linalg.norm(r); V = [r / beta]; Z = []; H = np.zeros((m + 1, m)); g = np.zeros(m + 1); g[0] = beta
+        for jj in range(m):
+            z = Minv(V[jj]); apps += 1; Z.append(z); w = A @ z
+            for ii in range(jj + 1):
+                H[ii, jj] = V[ii] @ w; w -= H[ii, jj] * V[ii]
+            H[jj + 1, jj] = np.linalg.norm(w); V.append(w / H[jj + 1, jj])
+            y, res, *_ = np.linalg.lstsq(H[: jj + 2, : jj + 1], g[: jj + 2], rcond=None)
+            rn = np.linalg.norm(H[: jj + 2, : jj + 1] @ y - g[: jj + 2])
+            if rn / r0 <= rtol or jj == m - 1:
+                x += sum(yk * zk for yk, zk in zip(y, Z)); r = b - A @ x
+                break
+        if np.linalg.norm(r) / r0 <= rtol:
+            return apps
+    return apps
+
+
+if os.environ.get("OUTER"):
+    print("outer iterations with red-black passes as M^-1 (preconditioner applications to rtol 1e-5):")
+    for P_ in (6, 10, 14):
+        Minv = gs_passes(rb, [q % 2 for q in range(P_)])
+        print(f"  {P_:2d} passes: BiCGStab {2 * fbcgs(Minv):3d} apps | FGMRES {fgmres(Minv):3d} apps | Richardson {richardson(Minv):3d} apps", flush=True)
