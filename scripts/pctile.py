@@ -16,6 +16,6 @@ for tile in os.environ.get("TILES", "0,0;128,128;128,64;64,64;32,32").split(";")
     s.set_optprop(t(kabs), t(ksca), t(g), torch.full((Ny, Nx, Nz), 50.0, dtype=torch.float64, device=dev), 100.0,
                   torch.zeros(Nz, dtype=torch.uint8, device=dev), t(np.zeros_like(kabs)), t(np.zeros_like(kabs)), t(alb))
     x = torch.zeros_like(b)
-    info = s.solve(b, x, pc=2, pc_sweeps=5)
+    info = s.solve(b, x, pc=int(os.environ.get("PC", 3)), pc_sweeps=int(os.environ.get("SWEEPS", 9)))
     print(json.dumps(dict(tile=tile, its=info.niter, solve_ms=info.solve_ms, reason=info.reason)))
     s.close()
