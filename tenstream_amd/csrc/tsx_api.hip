@@ -920,11 +920,11 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   // Jacobi refinement and pc_coeff_fp16 = 0 work on fp64 directions and the exact blocks
   s->mixed = o->fp32_directions != 0 && !(o->pc == TSX_PC_COLUMN && o->pc_sweeps > 1) &&
              (o->pc == TSX_PC_NONE || o->pc_coeff_fp16 != 0);
-  // red-black ordering exists for 3_10 on the packed path; it needs an even number of columns per row, and an even
+  // red-black ordering exists on the packed path; it needs an even number of columns per row, and an even
   // number of rows where the rank wraps onto itself in y (a periodic seam between equal colours) -- else zebra rows
   if (s->pc == TSX_PC_REDBLACK) {
     const TsxGeo &g = s->geo;
-    const bool ok = s->mixed && g.ntop == 2 && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0);
+    const bool ok = s->mixed && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0);
     if (!ok) s->pc = TSX_PC_ZEBRA;
   }
   s->pc_split = s->pc == TSX_PC_REDBLACK;
@@ -992,7 +992,7 @@ extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int 
   s->pc_sweeps = pc_sweeps;
   if (s->pc == TSX_PC_REDBLACK) {  // same eligibility rule as prepare_ksp
     const TsxGeo &g = s->geo;
-    if (!(mixed && g.ntop == 2 && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0))) s->pc = TSX_PC_ZEBRA;
+    if (!(mixed && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0))) s->pc = TSX_PC_ZEBRA;
   }
   s->pc_split = s->pc == TSX_PC_REDBLACK;
   int rc = tsx_pc_ensure_buffers(s);

@@ -1394,6 +1394,308 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   for (int d = NTOP; d < D; ++d) zt[(size_t)d * ncol + col] = (float)rt[(size_t)d * ncol + col];
 }
 
+// 8_16 in red-black order: tsx_k_pc_column_p16h with the index mapping of tsx_k_pc_column_rb (colour-split private
+// arrays, natural-layout output only in the FINAL pass of a colour)
+template <bool GS, bool HAS1D, bool FINAL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void tsx_k_pc_column_rbh(
+    TsxGeo g, const uint4 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
+    const double *__restrict__ a12, const double *__restrict__ albedo, const float *__restrict__ r, float *__restrict__ z,
+    const float *__restrict__ zc, float *__restrict__ zfin, float4 *__restrict__ tmp_, const int *__restrict__ done, int rbc) {
+  constexpr int D = 16, NTOP = 8, NSIDE = 4, H = 4;
+  constexpr bool XL = GS;
+  const float *__restrict__ zx = zc;
+  uint4 *__restrict__ tmp = reinterpret_cast<uint4 *>(tmp_);
+  constexpr int PU = 2, PD = 1;
+  using SM = TsxSm<H>;
+  if (done && *done) return;
+  const int h = g.xm >> 1;
+  const int t_ = blockIdx.x * 64 + threadIdx.x;
+  if (t_ >= g.ym * h) return;
+  const long long Nc = g.Nc;
+  const int Nz = g.Nz, ncol = g.ncol;
+  const int jrow = t_ / h, qh = t_ - jrow * h;
+  const int par = (jrow + rbc) & 1;
+  const int icol = 2 * qh + par;
+  const int ncl = jrow * g.xm + icol;          // natural column index
+  const int col = jrow * g.xm + rbc * h + qh;  // colour-split column index
+  const long long oc = (long long)(1 - 2 * rbc) * h;
+  const int jn = jrow + 1 < g.ym ? jrow + 1 : (g.wrap_y ? 0 : -1), js = jrow > 0 ? jrow - 1 : (g.wrap_y ? g.ym - 1 : -1);
+  const int qw = par ? qh : (qh > 0 ? qh - 1 : (g.wrap_x ? h - 1 : -1)), qe = par ? (qh + 1 < h ? qh + 1 : (g.wrap_x ? 0 : -1)) : qh;
+  const long long offN = jn >= 0 ? (long long)(jn - jrow) * g.xm + oc : 0;
+  const long long offS = js >= 0 ? (long long)(js - jrow) * g.xm + oc : 0;
+  const long long offE = qe >= 0 ? oc + (qe - qh) : 0;
+  const long long offW = qw >= 0 ? oc + (qw - qh) : 0;
+  const float *__restrict__ rt = r + (size_t)D * Nc;
+  float *__restrict__ zt = z + (size_t)D * Nc;
+  float *__restrict__ zft = FINAL ? zfin + (size_t)D * Nc : nullptr;
+  const double albh = albedo[ncl] / (double)H;  // assembled surface row: albedo/streams on every pair
+
+  auto load_up = [&](int k) {
+    TsxUpRawH u;
+    const size_t c = (size_t)k * ncol + col;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) u.row[t] = __builtin_bit_cast(tsx_h8, P[(size_t)t * Nc + c]);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) u.r[t] = r[(size_t)t * Nc + c];
+    if (GS) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) u.cy[m] = P[(size_t)(8 + m) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) u.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
+    }
+    if (XL) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) u.cx[m] = P[(size_t)(10 + m) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) u.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
+    }
+    if (HAS1D) {
+      u.t11 = a11[(size_t)k * ncol + ncl];
+      u.t12 = a12[(size_t)k * ncol + ncl];
+    }
+    return u;
+  };
+
+  double A[H][H], B[H];
+#pragma unroll
+  for (int a = 0; a < H; ++a) {
+    B[a] = rt[(size_t)(2 * a) * ncol + col];
+#pragma unroll
+    for (int b = 0; b < H; ++b) A[a][b] = albh;
+  }
+  auto step_up = [&](int k, const TsxUpRawH &u) {
+    const size_t c = (size_t)k * ncol + col;
+    bool one = false;
+    if (HAS1D) one = l1d[k] != 0;
+    double Tuu[H][H], Rud[H][H], Rdu[H][H], Tdd[H][H], ru[H], rd[H];
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+#pragma unroll
+      for (int b = 0; b < H; ++b) {
+        const double dg = a == b ? 1.0 : 0.0;
+        Tuu[a][b] = one ? dg * u.t11 : (double)u.row[2 * a][2 * b];
+        Rud[a][b] = one ? dg * u.t12 : (double)u.row[2 * a][2 * b + 1];
+        Rdu[a][b] = one ? dg * u.t12 : (double)u.row[2 * a + 1][2 * b];
+        Tdd[a][b] = one ? dg * u.t11 : (double)u.row[2 * a + 1][2 * b + 1];
+      }
+      float gu8 = 0.0f, gd8 = 0.0f;  // coupling sums in fp8 units (x TSX_FP8_SCALE)
+      if (GS) {
+        const unsigned wu = a < 2 ? (a == 0 ? u.cy[0].x : u.cy[0].z) : (a == 2 ? u.cy[1].x : u.cy[1].z);  // dst 2a
+        const unsigned wd = a < 2 ? (a == 0 ? u.cy[0].y : u.cy[0].w) : (a == 2 ? u.cy[1].y : u.cy[1].w);  // dst 2a+1
+        float cu4[4], cd4[4];
+        tsx_fp8x4(wu, cu4);
+        tsx_fp8x4(wd, cd4);
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) {
+          const float zv = (tsx_inward(q) ? offS : offN) ? u.zy[q] : 0.0f;  // select: the unused slot may hold NaN
+          gu8 += cu4[q] * zv;
+          gd8 += cd4[q] * zv;
+        }
+      }
+      if (XL) {
+        const unsigned wu = a < 2 ? (a == 0 ? u.cx[0].x : u.cx[0].z) : (a == 2 ? u.cx[1].x : u.cx[1].z);
+        const unsigned wd = a < 2 ? (a == 0 ? u.cx[0].y : u.cx[0].w) : (a == 2 ? u.cx[1].y : u.cx[1].w);
+        float cu4[4], cd4[4];
+        tsx_fp8x4(wu, cu4);
+        tsx_fp8x4(wd, cd4);
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) {
+          const float zv = (tsx_inward(q) ? offW : offE) ? u.zx[q] : 0.0f;
+          gu8 += cu4[q] * zv;
+          gd8 += cd4[q] * zv;
+        }
+      }
+      ru[a] = (double)u.r[2 * a] + (one ? 0.0 : (double)gu8 * (1.0 / TSX_FP8_SCALE));
+      rd[a] = (double)u.r[2 * a + 1] + (one ? 0.0 : (double)gd8 * (1.0 / TSX_FP8_SCALE));
+    }
+    double RA[H][H], G[H][H], GT[H][H], w[H], Gw[H], AGw[H], TA[H][H], An[H][H], Bn[H];
+    SM::matmul(Rdu, A, RA);
+    SM::inv_i_minus(RA, G);
+    SM::matvec(Rdu, B, w);
+#pragma unroll
+    for (int a = 0; a < H; ++a) w[a] += rd[a];
+    SM::matvec(G, w, Gw);
+    SM::matmul(G, Tdd, GT);
+    tmp[(size_t)0 * Nc + c] = __builtin_bit_cast(uint4, make_float4((float)Gw[0], (float)Gw[1], (float)Gw[2], (float)Gw[3]));
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2) {  // two matrix rows per record
+      tmp[(size_t)(1 + a2) * Nc + c] =
+          make_uint4(tsx_to_h2((float)GT[2 * a2][0], (float)GT[2 * a2][1]), tsx_to_h2((float)GT[2 * a2][2], (float)GT[2 * a2][3]),
+                     tsx_to_h2((float)GT[2 * a2 + 1][0], (float)GT[2 * a2 + 1][1]), tsx_to_h2((float)GT[2 * a2 + 1][2], (float)GT[2 * a2 + 1][3]));
+      tmp[(size_t)(3 + a2) * Nc + c] =
+          make_uint4(tsx_to_h2((float)A[2 * a2][0], (float)A[2 * a2][1]), tsx_to_h2((float)A[2 * a2][2], (float)A[2 * a2][3]),
+                     tsx_to_h2((float)A[2 * a2 + 1][0], (float)A[2 * a2 + 1][1]), tsx_to_h2((float)A[2 * a2 + 1][2], (float)A[2 * a2 + 1][3]));
+    }
+    tmp[(size_t)5 * Nc + c] = __builtin_bit_cast(uint4, make_float4((float)B[0], (float)B[1], (float)B[2], (float)B[3]));
+    SM::matvec(A, Gw, AGw);
+#pragma unroll
+    for (int a = 0; a < H; ++a) AGw[a] += B[a];
+    SM::matvec(Tuu, AGw, Bn);
+    SM::matmul(Tuu, A, TA);
+    SM::matmul(TA, GT, An);
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      B[a] = Bn[a] + ru[a];
+#pragma unroll
+      for (int b = 0; b < H; ++b) A[a][b] = An[a][b] + Rud[a][b];
+    }
+  };
+
+  // ---- upward sweep
+  {
+    int k = Nz - 1;
+    for (int rr = Nz % PU; rr > 0; --rr, --k) {
+      const TsxUpRawH u = load_up(k);
+      step_up(k, u);
+    }
+    if (k >= 0) {
+      TsxUpRawH q[PU];
+#pragma unroll
+      for (int p = 0; p < PU; ++p) q[p] = load_up(k - p);
+      for (; k >= 0; k -= PU) {
+#pragma unroll
+        for (int p = 0; p < PU; ++p) {
+          const TsxUpRawH cu = q[p];
+          const int kn = k - p - PU;
+          q[p] = load_up(kn >= 0 ? kn : 0);
+          step_up(k - p, cu);
+        }
+      }
+    }
+  }
+
+  auto load_dn = [&](int k) {
+    TsxDnRawH d;
+    const size_t c = (size_t)k * ncol + col;
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) d.row[dd] = __builtin_bit_cast(tsx_h8, P[(size_t)(12 + dd) * Nc + c]);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) d.t[q] = tmp[(size_t)q * Nc + c];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+    if (GS) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) d.cy[m] = P[(size_t)(20 + m) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) d.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
+    }
+    if (XL) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) d.cx[m] = P[(size_t)(22 + m) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) d.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
+    }
+    return d;
+  };
+
+  double V[H], U[H];
+#pragma unroll
+  for (int a = 0; a < H; ++a) {
+    V[a] = rt[(size_t)(2 * a + 1) * ncol + col];  // V_0 = rd_0 (TOA identity rows)
+    zt[(size_t)(2 * a + 1) * ncol + col] = (float)V[a];
+    if (FINAL) zft[(size_t)(2 * a + 1) * ncol + ncl] = (float)V[a];
+  }
+  SM::matvec(A, V, U);  // A, B hold level 0
+#pragma unroll
+  for (int a = 0; a < H; ++a) U[a] += B[a];
+
+  auto f4 = [](const uint4 &u, int i) {  // element i of a record of 4 floats
+    const float4 v = __builtin_bit_cast(float4, u);
+    return (double)(i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w);
+  };
+  auto h8 = [](const uint4 &u, int i) { return (double)__builtin_bit_cast(tsx_h8, u)[i]; };  // element i of 8 halves
+  auto step_dn = [&](int k, const TsxDnRawH &d) {
+    const size_t c = (size_t)k * ncol + col;
+    bool one = false;
+    if (HAS1D) one = l1d[k] != 0;
+    double Vn[H], Un[H];
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      double v = f4(d.t[0], a);
+#pragma unroll
+      for (int b = 0; b < H; ++b) v += h8(d.t[1 + (a >> 1)], (a & 1) * 4 + b) * V[b];
+      Vn[a] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < H; ++a) {  // U_{k+1} = A_{k+1} V_{k+1} + B_{k+1} (the surface closure is what the sweep started from)
+      double v = f4(d.t[5], a);
+#pragma unroll
+      for (int b = 0; b < H; ++b) v += h8(d.t[3 + (a >> 1)], (a & 1) * 4 + b) * Vn[b];
+      Un[a] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      z[(size_t)(2 * a) * Nc + c] = (float)U[a];
+      z[(size_t)(2 * a + 1) * Nc + c] = (float)Vn[a];
+      if (FINAL) {
+        zfin[(size_t)(2 * a) * Nc + (size_t)k * ncol + ncl] = (float)U[a];
+        zfin[(size_t)(2 * a + 1) * Nc + (size_t)k * ncol + ncl] = (float)Vn[a];
+      }
+    }
+    float zy[NSIDE], zq[NSIDE];
+    if (GS) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) zy[q] = (tsx_inward(q) ? offS : offN) ? d.zy[q] : 0.0f;
+    }
+    if (XL) {
+#pragma unroll
+      for (int q = 0; q < NSIDE; ++q) zq[q] = (tsx_inward(q) ? offW : offE) ? d.zx[q] : 0.0f;
+    }
+    const unsigned wy[8] = {d.cy[0].x, d.cy[0].y, d.cy[0].z, d.cy[0].w, d.cy[1].x, d.cy[1].y, d.cy[1].z, d.cy[1].w};
+    const unsigned wx[8] = {d.cx[0].x, d.cx[0].y, d.cx[0].z, d.cx[0].w, d.cx[1].x, d.cx[1].y, d.cx[1].z, d.cx[1].w};
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) {
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < H; ++a) acc += (double)d.row[dd][2 * a] * Un[a] + (double)d.row[dd][2 * a + 1] * V[a];
+      float a8 = 0.0f;
+      if (GS) {
+        float cq[4];
+        tsx_fp8x4(wy[dd], cq);
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) a8 += cq[q] * zy[q];
+      }
+      if (XL) {
+        float cq[4];
+        tsx_fp8x4(wx[dd], cq);
+#pragma unroll
+        for (int q = 0; q < NSIDE; ++q) a8 += cq[q] * zq[q];
+      }
+      acc += (double)a8 * (1.0 / TSX_FP8_SCALE);
+      const float zo = (float)(d.rs[dd] + (one ? 0.0 : acc));
+      z[(size_t)(NTOP + dd) * Nc + c] = zo;
+      if (FINAL) zfin[(size_t)(NTOP + dd) * Nc + (size_t)k * ncol + ncl] = zo;
+    }
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      V[a] = Vn[a];
+      U[a] = Un[a];
+    }
+  };
+
+  // ---- downward sweep
+  {
+    TsxDnRawH cd = load_dn(0);
+    for (int k = 0; k < Nz; ++k) {
+      const TsxDnRawH nx = load_dn(k + 1 < Nz ? k + 1 : k);
+      step_dn(k, cd);
+      cd = nx;
+    }
+    (void)PD;
+  }
+#pragma unroll
+  for (int a = 0; a < H; ++a) {
+    zt[(size_t)(2 * a) * ncol + col] = (float)U[a];  // U_Nz
+    if (FINAL) zft[(size_t)(2 * a) * ncol + ncl] = (float)U[a];
+  }
+#pragma unroll
+  for (int d = NTOP; d < D; ++d) {
+    const float v = rt[(size_t)d * ncol + col];
+    zt[(size_t)d * ncol + col] = v;
+    if (FINAL) zft[(size_t)d * ncol + ncl] = v;
+  }
+}
+
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_narrow(TsxGeo g, int split, const double *__restrict__ a, float *__restrict__ o) {
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < g.N; q += (long long)gridDim.x * TSX_BLOCK)
     o[split ? tsx_split_pos(q, g) : q] = (float)a[q];

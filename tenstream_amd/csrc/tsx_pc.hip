@@ -101,7 +101,7 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
   const TsxGeo &g = s->geo;
   const int *done = in_solve ? &s->scal->done : nullptr;
   int rc;
-  if constexpr (NTOP == 2 && std::is_same<ZT, float>::value) {
+  if constexpr (std::is_same<ZT, float>::value) {
     if (s->pc == TSX_PC_REDBLACK) {
       // pc_sweeps + 1 passes, colours alternately; the iterate lives colour-split in s->vw; the last pass of each colour
       // also writes the Krylov-layout result z
@@ -118,11 +118,18 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
         const char *e = getenv("TSX_PC_LDS");
         use_lds = e ? atoi(e) : 1;
       }
-      const bool ld = use_lds && lds <= (size_t)s->max_lds;
+      const bool ld = NTOP == 2 && use_lds && lds <= (size_t)s->max_lds;
 #define TSX_RB_LAUNCH(GSV, HAS, LDSV, FIN)                                                                                      \
-  hipLaunchKernelGGL((tsx_k_pc_column_rb<GSV, HAS, LDSV, FIN>), dim3(nb), dim3(64), LDSV ? lds : 0, s->stream, g,                \
-                     (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, zs,                    \
-                     (const float *)zs, (float *)z, (float4 *)s->pc_tmp, done, pass & 1)
+  do {                                                                                                                          \
+    if constexpr (NTOP == 2)                                                                                                    \
+      hipLaunchKernelGGL((tsx_k_pc_column_rb<GSV, HAS, LDSV, FIN>), dim3(nb), dim3(64), LDSV ? lds : 0, s->stream, g,            \
+                         (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, zs,                \
+                         (const float *)zs, (float *)z, (float4 *)s->pc_tmp, done, pass & 1);                                   \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((tsx_k_pc_column_rbh<GSV, HAS, FIN>), dim3(nb), dim3(64), 0, s->stream, g,                              \
+                         (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, zs,                \
+                         (const float *)zs, (float *)z, (float4 *)s->pc_tmp, done, pass & 1);                                   \
+  } while (0)
 #define TSX_RB_L2(GSV, HAS, FIN)                                                                                                \
   do {                                                                                                                          \
     if (ld) TSX_RB_LAUNCH(GSV, HAS, true, FIN);                                                                                 \

@@ -127,17 +127,18 @@ def test_solve_default_tolerances_and_warm_start(gpu):
     assert info2.niter < info.niter and info2.reason in (2, 3)
 
 
-@pytest.mark.parametrize("Nx,Ny,Nz,n1d", [(8, 6, 6, 1), (6, 8, 5, 0), (12, 4, 7, 0)])
+@pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 8, 6, 6, 1), ("3_10", 6, 8, 5, 0), ("3_10", 12, 4, 7, 0),
+                                                  ("8_16", 6, 4, 5, 1), ("8_16", 4, 6, 4, 0)])
 @pytest.mark.parametrize("sweeps", [1, 2, 3, 5])
-def test_red_black_preconditioner_is_checkerboard_gauss_seidel(gpu, Nx, Ny, Nz, n1d, sweeps):
+def test_red_black_preconditioner_is_checkerboard_gauss_seidel(gpu, solver, Nx, Ny, Nz, n1d, sweeps):
     """TSX_PC_REDBLACK = Gauss-Seidel over the column blocks in checkerboard order: colour (i + j) & 1 == 0, then 1, ...;
     each pass an exact column-block solve with *all* couplings to the other colour (x and y) on the right-hand side.
     Only the reduced-precision path exists (fp16 block, fp8 couplings, fp32 iterate): compared at 6 % of max."""
     import scipy.sparse as sp
     import scipy.sparse.linalg as spla
 
-    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
-    lay = O.layout("3_10", Nz, Nx, Ny)
+    P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
+    lay = O.layout(solver, Nz, Nx, Ny)
     M, A = _column_block_matrix(P, lay)
     D, L = lay.D, Nz + 1
     idx = np.arange(A.shape[0])
@@ -158,7 +159,7 @@ def test_red_black_preconditioner_is_checkerboard_gauss_seidel(gpu, Nx, Ny, Nz, 
         rhs = v.ravel() - (Noff @ x if p_ > 0 else 0.0)
         mk = colour == (p_ % 2)
         x[mk] = lu.solve(rhs)[mk]
-    s = DiffuseSolver("3_10", Nz, Nx, Ny)
+    s = DiffuseSolver(solver, Nz, Nx, Ny)
     s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
     z = s.pc_apply(v, pc=3, sweeps=sweeps, mixed=True)
     assert np.abs(z.ravel() - x).max() <= 6e-2 * np.abs(x).max()
