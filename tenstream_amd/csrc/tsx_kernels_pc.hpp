@@ -874,6 +874,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   long long offS = js >= 0 ? (long long)(js - jrow) * g.xm + oc : 0;
   long long offE = qe >= 0 ? oc + (qe - qh) : 0;
   long long offW = qw >= 0 ? oc + (qw - qh) : 0;
+  // FINAL (the very last pass): this lane's value and its row partner's (columns 2q, 2q+1: one of each colour; the
+  // partner's final value sits at the same q in the other colour's half, offset oc) go out as one aligned float2 in the
+  // Krylov layout -- contiguous stores instead of two stride-2 passes
+  const int ncp = jrow * g.xm + 2 * qh;  // natural index of the pair's first column
+  auto cn0 = [&](int k) { return (size_t)k * ncol + ncp; };
+  auto wpair = [&](float *dst, float mine, float partner) {
+    *reinterpret_cast<float2 *>(dst) = par ? make_float2(partner, mine) : make_float2(mine, partner);
+  };
   if (g.pc_tile_x > 0) {  // analysis knob: behave like a rank of pc_tile_x x pc_tile_y columns
     if ((icol + 1) % g.pc_tile_x == 0) offE = 0;
     if (icol % g.pc_tile_x == 0) offW = 0;
@@ -1008,7 +1016,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 
   double V = rt[(size_t)ncol + col];  // V_0 = rd_0 (TOA identity row)
   zt[(size_t)ncol + col] = (float)V;
-  if (FINAL) zft[(size_t)ncol + ncl] = (float)V;
+  if (FINAL) wpair(zft + (size_t)ncol + ncp, (float)V, zt[(size_t)ncol + col + oc]);
   double U = A * V + B;               // A, B hold level 0
   auto step_dn = [&](int k, const TsxDnRaw &d) {
     const size_t c = (size_t)k * ncol + col;
@@ -1017,12 +1025,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const float4 t = d.t;
     const double Vn = (double)t.x + (double)t.y * V;
     const double Un = (double)t.z * Vn + (double)t.w;
-    const size_t cn = (size_t)k * ncol + ncl;
     z[c] = (float)U;
     z[(size_t)Nc + c] = (float)Vn;
     if (FINAL) {
-      zfin[cn] = (float)U;
-      zfin[(size_t)Nc + cn] = (float)Vn;
+      wpair(zfin + cn0(k), (float)U, z[c + oc]);
+      wpair(zfin + (size_t)Nc + cn0(k), (float)Vn, z[(size_t)Nc + c + oc]);
     }
     float zy[NSIDE], zq[NSIDE];
     if (GS) {
@@ -1055,7 +1062,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       acc += (double)a8 * (1.0 / TSX_FP8_SCALE);
       const float zo = (float)(d.rs[dd] + (one ? 0.0 : acc));
       z[(size_t)(NTOP + dd) * Nc + c] = zo;
-      if (FINAL) zfin[(size_t)(NTOP + dd) * Nc + cn] = zo;
+      if (FINAL) wpair(zfin + (size_t)(NTOP + dd) * Nc + cn0(k), zo, z[(size_t)(NTOP + dd) * Nc + c + oc]);
     }
     V = Vn;
     U = Un;
@@ -1084,12 +1091,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     }
   }
   zt[col] = (float)U;  // U_Nz
-  if (FINAL) zft[ncl] = (float)U;
+  if (FINAL) wpair(zft + ncp, (float)U, zt[col + oc]);
 #pragma unroll
   for (int d = NTOP; d < D; ++d) {
     const float v = rt[(size_t)d * ncol + col];
     zt[(size_t)d * ncol + col] = v;
-    if (FINAL) zft[(size_t)d * ncol + ncl] = v;
+    if (FINAL) wpair(zft + (size_t)d * ncol + ncp, v, zt[(size_t)d * ncol + col + oc]);
   }
 }
 
@@ -1425,6 +1432,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   const long long offS = js >= 0 ? (long long)(js - jrow) * g.xm + oc : 0;
   const long long offE = qe >= 0 ? oc + (qe - qh) : 0;
   const long long offW = qw >= 0 ? oc + (qw - qh) : 0;
+  // FINAL (the very last pass): this lane's value and its row partner's (columns 2q, 2q+1: one of each colour; the
+  // partner's final value sits at the same q in the other colour's half, offset oc) go out as one aligned float2 in the
+  // Krylov layout -- contiguous stores instead of two stride-2 passes
+  const int ncp = jrow * g.xm + 2 * qh;  // natural index of the pair's first column
+  auto cn0 = [&](int k) { return (size_t)k * ncol + ncp; };
+  auto wpair = [&](float *dst, float mine, float partner) {
+    *reinterpret_cast<float2 *>(dst) = par ? make_float2(partner, mine) : make_float2(mine, partner);
+  };
   const float *__restrict__ rt = r + (size_t)D * Nc;
   float *__restrict__ zt = z + (size_t)D * Nc;
   float *__restrict__ zft = FINAL ? zfin + (size_t)D * Nc : nullptr;
@@ -1593,7 +1608,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   for (int a = 0; a < H; ++a) {
     V[a] = rt[(size_t)(2 * a + 1) * ncol + col];  // V_0 = rd_0 (TOA identity rows)
     zt[(size_t)(2 * a + 1) * ncol + col] = (float)V[a];
-    if (FINAL) zft[(size_t)(2 * a + 1) * ncol + ncl] = (float)V[a];
+    if (FINAL) wpair(zft + (size_t)(2 * a + 1) * ncol + ncp, (float)V[a], zt[(size_t)(2 * a + 1) * ncol + col + oc]);
   }
   SM::matvec(A, V, U);  // A, B hold level 0
 #pragma unroll
@@ -1628,8 +1643,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       z[(size_t)(2 * a) * Nc + c] = (float)U[a];
       z[(size_t)(2 * a + 1) * Nc + c] = (float)Vn[a];
       if (FINAL) {
-        zfin[(size_t)(2 * a) * Nc + (size_t)k * ncol + ncl] = (float)U[a];
-        zfin[(size_t)(2 * a + 1) * Nc + (size_t)k * ncol + ncl] = (float)Vn[a];
+        wpair(zfin + (size_t)(2 * a) * Nc + cn0(k), (float)U[a], z[(size_t)(2 * a) * Nc + c + oc]);
+        wpair(zfin + (size_t)(2 * a + 1) * Nc + cn0(k), (float)Vn[a], z[(size_t)(2 * a + 1) * Nc + c + oc]);
       }
     }
     float zy[NSIDE], zq[NSIDE];
@@ -1664,7 +1679,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       acc += (double)a8 * (1.0 / TSX_FP8_SCALE);
       const float zo = (float)(d.rs[dd] + (one ? 0.0 : acc));
       z[(size_t)(NTOP + dd) * Nc + c] = zo;
-      if (FINAL) zfin[(size_t)(NTOP + dd) * Nc + (size_t)k * ncol + ncl] = zo;
+      if (FINAL) wpair(zfin + (size_t)(NTOP + dd) * Nc + cn0(k), zo, z[(size_t)(NTOP + dd) * Nc + c + oc]);
     }
 #pragma unroll
     for (int a = 0; a < H; ++a) {
@@ -1686,13 +1701,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
   for (int a = 0; a < H; ++a) {
     zt[(size_t)(2 * a) * ncol + col] = (float)U[a];  // U_Nz
-    if (FINAL) zft[(size_t)(2 * a) * ncol + ncl] = (float)U[a];
+    if (FINAL) wpair(zft + (size_t)(2 * a) * ncol + ncp, (float)U[a], zt[(size_t)(2 * a) * ncol + col + oc]);
   }
 #pragma unroll
   for (int d = NTOP; d < D; ++d) {
     const float v = rt[(size_t)d * ncol + col];
     zt[(size_t)d * ncol + col] = v;
-    if (FINAL) zft[(size_t)d * ncol + ncl] = v;
+    if (FINAL) wpair(zft + (size_t)d * ncol + ncp, v, zt[(size_t)d * ncol + col + oc]);
   }
 }
 

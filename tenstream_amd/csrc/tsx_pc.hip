@@ -103,8 +103,8 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
   int rc;
   if constexpr (std::is_same<ZT, float>::value) {
     if (s->pc == TSX_PC_REDBLACK) {
-      // pc_sweeps + 1 passes, colours alternately; the iterate lives colour-split in s->vw; the last pass of each colour
-      // also writes the Krylov-layout result z
+      // pc_sweeps + 1 passes, colours alternately; the iterate lives colour-split in s->vw; the last pass also writes the
+      // Krylov-layout result z for both colours
       if (!s->pc_half || !s->v32 || !s->coef_h_split) {
         tsx_set_error("preconditioner: red-black ordering needs the colour-split packed blocks (internal state error)");
         return TSX_ERR_STATE;
@@ -141,7 +141,7 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
     else TSX_RB_L2(GSV, false, FIN);                                                                                            \
   } while (0)
       for (int pass = 0; pass < P; ++pass) {
-        const bool fin = pass >= P - 2;
+        const bool fin = pass == P - 1;  // the last pass writes both colours' results in the Krylov layout
         if (pass == 0) {
           if (fin) TSX_RB_L1(false, true);
           else TSX_RB_L1(false, false);
