@@ -842,18 +842,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // get that in y and lag in x).  Measured on the CPU model (scripts/pc_study.py): the same iteration count with 2/3 of the
 // passes, or ~27 % fewer iterations at the same number of passes.  Lanes run over every other column, so everything the
 // preconditioner owns -- packed blocks P, fp32 right-hand side r, its iterate zs -- is stored colour-split: within a row
-// the xm/2 columns of colour 0 first, then colour 1 (tsx_split_col); loads and stores stay contiguous.  Only the FINAL pass
-// of a colour also writes the result in the Krylov layout (stride-2 stores).  rbc = colour of this pass, (i + j) & 1.
-template <bool GS, bool HAS1D, bool LDST, bool FINAL>
+// the xm/2 columns of colour 0 first, then colour 1 (tsx_split_col); loads and stores stay contiguous.
+// rbc = colour of this pass, (i + j) & 1.
+// MODE 0: an intermediate pass -- its result is only ever read as a neighbour value by later passes, i.e. the 8 side streams,
+//         stored as bf16 in zb (the top streams and the tail rows are not stored at all); reads its neighbours from zb.
+// MODE 1: the last pass of the first colour: all 10 streams in fp32 to z (colour-split); neighbours from zb.
+// MODE 2: the very last pass: neighbours and the row partner's final values from z (fp32), result for both colours as
+//         aligned pairs in the Krylov layout zfin.
+struct TsxUpRawB {
+  uint4 c0;
+  uint2 c1;
+  float ru, rd;
+  double t11, t12;
+  unsigned zy[4], zx[4];  // neighbour values as loaded: fp32 bits (MODE 2) or bf16 (MODE 0/1)
+};
+struct TsxDnRawB {
+  uint4 cu, cv, cy[2], cx[2];
+  float4 t;
+  float rs[8];
+  unsigned zy[4], zx[4];
+};
+__device__ __forceinline__ unsigned short tsx_to_bf16(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+  return (unsigned short)(u >> 16);
+}
+
+template <bool GS, bool HAS1D, bool LDST, int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void tsx_k_pc_column_rb(
     TsxGeo g, const uint4 *__restrict__ P, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
     const double *__restrict__ a12, const double *__restrict__ albedo, const float *__restrict__ r, float *__restrict__ z,
-    const float *__restrict__ zc, float *__restrict__ zfin, float4 *__restrict__ tmp, const int *__restrict__ done,
+    unsigned short *__restrict__ zb, float *__restrict__ zfin, float4 *__restrict__ tmp, const int *__restrict__ done,
     int rbc) {
   constexpr int D = 10, NTOP = 2, NSIDE = 4;
   constexpr int PU = 4, PD = 2;  // prefetch depth of the upward / downward sweep (levels)
   constexpr bool XL = GS;        // x and y couplings alike
-  const float *__restrict__ zx = zc;
+  constexpr bool FINAL = MODE == 2;
+  using TsxUpRaw = TsxUpRawB;
+  using TsxDnRaw = TsxDnRawB;
+  auto nbr_ld = [&](size_t idx) -> unsigned { return MODE == 2 ? __float_as_uint(z[idx]) : (unsigned)zb[idx]; };
+  auto nbr_val = [](unsigned v) -> float { return MODE == 2 ? __uint_as_float(v) : __uint_as_float(v << 16); };
   extern __shared__ float4 tsx_pc_lds[];
   if (done && *done) return;
   const int h = g.xm >> 1;
@@ -905,11 +933,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     u.rd = r[(size_t)Nc + c];
     if (GS) {
 #pragma unroll
-      for (int q = 0; q < NSIDE; ++q) u.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
+      for (int q = 0; q < NSIDE; ++q) u.zy[q] = nbr_ld((size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN));
     }
     if (XL) {
 #pragma unroll
-      for (int q = 0; q < NSIDE; ++q) u.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
+      for (int q = 0; q < NSIDE; ++q) u.zx[q] = nbr_ld((size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE));
     }
     if (HAS1D) {
       u.t11 = a11[(size_t)k * ncol + ncl];
@@ -930,7 +958,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       tsx_fp8x4(u.c0.w, cb);
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) {
-        const float zv = (tsx_inward(q) ? offS : offN) ? u.zy[q] : 0.0f;  // select: the unused slot may hold NaN
+        const float zv = (tsx_inward(q) ? offS : offN) ? nbr_val(u.zy[q]) : 0.0f;  // select: the unused slot may hold NaN
         gu8 += (q < 2 ? ca[2 * q] : cb[2 * (q - 2)]) * zv;
         gd8 += (q < 2 ? ca[2 * q + 1] : cb[2 * (q - 2) + 1]) * zv;
       }
@@ -941,7 +969,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       tsx_fp8x4(u.c1.y, cb);
 #pragma unroll
       for (int q = 0; q < NSIDE; ++q) {
-        const float zv = (tsx_inward(q) ? offW : offE) ? u.zx[q] : 0.0f;
+        const float zv = (tsx_inward(q) ? offW : offE) ? nbr_val(u.zx[q]) : 0.0f;
         gu8 += (q < 2 ? ca[2 * q] : cb[2 * (q - 2)]) * zv;
         gd8 += (q < 2 ? ca[2 * q + 1] : cb[2 * (q - 2) + 1]) * zv;
       }
@@ -1003,19 +1031,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #pragma unroll
       for (int m = 0; m < 2; ++m) d.cy[m] = P[(size_t)(4 + m) * Nc + c];
 #pragma unroll
-      for (int q = 0; q < NSIDE; ++q) d.zy[q] = zc[(size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN)];
+      for (int q = 0; q < NSIDE; ++q) d.zy[q] = nbr_ld((size_t)(NTOP + NSIDE + q) * Nc + c + (tsx_inward(q) ? offS : offN));
     }
     if (XL) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) d.cx[m] = P[(size_t)(6 + m) * Nc + c];
 #pragma unroll
-      for (int q = 0; q < NSIDE; ++q) d.zx[q] = zx[(size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE)];
+      for (int q = 0; q < NSIDE; ++q) d.zx[q] = nbr_ld((size_t)(NTOP + q) * Nc + c + (tsx_inward(q) ? offW : offE));
     }
     return d;
   };
 
   double V = rt[(size_t)ncol + col];  // V_0 = rd_0 (TOA identity row)
-  zt[(size_t)ncol + col] = (float)V;
+  if (MODE == 1) zt[(size_t)ncol + col] = (float)V;
   if (FINAL) wpair(zft + (size_t)ncol + ncp, (float)V, zt[(size_t)ncol + col + oc]);
   double U = A * V + B;               // A, B hold level 0
   auto step_dn = [&](int k, const TsxDnRaw &d) {
@@ -1025,8 +1053,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const float4 t = d.t;
     const double Vn = (double)t.x + (double)t.y * V;
     const double Un = (double)t.z * Vn + (double)t.w;
-    z[c] = (float)U;
-    z[(size_t)Nc + c] = (float)Vn;
+    if (MODE == 1) {
+      z[c] = (float)U;
+      z[(size_t)Nc + c] = (float)Vn;
+    }
     if (FINAL) {
       wpair(zfin + cn0(k), (float)U, z[c + oc]);
       wpair(zfin + (size_t)Nc + cn0(k), (float)Vn, z[(size_t)Nc + c + oc]);
@@ -1034,11 +1064,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     float zy[NSIDE], zq[NSIDE];
     if (GS) {
 #pragma unroll
-      for (int q = 0; q < NSIDE; ++q) zy[q] = (tsx_inward(q) ? offS : offN) ? d.zy[q] : 0.0f;
+      for (int q = 0; q < NSIDE; ++q) zy[q] = (tsx_inward(q) ? offS : offN) ? nbr_val(d.zy[q]) : 0.0f;
     }
     if (XL) {
 #pragma unroll
-      for (int q = 0; q < NSIDE; ++q) zq[q] = (tsx_inward(q) ? offW : offE) ? d.zx[q] : 0.0f;
+      for (int q = 0; q < NSIDE; ++q) zq[q] = (tsx_inward(q) ? offW : offE) ? nbr_val(d.zx[q]) : 0.0f;
     }
     const tsx_h8 hcu = __builtin_bit_cast(tsx_h8, d.cu), hcv = __builtin_bit_cast(tsx_h8, d.cv);
     const unsigned wy[8] = {d.cy[0].x, d.cy[0].y, d.cy[0].z, d.cy[0].w, d.cy[1].x, d.cy[1].y, d.cy[1].z, d.cy[1].w};
@@ -1061,7 +1091,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       }
       acc += (double)a8 * (1.0 / TSX_FP8_SCALE);
       const float zo = (float)(d.rs[dd] + (one ? 0.0 : acc));
-      z[(size_t)(NTOP + dd) * Nc + c] = zo;
+      if (MODE == 0) zb[(size_t)(NTOP + dd) * Nc + c] = tsx_to_bf16(zo);
+      if (MODE == 1) z[(size_t)(NTOP + dd) * Nc + c] = zo;
       if (FINAL) wpair(zfin + (size_t)(NTOP + dd) * Nc + cn0(k), zo, z[(size_t)(NTOP + dd) * Nc + c + oc]);
     }
     V = Vn;
@@ -1090,12 +1121,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       }
     }
   }
-  zt[col] = (float)U;  // U_Nz
+  if (MODE == 1) zt[col] = (float)U;  // U_Nz
   if (FINAL) wpair(zft + ncp, (float)U, zt[col + oc]);
 #pragma unroll
   for (int d = NTOP; d < D; ++d) {
     const float v = rt[(size_t)d * ncol + col];
-    zt[(size_t)d * ncol + col] = v;
+    if (MODE == 1) zt[(size_t)d * ncol + col] = v;
     if (FINAL) wpair(zft + (size_t)d * ncol + ncp, v, zt[(size_t)d * ncol + col + oc]);
   }
 }

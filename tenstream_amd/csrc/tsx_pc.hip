@@ -110,7 +110,8 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
         return TSX_ERR_STATE;
       }
       const int P = s->pc_sweeps + 1;
-      float *zs = (float *)s->vw;
+      float *zs = (float *)s->vw;                                   // fp32 iterate (written by the last pass of colour P % 2)
+      unsigned short *zb = (unsigned short *)(zs + (size_t)g.N);   // bf16 neighbour values of the intermediate passes
       const int nb = (g.ym * (g.xm / 2) + 63) / 64;
       const size_t lds = (size_t)g.Nz * 64 * sizeof(float4);
       static int use_lds = -1;
@@ -119,35 +120,38 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
         use_lds = e ? atoi(e) : 1;
       }
       const bool ld = NTOP == 2 && use_lds && lds <= (size_t)s->max_lds;
-#define TSX_RB_LAUNCH(GSV, HAS, LDSV, FIN)                                                                                      \
+      // 3_10: pass modes 0 (intermediate: bf16 side streams only), 1 (first colour's last pass: fp32), 2 (last pass: pairs).
+      // 8_16 keeps fp32 iterates throughout: its kernel knows FINAL (= mode 2) only.
+#define TSX_RB_LAUNCH(GSV, HAS, LDSV, MODEV)                                                                                    \
   do {                                                                                                                          \
     if constexpr (NTOP == 2)                                                                                                    \
-      hipLaunchKernelGGL((tsx_k_pc_column_rb<GSV, HAS, LDSV, FIN>), dim3(nb), dim3(64), LDSV ? lds : 0, s->stream, g,            \
-                         (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, zs,                \
-                         (const float *)zs, (float *)z, (float4 *)s->pc_tmp, done, pass & 1);                                   \
+      hipLaunchKernelGGL((tsx_k_pc_column_rb<GSV, HAS, LDSV, MODEV>), dim3(nb), dim3(64), LDSV ? lds : 0, s->stream, g,          \
+                         (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, zs, zb,            \
+                         (float *)z, (float4 *)s->pc_tmp, done, pass & 1);                                                      \
     else                                                                                                                        \
-      hipLaunchKernelGGL((tsx_k_pc_column_rbh<GSV, HAS, FIN>), dim3(nb), dim3(64), 0, s->stream, g,                              \
+      hipLaunchKernelGGL((tsx_k_pc_column_rbh<GSV, HAS, (MODEV == 2)>), dim3(nb), dim3(64), 0, s->stream, g,                     \
                          (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, zs,                \
                          (const float *)zs, (float *)z, (float4 *)s->pc_tmp, done, pass & 1);                                   \
   } while (0)
-#define TSX_RB_L2(GSV, HAS, FIN)                                                                                                \
+#define TSX_RB_L2(GSV, HAS, MODEV)                                                                                              \
   do {                                                                                                                          \
-    if (ld) TSX_RB_LAUNCH(GSV, HAS, true, FIN);                                                                                 \
-    else TSX_RB_LAUNCH(GSV, HAS, false, FIN);                                                                                   \
+    if (ld) TSX_RB_LAUNCH(GSV, HAS, true, MODEV);                                                                               \
+    else TSX_RB_LAUNCH(GSV, HAS, false, MODEV);                                                                                 \
   } while (0)
-#define TSX_RB_L1(GSV, FIN)                                                                                                     \
+#define TSX_RB_L1(GSV, MODEV)                                                                                                   \
   do {                                                                                                                          \
-    if (s->any_l1d) TSX_RB_L2(GSV, true, FIN);                                                                                  \
-    else TSX_RB_L2(GSV, false, FIN);                                                                                            \
+    if (s->any_l1d) TSX_RB_L2(GSV, true, MODEV);                                                                                \
+    else TSX_RB_L2(GSV, false, MODEV);                                                                                          \
   } while (0)
       for (int pass = 0; pass < P; ++pass) {
-        const bool fin = pass == P - 1;  // the last pass writes both colours' results in the Krylov layout
+        const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
         if (pass == 0) {
-          if (fin) TSX_RB_L1(false, true);
-          else TSX_RB_L1(false, false);
+          if (mode == 1) TSX_RB_L1(false, 1);
+          else TSX_RB_L1(false, 0);
         } else {
-          if (fin) TSX_RB_L1(true, true);
-          else TSX_RB_L1(true, false);
+          if (mode == 2) TSX_RB_L1(true, 2);
+          else if (mode == 1) TSX_RB_L1(true, 1);
+          else TSX_RB_L1(true, 0);
         }
       }
 #undef TSX_RB_L1
