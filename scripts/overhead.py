@@ -14,11 +14,11 @@ t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
 s.set_optprop(t(kabs), t(ksca), t(g), torch.full((Ny, Nx, Nz), 50.0, dtype=torch.float64, device=dev), 100.0,
               torch.zeros(Nz, dtype=torch.uint8, device=dev), t(np.zeros_like(kabs)), t(np.zeros_like(kabs)), t(alb))
 x = torch.zeros_like(b)
-for ce in (1, 2, 4, 8):
+for ce in (1, 2, 4, 5, 10, 16):
     for rep in range(3):
         x.zero_(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        info = s.solve(b, x, pc=2, pc_sweeps=5, check_every=ce)
+        info = s.solve(b, x, check_every=ce)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) * 1e3
     print(json.dumps(dict(check_every=ce, its=info.niter, wall_ms=wall, solve_ms=info.solve_ms, import_ms=info.import_ms, export_ms=info.export_ms)))

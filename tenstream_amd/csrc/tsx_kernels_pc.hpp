@@ -878,6 +878,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   constexpr int PU = 4, PD = 2;  // prefetch depth of the upward / downward sweep (levels)
   constexpr bool XL = GS;        // x and y couplings alike
   constexpr bool FINAL = MODE == 2;
+  using real = float;  // the sweeps run in fp32: M^-1 is an approximation anyway (fp8 couplings), fp64 only costs issue slots
   using TsxUpRaw = TsxUpRawB;
   using TsxDnRaw = TsxDnRawB;
   auto nbr_ld = [&](size_t idx) -> unsigned { return MODE == 2 ? __float_as_uint(z[idx]) : (unsigned)zb[idx]; };
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   const float *__restrict__ rt = r + (size_t)D * Nc;
   float *__restrict__ zt = z + (size_t)D * Nc;
   float *__restrict__ zft = FINAL ? zfin + (size_t)D * Nc : nullptr;
-  const double albc = albedo[ncl], rsurf = rt[col];
+  const real albc = (real)albedo[ncl], rsurf = rt[col];
 
   // loads only: nothing here depends on loaded data, so that the whole record of a level is in flight at once
   auto load_up = [&](int k) {
@@ -946,11 +947,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     return u;
   };
 
-  double A = albc, B = rsurf;
+  real A = albc, B = rsurf;
   auto step_up = [&](int k, const TsxUpRaw &u) {
     const size_t c = (size_t)k * ncol + col;
     const tsx_h4 tt = __builtin_bit_cast(tsx_h4, make_uint2(u.c0.x, u.c0.y));
-    double tuu = (double)tt[0], rud = (double)tt[1], rdu = (double)tt[2], tdd = (double)tt[3];
+    real tuu = (real)tt[0], rud = (real)tt[1], rdu = (real)tt[2], tdd = (real)tt[3];
     float gu8 = 0.0f, gd8 = 0.0f;  // coupling sums in fp8 units (x TSX_FP8_SCALE), fp32 accumulation
     if (GS) {
       float ca[4], cb[4];  // [c(y0->0) c(y0->1) c(y1->0) c(y1->1)], [y2, y3]
@@ -974,24 +975,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         gd8 += (q < 2 ? ca[2 * q + 1] : cb[2 * (q - 2) + 1]) * zv;
       }
     }
-    double gu = (double)gu8 * (1.0 / TSX_FP8_SCALE), gd = (double)gd8 * (1.0 / TSX_FP8_SCALE);
+    real gu = (real)gu8 * (real)(1.0 / TSX_FP8_SCALE), gd = (real)gd8 * (real)(1.0 / TSX_FP8_SCALE);
     if (HAS1D) {
       const bool one = l1d[k] != 0;
       tuu = one ? u.t11 : tuu;
       tdd = one ? u.t11 : tdd;
       rud = one ? u.t12 : rud;
       rdu = one ? u.t12 : rdu;
-      gu = one ? 0.0 : gu;
-      gd = one ? 0.0 : gd;
+      gu = one ? (real)0.0 : gu;
+      gd = one ? (real)0.0 : gd;
     }
-    const double ru = u.ru + gu, rd = u.rd + gd;
-    const double G = 1.0 / (1.0 - rdu * A);
-    const double Gw = G * (rd + rdu * B);
-    const double GT = G * tdd;
+    const real ru = u.ru + gu, rd = u.rd + gd;
+    const real G = (real)1.0 / ((real)1.0 - rdu * A);
+    const real Gw = G * (rd + rdu * B);
+    const real GT = G * tdd;
     if (LDST) tsx_pc_lds[k * 64 + threadIdx.x] = make_float4((float)Gw, (float)GT, (float)A, (float)B);
     else tmp[c] = make_float4((float)Gw, (float)GT, (float)A, (float)B);
-    const double Bn = ru + tuu * (B + A * Gw);
-    const double An = tuu * A * GT + rud;
+    const real Bn = ru + tuu * (B + A * Gw);
+    const real An = tuu * A * GT + rud;
     A = An;
     B = Bn;
   };
@@ -1042,17 +1043,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     return d;
   };
 
-  double V = rt[(size_t)ncol + col];  // V_0 = rd_0 (TOA identity row)
+  real V = rt[(size_t)ncol + col];  // V_0 = rd_0 (TOA identity row)
   if (MODE == 1) zt[(size_t)ncol + col] = (float)V;
   if (FINAL) wpair(zft + (size_t)ncol + ncp, (float)V, zt[(size_t)ncol + col + oc]);
-  double U = A * V + B;               // A, B hold level 0
+  real U = A * V + B;               // A, B hold level 0
   auto step_dn = [&](int k, const TsxDnRaw &d) {
     const size_t c = (size_t)k * ncol + col;
     bool one = false;
     if (HAS1D) one = l1d[k] != 0;
     const float4 t = d.t;
-    const double Vn = (double)t.x + (double)t.y * V;
-    const double Un = (double)t.z * Vn + (double)t.w;
+    const real Vn = (real)t.x + (real)t.y * V;
+    const real Un = (real)t.z * Vn + (real)t.w;
     if (MODE == 1) {
       z[c] = (float)U;
       z[(size_t)Nc + c] = (float)Vn;
@@ -1075,7 +1076,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const unsigned wx[8] = {d.cx[0].x, d.cx[0].y, d.cx[0].z, d.cx[0].w, d.cx[1].x, d.cx[1].y, d.cx[1].z, d.cx[1].w};
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd) {
-      double acc = (double)hcu[dd] * Un + (double)hcv[dd] * V;
+      real acc = (real)hcu[dd] * Un + (real)hcv[dd] * V;
       float a8 = 0.0f;  // couplings: fp8 units, fp32 accumulation
       if (GS) {
         float cq[4];
@@ -1089,8 +1090,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #pragma unroll
         for (int q = 0; q < NSIDE; ++q) a8 += cq[q] * zq[q];
       }
-      acc += (double)a8 * (1.0 / TSX_FP8_SCALE);
-      const float zo = (float)(d.rs[dd] + (one ? 0.0 : acc));
+      acc += (real)a8 * (real)(1.0 / TSX_FP8_SCALE);
+      const float zo = (float)(d.rs[dd] + (one ? (real)0.0 : acc));
       if (MODE == 0) zb[(size_t)(NTOP + dd) * Nc + c] = tsx_to_bf16(zo);
       if (MODE == 1) z[(size_t)(NTOP + dd) * Nc + c] = zo;
       if (FINAL) wpair(zfin + (size_t)(NTOP + dd) * Nc + cn0(k), zo, z[(size_t)(NTOP + dd) * Nc + c + oc]);
