@@ -861,6 +861,7 @@ struct TsxDnRawB {
   float4 t;
   float rs[8];
   unsigned zy[4], zx[4];
+  float pz[10];  // MODE 2: the row partner's final values (prefetched with the level, not loaded at the store)
 };
 __device__ __forceinline__ unsigned short tsx_to_bf16(float x) {
   unsigned u = __float_as_uint(x);
@@ -1028,6 +1029,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     d.t = LDST ? tsx_pc_lds[k * 64 + threadIdx.x] : tmp[c];  // prefetched with the rest of the level: off the recurrence
 #pragma unroll
     for (int q = 0; q < 8; ++q) d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+    if (FINAL) {
+#pragma unroll
+      for (int q = 0; q < D; ++q) d.pz[q] = z[(size_t)q * Nc + c + oc];
+    }
     if (GS) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) d.cy[m] = P[(size_t)(4 + m) * Nc + c];
@@ -1059,8 +1064,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       z[(size_t)Nc + c] = (float)Vn;
     }
     if (FINAL) {
-      wpair(zfin + cn0(k), (float)U, z[c + oc]);
-      wpair(zfin + (size_t)Nc + cn0(k), (float)Vn, z[(size_t)Nc + c + oc]);
+      wpair(zfin + cn0(k), (float)U, d.pz[0]);
+      wpair(zfin + (size_t)Nc + cn0(k), (float)Vn, d.pz[1]);
     }
     float zy[NSIDE], zq[NSIDE];
     if (GS) {
@@ -1094,7 +1099,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       const float zo = (float)(d.rs[dd] + (one ? (real)0.0 : acc));
       if (MODE == 0) zb[(size_t)(NTOP + dd) * Nc + c] = tsx_to_bf16(zo);
       if (MODE == 1) z[(size_t)(NTOP + dd) * Nc + c] = zo;
-      if (FINAL) wpair(zfin + (size_t)(NTOP + dd) * Nc + cn0(k), zo, z[(size_t)(NTOP + dd) * Nc + c + oc]);
+      if (FINAL) wpair(zfin + (size_t)(NTOP + dd) * Nc + cn0(k), zo, d.pz[NTOP + dd]);
     }
     V = Vn;
     U = Un;
@@ -1611,8 +1616,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
   }
 
+  struct DnRaw : TsxDnRawH {
+    float pz[16];  // FINAL: the row partner's final values, prefetched with the level
+  };
   auto load_dn = [&](int k) {
-    TsxDnRawH d;
+    DnRaw d;
     const size_t c = (size_t)k * ncol + col;
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd) d.row[dd] = __builtin_bit_cast(tsx_h8, P[(size_t)(12 + dd) * Nc + c]);
@@ -1620,6 +1628,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int q = 0; q < 6; ++q) d.t[q] = tmp[(size_t)q * Nc + c];
 #pragma unroll
     for (int q = 0; q < 8; ++q) d.rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+    if (FINAL) {
+#pragma unroll
+      for (int q = 0; q < D; ++q) d.pz[q] = z[(size_t)q * Nc + c + oc];
+    }
     if (GS) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) d.cy[m] = P[(size_t)(20 + m) * Nc + c];
@@ -1651,7 +1663,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     return (double)(i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w);
   };
   auto h8 = [](const uint4 &u, int i) { return (double)__builtin_bit_cast(tsx_h8, u)[i]; };  // element i of 8 halves
-  auto step_dn = [&](int k, const TsxDnRawH &d) {
+  auto step_dn = [&](int k, const DnRaw &d) {
     const size_t c = (size_t)k * ncol + col;
     bool one = false;
     if (HAS1D) one = l1d[k] != 0;
@@ -1675,8 +1687,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       z[(size_t)(2 * a) * Nc + c] = (float)U[a];
       z[(size_t)(2 * a + 1) * Nc + c] = (float)Vn[a];
       if (FINAL) {
-        wpair(zfin + (size_t)(2 * a) * Nc + cn0(k), (float)U[a], z[(size_t)(2 * a) * Nc + c + oc]);
-        wpair(zfin + (size_t)(2 * a + 1) * Nc + cn0(k), (float)Vn[a], z[(size_t)(2 * a + 1) * Nc + c + oc]);
+        wpair(zfin + (size_t)(2 * a) * Nc + cn0(k), (float)U[a], d.pz[2 * a]);
+        wpair(zfin + (size_t)(2 * a + 1) * Nc + cn0(k), (float)Vn[a], d.pz[2 * a + 1]);
       }
     }
     float zy[NSIDE], zq[NSIDE];
@@ -1711,7 +1723,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       acc += (double)a8 * (1.0 / TSX_FP8_SCALE);
       const float zo = (float)(d.rs[dd] + (one ? 0.0 : acc));
       z[(size_t)(NTOP + dd) * Nc + c] = zo;
-      if (FINAL) wpair(zfin + (size_t)(NTOP + dd) * Nc + cn0(k), zo, z[(size_t)(NTOP + dd) * Nc + c + oc]);
+      if (FINAL) wpair(zfin + (size_t)(NTOP + dd) * Nc + cn0(k), zo, d.pz[NTOP + dd]);
     }
 #pragma unroll
     for (int a = 0; a < H; ++a) {
@@ -1722,9 +1734,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
   // ---- downward sweep
   {
-    TsxDnRawH cd = load_dn(0);
+    DnRaw cd = load_dn(0);
     for (int k = 0; k < Nz; ++k) {
-      const TsxDnRawH nx = load_dn(k + 1 < Nz ? k + 1 : k);
+      const DnRaw nx = load_dn(k + 1 < Nz ? k + 1 : k);
       step_dn(k, cd);
       cd = nx;
     }
