@@ -85,7 +85,7 @@ def test_apply_fp64_coefficients_kept_when_lossy(gpu):
 
 @pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 12, 10, 8, 2), ("3_10", 33, 17, 20, 0), ("8_16", 8, 6, 6, 0)])
 @pytest.mark.parametrize("force_halo", [False, True])
-@pytest.mark.parametrize("pc", [0, 2])  # bare operator / the default preconditioner
+@pytest.mark.parametrize("pc", [0, 2, 3])  # bare operator / zebra rows / red-black (default; falls back to zebra on odd grids)
 def test_solve_matches_oracle(gpu, solver, Nx, Ny, Nz, n1d, force_halo, pc):
     P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
     s = DiffuseSolver(solver, Nz, Nx, Ny, force_halo=force_halo)
