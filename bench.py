@@ -174,6 +174,8 @@ def main():
                             f"single solar g-point, rtol 1e-5 / reference atol, zero initial guess",
                 "process_grid": f"{npx}x{npy}",
                 "coeff_storage": "fp32 blocks (lossless), fp64 vectors",
+                "preconditioner_storage": "inside M^-1 only: fp16 column blocks + fp8 couplings, fp32/bf16 iterates; operator, "
+                                          "Krylov vectors, dots and stop rule fp64 on the exact blocks",
                 "coeff_source": "device N-linear LUT interpolation (tsx_diff_set_optprop), synthetic table",
                 "coeff_setup_ms": t_setup * 1e3,
                 "preconditioner": {0: "none", 1: "column-jacobi", 2: f"column-zebra({args.pc_sweeps + 1} passes)",
