@@ -86,8 +86,9 @@ typedef struct {
   int32_t pc;                 /* TSX_PC_* */
   int32_t pc_sweeps;          /* ZEBRA / REDBLACK: pc_sweeps + 1 half-grid passes per application; COLUMN: Jacobi sweeps (1..16) */
   int32_t check_every;        /* host looks at the device convergence flag every n iterations */
-  int32_t fp32_directions;    /* 1 (default): preconditioned directions p-hat/s-hat and the shadow residual are stored in
-                                 fp32 -- flexible BiCGStab accepts any direction; x, r, p, s, v, t stay fp64.  0: all fp64 */
+  int32_t fp32_directions;    /* 1 (default): the directions p, p-hat, s-hat and the shadow residual are stored in fp32 --
+                                 flexible BiCGStab accepts any direction: x and r are updated consistently with A p-hat,
+                                 A s-hat whatever they are; x, r, s, v, t, the dots and the stop rule stay fp64.  0: all fp64 */
   int32_t pc_coeff_fp16;      /* 1 (default): with fp32 directions the preconditioner reads a packed reduced-precision copy
                                  of the transport blocks (fp16; for 3_10 the couplings to neighbouring columns fp8 e4m3) and
                                  keeps its sweep temporaries in fp32 -- the preconditioner is an approximation anyway; the

@@ -236,7 +236,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   if (!s) return TSX_OK;
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
-  void *ptrs[] = {s->v32, s->dsend[0], s->dsend[1], s->dsend[2], s->dsend[3], s->drecv[0], s->drecv[1], s->drecv[2], s->drecv[3],
+  void *ptrs[] = {s->v32, s->p32, s->dsend[0], s->dsend[1], s->dsend[2], s->dsend[3], s->drecv[0], s->drecv[1], s->drecv[2], s->drecv[3],
                   s->coef_h, s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
@@ -751,17 +751,23 @@ static int enqueue_iteration_t(tsx_solver *s, bool first) {
   const int nbv = grid_for(n2);
   int rc;
   if (!first) {
-    hipLaunchKernelGGL(tsx_k_pupdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
-                       (double2 *)s->vp, (const double2 *)s->vv, (MIX && s->pc != TSX_PC_NONE) ? (float2 *)s->v32 : (float2 *)nullptr, g, (int)s->pc_split);
+    if (MIX && s->pc != TSX_PC_NONE)  // p lives in fp32 only (s->v32), see tsx_k_pupdate32
+      hipLaunchKernelGGL(tsx_k_pupdate32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
+                         (const double2 *)s->vv, s->p32, g, (int)s->pc_split);
+    else
+      hipLaunchKernelGGL(tsx_k_pupdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
+                         (double2 *)s->vp, (const double2 *)s->vv, (float2 *)nullptr, g, 0);
   }
   const RT *rhat = (const RT *)s->vrhat;
   if (s->pc != TSX_PC_NONE) {
     PT *ph = (PT *)s->vph, *sh = (PT *)s->vsh;
+    s->pc_rhs = s->p32;
     if ((rc = tsx_pc_apply(s, s->vp, ph, std::is_same<PT, float>::value, true))) return rc;
     if ((rc = launch_spmv<NTOP, NSIDE, 1, PT, RT>(s, ph, s->vv, rhat, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
     hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
                        (const double2 *)s->vv, (double2 *)s->vs, MIX ? (float2 *)s->v32 : (float2 *)nullptr, g, (int)s->pc_split);
+    s->pc_rhs = s->v32;
     if ((rc = tsx_pc_apply(s, s->vs, sh, std::is_same<PT, float>::value, true))) return rc;
     if ((rc = launch_spmv<NTOP, NSIDE, 5, PT, double>(s, sh, s->vt, s->vs, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
@@ -810,7 +816,7 @@ static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o, bool restart = fal
   const int nbv = grid_for(g.N);
   if (s->mixed)
     hipLaunchKernelGGL(tsx_k_residual0<float>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr,
-                       (float *)s->vrhat, s->vp, s->pc != TSX_PC_NONE ? s->v32 : (float *)nullptr, s->partials, g, (int)s->pc_split);
+                       (float *)s->vrhat, s->vp, s->pc != TSX_PC_NONE ? s->p32 : (float *)nullptr, s->partials, g, (int)s->pc_split);
   else
     hipLaunchKernelGGL(tsx_k_residual0<double>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr, s->vrhat,
                        s->vp, (float *)nullptr, s->partials, g, 0);

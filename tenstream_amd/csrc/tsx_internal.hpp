@@ -110,7 +110,9 @@ struct tsx_solver {
   bool have_optprop;
   double *a13, *a23, *a33;       // cell-indexed, 1-D layers only
   double *planck;                // (L, xm, ym) reference layout
-  float *v32;                    // fp32 copy of the preconditioner's right-hand side (mixed path)
+  float *v32;                    // fp32 copy of the preconditioner's right-hand side s (mixed path)
+  float *p32;                    // the search direction p, kept in fp32 only on the mixed + preconditioned path
+  const float *pc_rhs;           // which of the two the next tsx_pc_apply (fp32 directions) reads
   double *edir_a, *edir_b;       // direct streams, current / scratch
   double *dsend[4], *drecv[4];   // direct-beam face buffers W, E, S, N (several ranks)
   void *dsc, *dsc_host;          // TsxDirScalars device / pinned

@@ -18,8 +18,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_residual0(long long n, const 
     const double v = b[q] - y[q];
     r[q] = v;
     rhat[q] = (RT)v;
-    p[q] = v;
-    if (p32) p32[split ? tsx_split_pos(q, g) : q] = (float)v;  // what the fp32-direction preconditioner reads (see tsx_k_pupdate)
+    if (p32) p32[split ? tsx_split_pos(q, g) : q] = (float)v;  // fp32 directions with a preconditioner: p lives in fp32 only
+    else p[q] = v;
     sum[0] += (double)(RT)v * v;
     sum[1] += v * v;
   }
@@ -49,6 +49,24 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pupdate(long long n2, const T
         p32[q] = make_float2((float)o.x, (float)o.y);
       }
     }
+  }
+}
+
+// p = r + beta (p - omega v) with p stored in fp32 only (fp32 directions + preconditioner): p enters the iteration only
+// through p-hat = M^-1 p, and x, r are updated with v = A p-hat whatever p-hat is, so rounding p perturbs the choice of the
+// direction, not the consistency of x and r -- the same licence flexible BiCGStab gives the preconditioner.  p32 may be in
+// the colour-split order of the red-black preconditioner.
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pupdate32(long long n2, const TsxScalars *__restrict__ sc,
+                                                             const double2 *__restrict__ r, const double2 *__restrict__ v,
+                                                             float *__restrict__ p32, TsxGeo g, int split) {
+  if (sc->done) return;
+  const double beta = sc->beta, omega = sc->omega;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double2 rr = r[q], vv = v[q];
+    const long long i0 = split ? tsx_split_pos(2 * q, g) : 2 * q, i1 = split ? tsx_split_pos(2 * q + 1, g) : 2 * q + 1;
+    const double p0 = (double)p32[i0], p1 = (double)p32[i1];
+    p32[i0] = (float)(rr.x + beta * (p0 - omega * vv.x));
+    p32[i1] = (float)(rr.y + beta * (p1 - omega * vv.y));
   }
 }
 

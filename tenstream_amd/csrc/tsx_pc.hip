@@ -16,7 +16,7 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
   const int nb = (ncols + 63) / 64;
   if constexpr (std::is_same<ZT, float>::value) {
     // fp32 directions: always the packed reduced-precision blocks (tsx_pc_ensure_half) and the fp32 right-hand side s->v32
-    if (!s->pc_half || !s->v32) {
+    if (!s->pc_half || !s->pc_rhs) {
       tsx_set_error("preconditioner: fp32 directions need the packed blocks (internal state error)");
       return TSX_ERR_STATE;
     }
@@ -30,7 +30,7 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
       }
 #define TSX_P16_LAUNCH(HAS, LDST, BYTES)                                                                                        \
   hipLaunchKernelGGL((tsx_k_pc_column_p16<ROWS, GS, HAS, XL, LDST>), dim3(nb), dim3(64), BYTES, s->stream, g,                    \
-                     (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,             \
+                     (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->pc_rhs, z, zy, zx,             \
                      (float4 *)s->pc_tmp, done)
       if (use_lds && lds <= (size_t)s->max_lds) {
         if (s->any_l1d) TSX_P16_LAUNCH(true, true, lds);
@@ -43,11 +43,11 @@ static int pc_column_launch(tsx_solver *s, const double *v, ZT *z, const ZT *zy,
     } else {
       if (s->any_l1d)
         hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, true, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,
+                           (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->pc_rhs, z, zy, zx,
                            (float4 *)s->pc_tmp, done);
       else
         hipLaunchKernelGGL((tsx_k_pc_column_p16h<ROWS, GS, false, XL>), dim3(nb), dim3(64), 0, s->stream, g,
-                           (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, z, zy, zx,
+                           (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->pc_rhs, z, zy, zx,
                            (float4 *)s->pc_tmp, done);
     }
     HIPCHK(hipGetLastError());
@@ -105,7 +105,7 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
     if (s->pc == TSX_PC_REDBLACK) {
       // pc_sweeps + 1 passes, colours alternately; the iterate lives colour-split in s->vw; the last pass also writes the
       // Krylov-layout result z for both colours
-      if (!s->pc_half || !s->v32 || !s->coef_h_split) {
+      if (!s->pc_half || !s->pc_rhs || !s->coef_h_split) {
         tsx_set_error("preconditioner: red-black ordering needs the colour-split packed blocks (internal state error)");
         return TSX_ERR_STATE;
       }
@@ -126,11 +126,11 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
   do {                                                                                                                          \
     if constexpr (NTOP == 2)                                                                                                    \
       hipLaunchKernelGGL((tsx_k_pc_column_rb<GSV, HAS, LDSV, MODEV>), dim3(nb), dim3(64), LDSV ? lds : 0, s->stream, g,          \
-                         (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, zs, zb,            \
+                         (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->pc_rhs, zs, zb,            \
                          (float *)z, (float4 *)s->pc_tmp, done, pass & 1);                                                      \
     else                                                                                                                        \
       hipLaunchKernelGGL((tsx_k_pc_column_rbh<GSV, HAS, (MODEV == 2)>), dim3(nb), dim3(64), 0, s->stream, g,                     \
-                         (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->v32, zs,                \
+                         (const uint4 *)s->coef_h, s->l1d, s->a11, s->a12, s->albedo, (const float *)s->pc_rhs, zs,             \
                          (const float *)zs, (float *)z, (float4 *)s->pc_tmp, done, pass & 1);                                   \
   } while (0)
 #define TSX_RB_L2(GSV, HAS, MODEV)                                                                                              \
@@ -210,7 +210,9 @@ static int ensure_pc_buffers_t(tsx_solver *s) {
   if (s->vph == s->vp || !s->vph) HIPCHK(hipMalloc((void **)&s->vph, nb));  // fp64-sized: also holds the fp32 form
   if (s->vsh == s->vs || !s->vsh) HIPCHK(hipMalloc((void **)&s->vsh, nb));
   if (!s->vw) HIPCHK(hipMalloc((void **)&s->vw, nb));
-  if (!s->v32) HIPCHK(hipMalloc((void **)&s->v32, (size_t)g.N * sizeof(float)));  // fp32 right-hand side of the mixed path
+  if (!s->v32) HIPCHK(hipMalloc((void **)&s->v32, (size_t)g.N * sizeof(float)));  // fp32 right-hand sides of the mixed path
+  if (!s->p32) HIPCHK(hipMalloc((void **)&s->p32, (size_t)g.N * sizeof(float)));
+  if (!s->pc_rhs) s->pc_rhs = s->v32;
   return TSX_OK;
 }
 
@@ -251,6 +253,7 @@ int tsx_pc_apply(tsx_solver *s, const double *v, void *z, bool z_is_float, bool 
 
 int tsx_pc_narrow(tsx_solver *s, const double *a) {  // s->v32 = (float) a: the mixed path's right-hand side
   hipLaunchKernelGGL(tsx_k_narrow, dim3(grid_for(s->geo.N)), dim3(TSX_BLOCK), 0, s->stream, s->geo, (int)s->pc_split, a, s->v32);
+  s->pc_rhs = s->v32;
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
