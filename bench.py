@@ -173,7 +173,7 @@ def main():
                 "workload": f"pprts {solver} diffuse solve, {Nx}x{Ny}x{Nz} cells ({args.nx}x{args.ny}x{Nz} per GPU), "
                             f"single solar g-point, rtol 1e-5 / reference atol, zero initial guess",
                 "process_grid": f"{npx}x{npy}",
-                "coeff_storage": "fp32 blocks (lossless), fp64 vectors",
+                "coeff_storage": "fp32 blocks (lossless); x, r, s, v, t fp64; directions p, p-hat, s-hat and shadow residual fp32",
                 "preconditioner_storage": "inside M^-1 only: fp16 column blocks + fp8 couplings, fp32/bf16 iterates; operator, "
                                           "Krylov vectors, dots and stop rule fp64 on the exact blocks",
                 "coeff_source": "device N-linear LUT interpolation (tsx_diff_set_optprop), synthetic table",
