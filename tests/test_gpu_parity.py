@@ -172,6 +172,28 @@ def test_red_black_preconditioner_is_checkerboard_gauss_seidel(gpu, solver, Nx, 
     s.close()
 
 
+@pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [
+    ("3_10", 2, 2, 3, 0), ("3_10", 2, 3, 2, 0), ("3_10", 4, 2, 1, 0), ("3_10", 64, 2, 5, 1), ("3_10", 2, 64, 4, 0),
+    ("3_10", 130, 4, 3, 0), ("3_10", 6, 6, 70, 3),   # Nz = 70: the sweep temporaries no longer fit the LDS block -> global
+    ("3_10", 66, 6, 65, 0), ("8_16", 2, 2, 2, 0), ("8_16", 4, 6, 66, 2), ("8_16", 10, 3, 3, 0)])
+def test_default_solver_on_awkward_shapes(gpu, solver, Nx, Ny, Nz, n1d):
+    """The default configuration (red-black where it applies, zebra rows otherwise; LDS or global sweep temporaries) on
+    minimal, thin, tall and odd grids against a sparse direct solve of the oracle's CSR."""
+    import scipy.sparse.linalg as spla
+
+    P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
+    lay = O.layout(solver, Nz, Nx, Ny)
+    A = O.assemble_csr(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x_ref = spla.spsolve(A.tocsc(), P["b"].ravel()).reshape(P["b"].shape)
+    s = DiffuseSolver(solver, Nz, Nx, Ny)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x = np.zeros(s.vec_shape)
+    info = s.solve(P["b"], x, rtol=1e-10, atol=1e-30)
+    assert info.reason == 2, info
+    assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    s.close()
+
+
 def test_stop_rule_reason_codes_like_MyKSPConverged(gpu):
     """Diverged reasons of MyKSPConverged (src/pprts.F90:4437-4486): -3 iteration limit, -9 NaN; the oracle's restatement
     of KSPFBCGS gives the same reason and iteration count for the bare operator."""
