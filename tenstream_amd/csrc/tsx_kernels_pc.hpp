@@ -839,7 +839,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 
 // ---- red-black (checkerboard) ordering of the column blocks: all four lateral neighbours of a column have the other
 // colour, so every pass is a true Gauss-Seidel step in x *and* y with the other colour's latest values (zebra rows only
-// get that in y and lag in x).  Measured on the CPU model (scripts/pc_study.py): the same iteration count with 2/3 of the
+// get that in y and lag in x).  Measured on the CPU model (tests/studies/pc_study.py): the same iteration count with 2/3 of the
 // passes, or ~27 % fewer iterations at the same number of passes.  Lanes run over every other column, so everything the
 // preconditioner owns -- packed blocks P, fp32 right-hand side r, its iterate zs -- is stored colour-split: within a row
 // the xm/2 columns of colour 0 first, then colour 1 (tsx_split_col); loads and stores stay contiguous.

@@ -2,7 +2,7 @@
 small synthetic problem.  Variants differ only in the colouring / ordering of the column-block Gauss-Seidel."""
 import sys, os
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as O
 from tenstream_amd import synthetic
 
