@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--ny", type=int, default=256)
     ap.add_argument("--nz", type=int, default=64)
     ap.add_argument("--pc-sweeps", type=int, default=0, help="0 = library default")
+    ap.add_argument("--phi0", type=float, default=180.0)
+    ap.add_argument("--theta0", type=float, default=40.0)
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -65,7 +67,7 @@ def main():
     T = torch.linspace(220.0, 288.0, Nz + 1, dtype=torch.float64, device=dev)
     planck0 = (5.670374419e-8 * T**4 / np.pi).expand(Ny, Nx, Nz + 1).contiguous()
 
-    P = PprtsSolver(Nz, Nx, Ny, dx, dx, 180.0, 40.0, device=local_rank)
+    P = PprtsSolver(Nz, Nx, Ny, dx, dx, args.phi0, args.theta0, device=local_rank)
     P.set_lut_diffuse(LUT.synthetic_diffuse_table("3_10"), LUT.diffuse_axes("3_10"))
     dax = LUT.direct_axes()
     Tdir, Sdir = LUT.synthetic_direct_tables(dax)
