@@ -28,6 +28,18 @@ def test_library_exports_every_declared_symbol():
     assert declared <= exported
 
 
+def test_f2c_library_exports_the_reference_c_abi():
+    """libtsx_f2c.so must export exactly the entry points include/tsx_f2c.h declares (c_wrapper/f2c_pprts.h:48-52)."""
+    hdr = open(os.path.join(ROOT, "include", "tsx_f2c.h")).read()
+    declared = set(re.findall(r"\b(pprts_f2c_[a-z_]+)\s*\(", hdr))
+    assert declared == {"pprts_f2c_init", "pprts_f2c_set_global_optical_properties", "pprts_f2c_solve",
+                        "pprts_f2c_get_result", "pprts_f2c_destroy"}
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libtsx_f2c.so")
+    nm = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (pprts_f2c_[a-z_]+)", nm))
+    assert declared <= exported, declared - exported
+
+
 def test_product_never_references_the_oracle():
     """The product path must not import, link or call anything under oracle/."""
     pkg = os.path.join(ROOT, "tenstream_amd")
