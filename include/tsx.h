@@ -228,9 +228,12 @@ int tsx_pprts_get_field(tsx_solver *s, int which, double *out, int where);
 int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps, int mixed);
 
 /* ---- measurement helpers (bench.py): time `reps` launches of the dominant kernel with HIP events on
- *      the solver's stream.  kernel: 0 = SpMV (diffuse operator apply), 1 = one full BiCGStab iteration */
+ *      the solver's stream.  kernel: 0 = SpMV (diffuse operator apply), 1 = one full BiCGStab iteration,
+ *      2 = one application of the default preconditioner (pc_sweeps + 1 half-grid passes), 3 = one intermediate
+ *      Gauss-Seidel pass of it (3_10 scan kernels) */
 int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_ms);
-/* algorithmic bytes per launch of that kernel (Nc*D^2*sc + 2*N*sv for the SpMV) */
+/* algorithmic bytes per launch of that kernel (Nc*D^2*sc + 2*N*sv for the SpMV; the preconditioner passes:
+ * packed records + fp32 right-hand side + neighbour records + stores, 200 B per cell of the pass's colour) */
 int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes);
 /* device STREAM-like copy bandwidth probe (GB/s) for reporting against the measured peak */
 int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps);

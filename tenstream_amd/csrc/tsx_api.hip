@@ -151,6 +151,7 @@ extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstr
   return TSX_OK;
 }
 
+static int create_fill(tsx_solver *s, const tsx_grid *grid);
 extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
   ARGCHK(grid && out, "tsx_create: null argument");
   ARGCHK(grid->solver_id == TSX_SOLVER_3_10 || grid->solver_id == TSX_SOLVER_8_16,
@@ -165,6 +166,16 @@ extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
   }
   tsx_solver *s = new tsx_solver();
   memset((void *)s, 0, sizeof(*s));
+  const int rc = create_fill(s, grid);
+  if (rc) {  // release the half-built solver (streams, events, buffers) on any failure
+    (void)tsx_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return TSX_OK;
+}
+
+static int create_fill(tsx_solver *s, const tsx_grid *grid) {
   s->grid = *grid;
   if (grid->device >= 0) s->device = grid->device;
   else HIPCHK(hipGetDevice(&s->device));
@@ -191,6 +202,9 @@ extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
   s->own_stream = true;
   HIPCHK(hipEventCreate(&s->ev0));
   HIPCHK(hipEventCreate(&s->ev1));
+  HIPCHK(hipEventCreate(&s->ev_imp0));
+  HIPCHK(hipEventCreate(&s->ev_imp1));
+  HIPCHK(hipEventCreate(&s->ev_exp1));
   HIPCHK(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
   HIPCHK(hipDeviceGetAttribute(&s->max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, s->device));
   HIPCHK(hipEventCreateWithFlags(&s->ev_pack, hipEventDisableTiming));
@@ -228,14 +242,13 @@ extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
   HIPCHK(hipMalloc((void **)&s->l1d, (size_t)g.Nz));
   HIPCHK(hipMalloc((void **)&s->albedo, sizeof(double) * g.ncol));
   HIPCHK(hipStreamSynchronize(s->stream));
-  *out = s;
   return TSX_OK;
 }
 
 extern "C" int tsx_destroy(tsx_solver *s) {
   if (!s) return TSX_OK;
   (void)hipSetDevice(s->device);
-  (void)hipStreamSynchronize(s->stream);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->v32, s->p32, s->dsend[0], s->dsend[1], s->dsend[2], s->dsend[3], s->drecv[0], s->drecv[1], s->drecv[2], s->drecv[3],
                   s->coef_h, s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
@@ -253,12 +266,10 @@ extern "C" int tsx_destroy(tsx_solver *s) {
     if (s->host_recv[q]) (void)hipHostFree(s->host_recv[q]);
   }
   if (s->comm_ready && g_rccl.CommDestroy) g_rccl.CommDestroy(s->nccl_comm);
-  (void)hipEventDestroy(s->ev0);
-  (void)hipEventDestroy(s->ev1);
-  (void)hipEventDestroy(s->ev_pack);
-  (void)hipEventDestroy(s->ev_recv);
-  (void)hipStreamDestroy(s->comm_stream);
-  if (s->own_stream) (void)hipStreamDestroy(s->stream);
+  for (hipEvent_t e : {s->ev0, s->ev1, s->ev_imp0, s->ev_imp1, s->ev_exp1, s->ev_pack, s->ev_recv})
+    if (e) (void)hipEventDestroy(e);
+  if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
+  if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return TSX_OK;
 }
@@ -490,23 +501,22 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
   if (rc) return rc;
 
   const void *src_dev = diff2diff;
-  void *tmp = nullptr;
+  TsxDevTmp tmp, flag_guard;  // released on every exit path (one call per g-point: a leak here is 3.4 GB per call)
   if (where == TSX_HOST) {
-    HIPCHK(hipMalloc(&tmp, ncoef * coeff_kind));
-    HIPCHK(hipMemcpyAsync(tmp, diff2diff, ncoef * coeff_kind, hipMemcpyHostToDevice, s->stream));
-    src_dev = tmp;
+    HIPCHK(tmp.alloc(ncoef * coeff_kind));
+    HIPCHK(hipMemcpyAsync(tmp.p, diff2diff, ncoef * coeff_kind, hipMemcpyHostToDevice, s->stream));
+    src_dev = tmp.p;
   }
   int out_bytes = 4;
   if (coeff_kind == 8) {  // keep fp64 unless every value survives the round trip through fp32
-    int *flag = nullptr;
-    HIPCHK(hipMalloc((void **)&flag, sizeof(int)));
+    HIPCHK(flag_guard.alloc(sizeof(int)));
+    int *flag = flag_guard.as<int>();
     HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), s->stream));
     hipLaunchKernelGGL(tsx_k_check_fp32_lossless, dim3(grid_for((long long)ncoef)), dim3(TSX_BLOCK), 0, s->stream,
                        (long long)ncoef, (const double *)src_dev, flag);
     int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    HIPCHK(hipFree(flag));
     out_bytes = bad ? 8 : 4;
   }
   if ((rc = ensure_coef_storage(s, out_bytes))) return rc;
@@ -879,10 +889,7 @@ static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, co
   int rc;
   const double *bd = b;
   double *xd = x;
-  hipEvent_t e_imp0, e_imp1, e_exp1;
-  HIPCHK(hipEventCreate(&e_imp0));
-  HIPCHK(hipEventCreate(&e_imp1));
-  HIPCHK(hipEventCreate(&e_exp1));
+  const hipEvent_t e_imp0 = s->ev_imp0, e_imp1 = s->ev_imp1, e_exp1 = s->ev_exp1;  // created once in tsx_create
   if (where == TSX_HOST) {
     if ((rc = ensure_stage(s))) return rc;
     HIPCHK(hipMemcpyAsync(s->stage_a, b, nb, hipMemcpyHostToDevice, s->stream));
@@ -907,9 +914,6 @@ static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, co
     HIPCHK(hipEventElapsedTime(&res->import_ms, e_imp0, e_imp1));
     HIPCHK(hipEventElapsedTime(&res->export_ms, s->ev1, e_exp1));
   }
-  (void)hipEventDestroy(e_imp0);
-  (void)hipEventDestroy(e_imp1);
-  (void)hipEventDestroy(e_exp1);
   return TSX_OK;
 }
 
@@ -1017,8 +1021,16 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
   const double bspmv = (double)g.Nc * g.D * g.D * sc + 2.0 * (double)g.N * sv;
   if (kernel == 0) *bytes = bspmv;
   else if (kernel == 1) *bytes = 2.0 * bspmv + 16.0 * (double)g.N * sv;
-  else {
-    tsx_set_error("tsx_algorithmic_bytes: kernel must be 0 or 1");
+  else if (kernel == 3 || kernel == 2) {
+    // the red-black passes of 3_10 on the packed blocks (tsx_kernels_pcs.hpp), per cell of the pass's colour:
+    //   Gauss-Seidel pass: 8 records x 16 B + rhs 10 x 4 B + 4 neighbour records x 4 B (bf16 pairs) + 4 x 4 B stored = 200 B
+    //   first pass (no neighbours): 3 records + rhs + stores = 104 B;  fp32 pass of the first colour: 224 B;
+    //   last pass (fp32 neighbours, the row partner's 10 values, both colours' result in the Krylov layout): 320 B
+    const double half = 0.5 * (double)g.Nc;
+    const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : 10;
+    *bytes = kernel == 3 ? 200.0 * half : (104.0 + 200.0 * (P > 3 ? P - 3 : 0) + 224.0 + 320.0) * half;
+  } else {
+    tsx_set_error("tsx_algorithmic_bytes: kernel must be 0..3");
     return TSX_ERR_ARG;
   }
   return TSX_OK;
@@ -1032,6 +1044,25 @@ static int bench_kernel_t(tsx_solver *s, int kernel, int reps, float *avg_ms) {
     HIPCHK(hipEventRecord(s->ev0, s->stream));
     for (int q = 0; q < reps; ++q)
       if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vp, s->vv, (const double *)nullptr, false))) return rc;
+    HIPCHK(hipEventRecord(s->ev1, s->stream));
+  } else if (kernel == 2 || kernel == 3) {
+    // the default preconditioner on the fp32 right-hand side p32: 2 = one application (pc_sweeps + 1 half-grid passes),
+    // 3 = one intermediate Gauss-Seidel pass of the scan kernels
+    tsx_ksp_opts o, ou;
+    if ((rc = prepare_ksp(s, nullptr, &o))) return rc;
+    (void)ou;
+    s->pc_rhs = s->p32;
+    if (kernel == 3 && !s->coef_h_scan) {
+      tsx_set_error("tsx_bench_kernel: kernel 3 needs the scan preconditioner (3_10, red-black, TSX_PC_SCAN != 0)");
+      return TSX_ERR_UNSUPPORTED;
+    }
+    if ((rc = tsx_pc_apply(s, s->vp, s->vph, true, false))) return rc;  // warm
+    HIPCHK(hipEventRecord(s->ev0, s->stream));
+    for (int q = 0; q < reps; ++q) {
+      if (kernel == 2) rc = tsx_pc_apply(s, s->vp, s->vph, true, false);
+      else rc = tsx_pcs_pass(s, 2 + (q & 1), 0, (float *)s->vph, nullptr);
+      if (rc) return rc;
+    }
     HIPCHK(hipEventRecord(s->ev1, s->stream));
   } else {
     // iterations on whatever state the vectors hold; scalars are neutralised so nothing diverges/stops
@@ -1058,7 +1089,7 @@ static int bench_kernel_t(tsx_solver *s, int kernel, int reps, float *avg_ms) {
 
 extern "C" int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_ms) {
   ARGCHK(s && avg_ms && reps >= 1, "tsx_bench_kernel: bad argument");
-  ARGCHK(kernel == 0 || kernel == 1, "tsx_bench_kernel: kernel must be 0 or 1");
+  ARGCHK(kernel >= 0 && kernel <= 3, "tsx_bench_kernel: kernel must be 0..3");
   if (!s->have_coeffs) {
     tsx_set_error("tsx_bench_kernel: call tsx_diff_set_coeffs first");
     return TSX_ERR_STATE;

@@ -115,3 +115,8 @@ int tsx_pc_ensure_buffers(tsx_solver *s);
 int tsx_pc_ensure_half(tsx_solver *s);
 int tsx_pc_narrow(tsx_solver *s, const double *a);
 int tsx_pc_widen(tsx_solver *s, const float *a, double *o);  // o = (double) a over the N unknowns
+// the red-black preconditioner of 3_10 as a segmented scan over the levels (tsx_pcs.hip); packed layout "S16" in s->coef_h
+bool tsx_pcs_eligible(const tsx_solver *s);
+int tsx_pcs_pack(tsx_solver *s);
+int tsx_pcs_apply(tsx_solver *s, float *z, const int *done);
+int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done);

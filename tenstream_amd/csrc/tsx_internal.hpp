@@ -70,6 +70,7 @@ struct tsx_solver {
   int coef_bytes;      // 4 or 8
   void *coef_h;        // packed fp16 copy of the blocks for the preconditioner (tsx_k_pack_p16; built in prepare_ksp)
   bool coef_h_valid, pc_half;
+  bool coef_h_scan;    // the packed copy is in the scan kernels' layout "S16" (tsx_kernels_pcs.hpp; always colour-split)
   bool coef_h_split;   // layout of the packed copy: colour-split (red-black preconditioner) or natural
   bool pc_split;       // the preconditioner's private arrays (packed blocks, fp32 rhs) are in colour-split order
   uint8_t *l1d;        // [Nz]
@@ -129,6 +130,7 @@ struct tsx_solver {
   double *host_send[4], *host_recv[4];  // pinned staging, order W,E,S,N
 
   hipEvent_t ev0, ev1;
+  hipEvent_t ev_imp0, ev_imp1, ev_exp1;  // import / export timing of tsx_diff_solve
   hipStream_t comm_stream;   // face exchange runs here while the interior SpMV runs on `stream`
   hipEvent_t ev_pack, ev_recv;
   int max_lds;               // hipDeviceAttributeMaxSharedMemoryPerBlock

@@ -1,6 +1,7 @@
 // tsx_kernels_pc.hpp -- column-block preconditioner kernels (see tsx_dev.hpp)
 #pragma once
 #include "tsx_dev.hpp"
+#include "tsx_pack.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // Column preconditioner  z = M^-1 r,  M = the column-diagonal blocks of A in dst-owned storage.
@@ -498,33 +499,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 //   grp 1: c(x_q->0) c(x_q->1), q = 0..3 (fp8) | pad
 //   grp 2: c(0 -> side d), d = 2..9 (fp16)        grp 3: c(1 -> side d) (fp16)
 //   grp 4, 5: c(y_q -> side 2+dd), byte 4 dd + q (fp8)       grp 6, 7: c(x_q -> side 2+dd) (fp8)
-typedef _Float16 tsx_h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 tsx_h4 __attribute__((ext_vector_type(4)));
-constexpr int TSX_P16_GROUPS = 8;
-constexpr float TSX_FP8_SCALE = 64.0f;
-
-// four fp8 e4m3 bytes of one word -> floats (still scaled by TSX_FP8_SCALE)
-__device__ __forceinline__ void tsx_fp8x4(unsigned w, float (&o)[4]) {
-  const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
-  const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
-  o[0] = lo[0];
-  o[1] = lo[1];
-  o[2] = hi[0];
-  o[3] = hi[1];
-}
-__device__ __forceinline__ unsigned tsx_to_fp8x4(float a, float b, float c, float d) {
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a * TSX_FP8_SCALE, b * TSX_FP8_SCALE, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c * TSX_FP8_SCALE, d * TSX_FP8_SCALE, w, true);
-  return (unsigned)w;
-}
-__device__ __forceinline__ unsigned tsx_to_h2(float a, float b) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  h2 v;
-  v[0] = (_Float16)a;
-  v[1] = (_Float16)b;
-  return __builtin_bit_cast(unsigned, v);
-}
-
 // 8_16 (D = 16): 24 records.  t = top dst 0..7, d = side dst 8..15, y_q = src 12+q, x_q = src 8+q.
 //   grp 0..7:    c(src 0..7 -> top dst t = grp), fp16                (Tuu/Rud/Rdu/Tdd interleaved by stream parity)
 //   grp 8, 9:    c(y_q -> t), byte 4 t + q, fp8        grp 10, 11: c(x_q -> t), fp8
@@ -863,11 +837,6 @@ struct TsxDnRawB {
   unsigned zy[4], zx[4];
   float pz[10];  // MODE 2: the row partner's final values (prefetched with the level, not loaded at the store)
 };
-__device__ __forceinline__ unsigned short tsx_to_bf16(float x) {
-  unsigned u = __float_as_uint(x);
-  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
-  return (unsigned short)(u >> 16);
-}
 
 template <bool GS, bool HAS1D, bool LDST, int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void tsx_k_pc_column_rb(

@@ -109,6 +109,7 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
         tsx_set_error("preconditioner: red-black ordering needs the colour-split packed blocks (internal state error)");
         return TSX_ERR_STATE;
       }
+      if (NTOP == 2 && s->coef_h_scan) return tsx_pcs_apply(s, (float *)z, done);
       const int P = s->pc_sweeps + 1;
       float *zs = (float *)s->vw;                                   // fp32 iterate (written by the last pass of colour P % 2)
       unsigned short *zb = (unsigned short *)(zs + (size_t)g.N);   // bf16 neighbour values of the intermediate passes
@@ -221,7 +222,16 @@ int tsx_pc_ensure_half(tsx_solver *s) {
   const bool h1 = s->geo.ntop == 2;
   const long long n = (long long)(h1 ? TSX_P16_GROUPS : TSX_P16H_GROUPS) * s->geo.Nc;
   if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
-  if (!s->coef_h_valid || s->coef_h_split != s->pc_split) {
+  const bool scan = s->pc_split && tsx_pcs_eligible(s);
+  if (scan && (!s->coef_h_valid || !s->coef_h_scan)) {
+    int rc = tsx_pcs_pack(s);
+    if (rc) return rc;
+    s->coef_h_valid = true;
+    s->coef_h_scan = true;
+    s->coef_h_split = true;
+  }
+  if (!scan && (!s->coef_h_valid || s->coef_h_scan || s->coef_h_split != s->pc_split)) {
+    s->coef_h_scan = false;
     const int sx = s->pc_split ? s->geo.xm : 0, sy = s->pc_split ? s->geo.ym : 0;
 #define TSX_PACK(CTYPE, NT)                                                                                        \
   hipLaunchKernelGGL((tsx_k_pack_p16<CTYPE, NT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, s->geo.Nc,      \

@@ -1,0 +1,122 @@
+// tsx_pcs.hip -- host side of the segmented-scan red-black preconditioner (kernels: tsx_kernels_pcs.hpp)
+#include <stdio.h>
+
+#include "tsx_host.hpp"
+#include "tsx_kernels_pcs.hpp"
+
+struct PcsCfg {
+  int lseg, nseg, cw;
+};
+
+// (LSEG, NSEG) pairs that are instantiated; CW in {64, 32, 16}
+static const int k_pairs[][2] = {{4, 16}, {8, 8}, {8, 16}, {16, 16}};
+
+static PcsCfg pcs_config(const tsx_solver *s) {
+  const TsxGeo &g = s->geo;
+  PcsCfg c = {0, 0, 0};
+  int e_l = 0, e_s = 0, e_cw = 0;  // TSX_PCS_CFG=lseg,nseg,cw (A/B knob; read per call so that tests can switch it)
+  if (const char *e = getenv("TSX_PCS_CFG")) sscanf(e, "%d,%d,%d", &e_l, &e_s, &e_cw);
+  if (e_l > 0 && e_l * e_s >= g.Nz) {
+    for (const auto &p : k_pairs)
+      if (p[0] == e_l && p[1] == e_s) {
+        c.lseg = e_l;
+        c.nseg = e_s;
+      }
+  }
+  const long long nthr = (long long)g.ym * (g.xm / 2);  // columns per pass
+  if (!c.lseg) {
+    // measured (scripts/pcsbench.py): 8 levels x 8 segments on large passes (>= 16 K columns: fewer, fatter threads),
+    // 4 x 16 on small ones (more waves); deeper columns take the smallest pair that holds them
+    if (g.Nz <= 64) {
+      c.lseg = nthr >= 16384 ? 8 : 4;
+      c.nseg = nthr >= 16384 ? 8 : 16;
+    } else if (g.Nz <= 128) {
+      c.lseg = 8;
+      c.nseg = 16;
+    } else if (g.Nz <= 256) {
+      c.lseg = c.nseg = 16;
+    }
+  }
+  if (!c.lseg) return c;  // Nz > 256: not eligible
+  // 32 columns per workgroup measured best on 128^2 and 256^2 columns; 16 keeps >= 256 workgroups on small domains
+  c.cw = (e_cw == 64 || e_cw == 32 || e_cw == 16) ? e_cw : (nthr >= 8192 && c.lseg < 16 ? 32 : 16);
+  return c;
+}
+
+bool tsx_pcs_eligible(const tsx_solver *s) {
+  const char *e = getenv("TSX_PC_SCAN");  // TSX_PC_SCAN=0: the one-lane-per-column kernels (A/B knob)
+  const int on = e ? atoi(e) : 1;
+  return on && s->geo.ntop == 2 && pcs_config(s).lseg > 0;
+}
+
+int tsx_pcs_pack(tsx_solver *s) {
+  const TsxGeo &g = s->geo;
+  uint4 *P = (uint4 *)s->coef_h;
+  if (s->coef_bytes == 4) {
+    hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->coef,
+                       s->l1d, s->a11, s->a12, s->albedo, P);
+    hipLaunchKernelGGL((tsx_k_pcs_pack<float>), dim3(grid_for(7 * g.Nc)), dim3(TSX_BLOCK), 0, s->stream, g, (const float *)s->coef,
+                       s->l1d, P);
+  } else {
+    hipLaunchKernelGGL((tsx_k_pcs_pack_col<double>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const double *)s->coef,
+                       s->l1d, s->a11, s->a12, s->albedo, P);
+    hipLaunchKernelGGL((tsx_k_pcs_pack<double>), dim3(grid_for(7 * g.Nc)), dim3(TSX_BLOCK), 0, s->stream, g,
+                       (const double *)s->coef, s->l1d, P);
+  }
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+template <int L, int S, int CW>
+static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin, const int *done) {
+  const TsxGeo &g = s->geo;
+  const long long nthr = (long long)g.ym * (g.xm / 2);
+  const int nb = (int)((nthr + CW - 1) / CW);
+  const uint4 *P = (const uint4 *)s->coef_h;
+  const float *r = (const float *)s->pc_rhs;
+#define TSX_PCS_GO(GSV, MODEV)                                                                                                   \
+  hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb, zfin, done, rbc, \
+                     nonbr)
+  if (!gs) TSX_PCS_GO(false, 0);
+  else if (mode == 0) TSX_PCS_GO(true, 0);
+  else if (mode == 1) TSX_PCS_GO(true, 1);
+  else TSX_PCS_GO(true, 2);
+#undef TSX_PCS_GO
+}
+
+template <int L, int S>
+static void pcs_launch_cw(tsx_solver *s, int cw, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin,
+                          const int *done) {
+  if (cw == 64) pcs_launch<L, S, 64>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done);
+  else if (cw == 32) pcs_launch<L, S, 32>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done);
+  else pcs_launch<L, S, 16>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done);
+}
+
+// one pass: mode as in tsx_k_pcs_rb; first = no neighbour values exist yet
+int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done) {
+  const TsxGeo &g = s->geo;
+  const PcsCfg c = pcs_config(s);
+  float *zs = (float *)s->vw;                        // fp32 iterate (mode 1 writes, mode 2 reads)
+  unsigned *zb = (unsigned *)(zs + (size_t)g.N);     // bf16 side-stream records of the intermediate passes
+  const bool first = pass == 0;
+  const bool gs = !(first && mode == 0);
+  const int nonbr = first && mode != 0;
+  const int rbc = pass & 1;
+  if (c.lseg == 4) pcs_launch_cw<4, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done);
+  else if (c.lseg == 8 && c.nseg == 8) pcs_launch_cw<8, 8>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done);
+  else if (c.lseg == 8) pcs_launch_cw<8, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done);
+  else pcs_launch_cw<16, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done);
+  return TSX_OK;
+}
+
+// z = M^-1 r (r = s->pc_rhs, fp32, colour-split): pc_sweeps + 1 half-grid passes, colours alternately
+int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
+  const int P = s->pc_sweeps + 1;
+  for (int pass = 0; pass < P; ++pass) {
+    const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
+    int rc = tsx_pcs_pass(s, pass, mode, z, done);
+    if (rc) return rc;
+  }
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}

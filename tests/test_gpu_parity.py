@@ -446,3 +446,58 @@ def test_zebra_preconditioner_is_line_gauss_seidel(gpu, solver, Nx, Ny, Nz, n1d,
     ij = s.solve(P["b"], xj, rtol=1e-10, atol=1e-30, pc=1, pc_sweeps=1)
     assert iz.reason == 2 and iz.niter <= ij.niter
     assert np.abs(xs - xj).max() <= 1e-8 * np.abs(xj).max()
+
+
+@pytest.mark.parametrize("Nx,Ny,Nz,n1d,cfg", [
+    (12, 6, 6, 1, "4,16,16"), (12, 6, 11, 0, "4,16,32"), (34, 6, 20, 3, "8,8,64"), (10, 4, 37, 0, "8,8,16"),
+    (8, 6, 70, 2, "8,16,32"), (6, 4, 130, 0, "16,16,16"), (130, 2, 9, 0, "4,16,64"), (6, 4, 64, 0, "4,16,16"),
+    (6, 4, 64, 0, "8,8,32"), (20, 10, 33, 4, "")])
+def test_scan_preconditioner_equals_the_column_sweep(gpu, monkeypatch, Nx, Ny, Nz, n1d, cfg):
+    """tsx_k_pcs_rb (segmented scan over the levels: LSEG x NSEG levels, CW columns per workgroup; ragged last segment,
+    idle segments, columns that do not fill a workgroup) computes the same red-black M^-1 as the one-lane-per-column
+    sweep tsx_k_pc_column_rb and as the sparse model.  Both run on reduced-precision blocks (roundings differ: the scan
+    stores the matrix-only recurrences in fp16, the sweep the four top coefficients): 2 % of max between them, 6 % of max
+    against the exact model, like test_red_black_preconditioner_is_checkerboard_gauss_seidel."""
+    import scipy.sparse.linalg as spla
+
+    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
+    lay = O.layout("3_10", Nz, Nx, Ny)
+    v = np.random.default_rng(11).standard_normal(P["b"].shape)
+    out = {}
+    for scan in ("0", "1"):
+        monkeypatch.setenv("TSX_PC_SCAN", scan)
+        if cfg:
+            monkeypatch.setenv("TSX_PCS_CFG", cfg)
+        s = DiffuseSolver("3_10", Nz, Nx, Ny)
+        s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+        out[scan] = [s.pc_apply(v, pc=3, sweeps=sw, mixed=True) for sw in (1, 2, 4)]
+        x = np.zeros(s.vec_shape)
+        info = s.solve(P["b"], x, rtol=1e-10, atol=1e-30)
+        out["its" + scan], out["x" + scan] = info.niter, x
+        assert info.reason == 2
+        s.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.abs(a - b).max() <= 2e-2 * np.abs(a).max()
+    assert abs(out["its0"] - out["its1"]) <= 1
+    assert np.abs(out["x0"] - out["x1"]).max() <= 1e-8 * np.abs(out["x0"]).max()
+    # against the model: red-black Gauss-Seidel on the exact column blocks, 5 passes
+    M, A = _column_block_matrix(P, lay)
+    D, L = lay.D, Nz + 1
+    idx = np.arange(A.shape[0])
+    d, k = idx % D, (idx // D) % L
+    i, j = (idx // (D * L)) % Nx, idx // (D * L * Nx)
+    oi, oj = i.copy(), j.copy()
+    qx, qy = d - 2, d - 6
+    mx = (qx >= 0) & (qx < 4) & (qx % 2 == 1) & (k < Nz)
+    my = (qy >= 0) & (qy < 4) & (qy % 2 == 1) & (k < Nz)
+    oi[mx] = (i[mx] - 1) % Nx
+    oj[my] = (j[my] - 1) % Ny
+    colour = (oi + oj) % 2
+    Noff = (A - M.tocsr()).tocsr()
+    lu = spla.splu(M.tocsc(), permc_spec="NATURAL")
+    x = np.zeros(v.size)
+    for p_ in range(5):
+        rhs = v.ravel() - (Noff @ x if p_ > 0 else 0.0)
+        mk = colour == (p_ % 2)
+        x[mk] = lu.solve(rhs)[mk]
+    assert np.abs(out["1"][2].ravel() - x).max() <= 6e-2 * np.abs(x).max()
