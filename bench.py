@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- pprts 3_10 diffuse-solve throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one diffuse solve (I - T) x = b with the reference's stop rule (rtol 1e-5, atol
 1e-4*Nx*Ny*(Nz+1), src/pprts_base.F90:1126-1131) from a zero initial guess on one synthetic solar
 g-point; inputs (coefficient blocks, RHS) are resident in HBM before the timed region.  At N > 1 the
-domain is sharded 2-D in x/y exactly like the reference's DMDA (src/pprts_base.F90:747-790), one rank
-per GPU, weak scaling (every GPU owns a 256x256x64 block), face halos + dot products over RCCL.
+domain is sharded 2-D in x/y exactly like the reference's DMDA (src/pprts_base.F90:747-790, 972-990), one rank
+per GPU, face halos + dot products over RCCL (host-staged gloo when several ranks have to share a device).
+Domain:  --scaling weak (default): every GPU owns --nx x --ny columns (256 x 256 x 64: the BASELINE metric domain per GPU);
+         --scaling strong: the global domain is --nx x --ny whatever N is (256 x 256 x 64 at 1/2/4/8 GPUs);
+         --global-nx / --global-ny: an explicit global domain, e.g. config 3 = `--gpus 8 --global-nx 512 --global-ny 512`
+         (2 x 4 ranks of 256 x 128 columns).
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -35,8 +39,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nx", type=int, default=256, help="columns per GPU in x")
-    ap.add_argument("--ny", type=int, default=256, help="columns per GPU in y")
+    ap.add_argument("--nx", type=int, default=256, help="columns in x: per GPU (weak scaling) or of the global domain (strong)")
+    ap.add_argument("--ny", type=int, default=256, help="columns in y, likewise")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--global-nx", type=int, default=0, help="explicit global domain (implies fixed total work)")
+    ap.add_argument("--global-ny", type=int, default=0)
+    ap.add_argument("--transport", choices=("auto", "rccl", "host"), default="auto",
+                    help="auto: RCCL when every rank has a device of its own, else host-staged (gloo)")
     ap.add_argument("--nz", type=int, default=64)
     ap.add_argument("--solver", default="3_10")
     ap.add_argument("--pc", type=int, default=3,
@@ -49,8 +58,47 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes from here.  This parent never touches
+    the GPU (no torch import, no HIP call); it relays rank 0's JSON line and exits with the first non-zero exit code."""
+    import subprocess
+
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TSX_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        out0 = procs[0].communicate()[0]
+        for pr in procs:
+            pr.wait()
+            rc = rc or pr.returncode
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -62,17 +110,34 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count must equal --gpus")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible (libtsx has no CPU fallback)")
+    transport = args.transport
+    if transport == "auto":
+        transport = "rccl" if ndev >= world else "host"
+    if transport == "rccl" and ndev < world:
+        raise SystemExit(f"bench.py: RCCL needs one device per rank ({world} ranks, {ndev} devices); use --transport host")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if transport == "rccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    # ---- domain: weak scaling, every rank owns nx x ny columns ------------------------------------
+    # ---- domain -------------------------------------------------------------------------------------
     npx, npy = decompose(world)
-    Nx, Ny, Nz = args.nx * npx, args.ny * npy, args.nz
+    Nz = args.nz
+    if args.global_nx or args.global_ny:
+        Nx, Ny, scaling = args.global_nx or args.nx, args.global_ny or args.ny, "strong"
+    elif args.scaling == "strong":
+        Nx, Ny, scaling = args.nx, args.ny, "strong"
+    else:
+        Nx, Ny, scaling = args.nx * npx, args.ny * npy, "weak"
     co = decompose.coord(rank, world, Nx, Ny)
     dx, dz, albedo = 100.0, 50.0, 0.1
     solver = args.solver
@@ -95,11 +160,15 @@ def main():
     alb = torch.full((co.ym, co.xm), albedo, dtype=torch.float64, device=dev)
 
     s = DiffuseSolver(solver, Nz, co.xm, co.ym, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank, nranks=world,
-                      neighbors=(co.west, co.east, co.south, co.north), device=local_rank)
-    if world > 1:
+                      neighbors=(co.west, co.east, co.south, co.north), device=dev_index)
+    if world > 1 and transport == "rccl":
         uid = [s.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         s.comm_init(uid[0])
+    elif world > 1:
+        from tenstream_amd import hostcomm
+
+        hostcomm.attach(s, rank)
     # coefficient blocks come from the product path: LUT (synthetic stand-in table in the reference's exact
     # shape/ordering) uploaded once, then N-linear interpolation per cell on the device (tsx_diff_set_optprop)
     from tenstream_amd import lut as LUT
@@ -133,7 +202,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if transport == "rccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     cells_total = Nx * Ny * Nz
@@ -145,19 +214,46 @@ def main():
     tight = s.solve(b, x, rtol=1e-8, atol=1e-30, pc=args.pc, pc_sweeps=args.pc_sweeps)
     warm = s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps)
 
-    # ---- roofline of the dominant kernel (the operator apply), HIP events on the solver's stream --------
+    # ---- rooflines, HIP events on the solver's stream (tsx_bench_kernel): the operator apply, one whole iteration, and
+    # the preconditioner (one application = pc_sweeps + 1 half-grid passes; one intermediate pass of the scan kernels)
     spmv_ms = s.bench_kernel(0, args.kernel_reps)
     iter_ms = s.bench_kernel(1, max(4, args.kernel_reps // 4))
     bytes_spmv = s.algorithmic_bytes(0)
     bytes_iter = s.algorithmic_bytes(1)
-    achieved = bytes_spmv / (spmv_ms * 1e-3) / 1e9
+    pc_ms = pass_ms = None
+    if args.pc == 3 and args.pc_sweeps == 9:
+        try:
+            pc_ms = s.bench_kernel(2, args.kernel_reps)
+            pass_ms = s.bench_kernel(3, 4 * args.kernel_reps)
+        except Exception:  # 8_16 / odd grids: no scan kernels (pass_ms stays None)
+            pass
     copy_gbps = s.probe_copy_bandwidth(1 << 30, 10)
+
+    def roof(kernel, ms, nbytes, patterns):
+        ach = nbytes / (ms * 1e-3) / 1e9
+        traffic, src = pmc_traffic(solver, f"{co.xm}x{co.ym}x{Nz}", patterns)
+        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                "traffic": traffic, "traffic_source": src, "bytes_per_launch": nbytes, "ms_per_launch": ms,
+                "traffic_GBps": None if traffic is None else traffic / (ms * 1e-3) / 1e9}
 
     out = None
     if rank == 0:
-        traffic, traffic_src = pmc_traffic(f"{args.nx}x{args.ny}x{Nz}")
+        r_spmv = roof("tsx_k_spmv_w (y = (I - T) x, fp64 x and y)", spmv_ms, bytes_spmv, ["tsx_k_spmv", ",0,2,double,double"])
+        r_iter = roof("one BiCGStab iteration (2 M^-1, 2 SpMV, 3 vector updates)", iter_ms, bytes_iter, None)
+        r_pass = None
+        if pass_ms is not None:
+            r_pass = roof("tsx_k_pcs_rb<..., GS, MODE 0> (one intermediate red-black pass of M^-1)", pass_ms,
+                          s.algorithmic_bytes(3), ["tsx_k_pcs_rb", ",true,0>"])
+        r_pc = None
+        if pc_ms is not None:
+            r_pc = {"kernel": f"M^-1: {args.pc_sweeps + 1} half-grid passes", "ms_per_application": pc_ms,
+                    "bytes_per_application": s.algorithmic_bytes(2),
+                    "achieved": s.algorithmic_bytes(2) / (pc_ms * 1e-3) / 1e9, "unit": "GB/s"}
+        # the kernel the solve spends most of its time in: the preconditioner pass (about half of an iteration) when the
+        # scan kernels run, else the operator apply
+        dominant = r_pass if r_pass is not None else r_spmv
         out = {
-            "metric": "pprts 3_10 diffuse-solve cells/s",
+            "metric": f"pprts {solver} diffuse-solve cells/s",
             "value": value,
             "unit": "cells/s",
             "n_gpus": world,
@@ -165,14 +261,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"pprts {solver} diffuse solve, {Nx}x{Ny}x{Nz} cells ({args.nx}x{args.ny}x{Nz} per GPU), "
-                            f"single solar g-point, rtol 1e-5 / reference atol, zero initial guess",
+                "workload": f"pprts {solver} diffuse solve, {Nx}x{Ny}x{Nz} cells global ({co.xm}x{co.ym}x{Nz} on rank 0), "
+                            f"{scaling} scaling, single solar g-point, rtol 1e-5 / reference atol, zero initial guess",
                 "process_grid": f"{npx}x{npy}",
+                "transport": "none (1 rank)" if world == 1 else ("RCCL" if transport == "rccl" else "host-staged (gloo)"),
                 "coeff_storage": "fp32 blocks (lossless); x, r, s, v, t fp64; directions p, p-hat, s-hat and shadow residual fp32",
                 "preconditioner_storage": "inside M^-1 only: fp16 column blocks + fp8 couplings, fp32/bf16 iterates; operator, "
                                           "Krylov vectors, dots and stop rule fp64 on the exact blocks",
@@ -192,18 +289,10 @@ def main():
                 "iter_GBps": bytes_iter / (iter_ms * 1e-3) / 1e9,
                 "copy_GBps_measured": copy_gbps,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "tsx_k_spmv",
-                "achieved": achieved,
-                "peak": 8000.0,
-                "unit": "GB/s",
-                "frac": achieved / 8000.0,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "bytes_per_launch": bytes_spmv,
-                "ms_per_launch": spmv_ms,
-            },
+            "roofline": dominant,
+            "roofline_spmv": r_spmv,
+            "roofline_iter": r_iter,
+            "roofline_pc": r_pc,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, solver, dx, dz, albedo)
@@ -214,24 +303,28 @@ def main():
         print(json.dumps(out))
 
 
-def pmc_traffic(key):
-    """HBM-side bytes per SpMV launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/rNN/traffic_<key>.json, written by scripts/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes,
-    gfx950 FETCH_SIZE x2 correction).  PMC passes cannot run inside the timed bench, so the figure is looked up;
-    None if no profile of this workload size is committed."""
+def pmc_traffic(solver, size, patterns):
+    """HBM-side bytes per launch of one kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN/traffic_<solver>_<local size>.json, written by scripts/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE
+    passes, gfx950 FETCH_SIZE x2 correction, launches that exit at once after convergence excluded).  PMC passes cannot run
+    inside the timed bench, so the figure is looked up; None if no profile of this solver and size is committed.
+    patterns: substrings the kernel name must contain; None = the sum over one iteration (entry "iteration")."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", f"traffic_{key}.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", f"traffic_{solver}_{size}.json")), reverse=True):
         try:
-            k = json.load(open(path))["kernels"]
+            doc = json.load(open(path))
         except Exception:
             continue
-        # the variant tsx_bench_kernel(0) times: FUSE=0, fp64 x and y
-        spmv = [v for name, v in k.items() if name.startswith("tsx_k_spmv") and ",0,2,double,double" in name]
-        spmv = spmv or [v for name, v in k.items() if name.startswith("tsx_k_spmv") and v["launches"] > 0]
-        if spmv:
-            n = sum(v["launches"] for v in spmv)
-            return sum(v["traffic_bytes_per_launch"] * v["launches"] for v in spmv) / n, os.path.relpath(path, here)
+        if patterns is None:
+            it = doc.get("iteration")
+            if it:
+                return it["traffic_bytes"], os.path.relpath(path, here)
+            continue
+        hit = [v for name, v in doc["kernels"].items() if all(p in name for p in patterns) and v["launches"] > 0]
+        if hit:
+            n = sum(v["launches"] for v in hit)
+            return sum(v["traffic_bytes_per_launch"] * v["launches"] for v in hit) / n, os.path.relpath(path, here)
     return None, None
 
 
@@ -274,7 +367,27 @@ def cpu_baseline(args, solver, dx, dz, albedo):
     x, info = O.solve_bjacobi_ilu_mt(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"],
                                      P["b"], npx, npy, rtol=rt, atol=at, maxit=mx)
     cells = n * n * args.nz
+    # SURVEY 8(d) B2 / B3 beside it, one core each on a smaller sample of the same generator (both are serial codes in the
+    # oracle: the matrix-free FBCGS without preconditioner -- the algorithm of the GPU path minus M^-1 --, and the
+    # reference's PETSc-free explicit SOR, src/pprts_explicit.F90:461-713), same tolerances rule
+    m = 32
+    Pm = S.make_problem(solver, Nx=m, Ny=m, Nz=args.nz, dx=dx, dz=dz, albedo=albedo)
+    laym = O.layout(solver, args.nz, m, m)
+    rtm, atm, mxm = O.default_tolerances(m, m, args.nz + 1)
+    cm = Pm["coeff"].astype(np.float64)
+    t0 = time.perf_counter()
+    _, i2 = O.solve_matfree(laym, cm, Pm["l1d"], Pm["a11"], Pm["a12"], Pm["albedo"], Pm["b"], rtol=rtm, atol=atm, maxit=mxm)
+    t2 = time.perf_counter() - t0
+    others = [{"name": "B2 matrix-free FBCGS, no preconditioner", "value": m * m * args.nz / t2, "unit": "cells/s", "cores": 1,
+               "sample": f"{m}x{m}x{args.nz}, {i2['niter']} its, reason {i2['reason']}, {t2:.2f}s"}]
+    if solver == "3_10":
+        t0 = time.perf_counter()
+        _, i3 = O.solve_sor(laym, cm, Pm["l1d"], Pm["a11"], Pm["a12"], Pm["albedo"], Pm["b"], rtol=rtm, atol=atm)
+        t3 = time.perf_counter() - t0
+        others.append({"name": "B3 explicit SOR (explicit_ediff)", "value": m * m * args.nz / t3, "unit": "cells/s", "cores": 1,
+                       "sample": f"{m}x{m}x{args.nz}, {i3['niter']} sweeps, converged {i3['converged']}, {t3:.2f}s"})
     return {
+        "others": others,
         "value": cells / info["t_solve"],
         "unit": "cells/s",
         "cores": threads,

@@ -9,6 +9,9 @@ HBM bytes per launch = 2 * FETCH_SIZE * 1024  +  WRITE_SIZE * 1024
     4/8/16 B-per-lane access widths by scripts/calib_fetch.hip -> profiles/r01/calib_pmc_*.csv), hence the factor 2;
   * Infinity-Cache hits are counted by FETCH_SIZE, so this is fabric traffic, an upper bound on HBM traffic.
 The two counters are collected in separate passes (they do not fit one pass).
+Launches that exit at once (the Krylov loop enqueues up to check_every iterations ahead of the host's convergence check;
+those kernels return on the `done` flag) are excluded: only launches with at least half of the kernel's largest counter
+value are averaged.  "iteration" = the sum over the kernels of one default BiCGStab iteration (3_10, red-black, 10 passes).
 """
 import csv
 import json
@@ -45,6 +48,8 @@ def main():
     for k in sorted(set(F) | set(W)):
         f = [v for v, _ in F.get(k, [])]
         w = [v for v, _ in W.get(k, [])]
+        f = [v for v in f if v >= 0.5 * max(f)] if f and max(f) > 0 else f   # working launches only
+        w = [v for v in w if v >= 0.5 * max(w)] if w and max(w) > 0 else w
         fm = sum(f) / len(f) if f else 0.0
         wm = sum(w) / len(w) if w else 0.0
         kernels[k] = {
@@ -55,8 +60,22 @@ def main():
             "write_bytes_per_launch": wm * 1024.0,
             "traffic_bytes_per_launch": 2.0 * fm * 1024.0 + wm * 1024.0,
         }
-    json.dump({"workload": key, "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950)", "kernels": kernels},
-              open(out, "w"), indent=1)
+    # one default iteration: 2 applications of M^-1 (pass 0 without neighbours, 7 intermediate, the fp32 pass, the last
+    # pass), 2 operator applies with fused dots, 3 vector updates
+    per_iter = [("tsx_k_pcs_rb", ",false,0>", 2), ("tsx_k_pcs_rb", ",true,0>", 14), ("tsx_k_pcs_rb", ",true,1>", 2),
+                ("tsx_k_pcs_rb", ",true,2>", 2), ("tsx_k_spmv_w", ",1,2,float,float", 1), ("tsx_k_spmv_w", ",5,2,float,double", 1),
+                ("tsx_k_pupdate32", "", 1), ("tsx_k_supdate", "", 1), ("tsx_k_xrupdate", "", 1)]
+    it_bytes, missing = 0.0, []
+    for base, pat, mult in per_iter:
+        hit = [v for name, v in kernels.items() if name.startswith(base) and pat in name]
+        if hit:
+            it_bytes += mult * hit[0]["traffic_bytes_per_launch"]
+        else:
+            missing.append(base + pat)
+    doc = {"workload": key, "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950)", "kernels": kernels}
+    if not missing:
+        doc["iteration"] = {"traffic_bytes": it_bytes, "composition": [f"{m} x {b}{p}" for b, p, m in per_iter]}
+    json.dump(doc, open(out, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k[:70]:70s} n={v['launches']:5d} traffic={v['traffic_bytes_per_launch'] / 1e6:10.1f} MB")
 

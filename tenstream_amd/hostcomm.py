@@ -1,0 +1,40 @@
+"""Host-staged transport for several ranks that cannot use RCCL among themselves (processes sharing one GPU in tests
+and in `bench.py --gpus N` on a box with fewer devices; MPI hosts without GPU-aware transport): the callbacks of
+`tsx_comm_set_callbacks` on top of a torch.distributed process group (gloo).  Message matching follows
+`exchange_diffuse_boundary` (src/pprts_explicit.F90:769-843): recv[W] <- peer W's send[E], recv[E] <- peer E's send[W],
+recv[S] <- peer S's send[N], recv[N] <- peer N's send[S]."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def attach(solver, rank: int):
+    """install exchange / allreduce callbacks on a DiffuseSolver / PprtsSolver; the default process group must exist"""
+    import torch
+    import torch.distributed as dist
+
+    def exchange(send, recv, peers):
+        want_tag = [1, 0, 3, 2]  # the tag is the sender's face index: W = 0, E = 1, S = 2, N = 3
+        reqs, keep = [], []
+        for q in range(4):
+            if len(recv[q]) == 0 or peers[q] == rank:
+                continue
+            t = torch.from_numpy(recv[q])
+            keep.append(t)
+            reqs.append(dist.irecv(t, src=peers[q], tag=want_tag[q]))
+        for q in range(4):
+            if len(send[q]) == 0 or peers[q] == rank:
+                continue
+            t = torch.from_numpy(np.array(send[q], copy=True))
+            keep.append(t)
+            reqs.append(dist.isend(t, dst=peers[q], tag=q))
+        for q in range(4):  # self neighbours
+            if len(recv[q]) and peers[q] == rank:
+                recv[q][...] = send[q ^ 1]
+        for r in reqs:
+            r.wait()
+
+    def allreduce(buf):
+        dist.all_reduce(torch.from_numpy(buf))
+
+    solver.comm_set_callbacks(exchange, allreduce)

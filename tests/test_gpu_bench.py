@@ -1,0 +1,62 @@
+"""bench.py as the driver runs it: `python bench.py --gpus N` starts its own ranks (no launcher), prints one JSON line
+with the contract's keys, and can run the stated configurations (weak / strong scaling, an explicit global domain).  On a
+1-GPU box the ranks share the device and the face exchange is host-staged (gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "1", "--warmup", "1", "--nz", "16", "--no-cpu-baseline", "--kernel-reps", "2"]
+
+
+def _run(args, env=None, timeout=600):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **(env or {})), cwd=ROOT)
+    return p
+
+
+def _line(p):
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_one_gpu_line_has_the_contract_keys(gpu):
+    out = _line(_run(["--nx", "64", "--ny", "32"] + SMALL))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "roofline_spmv", "roofline_iter", "roofline_pc"):
+        assert k in out, k
+    assert out["metric"].startswith("pprts 3_10") and out["n_gpus"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["reason"] in (2, 3)
+    assert "tsx_k_pcs_rb" in out["roofline"]["kernel"] and out["roofline"]["frac"] > 0
+    # the metric names the solver that ran
+    out8 = _line(_run(["--nx", "16", "--ny", "12", "--solver", "8_16"] + SMALL))
+    assert out8["metric"].startswith("pprts 8_16") and "tsx_k_spmv" in out8["roofline"]["kernel"]
+
+
+@pytest.mark.parametrize("extra,glob,local,scaling", [
+    (["--nx", "32", "--ny", "24"], (32, 48), (32, 24), "weak"),
+    (["--nx", "32", "--ny", "24", "--scaling", "strong"], (32, 24), (32, 12), "strong"),
+    (["--global-nx", "64", "--global-ny", "32"], (64, 32), (64, 16), "strong"),   # config-3 style: an explicit global domain
+])
+def test_bench_launches_its_own_ranks(gpu, extra, glob, local, scaling):
+    """`python bench.py --gpus 2` under no launcher: two rank processes (here sharing the one device, host-staged
+    exchange), one JSON line from rank 0, the requested decomposition (2 ranks -> 1 x 2, src/pprts_base.F90:757-763)."""
+    env = {k: "" for k in ()}
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra + SMALL, capture_output=True,
+                       text=True, timeout=900, env=clean, cwd=ROOT)
+    out = _line(p)
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["config"]["process_grid"] == "1x2"
+    assert f"{glob[0]}x{glob[1]}x16 cells global ({local[0]}x{local[1]}x16 on rank 0)" in out["config"]["workload"]
+    assert out["config"]["reason"] in (2, 3) and out["value"] > 0
+
+
+def test_bench_refuses_a_rank_count_mismatch(gpu):
+    p = _run(["--gpus", "2"] + SMALL, env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
