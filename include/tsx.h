@@ -185,12 +185,14 @@ int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int where, const t
  *   explicit_edir (src/pprts_explicit.F90:60-459)   -> column-marching sweeps iterated to the same stop rule
  *   setup_b (:4641-4987)                            -> written directly in dst-owned storage
  *   calc_flx_div (:5152-5504), scale_flx (:3682-3988), pprts_get_result (:5799-5888) -> tsx_pprts_get_result
- * Solver 3_10.  On several ranks the direct sweep exchanges one face per sweep with the upwind / downwind neighbours
+ * Solvers 3_10 (3 direct streams) and 8_16 (8 direct streams: 4 per top face, 2 per side face, src/pprts.F90:413-425;
+ * tables relabelled for the sun's quadrant by dir2dir8_coeff_symmetry / dir8_to_diff16_coeff_symmetry,
+ * src/optprop.F90:1186-1302).  On several ranks the direct sweep exchanges one face per sweep with the upwind / downwind neighbours
  * (exchange_direct_boundary, src/pprts_explicit.F90:1076-1140), its residual is the mean over ranks of the local norms
  * (:184), setup_b needs no exchange in dst-owned storage, and the flux divergence reads one halo update of the solution. */
 /* set_angles (src/pprts.F90:1100-1183): sun azimuth phi0 / zenith theta0 in degrees as pprts_f2c_init takes them */
 int tsx_pprts_set_angles(tsx_solver *s, double phi0, double theta0);
-/* direct tables Tdir (S*S per entry) and Sdir (S*D per entry), 6 axes [tau, w0, aspect_zx, g, phi, theta]
+/* direct tables Tdir (S*S per entry) and Sdir (S*D per entry; S = 3 / 8 for 3_10 / 8_16), 6 axes [tau, w0, aspect_zx, g, phi, theta]
  * (src/optprop_base.F90:228-240); same payload layout as the diffuse table */
 int tsx_lut_set_direct(tsx_solver *s, const float *Tdir, const float *Sdir, int64_t nentries, int32_t ndim,
                        const int32_t *n, const float *axes_concat, int where);

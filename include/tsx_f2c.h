@@ -9,7 +9,7 @@
  *     (f2c_pprts.F90:325-327, 458-459 -- the header's `int *lfinalizepetsc` notwithstanding, pprts.c passes 0);
  *   - one global solver instance, not re-entrant (module variable pprts_solver, f2c_pprts.F90:106);
  *   - no return codes: errors print and abort, like CHKERR (src/helper_functions.fypp:888-904).
- * Differences: `fcomm` is ignored (one process, one GPU in this round); solver_id must be 310 (3_10);
+ * Differences: `fcomm` is ignored (one process, one GPU); solver_id 310 (3_10) or 816 (8_16);
  * collapseindex must be <= 1; look-up tables are read from $LUT_BASENAME (src/tenstream_options.F90:103-105)
  * in `.mmap4` form (src/mmap.F90), file names as gen_lut_basename builds them (src/optprop_LUT.F90:364-374).
  */

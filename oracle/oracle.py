@@ -327,6 +327,12 @@ def dir_layout_3_10():
     return d
 
 
+def dir_layout(solver="3_10"):
+    d = DirLayout()
+    (lib().orc_dir_layout_3_10 if solver in ("3_10", 310) else lib().orc_dir_layout_8_16)(C.byref(d))
+    return d
+
+
 def suninfo(phi, theta):
     s = SunInfo()
     lib().orc_setup_suninfo(C.c_double(phi), C.c_double(theta), C.byref(s))

@@ -71,6 +71,7 @@ typedef struct {
   int top_div, side_div;    /* dirtop/dirside%area_divider */
 } orc_dir_layout;
 void orc_dir_layout_3_10(orc_dir_layout *d);
+void orc_dir_layout_8_16(orc_dir_layout *d);
 
 /* setup_suninfo: src/pprts.F90:1118-1183 (angles in degrees) */
 typedef struct {

@@ -25,6 +25,14 @@ void orc_dir_layout_3_10(orc_dir_layout *d) {
   d->side_div = 1;
 }
 
+/* t_solver_8_16: dirtop 4 streams (area_divider 4), dirside 2 (area_divider 2), src/pprts.F90:413-425 */
+void orc_dir_layout_8_16(orc_dir_layout *d) {
+  d->dtop = 4;
+  d->dside = 2;
+  d->top_div = 4;
+  d->side_div = 2;
+}
+
 static double deg2rad(double x) { return x * M_PI / 180.0; }
 static double rad2deg(double x) { return x * 180.0 / M_PI; }
 
@@ -71,6 +79,24 @@ void orc_get_coeff_dir(const orc_lut *lut, int is_dir2dir, int S, int D, double 
       SWAPBLK(9, 10)
     }
 #undef SWAPBLK
+  }
+  if (S == 8) { /* dir2dir8_coeff_symmetry (src/optprop.F90:1268-1302) / dir8_to_diff16_coeff_symmetry (:1186-1240):
+                   coeff(dst block) = newcoeff(src permutation + other dst block), east first, then north */
+    const int nb = is_dir2dir ? 8 : 16;
+    float nw[128];
+    static const int src_e[8] = {1, 0, 3, 2, 4, 5, 6, 7}, src_n[8] = {2, 3, 0, 1, 4, 5, 6, 7};
+    /* from[b] = the old block that becomes new block b (0-based) */
+    static const int t_e[8] = {1, 0, 3, 2, 4, 5, 6, 7}, t_n[8] = {2, 3, 0, 1, 4, 5, 6, 7};
+    static const int s_e[16] = {0, 1, 6, 7, 4, 5, 2, 3, 9, 8, 11, 10, 12, 13, 14, 15};
+    static const int s_n[16] = {4, 5, 2, 3, 0, 1, 6, 7, 8, 9, 10, 11, 13, 12, 15, 14};
+    for (int pass = 0; pass < 2; ++pass) {
+      if (!(pass == 0 ? lswitch_east : lswitch_north)) continue;
+      const int *from = is_dir2dir ? (pass == 0 ? t_e : t_n) : (pass == 0 ? s_e : s_n);
+      const int *sp = pass == 0 ? src_e : src_n;
+      memcpy(nw, out, sizeof(float) * (size_t)nb * 8);
+      for (int b = 0; b < nb; ++b)
+        for (int q = 0; q < 8; ++q) out[b * 8 + q] = nw[from[b] * 8 + sp[q]];
+    }
   }
 }
 

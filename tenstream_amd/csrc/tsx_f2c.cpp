@@ -51,7 +51,8 @@ extern "C" void pprts_f2c_init(int fcomm, int *solver_id, int *Nz, int *Nx, int 
       die("seems you changed the solver type id in between calls... you must destroy the solver first");
     return;
   }
-  if (*solver_id != TSX_SOLVER_3_10) die("solver_id " + std::to_string(*solver_id) + ": only 3_10 (310) is served by this back-end");
+  if (*solver_id != TSX_SOLVER_3_10 && *solver_id != TSX_SOLVER_8_16)  // SOLVER_ID_PPRTS_3_10 / _8_16, f2c_solver_ids.h
+    die("solver_id " + std::to_string(*solver_id) + ": this back-end serves 3_10 (310) and 8_16 (816)");
   if (*collapseindex > 1) die("collapseindex > 1 is not supported by this back-end");
   F2cState &st = g_st;
   st.solver_id = *solver_id;
@@ -80,12 +81,13 @@ extern "C" void pprts_f2c_init(int fcomm, int *solver_id, int *Nz, int *Nx, int 
   const char *base = getenv("LUT_BASENAME");
   if (!base) die("LUT_BASENAME is not set: cannot find the look-up tables");
   const std::string b(base);
-  const std::string diff = b + "_diffuse_10.tau31.w020.aspect_zx23.g6.ds1000.nc.Sdiff.mmap4";
+  const bool s310 = st.solver_id == TSX_SOLVER_3_10;
+  const std::string diff = b + (s310 ? "_diffuse_10" : "_diffuse_16") + ".tau31.w020.aspect_zx23.g6.ds1000.nc.Sdiff.mmap4";
   if (!file_exists(diff)) die("LUT Sdiff data not loaded -- mmap4 file missing: " + diff);
   chk(tsx_lut_load_diffuse_mmap4(st.h, diff.c_str()), "diffuse LUT");
   const char *dirdims = getenv("TSX_LUT_DIRECT_DIMS");  // e.g. "tau11.w05.aspect_zx6.g3.phi3.theta5" for thinned test tables
   const std::string dd = dirdims ? dirdims : "tau31.w020.aspect_zx23.g6.phi19.theta19";
-  const std::string dirb = b + "_direct_3_10." + dd + ".ds1000.nc.";
+  const std::string dirb = b + (s310 ? "_direct_3_10." : "_direct_8_16.") + dd + ".ds1000.nc.";
   if (file_exists(dirb + "Tdir.mmap4") && file_exists(dirb + "Sdir.mmap4"))
     chk(tsx_lut_load_direct_mmap4(st.h, (dirb + "Tdir.mmap4").c_str(), (dirb + "Sdir.mmap4").c_str()), "direct LUT");
   // (a missing direct table only matters for solar solves and is reported there)

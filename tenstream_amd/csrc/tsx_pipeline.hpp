@@ -12,8 +12,52 @@ struct TsxSun {
   int xinc, yinc;
 };
 
-// ---- K5: 6-D lookup [tau, w0, aspect, g, phi, theta] -> NV planes.  For dir2diff of 3_10 the destination blocks are
-//      permuted for sun from east / north (dir3_to_diff10_coeff_symmetry, src/optprop.F90:1009-1045).
+// Where coefficient q = dst * S + src of the table's entry goes after the sun-quadrant symmetries: the tables only hold
+// phi in [0, 90]; for a sun in the east (xinc == 0) / north (yinc == 0) the streams of the mirrored box are relabelled
+// (get_coeff_cube, src/optprop.F90:571-576): first the east swap, then the north swap, each a pair of involutions on the
+// dst blocks and on the sources:
+//   3_10  dir2dir: none (dir2dir_coeff_symmetry_none);  dir2diff (dir3_to_diff10_coeff_symmetry, :1009-1045):
+//         east: dst 3<->4, 5<->6; north: dst 7<->8, 9<->10 (1-based)
+//   8_16  dir2dir (dir2dir8_coeff_symmetry, :1268-1302): east: dst 1<->2, 3<->4, src [2,1,4,3,5..8];
+//         north: dst 1<->3, 2<->4, src [3,4,1,2,5..8]
+//         dir2diff (dir8_to_diff16_coeff_symmetry, :1186-1240): east: dst 3<->7, 4<->8, 9<->10, 11<->12, src as above;
+//         north: dst 1<->5, 2<->6, 13<->14, 15<->16, src as above
+// new(d, s) = old(pe_d(pn_d(d)), pe_s(pn_s(s))), so old entry (d0, s0) lands at d = pn_d(pe_d(d0)), s = pn_s(pe_s(s0)).
+template <int NV, int S, bool DIR2DIFF>
+__device__ __forceinline__ int tsx_dir_symmetry(int q, int east, int north) {
+  int d = q / S, s = q % S;
+  if (S == 3) {
+    if (!DIR2DIFF) return q;
+    if (east && d >= 2 && d <= 5) d ^= 1;
+    if (north && d >= 6 && d <= 9) d ^= 1;
+    return d * S + s;
+  }
+  // S == 8
+  if (east) {
+    if (s < 4) s ^= 1;  // [2,1,4,3]
+    if (DIR2DIFF) {
+      if (d == 2 || d == 3) d += 4;
+      else if (d == 6 || d == 7) d -= 4;
+      else if (d >= 8 && d <= 11) d ^= 1;
+    } else if (d < 4) {
+      d ^= 1;
+    }
+  }
+  if (north) {
+    if (s < 4) s ^= 2;  // [3,4,1,2]
+    if (DIR2DIFF) {
+      if (d == 0 || d == 1) d += 4;
+      else if (d == 4 || d == 5) d -= 4;
+      else if (d >= 12) d ^= 1;
+    } else if (d < 4) {
+      d ^= 2;
+    }
+  }
+  return d * S + s;
+}
+
+// ---- K5: 6-D lookup [tau, w0, aspect, g, phi, theta] -> NV planes, stream relabelling for a sun from east / north
+//      (tsx_dir_symmetry).
 template <int NV, int S, bool DIR2DIFF>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_dir(TsxGeo g, TsxLutDev L, const double *__restrict__ kabs,
                                                            const double *__restrict__ ksca, const double *__restrict__ gg,
@@ -62,17 +106,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_dir(TsxGeo g, TsxLutDev L
       for (int q = 0; q < NV; ++q) acc[q] = __fadd_rn(acc[q], __fmul_rn(w, colp[q]));
     }
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      int qo = q;
-      if (DIR2DIFF && S == 3 && NV == 30) {  // dst block (1-based) swaps 3<->4, 5<->6 (east), 7<->8, 9<->10 (north)
-        int dstb = q / S;
-        const int src = q % S;
-        if (lswitch_east && dstb >= 2 && dstb <= 5) dstb ^= 1;
-        if (lswitch_north && dstb >= 6 && dstb <= 9) dstb ^= 1;
-        qo = dstb * S + src;
-      }
-      C[(size_t)qo * Nc + c] = acc[q];
-    }
+    for (int q = 0; q < NV; ++q) C[(size_t)tsx_dir_symmetry<NV, S, DIR2DIFF>(q, lswitch_east, lswitch_north) * Nc + c] = acc[q];
   }
 }
 

@@ -80,6 +80,8 @@ def synthetic_direct_tables(axes, solver="3_10"):
     """Closed-form, energy-conserving stand-ins for Tdir (S*S) and Sdir (S*D), memory order [dst*S + src]:
     beam geometry decides which face a ray leaves through, exp(-tau/mu) what survives, the scattered part
     w0*(1-t) goes to the diffuse streams with forward bias g.  sum_dst(T) + sum_dst(S) = t + w0 (1 - t) <= 1."""
+    if solver == "8_16":
+        return _synthetic_direct_tables_8_16(axes)
     assert solver == "3_10"
     S, D = 3, 10
     tau, w0, asp, g, phi, theta = [np.asarray(a, dtype=np.float64) for a in axes]
@@ -111,3 +113,42 @@ def synthetic_direct_tables(axes, solver="3_10"):
     sc = (W * (1 - t))[..., None, None] * share[..., :, None] * np.ones(S)  # [dst, src]
     Sdir = sc.reshape(-1, D * S).astype(np.float32)
     return Tdir, Sdir
+
+
+def _synthetic_direct_tables_8_16(axes):
+    """Stand-ins for the 8_16 tables (Tdir 64, Sdir 128 per entry) built from the 3_10 surrogate: every stream behaves
+    like its parent stream of 3_10 (4 top sub-streams -> top, 2 per side -> side; the 8 top diffuse streams -> Eup / Edn),
+    and what arrives on a parent is spread over its sub-streams with weights that depend on source and beam geometry --
+    deliberately not invariant under the stream relabellings of dir2dir8 / dir8_to_diff16_coeff_symmetry, so that a
+    wrong permutation shows.  Column sums equal the 3_10 surrogate's: sum_dst(T) + sum_dst(S) = t + w0 (1 - t)."""
+    T3, S3 = synthetic_direct_tables(axes, "3_10")
+    n = T3.shape[0]
+    T3 = T3.reshape(n, 3, 3)      # [dst, src]
+    S3 = S3.reshape(n, 10, 3)
+    phi = np.asarray(axes[4], dtype=np.float64)
+    theta = np.asarray(axes[5], dtype=np.float64)
+    inner = n // (len(phi) * len(theta))
+    ph = np.repeat(np.tile(phi, len(theta)), inner) / 90.0        # entry order: tau fastest ... phi, theta slowest
+    th = np.repeat(theta, len(phi) * inner) / 90.0
+    pdir = np.array([0, 0, 0, 0, 1, 1, 2, 2])                      # parent of a direct stream
+    sdir = np.array([0, 1, 2, 3, 0, 1, 0, 1])                      # its sub-index
+    ndir = np.array([4, 4, 4, 4, 2, 2, 2, 2])
+    pdif = np.array([0, 1, 0, 1, 0, 1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+    sdif = np.array([0, 0, 1, 1, 2, 2, 3, 3, 0, 0, 0, 0, 0, 0, 0, 0])
+    ndif = np.array([4, 4, 4, 4, 4, 4, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1])
+
+    def weights(sub, nsub, src):
+        """share of sub-stream `sub` (of nsub) for source stream `src`: positive, sums to 1 over sub"""
+        if nsub == 1:
+            return np.ones(n)
+        raw = [1.0 + 0.6 * np.sin(1.3 * q + 0.7 * src + 2.0 * ph) + 0.3 * np.cos(0.9 * q * (1 + src) + 1.5 * th) for q in range(nsub)]
+        return raw[sub] / np.sum(raw, axis=0)
+
+    T8 = np.empty((n, 8, 8), dtype=np.float64)
+    S8 = np.empty((n, 16, 8), dtype=np.float64)
+    for s_ in range(8):
+        for d in range(8):
+            T8[:, d, s_] = T3[:, pdir[d], pdir[s_]] * weights(sdir[d], ndir[d], s_)
+        for d in range(16):
+            S8[:, d, s_] = S3[:, pdif[d], pdir[s_]] * weights(sdif[d], ndif[d], s_ + 8)
+    return T8.reshape(n, 64).astype(np.float32), S8.reshape(n, 128).astype(np.float32)

@@ -173,9 +173,10 @@ class PprtsSolver:
         return edn, eup, abso, edir
 
     def get_field(self, which):
-        shapes = {"edir": (0, (self.Ny, self.Nx, self.Nz + 1, 3)), "b": (1, self.core.vec_shape),
-                  "ediff": (2, self.core.vec_shape), "dir2dir": (3, (self.Ny, self.Nx, self.Nz, 9)),
-                  "dir2diff": (4, (self.Ny, self.Nx, self.Nz, 30))}
+        S, D = (3, 10) if self.core.D == 10 else (8, 16)
+        shapes = {"edir": (0, (self.Ny, self.Nx, self.Nz + 1, S)), "b": (1, self.core.vec_shape),
+                  "ediff": (2, self.core.vec_shape), "dir2dir": (3, (self.Ny, self.Nx, self.Nz, S * S)),
+                  "dir2diff": (4, (self.Ny, self.Nx, self.Nz, S * D))}
         idx, shp = shapes[which]
         out = np.empty(shp)
         _lib.check(self.lib.tsx_pprts_get_field(self.h, idx, _ptr(out, np.float64)[0], 0))

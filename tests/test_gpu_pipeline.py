@@ -13,34 +13,36 @@ from tenstream_amd.pprts import PprtsSolver, eddington_coeff_ec
 
 
 
-def _setup(Nx, Ny, Nz, phi0, theta0, tall_top=0, seed=5, **kw):
+def _setup(Nx, Ny, Nz, phi0, theta0, tall_top=0, seed=5, solver="3_10", **kw):
     dx = dy = 100.0
     kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=seed)
     kabs *= 20.0  # some real absorption so that abso is not tiny
     dz = np.full((Ny, Nx, Nz), 50.0)
     if tall_top:
         dz[:, :, :tall_top] = 400.0  # dz/dx > twostr_ratio -> 1-D layers at the top (src/pprts.F90:669-677)
-    P = PprtsSolver(Nz, Nx, Ny, dx, dy, phi0, theta0, **kw)
-    P.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
+    P = PprtsSolver(Nz, Nx, Ny, dx, dy, phi0, theta0, solver=solver, **kw)
+    P.set_lut_diffuse(lut.synthetic_diffuse_table(solver), lut.diffuse_axes(solver))
     dax = lut.direct_axes()
-    Tdir, Sdir = lut.synthetic_direct_tables(dax)
+    Tdir, Sdir = lut.synthetic_direct_tables(dax, solver)
     P.set_lut_direct(Tdir, Sdir, dax)
-    return P, dict(kabs=kabs, ksca=ksca, g=g, dz=dz, dx=dx, dy=dy, dax=dax, Tdir=Tdir, Sdir=Sdir)
+    return P, dict(kabs=kabs, ksca=ksca, g=g, dz=dz, dx=dx, dy=dy, dax=dax, Tdir=Tdir, Sdir=Sdir, solver=solver)
 
 
 def _oracle_pipeline(P, I, albedo, edirTOA, lsolar, planck=None, rtol=1e-10):
     F = P.fields
     Nz, Nx, Ny = P.Nz, P.Nx, P.Ny
-    lay = O.layout("3_10", Nz, Nx, Ny)
-    dlay = O.dir_layout_3_10()
+    solver = I.get("solver", "3_10")
+    S, D = (3, 10) if solver == "3_10" else (8, 16)
+    lay = O.layout(solver, Nz, Nx, Ny)
+    dlay = O.dir_layout(solver)
     sun = O.suninfo(P.phi0, P.theta0)
-    Ld = O.make_lut(lut.diffuse_axes("3_10"), lut.synthetic_diffuse_table("3_10"))
+    Ld = O.make_lut(lut.diffuse_axes(solver), lut.synthetic_diffuse_table(solver))
     c = O.alloc_coeff_diff2diff(Ld, F["kabs"], F["ksca"], F["g"], F["dz"], I["dx"], P.l1d)
     out = dict(diff2diff=c, sun=sun)
     if lsolar:
         LT, LS = O.make_lut(I["dax"], I["Tdir"]), O.make_lut(I["dax"], I["Sdir"])
-        t = O.alloc_coeff_dir(LT, True, F["kabs"], F["ksca"], F["g"], F["dz"], I["dx"], sun, P.l1d)
-        sd = O.alloc_coeff_dir(LS, False, F["kabs"], F["ksca"], F["g"], F["dz"], I["dx"], sun, P.l1d)
+        t = O.alloc_coeff_dir(LT, True, F["kabs"], F["ksca"], F["g"], F["dz"], I["dx"], sun, P.l1d, S=S, D=D)
+        sd = O.alloc_coeff_dir(LS, False, F["kabs"], F["ksca"], F["g"], F["dz"], I["dx"], sun, P.l1d, S=S, D=D)
         rt, at, _ = O.default_tolerances(Nx, Ny, Nz + 1)
         edir, di = O.explicit_edir(lay, dlay, sun, t, P.l1d, F["a33"], edirTOA, I["dx"], I["dy"], rtol=rt, atol=at)
         assert di["converged"]
@@ -63,9 +65,10 @@ def _oracle_pipeline(P, I, albedo, edirTOA, lsolar, planck=None, rtol=1e-10):
 @pytest.mark.gpu
 @pytest.mark.parametrize("force_halo", [False, True])  # True: rank faces go through the exchange buffers (self neighbours)
 @pytest.mark.parametrize("phi0,theta0,tall_top", [(180.0, 40.0, 0), (10.0, 60.0, 2), (250.0, 20.0, 0), (300.0, 0.0, 1)])
-def test_solar_pipeline_matches_oracle(gpu, phi0, theta0, tall_top, force_halo):
-    Nx, Ny, Nz = 10, 8, 12
-    P, I = _setup(Nx, Ny, Nz, phi0, theta0, tall_top, force_halo=force_halo)
+@pytest.mark.parametrize("solver", ["3_10", "8_16"])   # 8_16: 8 direct streams, dir2dir8 / dir8_to_diff16 symmetries per sun quadrant
+def test_solar_pipeline_matches_oracle(gpu, solver, phi0, theta0, tall_top, force_halo):
+    Nx, Ny, Nz = (10, 8, 12) if solver == "3_10" else (8, 6, 9)
+    P, I = _setup(Nx, Ny, Nz, phi0, theta0, tall_top, solver=solver, force_halo=force_halo)
     P.set_optical_properties(0.15, I["kabs"], I["ksca"], I["g"], I["dz"])
     assert P.l1d.sum() == tall_top
     info = P.solve(1000.0, rtol=1e-10, atol=1e-30, maxit=3000)
@@ -109,9 +112,10 @@ def test_solar_b_from_identical_edir_is_tight(gpu):
 
 
 @pytest.mark.gpu
-def test_thermal_pipeline_matches_oracle(gpu):
+@pytest.mark.parametrize("solver", ["3_10", "8_16"])
+def test_thermal_pipeline_matches_oracle(gpu, solver):
     Nx, Ny, Nz = 8, 6, 10
-    P, I = _setup(Nx, Ny, Nz, 0.0, 0.0, tall_top=1)
+    P, I = _setup(Nx, Ny, Nz, 0.0, 0.0, tall_top=1, solver=solver)
     planck = np.linspace(2.0, 6.0, Nz + 1)[None, None, :] * np.ones((Ny, Nx, 1)) * (1 + 0.05 * np.random.default_rng(0).random((Ny, Nx, 1)))
     P.set_optical_properties(0.05, I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck)
     info = P.solve(0.0, rtol=1e-10, atol=1e-30, maxit=3000)

@@ -20,15 +20,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _write_luts(tmp_path):
+def _write_luts(tmp_path, solver="3_10"):
     base = str(tmp_path / "LUT")
-    lut.write_mmap4(base + "_diffuse_10.tau31.w020.aspect_zx23.g6.ds1000.nc.Sdiff.mmap4", lut.synthetic_diffuse_table("3_10"))
+    D, tag = (10, "3_10") if solver == "3_10" else (16, "8_16")
+    lut.write_mmap4(base + f"_diffuse_{D}.tau31.w020.aspect_zx23.g6.ds1000.nc.Sdiff.mmap4", lut.synthetic_diffuse_table(solver))
     dax = lut.direct_axes()
-    Tdir, Sdir = lut.synthetic_direct_tables(dax)
+    Tdir, Sdir = lut.synthetic_direct_tables(dax, solver)
     dims = "tau{}.w0{}.aspect_zx{}.g{}.phi{}.theta{}".format(*[len(a) for a in dax])
-    tpath = f"{base}_direct_3_10.{dims}.ds1000.nc.Tdir.mmap4"
+    tpath = f"{base}_direct_{tag}.{dims}.ds1000.nc.Tdir.mmap4"
     lut.write_mmap4(tpath, Tdir)
-    lut.write_mmap4(f"{base}_direct_3_10.{dims}.ds1000.nc.Sdir.mmap4", Sdir)
+    lut.write_mmap4(f"{base}_direct_{tag}.{dims}.ds1000.nc.Sdir.mmap4", Sdir)
     with open(tpath + ".axes", "w") as f:
         f.write(f"{len(dax)}\n")
         for a in dax:
@@ -163,3 +164,48 @@ def test_config3_local_block_with_halo_faces(gpu):
     # iterations, the same fixed point within the stop rule
     assert out[0][2] <= out[1][2] + 6
     assert float((out[0][1] - out[1][1]).abs().max()) <= 2e-4 * float(out[1][1].abs().max())
+
+
+def test_config5_8_16_through_the_reference_c_abi(gpu, tmp_path, monkeypatch):
+    """pprts_f2c_init with SOLVER_ID_PPRTS_8_16 = 816 (c_wrapper/f2c_solver_ids.h; f2c_pprts.F90:270-272): tables
+    `_diffuse_16...` / `_direct_8_16...` from $LUT_BASENAME, a cloudy solar g-point; equal to the PprtsSolver-driven
+    pipeline (which tests/test_gpu_pipeline.py pins to the oracle) to float32 rounding."""
+    Nx, Ny, Nz, phi0, theta0 = 6, 5, 10, 200.0, 35.0
+    base, dims, dax, Tdir, Sdir = _write_luts(tmp_path, "8_16")
+    monkeypatch.setenv("LUT_BASENAME", base)
+    monkeypatch.setenv("TSX_LUT_DIRECT_DIMS", dims)
+    f2c = C.CDLL(os.path.join(ROOT, "tenstream_amd", "lib", "libtsx_f2c.so"))
+    i32 = lambda v: C.byref(C.c_int(v))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    hhl = (np.float32(40.41) * (Nz - np.arange(Nz + 1))).astype(np.float32)
+    kabs = np.full((Ny, Nx, Nz), 1e-4, dtype=np.float32)
+    ksca = np.full((Ny, Nx, Nz), 1e-4, dtype=np.float32)
+    g = np.zeros((Ny, Nx, Nz), dtype=np.float32)
+    for j in range(Ny):
+        for i in range(Nx):
+            if (i + 2 * j) % 5 < 2:
+                ksca[j, i, Nz // 3:Nz // 2] = 2e-2
+                kabs[j, i, Nz // 3:Nz // 2] = 1e-5
+                g[j, i, Nz // 3:Nz // 2] = 0.85
+    f2c.pprts_f2c_init(0, i32(816), i32(Nz), i32(Nx), i32(Ny), C.byref(C.c_double(100.0)), C.byref(C.c_double(100.0)), fp(hhl),
+                       C.byref(C.c_float(phi0)), C.byref(C.c_float(theta0)), i32(1))
+    alb = C.c_float(0.1)
+    f2c.pprts_f2c_set_global_optical_properties(Nz, Nx, Ny, C.byref(alb), fp(kabs), fp(ksca), fp(g), None)
+    f2c.pprts_f2c_solve.argtypes = [C.c_int, C.c_float]
+    f2c.pprts_f2c_solve(0, 1000.0)
+    edn, eup, edir = (np.zeros((Ny, Nx, Nz + 1), dtype=np.float32) for _ in range(3))
+    abso = np.zeros((Ny, Nx, Nz), dtype=np.float32)
+    f2c.pprts_f2c_get_result(Nz, Nx, Ny, fp(edn), fp(eup), fp(abso), fp(edir))
+    f2c.pprts_f2c_destroy.argtypes = [C.c_int]
+    f2c.pprts_f2c_destroy(0)
+    P = PprtsSolver(Nz, Nx, Ny, 100.0, 100.0, np.float32(phi0), np.float32(theta0), solver="8_16")
+    P.set_lut_diffuse(lut.synthetic_diffuse_table("8_16"), lut.diffuse_axes("8_16"))
+    P.set_lut_direct(Tdir, Sdir, dax)
+    dz = np.broadcast_to(hhl[:-1].astype(np.float64) - hhl[1:].astype(np.float64), (Ny, Nx, Nz))
+    P.set_optical_properties(float(np.float32(0.1)), kabs.astype(np.float64), ksca.astype(np.float64), g.astype(np.float64), dz)
+    P.solve(1000.0)
+    want = P.get_result()
+    P.close()
+    for got, w in zip((edn, eup, abso, edir), want):
+        assert np.abs(got - w.astype(np.float32)).max() <= 2e-6 * np.abs(w).max() + 1e-30
+    assert np.ptp(edir[:, :, -1]) > 10.0   # the clouds cast shadows (W/m2)
