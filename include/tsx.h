@@ -225,6 +225,15 @@ int tsx_pprts_get_result(tsx_solver *s, double *edn, double *eup, double *abso, 
  * 3 dir2dir (S*S, zs:ze-1, ...); 4 dir2diff (S*D, ...) -- reference layouts, real64 */
 int tsx_pprts_get_field(tsx_solver *s, int which, double *out, int where);
 
+/* ---- coefficient probe: pprts_f2c_opp_get_coeff / _get_info (c_wrapper/f2c_pprts.h:54-83, f2c_pprts.F90:627-760).
+ *      One raw table lookup on the device, get_coeff_cube semantics (src/optprop.F90:549-582): imode 1 dir2dir,
+ *      2 dir2diff (both with the quadrant relabelling for lswitch_east / lswitch_north), 3 diff2diff; only aspect_zx
+ *      is clamped (from below).  Ncoeff must equal S*S, S*D or D*D.  ranges20: [min, max] of diffuse tau, w0, g,
+ *      aspect_zx, then direct tau, w0, g, aspect_zx, phi, theta. */
+int tsx_opp_get_coeff(tsx_solver *s, float tauz, float w0, float g, float aspect_zx, float phi, float theta, int imode,
+                      int lswitch_east, int lswitch_north, int ncoeff, float *coeff);
+int tsx_opp_get_info(tsx_solver *s, int32_t *Ndir, int32_t *Ndiff, float *ranges20);
+
 /* ---- z = M^-1 v with the preconditioner the solve uses (exposed for parity tests: M is the column-block
  *      diagonal of the assembled matrix in the dst-owned numbering) */
 int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps, int mixed);

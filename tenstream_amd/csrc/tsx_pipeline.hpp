@@ -110,6 +110,53 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_dir(TsxGeo g, TsxLutDev L
   }
 }
 
+// ---- one raw table lookup (pprts_f2c_opp_get_coeff, c_wrapper/f2c_pprts.F90:627-685 -> get_coeff_cube,
+//      src/optprop.F90:549-582): the caller's (tauz, w0, g, aspect_zx[, phi, theta]) go to the interpolation as they are,
+//      only aspect_zx is raised to the table's lower bound; quadrant symmetry like the cell kernels.  One thread.
+template <int NDIM>
+__global__ void tsx_k_opp_point(TsxLutDev L, float tauz, float w0, float g, float aspect, float phi, float theta, int S,
+                                int dir2diff, int east, int north, float *__restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  aspect = fmaxf(L.axes[L.axis_off[2]], aspect);
+  float sample[NDIM];
+  sample[0] = tauz;
+  sample[1] = w0;
+  sample[2] = aspect;
+  sample[3] = g;
+  if (NDIM == 6) {
+    sample[NDIM - 2] = phi;
+    sample[NDIM - 1] = theta;
+  }
+  int ninterp;
+  long long ofs_base, ioff_lo[NDIM], ioff_hi[NDIM];
+  float wlo[NDIM], whi[NDIM];
+  tsx_lut_weights<NDIM>(L, sample, ninterp, ofs_base, ioff_lo, ioff_hi, wlo, whi);
+  const int NV = L.nvec;
+  for (int q = 0; q < NV; ++q) {
+    float acc = 0.0f;
+    for (int b = 0; b < (1 << ninterp); ++b) {
+      long long ofs = ofs_base;
+      float w = 1.0f;
+      for (int d = 0; d < ninterp; ++d) {
+        if (b & (1 << d)) {
+          ofs += ioff_hi[d];
+          w = __fmul_rn(w, whi[d]);
+        } else {
+          ofs += ioff_lo[d];
+          w = __fmul_rn(w, wlo[d]);
+        }
+      }
+      acc = __fadd_rn(acc, __fmul_rn(w, L.table[(size_t)ofs * NV + q]));
+    }
+    int qo = q;
+    if (NDIM == 6) {
+      if (S == 3) qo = dir2diff ? tsx_dir_symmetry<30, 3, true>(q, east, north) : q;
+      else qo = dir2diff ? tsx_dir_symmetry<128, 8, true>(q, east, north) : tsx_dir_symmetry<64, 8, false>(q, east, north);
+    }
+    out[qo] = acc;
+  }
+}
+
 // face buffers of the direct beam on several ranks (W, E, S, N); all null on one periodic rank
 struct TsxDirHalo {
   double *sendW, *sendE, *sendS, *sendN;

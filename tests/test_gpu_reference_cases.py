@@ -209,3 +209,165 @@ def test_config5_8_16_through_the_reference_c_abi(gpu, tmp_path, monkeypatch):
     for got, w in zip((edn, eup, abso, edir), want):
         assert np.abs(got - w.astype(np.float32)).max() <= 2e-6 * np.abs(w).max() + 1e-30
     assert np.ptp(edir[:, :, -1]) > 10.0   # the clouds cast shadows (W/m2)
+
+
+@pytest.mark.parametrize("solver", ["3_10", "8_16"])
+def test_f2c_opp_coefficient_probe_is_bit_exact(gpu, tmp_path, monkeypatch, solver):
+    """pprts_f2c_opp_* (c_wrapper/f2c_pprts.h:54-83; f2c_pprts.F90:587-760): raw table lookups served by the device
+    interpolation -- bit-exact against the oracle's get_coeff restatement (search, N-linear interpolation with lattice
+    snapping, quadrant symmetries) for imode 1 / 2 / 3 and every lswitch_east / lswitch_north combination."""
+    S, D, sid = (3, 10, 310) if solver == "3_10" else (8, 16, 816)
+    base, dims, dax, Tdir, Sdir = _write_luts(tmp_path, solver)
+    monkeypatch.setenv("LUT_BASENAME", base)
+    monkeypatch.setenv("TSX_LUT_DIRECT_DIMS", dims)
+    f2c = C.CDLL(os.path.join(ROOT, "tenstream_amd", "lib", "libtsx_f2c.so"))
+    opp, ierr = C.c_void_p(), C.c_int(-1)
+    f2c.pprts_f2c_opp_init(0, sid, C.byref(opp), C.byref(ierr))
+    assert ierr.value == 0 and opp.value
+    f2c.pprts_f2c_opp_get_coeff.argtypes = [C.c_void_p] + [C.c_float] * 6 + [C.c_int] * 4 + [C.c_void_p, C.POINTER(C.c_int)]
+    nd, nf = C.c_int(), C.c_int()
+    rng = [(C.c_float * 2)() for _ in range(10)]
+    f2c.pprts_f2c_opp_get_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)] + [C.c_void_p] * 10 + [C.POINTER(C.c_int)]
+    f2c.pprts_f2c_opp_get_info(opp, C.byref(nd), C.byref(nf), *rng, C.byref(ierr))
+    assert (nd.value, nf.value) == (S, D)
+    dfx = lut.diffuse_axes(solver)
+    want = [dfx[0], dfx[1], dfx[3], dfx[2], dax[0], dax[1], dax[3], dax[2], dax[4], dax[5]]   # tau, w0, g, aspect (, phi, theta)
+    for r, a in zip(rng, want):
+        assert (r[0], r[1]) == (np.float32(a[0]), np.float32(a[-1]))
+    Ld = O.make_lut(lut.diffuse_axes(solver), lut.synthetic_diffuse_table(solver))
+    LT, LS = O.make_lut(dax, Tdir), O.make_lut(dax, Sdir)
+    gen = np.random.default_rng(3)
+    n_checked = 0
+    for _ in range(40):
+        dz, dx = float(gen.uniform(20, 300)), 100.0
+        ext = 10 ** gen.uniform(-5, -1.5)
+        w = gen.uniform(0, 0.999)
+        kabs, ksca, g = ext * (1 - w), ext * w, float(gen.choice([0.0, 0.3, 0.85, gen.uniform(0, 0.85)]))
+        phi, theta = float(gen.choice([0.0, 45.0, 90.0, gen.uniform(0, 90)])), float(gen.uniform(0, 80))
+        tauz, w0, asp = np.float32((kabs + ksca) * dz), np.float32(ksca / max(kabs + ksca, np.finfo(float).eps)), np.float32(dz / dx)
+        if not (dax[0][0] <= tauz <= dax[0][-1] and dax[1][0] <= w0 <= dax[1][-1]):
+            continue   # get_coeff clamps these two (the probe does not): compare inside the tables only
+        for imode, table, L_ in ((1, S * S, LT), (2, S * D, LS), (3, D * D, Ld)):
+            for east in (0, 1):
+                for north in (0, 1):
+                    out = np.zeros(table, dtype=np.float32)
+                    f2c.pprts_f2c_opp_get_coeff(opp, tauz, w0, np.float32(g), asp, np.float32(phi), np.float32(theta), imode,
+                                                east, north, table, out.ctypes.data, C.byref(ierr))
+                    assert ierr.value == 0
+                    if imode == 3:
+                        ref = O.get_coeff_diff2diff(L_, kabs, ksca, g, dz, dx)
+                    else:
+                        ref = np.zeros(table, dtype=np.float32)
+                        O.lib().orc_get_coeff_dir(C.byref(L_), int(imode == 1), S, D, C.c_double(kabs), C.c_double(ksca),
+                                                  C.c_double(g), C.c_double(dz), C.c_double(dx), C.c_double(phi), C.c_double(theta),
+                                                  east, north, ref.ctypes.data_as(C.POINTER(C.c_float)))
+                    assert np.array_equal(out, ref), (imode, east, north)
+                    n_checked += 1
+    assert n_checked >= 200
+    f2c.pprts_f2c_opp_destroy(opp, C.byref(ierr))
+
+
+def _f2c_worker(rank, world, port, solver_id, Nx, Ny, Nz, lut_env, lsolar, ret):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from tenstream_amd import _lib
+
+    os.environ.update(lut_env)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _lib.load()   # libtsx_f2c links libtsx: same copy
+        f2c = C.CDLL(os.path.join(ROOT, "tenstream_amd", "lib", "libtsx_f2c.so"))
+
+        def _x(ctx, send, recv, count, peer):
+            want_tag = [1, 0, 3, 2]
+            reqs, keep = [], []
+            sb = [np.ctypeslib.as_array(send[q], shape=(count[q],)) if count[q] else None for q in range(4)]
+            rb = [np.ctypeslib.as_array(recv[q], shape=(count[q],)) if count[q] else None for q in range(4)]
+            for q in range(4):
+                if not count[q] or peer[q] == rank:
+                    continue
+                t = torch.from_numpy(rb[q])
+                keep.append(t)
+                reqs.append(dist.irecv(t, src=peer[q], tag=want_tag[q]))
+            for q in range(4):
+                if not count[q] or peer[q] == rank:
+                    continue
+                t = torch.from_numpy(np.array(sb[q], copy=True))
+                keep.append(t)
+                reqs.append(dist.isend(t, dst=peer[q], tag=q))
+            for q in range(4):
+                if count[q] and peer[q] == rank:
+                    rb[q][...] = sb[q ^ 1]
+            for r in reqs:
+                r.wait()
+            return 0
+
+        def _a(ctx, buf, n):
+            dist.all_reduce(torch.from_numpy(np.ctypeslib.as_array(buf, shape=(n,))))
+            return 0
+
+        cbx, cba = _lib.EXCHANGE_FN(_x), _lib.ALLREDUCE_FN(_a)
+        if world > 1:
+            f2c.tsx_f2c_set_comm.argtypes = [C.c_int, C.c_int, _lib.EXCHANGE_FN, _lib.ALLREDUCE_FN, C.c_void_p]
+            f2c.tsx_f2c_set_comm(rank, world, cbx, cba, None)
+        i32 = lambda v: C.byref(C.c_int(v))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        root = rank == 0
+        # only rank 0 holds meaningful arguments (f2c_pprts.F90:126-128): the others pass junk of the right size
+        junk = lambda a: a if root else np.full_like(a, np.nan)
+        hhl = (np.float32(50.0) * (Nz - np.arange(Nz + 1))).astype(np.float32)
+        gen = np.random.default_rng(7)
+        kabs = (1e-4 * (1 + gen.random((Ny, Nx, Nz)))).astype(np.float32)
+        ksca = (1e-4 * (1 + gen.random((Ny, Nx, Nz)))).astype(np.float32)
+        g = np.zeros((Ny, Nx, Nz), dtype=np.float32)
+        cloud = gen.random((Ny, Nx)) < 0.4
+        ksca[cloud, Nz // 3:Nz // 2] = 2e-2
+        g[cloud, Nz // 3:Nz // 2] = 0.85
+        planck = (3.0 + 2.0 * gen.random((Ny, Nx, Nz + 1))).astype(np.float32)
+        sid, nz, nx, ny = C.c_int(solver_id if root else -1), C.c_int(Nz), C.c_int(Nx if root else 0), C.c_int(Ny if root else 0)
+        dx, dy = C.c_double(100.0 if root else 0.0), C.c_double(100.0 if root else 0.0)
+        phi, theta, ci = C.c_float(200.0 if root else 0.0), C.c_float(35.0 if root else 0.0), C.c_int(1)
+        f2c.pprts_f2c_init(0, C.byref(sid), C.byref(nz), C.byref(nx), C.byref(ny), C.byref(dx), C.byref(dy), fp(junk(hhl)),
+                           C.byref(phi), C.byref(theta), C.byref(ci))
+        assert (sid.value, nx.value, ny.value, dx.value, phi.value) == (solver_id, Nx, Ny, 100.0, 200.0)   # written back on every rank
+        alb = C.c_float(0.1 if root else -1.0)
+        f2c.pprts_f2c_set_global_optical_properties(Nz, Nx, Ny, C.byref(alb), fp(junk(kabs)), fp(junk(ksca)), fp(junk(g)),
+                                                    None if lsolar else fp(junk(planck)))
+        f2c.pprts_f2c_solve.argtypes = [C.c_int, C.c_float]
+        f2c.pprts_f2c_solve(0, (1000.0 if lsolar else 0.0) if root else -5.0)
+        edn, eup, edir = (np.full((Ny, Nx, Nz + 1), -7.0, dtype=np.float32) for _ in range(3))
+        abso = np.full((Ny, Nx, Nz), -7.0, dtype=np.float32)
+        f2c.pprts_f2c_get_result(Nz, Nx, Ny, fp(edn), fp(eup), fp(abso), fp(edir))
+        f2c.pprts_f2c_destroy.argtypes = [C.c_int]
+        f2c.pprts_f2c_destroy(0)
+        ret[rank] = (edn, eup, abso, edir)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,solver_id,lsolar", [(2, 310, True), (4, 310, False), (2, 816, True)])
+def test_f2c_on_several_ranks_scatters_and_gathers_like_the_reference(gpu, tmp_path, world, solver_id, lsolar):
+    """pprts_f2c_* on 2 / 4 ranks (sharing the GPU; the communicator attached with tsx_f2c_set_comm): rank 0's arguments
+    are broadcast and written back, its global arrays scattered, the results gathered to rank 0
+    (c_wrapper/f2c_pprts.F90:189-230, 283-316, 347-382) -- and equal the one-rank run of the same ABI."""
+    from test_gpu_multirank import _spawn
+
+    solver = "3_10" if solver_id == 310 else "8_16"
+    base, dims, *_ = _write_luts(tmp_path, solver)
+    env = dict(LUT_BASENAME=base, TSX_LUT_DIRECT_DIMS=dims)
+    Nx, Ny, Nz = 8, 6, 7
+    many = _spawn(_f2c_worker, world, (solver_id, Nx, Ny, Nz, env, lsolar))
+    one = _spawn(_f2c_worker, 1, (solver_id, Nx, Ny, Nz, env, lsolar))
+    for got, want in zip(many[0], one[0]):
+        assert np.abs(got - want).max() <= 3e-4 * np.abs(want).max() + 1e-30   # both stop at the default tolerances
+    for r in range(1, world):   # "only zeroth node gets the results back"
+        assert all((a == -7.0).all() for a in many[r])
+    assert many[0][0].max() > 1.0

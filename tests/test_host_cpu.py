@@ -33,7 +33,8 @@ def test_f2c_library_exports_the_reference_c_abi():
     hdr = open(os.path.join(ROOT, "include", "tsx_f2c.h")).read()
     declared = set(re.findall(r"\b(pprts_f2c_[a-z_]+)\s*\(", hdr))
     assert declared == {"pprts_f2c_init", "pprts_f2c_set_global_optical_properties", "pprts_f2c_solve",
-                        "pprts_f2c_get_result", "pprts_f2c_destroy"}
+                        "pprts_f2c_get_result", "pprts_f2c_destroy", "pprts_f2c_opp_init", "pprts_f2c_opp_get_coeff",
+                        "pprts_f2c_opp_destroy", "pprts_f2c_opp_get_info"}
     path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libtsx_f2c.so")
     nm = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (pprts_f2c_[a-z_]+)", nm))
