@@ -5,13 +5,22 @@
     set_optical_properties -> (direct sweep -> setup_b | thermal setup_b) -> diffuse solve -> flux divergence ->
     get_result, accumulated on the device            (rrtmg/rrtmg/pprts_rrtmg.F90:999-1055 drives the same sequence)
 
+driven the way the reference's rrtmg wrapper drives pprts:
+  * the column is a merged grid (src/tenstr_atm.F90): thin dynamics layers (dz = 50 m at dx = 100 m) below thick
+    background-atmosphere layers (dz/dx > twostr_ratio = 2) -- those become 1-D (Eddington) rows inside the same operator
+    (src/pprts.F90:669-677), so every solve exercises the l1d branch of the operator, the preconditioner and setup_b;
+  * every g-point has its own solution uid (`opt_solution_uid=ib`, rrtmg/rrtmg/pprts_rrtmg.F90:1027): the first radiation
+    call starts each g-point from the previous g-point's solution (-initial_guess_from_last_uid, src/pprts.F90:2540-2552),
+    later calls from the g-point's own previous solution (tsx_pprts_select_solution; 252 slots of 0.22 GB stay resident
+    in the 288 GB of HBM);
+  * `--calls 2` (default) runs two radiation calls: the second one after the cloud field has moved by one column, like a
+    model time step.
 Optical properties per g-point: the benchmark cloud field with kabs/ksca scaled by a log-uniform factor in [1e-3, 30]
-(SURVEY 8(d) config 4); LW g-points get a Planck surrogate.  The previous solution is the initial guess (the reference
-keeps `solution` per uid).  Multi-GPU: the 288 GB of an MI355X hold the whole domain, so g-points -- independent
-solves -- are dealt round-robin to the ranks and only the four accumulated result arrays are all-reduced at the end:
-no data-path collective.  Not the headline metric: `bench.py` is; this prints one JSON line of its own.
+(SURVEY 8(d) config 4); LW g-points get a Planck surrogate.  Multi-GPU: g-points -- independent solves -- are dealt in
+contiguous blocks to the ranks and only the four accumulated result arrays are all-reduced at the end: no data-path
+collective.  Not the headline metric: `bench.py` is; this prints one JSON line of its own.
 
-    python bench_specint.py [--gpus N] [--sw 112] [--lw 140]
+    python bench_specint.py [--gpus N] [--sw 112] [--lw 140] [--calls 2]
 """
 from __future__ import annotations
 
@@ -28,7 +37,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--sw", type=int, default=112)
@@ -36,16 +45,123 @@ def main():
     ap.add_argument("--nx", type=int, default=256)
     ap.add_argument("--ny", type=int, default=256)
     ap.add_argument("--nz", type=int, default=64)
+    ap.add_argument("--nz-background", type=int, default=16, help="thick background layers on top of the dynamics grid (1-D rows)")
+    ap.add_argument("--calls", type=int, default=2, help="radiation calls (time steps); the first one is cold")
     ap.add_argument("--pc-sweeps", type=int, default=0, help="0 = library default")
     ap.add_argument("--phi0", type=float, default=180.0)
     ap.add_argument("--theta0", type=float, default=40.0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def column_dz(Nz, n_bg, dz_dyn=50.0):
+    """k = 0 is the top of the atmosphere (the rrtmg wrapper reverses its bottom-up columns, pprts_rrtmg.F90:1006-1008):
+    n_bg background layers growing from 300 m to 3 km, then the dynamics layers"""
+    dz = np.full(Nz, dz_dyn)
+    if n_bg > 0:
+        dz[:n_bg] = np.geomspace(3000.0, 300.0, n_bg)
+    return dz
+
+
+def run_loop(args, dev, rank=0, world=1, all_reduce=None):
     import torch
-    import torch.distributed as dist
 
     from tenstream_amd import lut as LUT
     from tenstream_amd import synthetic as S
     from tenstream_amd.pprts import PprtsSolver
+
+    Nx, Ny, Nz = args.nx, args.ny, args.nz
+    n_bg = min(args.nz_background, Nz - 1)
+    dx, albedo = 100.0, 0.1
+    dz1d = column_dz(Nz, n_bg)
+    # clouds live in the dynamics grid only; the background layers carry a thin gas extinction that falls off with height
+    kabs = np.full((Ny, Nx, Nz), 1e-5)
+    ksca = np.full((Ny, Nx, Nz), 1e-5)
+    g = np.zeros((Ny, Nx, Nz))
+    kd, sd, gd = S.cloud_field(Nx, Ny, Nz - n_bg, seed=20240611)
+    kabs[:, :, n_bg:], ksca[:, :, n_bg:], g[:, :, n_bg:] = kd, sd, gd
+    if n_bg:
+        fall = np.geomspace(0.02, 0.6, n_bg)
+        kabs[:, :, :n_bg] *= fall
+        ksca[:, :, :n_bg] *= fall
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    kabs0, ksca0, g0 = t64(kabs), t64(ksca), t64(g)
+    dz_d = t64(np.broadcast_to(dz1d, (Ny, Nx, Nz)).copy())
+    alb = torch.full((Ny, Nx), albedo, dtype=torch.float64, device=dev)
+    # Planck surrogate: 288 K at the surface to 220 K at the top, band-integrated ~ sigma T^4 / pi / n_lw
+    T = torch.linspace(220.0, 288.0, Nz + 1, dtype=torch.float64, device=dev)
+    planck0 = (5.670374419e-8 * T**4 / np.pi).expand(Ny, Nx, Nz + 1).contiguous()
+
+    P = PprtsSolver(Nz, Nx, Ny, dx, dx, args.phi0, args.theta0, device=dev.index)
+    P.set_lut_diffuse(LUT.synthetic_diffuse_table("3_10"), LUT.diffuse_axes("3_10"))
+    dax = LUT.direct_axes()
+    Tdir, Sdir = LUT.synthetic_direct_tables(dax)
+    P.set_lut_direct(Tdir, Sdir, dax)
+
+    rng = np.random.default_rng(7)
+    ng = args.sw + args.lw
+    factors = np.exp(rng.uniform(np.log(1e-3), np.log(30.0), ng))
+    weights = (rng.dirichlet(np.ones(args.sw)).tolist() if args.sw else []) + (rng.dirichlet(np.ones(args.lw)).tolist() if args.lw else [])
+    lo, hi = (rank * ng) // world, ((rank + 1) * ng) // world   # contiguous blocks: uid - 1 stays on the same rank
+    mine = list(range(lo, hi))
+
+    L = Nz + 1
+    acc = [torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev), torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev),
+           torch.zeros((Ny, Nx, Nz), dtype=torch.float64, device=dev), torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev)]
+    tmp = [torch.empty_like(a) for a in acc]
+    mu0 = float(np.cos(np.deg2rad(args.theta0)))
+    shift = {"n": 0}
+
+    def run(q):
+        f = float(factors[q])
+        lsolar = q < args.sw
+        roll = lambda a: torch.roll(a, shifts=shift["n"], dims=1) if shift["n"] else a
+        P.set_optical_properties(alb, roll(kabs0) * f, roll(ksca0) * f, roll(g0), dz_d, planck=None if lsolar else planck0 * weights[q])
+        kw = dict(pc_sweeps=args.pc_sweeps) if args.pc_sweeps > 0 else {}
+        e0 = 1361.0 * weights[q] if lsolar else 0.0
+        info = P.solve(e0, lsolar=lsolar, uid=q, **kw)
+        P.get_result(out=tmp)
+        for a, t in zip(acc, tmp):
+            a += t
+        # energy balance of this g-point: what the atmosphere absorbs is the convergence of the net flux (periodic domain)
+        edn, eup, abso, edir = tmp
+        net_toa = float((edn[:, :, 0] + edir[:, :, 0] - eup[:, :, 0]).sum())
+        net_srf = float((edn[:, :, -1] + edir[:, :, -1] - eup[:, :, -1]).sum())
+        atm = float((abso * dz_d).sum())
+        scale = max(abs(net_toa), abs(net_srf), float(eup[:, :, -1].sum()), 1e-30)
+        return info, abs(atm - (net_toa - net_srf)) / scale
+
+    def sync():
+        torch.cuda.synchronize()
+
+    calls = []
+    P.set_optical_properties(alb, kabs0, ksca0, g0, dz_d)   # allocations and first touch outside the timed loop
+    n1d = int(P.l1d.sum())
+    for call in range(args.calls):
+        shift["n"] = call
+        for a in acc:
+            a.zero_()
+        sync()
+        t0 = time.perf_counter()
+        out = [run(q) for q in mine]
+        if all_reduce is not None:
+            for a in acc:
+                all_reduce(a)
+        sync()
+        dt = time.perf_counter() - t0
+        infos = [o[0] for o in out]
+        its = np.array([i.niter for i in infos]) if infos else np.zeros(1)
+        calls.append(dict(seconds=dt, iterations_min_med_max=[int(its.min()), float(np.median(its)), int(its.max())],
+                          reasons=sorted({int(i.reason) for i in infos}), diffuse_solve_ms_total=float(sum(i.solve_ms for i in infos)),
+                          energy_balance_max=float(max((o[1] for o in out), default=0.0)),
+                          toa_net_down_Wm2=float((acc[0][:, :, 0] + acc[3][:, :, 0] - acc[1][:, :, 0]).mean())))
+    P.close()
+    return dict(ng=ng, rank_gpoints=len(mine), n1d_layers=n1d, calls=calls, mu0=mu0)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -55,79 +171,24 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    Nx, Ny, Nz = args.nx, args.ny, args.nz
-    dx, dz, albedo = 100.0, 50.0, 0.1
-
-    kabs, ksca, g = S.cloud_field(Nx, Ny, Nz, seed=20240611)
-    t64 = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
-    kabs0, ksca0, g0 = t64(kabs), t64(ksca), t64(g)
-    dz_d = torch.full((Ny, Nx, Nz), dz, dtype=torch.float64, device=dev)
-    alb = torch.full((Ny, Nx), albedo, dtype=torch.float64, device=dev)
-    # Planck surrogate: 288 K at the surface to 220 K at the top, band-integrated ~ sigma T^4 / pi / n_lw
-    T = torch.linspace(220.0, 288.0, Nz + 1, dtype=torch.float64, device=dev)
-    planck0 = (5.670374419e-8 * T**4 / np.pi).expand(Ny, Nx, Nz + 1).contiguous()
-
-    P = PprtsSolver(Nz, Nx, Ny, dx, dx, args.phi0, args.theta0, device=local_rank)
-    P.set_lut_diffuse(LUT.synthetic_diffuse_table("3_10"), LUT.diffuse_axes("3_10"))
-    dax = LUT.direct_axes()
-    Tdir, Sdir = LUT.synthetic_direct_tables(dax)
-    P.set_lut_direct(Tdir, Sdir, dax)
-
-    rng = np.random.default_rng(7)
-    ng = args.sw + args.lw
-    factors = np.exp(rng.uniform(np.log(1e-3), np.log(30.0), ng))
-    weights = rng.dirichlet(np.ones(args.sw)).tolist() + rng.dirichlet(np.ones(args.lw)).tolist()
-    mine = [q for q in range(ng) if q % world == rank]
-
-    L = Nz + 1
-    acc = [torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev), torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev),
-           torch.zeros((Ny, Nx, Nz), dtype=torch.float64, device=dev), torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev)]
-    tmp = [torch.empty_like(a) for a in acc]
-
-    def run(q):
-        f = float(factors[q])
-        lsolar = q < args.sw
-        P.set_optical_properties(alb, kabs0 * f, ksca0 * f, g0, dz_d, planck=None if lsolar else planck0 * weights[q])
-        kw = dict(pc_sweeps=args.pc_sweeps) if args.pc_sweeps > 0 else {}
-        info = P.solve(1361.0 * weights[q] if lsolar else 0.0, lsolar=lsolar, **kw)
-        P.get_result(out=tmp)
-        for a, t in zip(acc, tmp):
-            a += t
-        return info
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run(mine[0])  # warm-up (allocations, first-touch)
-    for a in acc:
-        a.zero_()
-    barrier()
-    t0 = time.perf_counter()
-    infos = [run(q) for q in mine]
+    R = run_loop(args, dev, rank, world, all_reduce=(dist.all_reduce if world > 1 else None))
+    secs = [c["seconds"] for c in R["calls"]]
     if world > 1:
-        for a in acc:
-            dist.all_reduce(a)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor(secs, dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    its = np.array([i.niter for i in infos])
-    reasons = sorted({int(i.reason) for i in infos})
-    solve_ms = float(sum(i.solve_ms for i in infos))
+        secs = [float(v) for v in tt.tolist()]
     if rank == 0:
+        Nx, Ny, Nz, ng = args.nx, args.ny, args.nz, R["ng"]
+        last = len(secs) - 1
         print(json.dumps({
-            "metric": "pprts 3_10 spectral loop g-points/s", "value": ng / dt, "unit": "g-points/s", "n_gpus": world,
-            "seconds": dt, "higher_is_better": True, "scaling": "strong", "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.sw} SW + {args.lw} LW g-points on {Nx}x{Ny}x{Nz}, whole pipeline per g-point on the "
-                                   f"device, g-points dealt round-robin to GPUs, results all-reduced once",
-                       "cells_gpoints_per_s": ng * Nx * Ny * Nz / dt, "rank0_gpoints": len(mine),
-                       "rank0_iterations_min_med_max": [int(its.min()), float(np.median(its)), int(its.max())],
-                       "rank0_reasons": reasons, "rank0_diffuse_solve_ms_total": solve_ms,
-                       "toa_net_down_Wm2": float((acc[0][:, :, 0] + acc[3][:, :, 0] - acc[1][:, :, 0]).mean())}}))
+            "metric": "pprts 3_10 spectral loop g-points/s", "value": ng / secs[last], "unit": "g-points/s", "n_gpus": world,
+            "seconds": secs[last], "higher_is_better": True, "scaling": "strong", "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.sw} SW + {args.lw} LW g-points on {Nx}x{Ny}x{Nz} ({R['n1d_layers']} thick background layers "
+                                   f"as 1-D rows), whole pipeline per g-point on the device, one solution uid per g-point, "
+                                   f"g-points dealt in blocks to the GPUs, results all-reduced once; value = radiation call {last + 1} "
+                                   f"of {len(secs)} (call 1 is cold: guess from the previous g-point)",
+                       "cells_gpoints_per_s": ng * Nx * Ny * Nz / secs[last], "rank0_gpoints": R["rank_gpoints"],
+                       "calls": [dict(c, seconds=s_, gpoints_per_s=ng / s_) for c, s_ in zip(R["calls"], secs)]}}))
     if world > 1:
         dist.destroy_process_group()
 

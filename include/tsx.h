@@ -218,6 +218,12 @@ int tsx_pprts_set_optprop(tsx_solver *s, const double *kabs, const double *ksca,
  * (src/pprts.F90:2542-2558) unless tsx_pprts_zero_guess was called. */
 int tsx_pprts_solve(tsx_solver *s, double edirTOA, int lsolar, const tsx_ksp_opts *opts, tsx_ksp_result *res);
 int tsx_pprts_zero_guess(tsx_solver *s);
+/* solve_pprts(..., opt_solution_uid) (src/pprts.F90:2487-2558; get_solution_uid): make `uid` the solution the next
+ * tsx_pprts_solve works on.  The current solution is parked under its own uid (as real32; the reference's
+ * lcompress_solutions does the like); the initial guess becomes uid's previous solution, or, for a uid never solved, the
+ * solution of uid - 1 (-initial_guess_from_last_uid, on by default in the reference), or zero.  Read the result of a
+ * solve before selecting another uid (as rrtmg/rrtmg/pprts_rrtmg.F90:999-1055 does). */
+int tsx_pprts_select_solution(tsx_solver *s, int32_t uid);
 /* restore_solution + pprts_get_result: edn, eup, edir (zs:ze, xs:xe, ys:ye), abso (zs:ze-1, xs:xe, ys:ye), W/m2 and
  * W/m3, solar results multiplied by sun%mu (src/pprts.F90:5883-5888).  edir may be NULL. */
 int tsx_pprts_get_result(tsx_solver *s, double *edn, double *eup, double *abso, double *edir, int where);

@@ -53,7 +53,7 @@ SYMBOLS = (
     "tsx_diff_set_coeffs", "tsx_lut_set_diffuse", "tsx_lut_load_diffuse_mmap4", "tsx_diff_set_optprop",
     "tsx_diff_get_coeffs", "tsx_pprts_set_angles", "tsx_lut_set_direct", "tsx_lut_load_direct_mmap4", "tsx_pprts_set_optprop", "tsx_pprts_set_optical_properties", "tsx_pprts_solve",
     "tsx_pprts_zero_guess", "tsx_pprts_get_result", "tsx_pprts_get_field", "tsx_diff_apply", "tsx_diff_solve", "tsx_diff_pc_apply", "tsx_bench_kernel", "tsx_algorithmic_bytes",
-    "tsx_probe_copy_bandwidth", "tsx_opp_get_coeff", "tsx_opp_get_info",
+    "tsx_probe_copy_bandwidth", "tsx_opp_get_coeff", "tsx_opp_get_info", "tsx_pprts_select_solution",
 )
 
 _lib = None
@@ -94,6 +94,7 @@ def load():
     lib.tsx_pprts_set_optical_properties.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, ip, ip]
     lib.tsx_pprts_solve.argtypes = [vp, C.c_double, ip, C.POINTER(KspOpts), C.POINTER(KspResult)]
     lib.tsx_pprts_zero_guess.argtypes = [vp]
+    lib.tsx_pprts_select_solution.argtypes = [vp, C.c_int32]
     lib.tsx_pprts_get_result.argtypes = [vp, vp, vp, vp, vp, ip]
     lib.tsx_pprts_get_field.argtypes = [vp, ip, vp, ip]
     lib.tsx_diff_apply.argtypes = [vp, vp, vp, ip]

@@ -152,6 +152,7 @@ extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstr
 }
 
 static int create_fill(tsx_solver *s, const tsx_grid *grid);
+static void slots_free(tsx_solver *s);
 extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
   ARGCHK(grid && out, "tsx_create: null argument");
   ARGCHK(grid->solver_id == TSX_SOLVER_3_10 || grid->solver_id == TSX_SOLVER_8_16,
@@ -265,6 +266,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
     if (s->host_send[q]) (void)hipHostFree(s->host_send[q]);
     if (s->host_recv[q]) (void)hipHostFree(s->host_recv[q]);
   }
+  slots_free(s);
   if (s->comm_ready && g_rccl.CommDestroy) g_rccl.CommDestroy(s->nccl_comm);
   for (hipEvent_t e : {s->ev0, s->ev1, s->ev_imp0, s->ev_imp1, s->ev_exp1, s->ev_pack, s->ev_recv})
     if (e) (void)hipEventDestroy(e);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,12 @@ struct TsxLutHost {  // device copy of one LUT + its description
   long long nentries;
   float *d_axes;
   float *d_table;
+};
+
+struct TsxSolSlot {  // one stored solution (initial guess of the next solve with that uid), compressed to real32
+  float *x32;    // diffuse streams, internal layout, N values
+  float *e32;    // direct streams, S planes of (Nz+1)*ncol values (null if the slot never held a solar solution)
+  int lsolar;
 };
 
 struct tsx_solver {
@@ -120,6 +127,9 @@ struct tsx_solver {
   double *abso;                  // (Nz, xm, ym) reference layout
   int last_lsolar;
   bool have_solution;
+  void *slots;         // std::map<int, TsxSolSlot>*: solver%solutions(uid), src/pprts_base.F90:163-190
+  int cur_uid;         // which uid the working vectors vx / edir_a belong to
+  bool guess_foreign;  // the working vectors hold another uid's solution as initial guess (any kind of radiation)
   int niter_dir;
 
   void *nccl_comm;     // ncclComm_t when nranks > 1 (or force_halo with comm)

@@ -137,8 +137,11 @@ class PprtsSolver:
         return l1d
 
     # -- solve_pprts -------------------------------------------------------------------------------------
-    def solve(self, edirTOA, lsolar=None, zero_guess=False, **opts) -> KspInfo:
+    def solve(self, edirTOA, lsolar=None, zero_guess=False, uid=None, **opts) -> KspInfo:
+        """uid: solve_pprts' opt_solution_uid -- the solution slot whose previous content is the initial guess"""
         lsolar = (edirTOA > 0) if lsolar is None else lsolar  # pprts_f2c_solve, c_wrapper/f2c_pprts.F90:340-341
+        if uid is not None:
+            _lib.check(self.lib.tsx_pprts_select_solution(self.h, int(uid)))
         if zero_guess:
             _lib.check(self.lib.tsx_pprts_zero_guess(self.h))
         o = None

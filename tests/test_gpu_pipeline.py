@@ -216,18 +216,43 @@ def test_reference_c_abi_end_to_end(gpu, tmp_path):
 
 @pytest.mark.gpu
 def test_spectral_loop_script_runs(gpu):
-    """bench_specint.py (config 4: many g-points through the whole device pipeline) on a tiny domain"""
+    """bench_specint.py (config 4: many g-points through the whole device pipeline, a merged column with thick 1-D
+    background layers, one solution uid per g-point, two radiation calls) on a tiny domain"""
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench_specint.py"), "--sw", "3", "--lw", "3", "--nx", "16",
-                          "--ny", "12", "--nz", "8"], capture_output=True, text=True, timeout=600)
+                          "--ny", "12", "--nz", "10", "--nz-background", "3"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["config"]["rank0_gpoints"] == 6 and set(d["config"]["rank0_reasons"]) <= {2, 3}
-    assert d["config"]["toa_net_down_Wm2"] > 0
+    assert d["config"]["rank0_gpoints"] == 6 and len(d["config"]["calls"]) == 2
+    for c in d["config"]["calls"]:
+        assert set(c["reasons"]) <= {2, 3} and c["toa_net_down_Wm2"] > 0 and c["energy_balance_max"] < 5e-3
+    assert "(3 thick background layers" in d["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_spectral_loop_full_size_energy_balance_and_uid_warm_start(gpu):
+    """Config 4 at BASELINE's size (256x256x64, 16 thick background layers -> l1d rows in every solve), a handful of
+    g-points: every g-point converges by the reference's rule (reason 2 or 3), its energy balance closes (absorbed =
+    convergence of the net flux) to the accuracy the solves are stopped at, and the second radiation call -- the cloud
+    field moved by one column, every g-point warm-started from its own uid's previous solution
+    (src/pprts.F90:2487-2558) -- needs fewer iterations than the cold first call."""
+    import torch
+
+    import bench_specint as B
+
+    args = B.parse(["--sw", "3", "--lw", "3", "--calls", "2"])
+    R = B.run_loop(args, torch.device("cuda", 0))
+    assert R["n1d_layers"] == 16 and R["rank_gpoints"] == 6
+    cold, warm = R["calls"]
+    for c in (cold, warm):
+        assert set(c["reasons"]) <= {2, 3}
+        assert c["energy_balance_max"] < 2e-3
+    assert sum(warm["iterations_min_med_max"]) < sum(cold["iterations_min_med_max"])
+    assert warm["diffuse_solve_ms_total"] < cold["diffuse_solve_ms_total"]
 
 
 def _abso_by_flux_divergence(P, edir, ediff, lsolar):
