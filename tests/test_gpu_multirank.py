@@ -256,3 +256,64 @@ def test_sharded_pipeline_equals_one_rank_pipeline(gpu, world, Nx, Ny, phi0, the
         assert max(e) < 3e-4, e
         reason, _, e = errs["thermal"]
         assert reason == 2 and max(e) < 1e-7, e
+
+
+# ---- RCCL with two real peers ---------------------------------------------------------------------------------------
+def _rccl_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from tenstream_amd import DiffuseSolver, coord, synthetic
+    from tenstream_amd._lib import TsxError
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Nx, Ny, Nz = 12, 8, 6
+        P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+        co = coord.coord(rank, world, Nx, Ny)
+        sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
+        s = DiffuseSolver("3_10", Nz, co.xm, co.ym, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank, nranks=world,
+                          neighbors=(co.west, co.east, co.south, co.north), device=0)
+        uid = [s.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        try:
+            s.comm_init(uid[0])
+        except TsxError as e:
+            ret[rank] = ("refused", str(e))
+            return
+        loc = lambda k: np.ascontiguousarray(P[k][sl])
+        s.set_coeffs(loc("coeff"), P["l1d"], loc("a11"), loc("a12"), loc("albedo"))
+        x = np.zeros(s.vec_shape)
+        info = s.solve(np.ascontiguousarray(P["b"][sl]), x, rtol=1e-10, atol=1e-30)
+        ret[rank] = ("ok", info.reason, info.niter, x)
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_transport_with_two_ranks_on_one_device(gpu):
+    """Two ranks, both on cuda:0, one RCCL communicator: exercises the grouped send/recv ordering of the face exchange
+    (W and E are the same peer with 2 ranks along a periodic axis) and the 3-double all-reduces with a real peer.  RCCL
+    (like NCCL) refuses two ranks of one communicator on the same device; where it does, the test is skipped with RCCL's
+    own message -- the driver's multi-GPU run is then the first execution with real peers."""
+    import scipy.sparse.linalg as spla
+
+    from oracle import oracle as O
+    from tenstream_amd import synthetic
+
+    ret = _spawn(_rccl_worker, 2, ())
+    if any(v[0] == "refused" for v in ret.values()):
+        pytest.skip("RCCL refuses two ranks on one device: " + "; ".join(str(v[1])[:200] for v in ret.values() if v[0] == "refused"))
+    Nx, Ny, Nz = 12, 8, 6
+    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+    lay = O.layout("3_10", Nz, Nx, Ny)
+    A = O.assemble_csr(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x_ref = spla.spsolve(A.tocsc(), P["b"].ravel()).reshape(P["b"].shape)
+    from tenstream_amd import coord
+
+    for rank, v in ret.items():
+        co = coord.coord(rank, 2, Nx, Ny)
+        sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
+        assert v[1] == 2 and np.abs(v[3] - x_ref[sl]).max() <= 1e-8 * np.abs(x_ref).max()
