@@ -252,6 +252,10 @@ int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_ms);
 /* algorithmic bytes per launch of that kernel (Nc*D^2*sc + 2*N*sv for the SpMV; the preconditioner passes:
  * packed records + fp32 right-hand side + neighbour records + stores, 200 B per cell of the pass's colour) */
 int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes);
+/* shared storage of bit-identical transport blocks (lossless; tsx_dedup.hip): how many distinct blocks the current
+ * coefficients hold and whether the operator apply / preconditioner read them through the per-cell index (they do when
+ * at most half of the cells need a block of their own; TSX_DEDUP=0 switches it off) */
+int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent);
 /* device STREAM-like copy bandwidth probe (GB/s) for reporting against the measured peak */
 int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps);
 

@@ -12,6 +12,10 @@ b = torch.tensor(S.solar_source("3_10", kabs, ksca, g, 50.0, 100.0, alb), device
 t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
 cfgs = [c for c in os.environ.get("CFGS", "old;4,16,64;8,8,64;4,16,32;8,8,32;4,16,16").split(";") if c]
 for cfg in cfgs:
+    if cfg.startswith("nodd:"):
+        os.environ["TSX_DEDUP"] = "0"; cfg = cfg[5:]
+    else:
+        os.environ["TSX_DEDUP"] = "1"
     if cfg == "old":
         os.environ["TSX_PC_SCAN"] = "0"; os.environ.pop("TSX_PCS_CFG", None)
     else:
@@ -26,6 +30,8 @@ for cfg in cfgs:
         x.zero_(); info = s.solve(b, x)
         best = min(best, info.solve_ms)
     out = dict(cfg=cfg, nx=Nx, nz=Nz, its=info.niter, reason=info.reason, rel=info.rnorm / info.rnorm0, hist=[float("%.3g" % (h / info.rnorm0)) for h in list(info.res_hist)[max(0, info.niter - 3):info.niter + 1]], solve_ms=best, Mcells_s=Nx * Ny * Nz / best / 1e3)
+    out["dedup"] = s.dedup_info()
+    out["spmv_ms"] = s.bench_kernel(0, 20)
     out["pc_apply_ms"] = s.bench_kernel(2, 20)
     out["pc_apply_GBps"] = s.algorithmic_bytes(2) / out["pc_apply_ms"] / 1e6
     if cfg != "old":

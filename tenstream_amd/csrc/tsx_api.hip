@@ -251,7 +251,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->v32, s->p32, s->dsend[0], s->dsend[1], s->dsend[2], s->dsend[3], s->drecv[0], s->drecv[1], s->drecv[2], s->drecv[3],
-                  s->coef_h, s->coef,  s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
+                  s->coef_h, s->coef, s->dd_coef, s->dd_cidx, s->dd_cidx_split, s->dd_ent_cell, s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
@@ -538,6 +538,8 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
   HIPCHK(hipStreamSynchronize(s->stream));
   s->have_coeffs = true;
   s->coef_h_valid = false;
+  s->dd_valid = false;
+  s->dd_on = false;
   return TSX_OK;
 }
 
@@ -686,6 +688,8 @@ extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const dou
   HIPCHK(hipStreamSynchronize(s->stream));
   s->have_coeffs = true;
   s->coef_h_valid = false;
+  s->dd_valid = false;
+  s->dd_on = false;
   return TSX_OK;
 }
 
@@ -748,6 +752,10 @@ extern "C" int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int whe
     return TSX_ERR_STATE;
   }
   HIPCHK(hipSetDevice(s->device));
+  {
+    int rc = tsx_dedup_ensure(s);
+    if (rc) return rc;
+  }
   return s->geo.ntop == 2 ? diff_apply_t<2, 4>(s, x, y, where) : diff_apply_t<8, 4>(s, x, y, where);
 }
 
@@ -941,6 +949,10 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   }
   s->pc_split = s->pc == TSX_PC_REDBLACK;
   s->pc_half = false;
+  {
+    int rc = tsx_dedup_ensure(s);  // shared storage of identical blocks (operator apply and scan preconditioner)
+    if (rc) return rc;
+  }
   if (o->pc != TSX_PC_NONE) {
     int rc = tsx_pc_ensure_buffers(s);
     if (rc) return rc;
@@ -1007,8 +1019,9 @@ extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int 
     if (!(mixed && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0))) s->pc = TSX_PC_ZEBRA;
   }
   s->pc_split = s->pc == TSX_PC_REDBLACK;
-  int rc = tsx_pc_ensure_buffers(s);
+  int rc = tsx_dedup_ensure(s);
   if (rc) return rc;
+  if ((rc = tsx_pc_ensure_buffers(s))) return rc;
   s->pc_half = false;
   if (mixed && (rc = tsx_pc_ensure_half(s))) return rc;
   return s->geo.ntop == 2 ? pc_apply_t<2, 4>(s, v, z, where, mixed != 0) : pc_apply_t<8, 4>(s, v, z, where, mixed != 0);
@@ -1097,7 +1110,21 @@ extern "C" int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_
     return TSX_ERR_STATE;
   }
   HIPCHK(hipSetDevice(s->device));
+  {
+    int rc = tsx_dedup_ensure(s);
+    if (rc) return rc;
+  }
   return s->geo.ntop == 2 ? bench_kernel_t<2, 4>(s, kernel, reps, avg_ms) : bench_kernel_t<8, 4>(s, kernel, reps, avg_ms);
+}
+
+extern "C" int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent) {
+  ARGCHK(s && on && nent, "tsx_dedup_info: null");
+  HIPCHK(hipSetDevice(s->device));
+  int rc = tsx_dedup_ensure(s);
+  if (rc) return rc;
+  *on = s->dd_on ? 1 : 0;
+  *nent = s->dd_nent;
+  return TSX_OK;
 }
 
 extern "C" int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps) {

@@ -1,0 +1,245 @@
+// tsx_dedup.hip -- shared storage of bit-identical transport blocks.
+//
+// The operator's 100 (3_10) / 256 (8_16) coefficients per cell are 400 of the 563 B a cell costs an operator apply and
+// 128 of the 200 B it costs a preconditioner pass.  Cells with *bit-identical* blocks -- every clear-sky cell of a
+// horizontally homogeneous background has the same (tau, w0, aspect, g) and therefore the same interpolated block; the
+// reference's own examples build their atmospheres that way (examples/pprts/pprts_ex1.F90:85-102,
+// examples/pprts/pprts_rrtm_lw_sw.F90) -- can share one stored copy behind a per-cell index.  Lossless: the operator
+// computes with the same numbers in the same order.  Built from the dense planes (whatever produced them), so it serves
+// tsx_diff_set_coeffs and the LUT path alike:
+//   1. hash every cell's block (64 bit);  2. open-addressing table keyed by the hash, owner = smallest cell index;
+//   3. every cell compares its block with its owner's bit for bit -- a hash collision just keeps the cell unique;
+//   4. exclusive scan over "I am a representative" -> entry ids in cell order (neighbouring unique cells get neighbouring
+//      entries: their loads stay coalesced);  5. compact planes Cd[q * Nent + id].
+// Cells of 1-D layers (their planes are never read: a11 / a12 are) all map to one entry.
+// Used only when it pays (Nent <= Nc / 2); the dense planes stay (setup_b thermal, flux divergence, export read them).
+#include "tsx_host.hpp"
+
+__device__ __forceinline__ unsigned long long tsx_mix64(unsigned long long h, unsigned long long v) {
+  h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  return h;
+}
+
+constexpr unsigned long long TSX_DD_EMPTY = 0ull;
+constexpr unsigned long long TSX_DD_H1D = 0x1d1d1d1d1d1d1d1dull;
+
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_hash(TsxGeo g, int DD, const float *__restrict__ C,
+                                                           const uint8_t *__restrict__ l1d, unsigned long long *__restrict__ h) {
+  const long long Nc = g.Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int k = (int)(c / g.ncol);
+    unsigned long long v = 0x243f6a8885a308d3ull;
+    if (l1d[k]) {
+      v = TSX_DD_H1D;
+    } else {
+      for (int q = 0; q < DD; ++q) v = tsx_mix64(v, (unsigned long long)__float_as_uint(C[(size_t)q * Nc + c]) + ((unsigned long long)q << 32));
+      if (v == TSX_DD_EMPTY || v == TSX_DD_H1D) v ^= 0x5555555555555555ull;
+    }
+    h[c] = v;
+  }
+}
+
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_insert(long long Nc, unsigned long long mask, const unsigned long long *__restrict__ h,
+                                                             unsigned long long *__restrict__ keys, int *__restrict__ owner) {
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const unsigned long long hv = h[c];
+    unsigned long long slot = hv & mask;
+    for (;;) {
+      const unsigned long long prev = atomicCAS(&keys[slot], TSX_DD_EMPTY, hv);
+      if (prev == TSX_DD_EMPTY || prev == hv) {
+        atomicMin(&owner[slot], (int)c);
+        break;
+      }
+      slot = (slot + 1) & mask;
+    }
+  }
+}
+
+// rep[c] = the representative cell of c's block; flag[c] = 1 where c represents itself
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_resolve(TsxGeo g, int DD, const float *__restrict__ C,
+                                                              const uint8_t *__restrict__ l1d, unsigned long long mask,
+                                                              const unsigned long long *__restrict__ h,
+                                                              const unsigned long long *__restrict__ keys,
+                                                              const int *__restrict__ owner, int *__restrict__ rep,
+                                                              int *__restrict__ flag) {
+  const long long Nc = g.Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const unsigned long long hv = h[c];
+    unsigned long long slot = hv & mask;
+    while (keys[slot] != hv) slot = (slot + 1) & mask;
+    const int o = owner[slot];
+    bool same = true;
+    if (o != (int)c && !(l1d[(int)(c / g.ncol)] && l1d[o / g.ncol])) {
+      for (int q = 0; q < DD; ++q)
+        same &= __float_as_uint(C[(size_t)q * Nc + c]) == __float_as_uint(C[(size_t)q * Nc + o]);
+    }
+    const int r = same ? o : (int)c;
+    rep[c] = r;
+    flag[c] = r == (int)c;
+  }
+}
+
+// ---- exclusive scan of int flags (three launches: per-block sums, scan of the sums by one block, write-out)
+constexpr int TSX_SCAN_CHUNK = 2048;  // elements per block
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_scan_sums(long long n, const int *__restrict__ f, int *__restrict__ sums) {
+  __shared__ int sm[TSX_BLOCK];
+  const long long b0 = (long long)blockIdx.x * TSX_SCAN_CHUNK;
+  int t = 0;
+  for (int q = threadIdx.x; q < TSX_SCAN_CHUNK; q += TSX_BLOCK)
+    if (b0 + q < n) t += f[b0 + q];
+  sm[threadIdx.x] = t;
+  __syncthreads();
+  for (int s2 = TSX_BLOCK / 2; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) sm[threadIdx.x] += sm[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = sm[0];
+}
+__global__ __launch_bounds__(1024) void tsx_k_scan_top(int nb, int *__restrict__ sums, int *__restrict__ total) {
+  // serial over chunks of 1024 block sums, Hillis-Steele inside a chunk; nb <= a few 10^4
+  __shared__ int sm[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += 1024) {
+    const int q = b0 + threadIdx.x;
+    const int v = q < nb ? sums[q] : 0;
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int a = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (q < nb) sums[q] = carry + sm[threadIdx.x] - v;  // exclusive
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sm[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_scan_write(long long n, const int *__restrict__ f, const int *__restrict__ sums,
+                                                              int *__restrict__ pos) {
+  // one wave-serial pass per block: chunk of 2048, thread t owns 8 consecutive elements
+  __shared__ int sm[TSX_BLOCK];
+  const long long b0 = (long long)blockIdx.x * TSX_SCAN_CHUNK;
+  constexpr int PER = TSX_SCAN_CHUNK / TSX_BLOCK;
+  int loc[PER], t = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const long long e = b0 + (long long)threadIdx.x * PER + q;
+    loc[q] = e < n ? f[e] : 0;
+    t += loc[q];
+  }
+  sm[threadIdx.x] = t;
+  __syncthreads();
+  for (int off = 1; off < TSX_BLOCK; off <<= 1) {
+    const int a = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += a;
+    __syncthreads();
+  }
+  int run = sums[blockIdx.x] + sm[threadIdx.x] - t;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const long long e = b0 + (long long)threadIdx.x * PER + q;
+    if (e < n) pos[e] = run;
+    run += loc[q];
+  }
+}
+
+// cidx[c] = entry of c's block (natural and colour-split order); ent_cell[id] = the representative cell
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_index(TsxGeo g, const int *__restrict__ rep, const int *__restrict__ pos,
+                                                            int *__restrict__ cidx, int *__restrict__ cidx_split,
+                                                            int *__restrict__ ent_cell) {
+  const long long Nc = g.Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int r = rep[c], id = pos[r];
+    cidx[c] = id;
+    if (cidx_split) {
+      const int i = (int)(c % g.xm);
+      const long long t = c / g.xm;
+      const int j = (int)(t % g.ym), k = (int)(t / g.ym);
+      cidx_split[(size_t)k * g.ncol + tsx_split_col(i, j, g.xm)] = id;
+    }
+    if (r == (int)c) ent_cell[id] = (int)c;
+  }
+}
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_compact(long long Nc, int DD, long long nent, const float *__restrict__ C,
+                                                              const int *__restrict__ ent_cell, float *__restrict__ Cd) {
+  const long long n = nent * DD;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
+    const long long pl = q / nent, id = q - pl * nent;
+    Cd[q] = C[(size_t)pl * Nc + ent_cell[id]];
+  }
+}
+
+static bool dedup_enabled() {
+  const char *e = getenv("TSX_DEDUP");  // TSX_DEDUP=0: always the dense planes (A/B knob)
+  return e ? atoi(e) != 0 : true;
+}
+
+// (re)build the shared-block storage for the current coefficients; leaves s->dd_on = false where it does not pay
+int tsx_dedup_ensure(tsx_solver *s) {
+  if (s->dd_valid) return TSX_OK;
+  s->dd_valid = true;
+  s->dd_on = false;
+  if (!dedup_enabled() || s->coef_bytes != 4 || !s->have_coeffs) return TSX_OK;
+  const TsxGeo &g = s->geo;
+  if (g.Nc >= (1ll << 31)) return TSX_OK;
+  const int DD = g.D * g.D;
+  const long long Nc = g.Nc;
+  unsigned long long tsz = 1;
+  while (tsz < (unsigned long long)(2 * Nc)) tsz <<= 1;
+  TsxDevTmp th, tk, to, trep, tflag, tpos, tsum, ttot;
+  HIPCHK(th.alloc(sizeof(unsigned long long) * (size_t)Nc));
+  HIPCHK(tk.alloc(sizeof(unsigned long long) * (size_t)tsz));
+  HIPCHK(to.alloc(sizeof(int) * (size_t)tsz));
+  HIPCHK(trep.alloc(sizeof(int) * (size_t)Nc));
+  HIPCHK(tflag.alloc(sizeof(int) * (size_t)Nc));
+  HIPCHK(tpos.alloc(sizeof(int) * (size_t)Nc));
+  const int nsb = (int)((Nc + TSX_SCAN_CHUNK - 1) / TSX_SCAN_CHUNK);
+  HIPCHK(tsum.alloc(sizeof(int) * (size_t)nsb));
+  HIPCHK(ttot.alloc(sizeof(int)));
+  HIPCHK(hipMemsetAsync(tk.p, 0, sizeof(unsigned long long) * (size_t)tsz, s->stream));
+  HIPCHK(hipMemsetAsync(to.p, 0x7f, sizeof(int) * (size_t)tsz, s->stream));
+  const float *C = (const float *)s->coef;
+  const int nb = grid_for(Nc, 8192);
+  hipLaunchKernelGGL(tsx_k_dd_hash, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, th.as<unsigned long long>());
+  hipLaunchKernelGGL(tsx_k_dd_insert, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, tsz - 1, th.as<unsigned long long>(),
+                     tk.as<unsigned long long>(), to.as<int>());
+  hipLaunchKernelGGL(tsx_k_dd_resolve, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, tsz - 1,
+                     th.as<unsigned long long>(), tk.as<unsigned long long>(), to.as<int>(), trep.as<int>(), tflag.as<int>());
+  hipLaunchKernelGGL(tsx_k_scan_sums, dim3(nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, tflag.as<int>(), tsum.as<int>());
+  hipLaunchKernelGGL(tsx_k_scan_top, dim3(1), dim3(1024), 0, s->stream, nsb, tsum.as<int>(), ttot.as<int>());
+  hipLaunchKernelGGL(tsx_k_scan_write, dim3(nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, tflag.as<int>(), tsum.as<int>(), tpos.as<int>());
+  HIPCHK(hipGetLastError());
+  int nent = 0;
+  HIPCHK(hipMemcpyAsync(&nent, ttot.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  s->dd_nent = nent;
+  if ((long long)nent * 2 > Nc) return TSX_OK;  // mostly unique blocks: the dense planes are the better layout
+  if (!s->dd_cidx) HIPCHK(hipMalloc((void **)&s->dd_cidx, sizeof(int) * (size_t)Nc));
+  if (!s->dd_cidx_split) HIPCHK(hipMalloc((void **)&s->dd_cidx_split, sizeof(int) * (size_t)Nc));
+  if (s->dd_cap < nent) {
+    if (s->dd_coef) HIPCHK(hipFree(s->dd_coef));
+    if (s->dd_ent_cell) HIPCHK(hipFree(s->dd_ent_cell));
+    s->dd_coef = nullptr;
+    s->dd_ent_cell = nullptr;
+    HIPCHK(hipMalloc((void **)&s->dd_coef, sizeof(float) * (size_t)DD * nent));
+    HIPCHK(hipMalloc((void **)&s->dd_ent_cell, sizeof(int) * (size_t)nent));
+    s->dd_cap = nent;
+  }
+  const bool split = g.xm % 2 == 0;
+  hipLaunchKernelGGL(tsx_k_dd_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, trep.as<int>(), tpos.as<int>(), s->dd_cidx,
+                     split ? s->dd_cidx_split : (int *)nullptr, s->dd_ent_cell);
+  hipLaunchKernelGGL(tsx_k_dd_compact, dim3(grid_for((long long)nent * DD, 8192)), dim3(TSX_BLOCK), 0, s->stream, Nc, DD,
+                     (long long)nent, C, s->dd_ent_cell, s->dd_coef);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s->stream));
+  s->dd_on = true;
+  return TSX_OK;
+}

@@ -77,6 +77,7 @@ struct tsx_solver {
   int coef_bytes;      // 4 or 8
   void *coef_h;        // packed fp16 copy of the blocks for the preconditioner (tsx_k_pack_p16; built in prepare_ksp)
   bool coef_h_valid, pc_half;
+  bool coef_h_dd;      // ... with groups 1..7 stored per distinct block (tsx_dedup.hip)
   bool coef_h_scan;    // the packed copy is in the scan kernels' layout "S16" (tsx_kernels_pcs.hpp; always colour-split)
   bool coef_h_split;   // layout of the packed copy: colour-split (red-black preconditioner) or natural
   bool pc_split;       // the preconditioner's private arrays (packed blocks, fp32 rhs) are in colour-split order
@@ -85,6 +86,13 @@ struct tsx_solver {
   double *albedo;      // [ncol]
   bool have_coeffs;
   bool any_l1d;
+  // shared storage of bit-identical blocks (tsx_dedup.hip): planes over entries + per-cell entry index
+  bool dd_valid, dd_on;
+  int dd_nent, dd_cap;
+  float *dd_coef;          // [D*D][dd_nent]
+  int *dd_cidx;            // [Nc] natural cell order
+  int *dd_cidx_split;      // [Nc] colour-split order (the preconditioner's)
+  int *dd_ent_cell;        // [dd_nent] representative cell of every entry
   int n1d;             // number of 1-D layers (unconstrained_fraction = 1 - n1d/Nz, src/pprts.F90:721-723)
   TsxLutHost lut_diff;
 

@@ -108,6 +108,43 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack(TsxGeo g, const CT *
   }
 }
 
+// ---- the same groups 1..7 per *distinct* block (tsx_dedup.hip): PE[(grp - 1) * nent + id]; an entry whose representative
+// cell lies in a 1-D layer stands for all 1-D cells: zero records
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent(int ncol, long long nent, const float *__restrict__ Cd,
+                                                                const int *__restrict__ ent_cell, const uint8_t *__restrict__ l1d,
+                                                                uint4 *__restrict__ PE) {
+  constexpr int D = 10;
+  const long long n = nent * 7;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
+    const int grp = 1 + (int)(q / nent);
+    const long long id = q - (long long)(grp - 1) * nent;
+    const int k = ent_cell[id] / ncol;
+    auto cf = [&](int dst, int src) { return Cd[(size_t)(dst * D + src) * nent + id]; };
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!l1d[k]) {
+      if (grp == 1) {
+        v.x = tsx_to_fp8x4(cf(0, 6), cf(1, 6), cf(0, 7), cf(1, 7));
+        v.y = tsx_to_fp8x4(cf(0, 8), cf(1, 8), cf(0, 9), cf(1, 9));
+        v.z = tsx_to_fp8x4(cf(0, 2), cf(1, 2), cf(0, 3), cf(1, 3));
+        v.w = tsx_to_fp8x4(cf(0, 4), cf(1, 4), cf(0, 5), cf(1, 5));
+      } else if (grp == 2 || grp == 3) {
+        const int s = grp - 2;
+        v.x = tsx_to_h2(cf(2, s), cf(3, s));
+        v.y = tsx_to_h2(cf(4, s), cf(5, s));
+        v.z = tsx_to_h2(cf(6, s), cf(7, s));
+        v.w = tsx_to_h2(cf(8, s), cf(9, s));
+      } else {
+        const int s0 = grp < 6 ? 6 : 2, d0 = 2 + 4 * ((grp - 4) & 1);
+        v.x = tsx_to_fp8x4(cf(d0 + 0, s0), cf(d0 + 0, s0 + 1), cf(d0 + 0, s0 + 2), cf(d0 + 0, s0 + 3));
+        v.y = tsx_to_fp8x4(cf(d0 + 1, s0), cf(d0 + 1, s0 + 1), cf(d0 + 1, s0 + 2), cf(d0 + 1, s0 + 3));
+        v.z = tsx_to_fp8x4(cf(d0 + 2, s0), cf(d0 + 2, s0 + 1), cf(d0 + 2, s0 + 2), cf(d0 + 2, s0 + 3));
+        v.w = tsx_to_fp8x4(cf(d0 + 3, s0), cf(d0 + 3, s0 + 1), cf(d0 + 3, s0 + 2), cf(d0 + 3, s0 + 3));
+      }
+    }
+    PE[q] = v;
+  }
+}
+
 __device__ __forceinline__ unsigned tsx_bf16x2(float lo, float hi) {
   return (unsigned)tsx_to_bf16(lo) | ((unsigned)tsx_to_bf16(hi) << 16);
 }
@@ -119,11 +156,14 @@ __device__ __forceinline__ unsigned tsx_bf16x2(float lo, float hi) {
 // MODE 2: the very last pass -- neighbours and the row partner's final values from z; the result of both colours goes out
 //         as aligned pairs in the Krylov layout zfin.
 // nonbr: run a GS kernel without neighbours (first pass of a short sequence).
-template <int LSEG, int NSEG, int CW, bool GS, int MODE>
+// IDX: groups 1..7 are stored per distinct block: PE[(grp - 1) * nent + cidx[cell]] (cidx in colour-split order); group 0
+// (the column recurrences) stays per cell.
+template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false>
 __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *__restrict__ P, const float *__restrict__ r,
                                                          float *__restrict__ z, unsigned *__restrict__ zb,
                                                          float *__restrict__ zfin, const int *__restrict__ done, int rbc,
-                                                         int nonbr) {
+                                                         int nonbr, const int *__restrict__ cidx, long long nent,
+                                                         const uint4 *__restrict__ PE) {
   constexpr int D = 10, NTOP = 2;
   constexpr bool FINAL = MODE == 2;
   __shared__ float2 sB[NSEG][CW], sV[NSEG][CW];
@@ -200,14 +240,17 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
   uint4 r0[LSEG], r1[LSEG];
   float ru[LSEG], rd[LSEG];
   uint2 nb[LSEG][4];
+  int eid[LSEG];
+  auto rec = [&](int grp, size_t c, int id) { return IDX ? PE[(size_t)(grp - 1) * nent + id] : P[(size_t)grp * Nc + c]; };
 #pragma unroll
   for (int l = 0; l < LSEG; ++l) {
     const size_t c = cell(l);
+    eid[l] = IDX ? cidx[c] : 0;
     r0[l] = P[c];
     ru[l] = r[c];
     rd[l] = r[(size_t)Nc + c];
     if (GS) {
-      r1[l] = P[(size_t)Nc + c];
+      r1[l] = rec(1, c, eid[l]);
       nbr_load(c, nb[l]);
     }
   }
@@ -298,13 +341,13 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
     const size_t c = cell(l);
     const size_t cn = (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + ncp;
     const tsx_h8 m = __builtin_bit_cast(tsx_h8, r0[l]);
-    const uint4 wcu = P[(size_t)2 * Nc + c], wcv = P[(size_t)3 * Nc + c];
+    const uint4 wcu = rec(2, c, eid[l]), wcv = rec(3, c, eid[l]);
     uint4 wy[2], wx[2];
     if (GS) {
-      wy[0] = P[(size_t)4 * Nc + c];
-      wy[1] = P[(size_t)5 * Nc + c];
-      wx[0] = P[(size_t)6 * Nc + c];
-      wx[1] = P[(size_t)7 * Nc + c];
+      wy[0] = rec(4, c, eid[l]);
+      wy[1] = rec(5, c, eid[l]);
+      wx[0] = rec(6, c, eid[l]);
+      wx[1] = rec(7, c, eid[l]);
     }
     float rs[8];
 #pragma unroll

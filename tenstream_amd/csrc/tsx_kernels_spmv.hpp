@@ -8,9 +8,27 @@
 // HALO: some face of the rank is not a periodic self-neighbour (edge threads then read the received face buffers);
 // HAS1D: some layer is 1-D.  Both are kernel-uniform and compiled out in the common case.  The gather is branch-free
 // (offset / pointer selects, unconditional loads): a conditional load ends a basic block and forces an s_waitcnt.
-template <int NTOP, int NSIDE, typename CT, int FUSE, int CPT, typename XT, typename WT, bool HALO, bool HAS1D>
+// IDX: the blocks are stored once per *distinct* block (tsx_dedup.hip): C holds planes over nent entries and cidx[c] is
+// the entry of cell c.  Cells that share an entry read the same addresses (one cache line per wave instruction), runs of
+// unique cells have consecutive entries; same numbers, same order of operations as the dense planes.
+template <int CPT> struct TsxIdx;
+template <> struct TsxIdx<1> {
+  static __device__ __forceinline__ void ids(const int *p, int (&o)[1]) { o[0] = p[0]; }
+  static __device__ __forceinline__ float ld(const float *pl, const int (&id)[1]) { return pl[id[0]]; }
+};
+template <> struct TsxIdx<2> {
+  static __device__ __forceinline__ void ids(const int *p, int (&o)[2]) {
+    const int2 v = *reinterpret_cast<const int2 *>(p);
+    o[0] = v.x;
+    o[1] = v.y;
+  }
+  static __device__ __forceinline__ float2 ld(const float *pl, const int (&id)[2]) { return make_float2(pl[id[0]], pl[id[1]]); }
+};
+
+template <int NTOP, int NSIDE, typename CT, int FUSE, int CPT, typename XT, typename WT, bool HALO, bool HAS1D, bool IDX = false>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
-    TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
+    TsxGeo g, const CT *__restrict__ C, const int *__restrict__ cidx, long long nent, const uint8_t *__restrict__ l1d,
+    const double *__restrict__ a11,
     const double *__restrict__ a12, const double *__restrict__ albedo, const XT *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ hW, const double *__restrict__ hE,
     const double *__restrict__ hS, const double *__restrict__ hN, const WT *__restrict__ w,
@@ -138,9 +156,14 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
     CV cfc[D], cfn[D];
     XV xoc, xon;
     WV wc, wn;
+    int eid[CPT];
+    if (IDX) TsxIdx<CPT>::ids(cidx + c, eid);
     auto issue_row = [&](int d, CV(&cf)[D], XV &xo_, WV &w_) {
 #pragma unroll
-      for (int s2 = 0; s2 < D; ++s2) cf[s2] = TsxRaw<CT, CPT>::ld(C + (size_t)(d * D + s2) * Nc + c);
+      for (int s2 = 0; s2 < D; ++s2) {
+        if constexpr (IDX) cf[s2] = TsxIdx<CPT>::ld(C + (size_t)(d * D + s2) * nent, eid);
+        else cf[s2] = TsxRaw<CT, CPT>::ld(C + (size_t)(d * D + s2) * Nc + c);
+      }
       xo_ = TsxRaw<XT, CPT>::ld(x + (size_t)d * Nc + c);
       if (FUSE & 1) w_ = TsxRaw<WT, CPT>::ld(w + (size_t)d * Nc + c);
     };

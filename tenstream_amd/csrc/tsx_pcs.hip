@@ -52,6 +52,17 @@ bool tsx_pcs_eligible(const tsx_solver *s) {
 int tsx_pcs_pack(tsx_solver *s) {
   const TsxGeo &g = s->geo;
   uint4 *P = (uint4 *)s->coef_h;
+  s->coef_h_dd = false;
+  if (s->dd_on && s->coef_bytes == 4) {
+    // group 0 per cell, groups 1..7 per distinct block behind it (7 * nent <= 7 * Nc records: the same buffer holds them)
+    hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->coef,
+                       s->l1d, s->a11, s->a12, s->albedo, P);
+    hipLaunchKernelGGL(tsx_k_pcs_pack_ent, dim3(grid_for(7ll * s->dd_nent)), dim3(TSX_BLOCK), 0, s->stream, g.ncol,
+                       (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d, P + g.Nc);
+    HIPCHK(hipGetLastError());
+    s->coef_h_dd = true;
+    return TSX_OK;
+  }
   if (s->coef_bytes == 4) {
     hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->coef,
                        s->l1d, s->a11, s->a12, s->albedo, P);
@@ -74,9 +85,19 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   const int nb = (int)((nthr + CW - 1) / CW);
   const uint4 *P = (const uint4 *)s->coef_h;
   const float *r = (const float *)s->pc_rhs;
+  const bool dd = s->coef_h_dd;
+  const int *cidx = (const int *)s->dd_cidx_split;
+  const long long nent = s->dd_nent;
+  const uint4 *PE = P + g.Nc;
 #define TSX_PCS_GO(GSV, MODEV)                                                                                                   \
-  hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb, zfin, done, rbc, \
-                     nonbr)
+  do {                                                                                                                           \
+    if (dd)                                                                                                                      \
+      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, true>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb, zfin,  \
+                         done, rbc, nonbr, cidx, nent, PE);                                                                      \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, false>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb, zfin, \
+                         done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr);                                   \
+  } while (0)
   if (!gs) TSX_PCS_GO(false, 0);
   else if (mode == 0) TSX_PCS_GO(true, 0);
   else if (mode == 1) TSX_PCS_GO(true, 1);

@@ -21,9 +21,18 @@ static void launch_spmv_variant(tsx_solver *s, const XT *x, double *y, const WT 
   const TsxGeo &g = s->geo;
   const int nbmain = grid_for(g.Nc / CPT, TSX_MAX_PARTIAL_BLOCKS - TSX_FRAME_BLOCKS);
   const int nb = part == 2 ? grid_for(frame_groups(g, CPT), TSX_FRAME_BLOCKS) : nbmain;
+  if constexpr (std::is_same<CT, float>::value) {
+    if (s->dd_on) {  // shared storage of identical blocks (tsx_dedup.hip)
+      hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, float, FUSE, CPT, XT, WT, HALO, HAS1D, true>), dim3(nb), dim3(TSX_BLOCK), 0,
+                         s->stream, g, (const float *)s->dd_coef, (const int *)s->dd_cidx, (long long)s->dd_nent, s->l1d, s->a11,
+                         s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS, s->recvN, w,
+                         s->partials + (part == 2 ? nbmain : 0), done, part);
+      return;
+    }
+  }
   hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT, XT, WT, HALO, HAS1D>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
-                     (const CT *)s->coef, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS, s->recvN,
-                     w, s->partials + (part == 2 ? nbmain : 0), done, part);
+                     (const CT *)s->coef, (const int *)nullptr, 0ll, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE,
+                     s->recvS, s->recvN, w, s->partials + (part == 2 ? nbmain : 0), done, part);
 }
 
 template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT>

@@ -276,6 +276,12 @@ class DiffuseSolver:
                        r.import_ms, r.export_ms)
 
     # -- measurement ---------------------------------------------------------------------------------
+    def dedup_info(self):
+        """(in use?, number of distinct transport blocks) of the current coefficients"""
+        on, n = C.c_int32(), C.c_int64()
+        _lib.check(self.lib.tsx_dedup_info(self.h, C.byref(on), C.byref(n)))
+        return bool(on.value), int(n.value)
+
     def bench_kernel(self, kernel: int, reps: int) -> float:
         ms = C.c_float()
         _lib.check(self.lib.tsx_bench_kernel(self.h, kernel, reps, C.byref(ms)))
