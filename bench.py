@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--solver", default="3_10")
     ap.add_argument("--pc", type=int, default=3,
                     help="0 none, 1 column-block Jacobi, 2 zebra line-GS over column blocks, 3 red-black GS over column blocks")
-    ap.add_argument("--pc-sweeps", type=int, default=9)
+    ap.add_argument("--pc-sweeps", type=int, default=0, help="half-grid passes - 1; 0 = the library's choice")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="edge of the CPU-baseline sample domain (columns); 0 = 256 with >= 16 threads, else 112")
@@ -221,7 +221,9 @@ def main():
     bytes_spmv = s.algorithmic_bytes(0)
     bytes_iter = s.algorithmic_bytes(1)
     pc_ms = pass_ms = None
-    if args.pc == 3 and args.pc_sweeps == 9:
+    dd_on, dd_nent = s.dedup_info()
+    sweeps = args.pc_sweeps if args.pc_sweeps > 0 else ((13 if (dd_on and solver == "3_10") else 9) if args.pc in (2, 3) else 1)
+    if args.pc == 3 and args.pc_sweeps == 0:
         try:
             pc_ms = s.bench_kernel(2, args.kernel_reps)
             pass_ms = s.bench_kernel(3, 4 * args.kernel_reps)
@@ -243,10 +245,10 @@ def main():
         r_pass = None
         if pass_ms is not None:
             r_pass = roof("tsx_k_pcs_rb<..., GS, MODE 0> (one intermediate red-black pass of M^-1)", pass_ms,
-                          s.algorithmic_bytes(3), ["tsx_k_pcs_rb", ",true,0>"])
+                          s.algorithmic_bytes(3), ["tsx_k_pcs_rb", (",true,0>", ",true,0,")])
         r_pc = None
         if pc_ms is not None:
-            r_pc = {"kernel": f"M^-1: {args.pc_sweeps + 1} half-grid passes", "ms_per_application": pc_ms,
+            r_pc = {"kernel": f"M^-1: {sweeps + 1} half-grid passes", "ms_per_application": pc_ms,
                     "bytes_per_application": s.algorithmic_bytes(2),
                     "achieved": s.algorithmic_bytes(2) / (pc_ms * 1e-3) / 1e9, "unit": "GB/s"}
         # the kernel the solve spends most of its time in: the preconditioner pass (about half of an iteration) when the
@@ -274,9 +276,12 @@ def main():
                 "preconditioner_storage": "inside M^-1 only: fp16 column blocks + fp8 couplings, fp32/bf16 iterates; operator, "
                                           "Krylov vectors, dots and stop rule fp64 on the exact blocks",
                 "coeff_source": "device N-linear LUT interpolation (tsx_diff_set_optprop), synthetic table",
+                "coeff_dedup": dict(in_use=dd_on, distinct_blocks=dd_nent, cells_local=co.xm * co.ym * Nz,
+                                    note="bit-identical blocks are stored once behind a per-cell index (lossless; TSX_DEDUP=0 "
+                                         "disables): actual traffic is below the algorithmic stored-block bytes"),
                 "coeff_setup_ms": t_setup * 1e3,
-                "preconditioner": {0: "none", 1: "column-jacobi", 2: f"column-zebra({args.pc_sweeps + 1} passes)",
-                                   3: f"column-red-black({args.pc_sweeps + 1} passes)"}.get(args.pc, str(args.pc)),
+                "preconditioner": {0: "none", 1: "column-jacobi", 2: f"column-zebra({sweeps + 1} passes)",
+                                   3: f"column-red-black({sweeps + 1} passes)"}.get(args.pc, str(args.pc)),
                 "iterations": info.niter,
                 "reason": info.reason,
                 "rel_residual": info.rnorm / info.rnorm0,
@@ -321,7 +326,8 @@ def pmc_traffic(solver, size, patterns):
             if it:
                 return it["traffic_bytes"], os.path.relpath(path, here)
             continue
-        hit = [v for name, v in doc["kernels"].items() if all(p in name for p in patterns) and v["launches"] > 0]
+        ok = lambda name, p: any(q in name for q in p) if isinstance(p, tuple) else p in name
+        hit = [v for name, v in doc["kernels"].items() if all(ok(name, p) for p in patterns) and v["launches"] > 0]
         if hit:
             n = sum(v["launches"] for v in hit)
             return sum(v["traffic_bytes_per_launch"] * v["launches"] for v in hit) / n, os.path.relpath(path, here)

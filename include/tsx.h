@@ -84,7 +84,8 @@ typedef struct {
   double rtol, atol, dtol;
   int32_t maxit;
   int32_t pc;                 /* TSX_PC_* */
-  int32_t pc_sweeps;          /* ZEBRA / REDBLACK: pc_sweeps + 1 half-grid passes per application; COLUMN: Jacobi sweeps (1..16) */
+  int32_t pc_sweeps;          /* ZEBRA / REDBLACK: pc_sweeps + 1 half-grid passes per application; COLUMN: Jacobi sweeps (1..16);
+                                 0 (default) = automatic: 13 where most blocks are shared (tsx_dedup_info), else 9 */
   int32_t check_every;        /* host looks at the device convergence flag every n iterations */
   int32_t fp32_directions;    /* 1 (default): the directions p, p-hat, s-hat and the shadow residual are stored in fp32 --
                                  flexible BiCGStab accepts any direction: x and r are updated consistently with A p-hat,

@@ -62,8 +62,8 @@ def main():
         }
     # one default iteration: 2 applications of M^-1 (pass 0 without neighbours, 7 intermediate, the fp32 pass, the last
     # pass), 2 operator applies with fused dots, 3 vector updates
-    per_iter = [("tsx_k_pcs_rb", ",false,0>", 2), ("tsx_k_pcs_rb", ",true,0>", 14), ("tsx_k_pcs_rb", ",true,1>", 2),
-                ("tsx_k_pcs_rb", ",true,2>", 2), ("tsx_k_spmv_w", ",1,2,float,float", 1), ("tsx_k_spmv_w", ",5,2,float,double", 1),
+    per_iter = [("tsx_k_pcs_rb", ",false,0", 2), ("tsx_k_pcs_rb", ",true,0", 14), ("tsx_k_pcs_rb", ",true,1", 2),
+                ("tsx_k_pcs_rb", ",true,2", 2), ("tsx_k_spmv_w", ",1,2,float,float", 1), ("tsx_k_spmv_w", ",5,2,float,double", 1),
                 ("tsx_k_pupdate32", "", 1), ("tsx_k_supdate", "", 1), ("tsx_k_xrupdate", "", 1)]
     it_bytes, missing = 0.0, []
     for base, pat, mult in per_iter:

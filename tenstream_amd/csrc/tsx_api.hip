@@ -133,7 +133,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->dtol = 1e4;    // PETSc KSP default divergence tolerance
   o->maxit = 1000;  // src/pprts_base.F90:1118
   o->pc = TSX_PC_REDBLACK;  // this back-end's default preconditioner: 10 half-grid passes
-  o->pc_sweeps = 9;
+  o->pc_sweeps = 0;  // automatic (prepare_ksp): 13 where the blocks are shared (a pass costs half), else 9
   o->check_every = 4;
   o->fp32_directions = 1;
   o->pc_coeff_fp16 = 1;
@@ -251,7 +251,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->v32, s->p32, s->dsend[0], s->dsend[1], s->dsend[2], s->dsend[3], s->drecv[0], s->drecv[1], s->drecv[2], s->drecv[3],
-                  s->coef_h, s->coef, s->dd_coef, s->dd_cidx, s->dd_cidx_split, s->dd_ent_cell, s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
+                  s->coef_h, s->coef, s->dd_coef, s->dd_cidx, s->dd_cidx_split, s->dd_ent_cell, s->dd_scratch, s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
@@ -932,7 +932,7 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   else tsx_default_ksp_opts(o);
   ARGCHK(o->maxit >= 1, "solve: maxit < 1");
   ARGCHK(o->pc >= TSX_PC_NONE && o->pc <= TSX_PC_REDBLACK, "solve: unsupported preconditioner");
-  ARGCHK(o->pc_sweeps >= 1 && o->pc_sweeps <= 16, "solve: pc_sweeps out of range");
+  ARGCHK(o->pc_sweeps >= 0 && o->pc_sweeps <= 16, "solve: pc_sweeps out of range");
   HIPCHK(hipSetDevice(s->device));
   s->pc = o->pc;
   s->pc_sweeps = o->pc_sweeps;
@@ -952,6 +952,13 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   {
     int rc = tsx_dedup_ensure(s);  // shared storage of identical blocks (operator apply and scan preconditioner)
     if (rc) return rc;
+  }
+  if (o->pc_sweeps == 0) {
+    // pass count of the Gauss-Seidel orderings, measured on the metric domain, config 2 and config 4's 252 g-points
+    // (scripts/pcbench.py, scripts/sweeps_study.py): 10 passes / 10 iterations when a pass streams every cell's own
+    // blocks, 14 passes / 8 iterations when most blocks are shared and a pass moves half the bytes
+    o->pc_sweeps = (o->pc == TSX_PC_REDBLACK || o->pc == TSX_PC_ZEBRA) ? (s->dd_on && s->geo.ntop == 2 ? 13 : 9) : 1;
+    s->pc_sweeps = o->pc_sweeps;
   }
   if (o->pc != TSX_PC_NONE) {
     int rc = tsx_pc_ensure_buffers(s);

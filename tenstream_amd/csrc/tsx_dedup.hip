@@ -43,16 +43,36 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_hash(TsxGeo g, int DD, con
 
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_insert(long long Nc, unsigned long long mask, const unsigned long long *__restrict__ h,
                                                              unsigned long long *__restrict__ keys, int *__restrict__ owner) {
-  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
-    const unsigned long long hv = h[c];
-    unsigned long long slot = hv & mask;
-    for (;;) {
-      const unsigned long long prev = atomicCAS(&keys[slot], TSX_DD_EMPTY, hv);
-      if (prev == TSX_DD_EMPTY || prev == hv) {
-        atomicMin(&owner[slot], (int)c);
-        break;
+  // Most cells of a homogeneous background carry the same hash: millions of atomics on one slot would serialise (measured:
+  // 40 ms).  A cell therefore looks first (relaxed loads): once the key is in place and the slot's owner is already a
+  // smaller cell index, it has nothing to add.  Cells are visited in ascending order within a wave and roughly so across
+  // the grid, so after the first arrivals almost nobody issues an atomic.
+  // ... and the lanes of a wave that carry the same hash send one of them (the lowest lane = the smallest cell index).
+  for (long long c0 = (long long)blockIdx.x * TSX_BLOCK; c0 < Nc; c0 += (long long)gridDim.x * TSX_BLOCK) {
+    const long long c = c0 + threadIdx.x;
+    const bool live = c < Nc;
+    const unsigned long long hv = live ? h[c] : TSX_DD_EMPTY;
+    bool pending = live;
+    while (__any(pending)) {
+      const unsigned long long todo = __ballot(pending);
+      const int lead = __ffsll((long long)todo) - 1;
+      const unsigned lo = (unsigned)__shfl((int)(unsigned)(hv & 0xffffffffull), lead, 64);
+      const unsigned hi = (unsigned)__shfl((int)(unsigned)(hv >> 32), lead, 64);
+      const unsigned long long lhv = ((unsigned long long)hi << 32) | lo;
+      const bool mine = pending && hv == lhv;
+      if (mine) pending = false;
+      if ((int)(threadIdx.x & 63) == lead) {
+        unsigned long long slot = hv & mask;
+        for (;;) {
+          unsigned long long cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (cur == TSX_DD_EMPTY) cur = atomicCAS(&keys[slot], TSX_DD_EMPTY, hv);
+          if (cur == TSX_DD_EMPTY || cur == hv) {
+            if (__hip_atomic_load(&owner[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int)c) atomicMin(&owner[slot], (int)c);
+            break;
+          }
+          slot = (slot + 1) & mask;
+        }
       }
-      slot = (slot + 1) & mask;
     }
   }
 }
@@ -177,6 +197,11 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_compact(long long Nc, int 
   }
 }
 
+struct TsxDdSlice {  // a piece of the solver's scratch allocation
+  void *p;
+  template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
 static bool dedup_enabled() {
   const char *e = getenv("TSX_DEDUP");  // TSX_DEDUP=0: always the dense planes (A/B knob)
   return e ? atoi(e) != 0 : true;
@@ -194,16 +219,29 @@ int tsx_dedup_ensure(tsx_solver *s) {
   const long long Nc = g.Nc;
   unsigned long long tsz = 1;
   while (tsz < (unsigned long long)(2 * Nc)) tsz <<= 1;
-  TsxDevTmp th, tk, to, trep, tflag, tpos, tsum, ttot;
-  HIPCHK(th.alloc(sizeof(unsigned long long) * (size_t)Nc));
-  HIPCHK(tk.alloc(sizeof(unsigned long long) * (size_t)tsz));
-  HIPCHK(to.alloc(sizeof(int) * (size_t)tsz));
-  HIPCHK(trep.alloc(sizeof(int) * (size_t)Nc));
-  HIPCHK(tflag.alloc(sizeof(int) * (size_t)Nc));
-  HIPCHK(tpos.alloc(sizeof(int) * (size_t)Nc));
+  // scratch kept with the solver (one allocation; hipMalloc / hipFree per g-point cost more than the kernels)
   const int nsb = (int)((Nc + TSX_SCAN_CHUNK - 1) / TSX_SCAN_CHUNK);
-  HIPCHK(tsum.alloc(sizeof(int) * (size_t)nsb));
-  HIPCHK(ttot.alloc(sizeof(int)));
+  TsxDdSlice th, tk, to, trep, tflag, tpos, tsum, ttot;
+  {
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t sz[8] = {al(sizeof(unsigned long long) * (size_t)Nc), al(sizeof(unsigned long long) * (size_t)tsz),
+                          al(sizeof(int) * (size_t)tsz), al(sizeof(int) * (size_t)Nc), al(sizeof(int) * (size_t)Nc),
+                          al(sizeof(int) * (size_t)Nc), al(sizeof(int) * (size_t)nsb), 256};
+    size_t tot = 0;
+    for (size_t v : sz) tot += v;
+    if (s->dd_scratch_bytes < tot) {
+      if (s->dd_scratch) HIPCHK(hipFree(s->dd_scratch));
+      s->dd_scratch = nullptr;
+      HIPCHK(hipMalloc(&s->dd_scratch, tot));
+      s->dd_scratch_bytes = tot;
+    }
+    TsxDdSlice *d[8] = {&th, &tk, &to, &trep, &tflag, &tpos, &tsum, &ttot};
+    size_t off = 0;
+    for (int q = 0; q < 8; ++q) {
+      d[q]->p = (char *)s->dd_scratch + off;
+      off += sz[q];
+    }
+  }
   HIPCHK(hipMemsetAsync(tk.p, 0, sizeof(unsigned long long) * (size_t)tsz, s->stream));
   HIPCHK(hipMemsetAsync(to.p, 0x7f, sizeof(int) * (size_t)tsz, s->stream));
   const float *C = (const float *)s->coef;

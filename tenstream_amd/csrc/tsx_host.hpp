@@ -37,12 +37,11 @@ static inline int grid_for(long long n, int cap = 2048) {
 
 // TSX_SPMV_CPT=1|2 selects cells per thread (default 2 when xm is even)
 static inline int spmv_cpt(const tsx_solver *s) {
-  static int env = -1;
-  if (env < 0) {
-    const char *e = getenv("TSX_SPMV_CPT");
-    env = e ? atoi(e) : 0;
-  }
-  int want = env > 0 ? env : TSX_DEFAULT_CPT;
+  const char *e = getenv("TSX_SPMV_CPT");  // read per call: tests switch it
+  const int env = e ? atoi(e) : 0;
+  // with shared block storage (tsx_dedup.hip) the coefficient loads are 4-byte gathers anyway: one cell per thread measured
+  // 5-8 % faster there (more waves, fewer registers)
+  int want = env > 0 ? env : (s->dd_on ? 1 : TSX_DEFAULT_CPT);
   if (want > 2) want = 2;
   while (want > 1 && (s->geo.xm % want) != 0) want >>= 1;
   return want;

@@ -93,6 +93,8 @@ struct tsx_solver {
   int *dd_cidx;            // [Nc] natural cell order
   int *dd_cidx_split;      // [Nc] colour-split order (the preconditioner's)
   int *dd_ent_cell;        // [dd_nent] representative cell of every entry
+  void *dd_scratch;        // work space of the build (hashes, table, scan)
+  size_t dd_scratch_bytes;
   int n1d;             // number of 1-D layers (unconstrained_fraction = 1 - n1d/Nz, src/pprts.F90:721-723)
   TsxLutHost lut_diff;
 

@@ -1,5 +1,7 @@
 // tsx_kernels_spmv.hpp -- the operator apply y = (I - T) x and its halo pack kernel (see tsx_dev.hpp)
 #pragma once
+#include <type_traits>
+
 #include "tsx_dev.hpp"
 
 // part: 0 = every cell; 1 = interior only (cells whose gather touches no received face: launched while the exchange is
@@ -153,69 +155,96 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
     using CV = typename TsxRaw<CT, CPT>::type;
     using XV = typename TsxRaw<XT, CPT>::type;
     using WV = typename TsxRaw<WT, CPT>::type;
-    CV cfc[D], cfn[D];
-    XV xoc, xon;
-    WV wc, wn;
     int eid[CPT];
-    if (IDX) TsxIdx<CPT>::ids(cidx + c, eid);
-    auto issue_row = [&](int d, CV(&cf)[D], XV &xo_, WV &w_) {
+    int id0 = 0;
+    bool wuni = false;
+    if constexpr (IDX) {
+      // all cells of this wave share one block (the usual case inside a homogeneous background): its 100 coefficients
+      // come through the scalar cache into SGPRs instead of 64 identical vector loads each
+      TsxIdx<CPT>::ids(cidx + c, eid);
+      id0 = __builtin_amdgcn_readfirstlane(eid[0]);
+      bool same = true;
 #pragma unroll
-      for (int s2 = 0; s2 < D; ++s2) {
-        if constexpr (IDX) cf[s2] = TsxIdx<CPT>::ld(C + (size_t)(d * D + s2) * nent, eid);
-        else cf[s2] = TsxRaw<CT, CPT>::ld(C + (size_t)(d * D + s2) * Nc + c);
-      }
-      xo_ = TsxRaw<XT, CPT>::ld(x + (size_t)d * Nc + c);
-      if (FUSE & 1) w_ = TsxRaw<WT, CPT>::ld(w + (size_t)d * Nc + c);
-    };
-    issue_row(0, cfc, xoc, wc);
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      if (d + 1 < D) issue_row(d + 1, cfn, xon, wn);
-      __builtin_amdgcn_sched_barrier(0);
-      double xo[CPT], acc[CPT];
-      TsxRaw<XT, CPT>::cvt(xoc, xo);
-      if (HAS1D && is1d) {
-#pragma unroll
-        for (int m = 0; m < CPT; ++m)
-          acc[m] = d < NTOP ? xo[m] - t11[m] * xs[d][m] - t12[m] * xs[d < NTOP ? (d ^ 1) : d][m] : xo[m];
-      } else {
-#pragma unroll
-        for (int m = 0; m < CPT; ++m) acc[m] = 0.0;
+      for (int m = 0; m < CPT; ++m) same &= eid[m] == id0;
+      wuni = __all(same);
+    }
+    auto rows = [&](auto uni_tag) {
+      constexpr bool UNI = decltype(uni_tag)::value;
+      using CH = typename std::conditional<UNI, float, CV>::type;  // a coefficient as held: wave-uniform scalar / per lane
+      CH cfc[D], cfn[D];
+      XV xoc, xon;
+      WV wc, wn;
+      auto issue_row = [&](int d, CH(&cf)[D], XV &xo_, WV &w_) {
 #pragma unroll
         for (int s2 = 0; s2 < D; ++s2) {
-          double cf[CPT];
-          TsxRaw<CT, CPT>::cvt(cfc[s2], cf);
-#pragma unroll
-          for (int m = 0; m < CPT; ++m) acc[m] += cf[m] * xs[s2][m];
+          if constexpr (UNI) cf[s2] = C[(size_t)(d * D + s2) * nent + id0];
+          else if constexpr (IDX) cf[s2] = TsxIdx<CPT>::ld(C + (size_t)(d * D + s2) * nent, eid);
+          else cf[s2] = TsxRaw<CT, CPT>::ld(C + (size_t)(d * D + s2) * Nc + c);
         }
+        xo_ = TsxRaw<XT, CPT>::ld(x + (size_t)d * Nc + c);
+        if (FUSE & 1) w_ = TsxRaw<WT, CPT>::ld(w + (size_t)d * Nc + c);
+      };
+      issue_row(0, cfc, xoc, wc);
 #pragma unroll
-        for (int m = 0; m < CPT; ++m) acc[m] = xo[m] - acc[m];
-      }
-      V::st(y + (size_t)d * Nc + c, acc);
-      if (d < NTOP && tsx_inward(d)) {
+      for (int d = 0; d < D; ++d) {
+        if (d + 1 < D) issue_row(d + 1, cfn, xon, wn);
+        __builtin_amdgcn_sched_barrier(0);
+        double xo[CPT], acc[CPT];
+        TsxRaw<XT, CPT>::cvt(xoc, xo);
+        if (HAS1D && is1d) {
 #pragma unroll
-        for (int m = 0; m < CPT; ++m) down[m] += xo[m];
-      }
-      if (FUSE & 1) {
-        double wv[CPT];
-        TsxRaw<WT, CPT>::cvt(wc, wv);
+          for (int m = 0; m < CPT; ++m)
+            acc[m] = d < NTOP ? xo[m] - t11[m] * xs[d][m] - t12[m] * xs[d < NTOP ? (d ^ 1) : d][m] : xo[m];
+        } else {
 #pragma unroll
-        for (int m = 0; m < CPT; ++m) sum[0] += wv[m] * acc[m];
-      }
-      if (FUSE & 2) {
+          for (int m = 0; m < CPT; ++m) acc[m] = 0.0;
 #pragma unroll
-        for (int m = 0; m < CPT; ++m) sum[1] += xo[m] * acc[m];
-      }
-      if (FUSE & 4) {
+          for (int s2 = 0; s2 < D; ++s2) {
+            double cf[CPT];
+            if constexpr (UNI) {
 #pragma unroll
-        for (int m = 0; m < CPT; ++m) sum[2] += acc[m] * acc[m];
-      }
-      if (d + 1 < D) {
+              for (int m = 0; m < CPT; ++m) cf[m] = (double)cfc[s2];
+            } else {
+              TsxRaw<CT, CPT>::cvt(cfc[s2], cf);
+            }
 #pragma unroll
-        for (int s2 = 0; s2 < D; ++s2) cfc[s2] = cfn[s2];
-        xoc = xon;
-        wc = wn;
+            for (int m = 0; m < CPT; ++m) acc[m] += cf[m] * xs[s2][m];
+          }
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) acc[m] = xo[m] - acc[m];
+        }
+        V::st(y + (size_t)d * Nc + c, acc);
+        if (d < NTOP && tsx_inward(d)) {
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) down[m] += xo[m];
+        }
+        if (FUSE & 1) {
+          double wv[CPT];
+          TsxRaw<WT, CPT>::cvt(wc, wv);
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) sum[0] += wv[m] * acc[m];
+        }
+        if (FUSE & 2) {
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) sum[1] += xo[m] * acc[m];
+        }
+        if (FUSE & 4) {
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) sum[2] += acc[m] * acc[m];
+        }
+        if (d + 1 < D) {
+#pragma unroll
+          for (int s2 = 0; s2 < D; ++s2) cfc[s2] = cfn[s2];
+          xoc = xon;
+          wc = wn;
+        }
       }
+    };
+    if constexpr (IDX) {
+      if (wuni) rows(std::true_type{});
+      else rows(std::false_type{});
+    } else {
+      rows(std::false_type{});
     }
     if (k == Nz - 1) {  // rows no cell writes: TOA Edn, surface Eup (albedo), bottom side dummies
       double alb[CPT];

@@ -28,8 +28,9 @@ static PcsCfg pcs_config(const tsx_solver *s) {
     // measured (scripts/pcsbench.py): 8 levels x 8 segments on large passes (>= 16 K columns: fewer, fatter threads),
     // 4 x 16 on small ones (more waves); deeper columns take the smallest pair that holds them
     if (g.Nz <= 64) {
-      c.lseg = nthr >= 16384 ? 8 : 4;
-      c.nseg = nthr >= 16384 ? 8 : 16;
+      const bool fat = nthr >= 16384 && !s->dd_on;  // with shared blocks a pass moves half the bytes: more waves win again
+      c.lseg = fat ? 8 : 4;
+      c.nseg = fat ? 8 : 16;
     } else if (g.Nz <= 128) {
       c.lseg = 8;
       c.nseg = 16;

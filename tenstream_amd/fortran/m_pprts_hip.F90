@@ -163,7 +163,7 @@ contains
     opts%maxit = maxit
     opts%pc = pc
     if (pc .eq. TSX_PC_ZEBRA) opts%pc_sweeps = 5
-    if (pc .eq. TSX_PC_REDBLACK) opts%pc_sweeps = 9
+    if (pc .eq. TSX_PC_REDBLACK) opts%pc_sweeps = 0  ! automatic (tsx_default_ksp_opts)
     ierr = tsx_diff_solve(handle, c_loc(vb), c_loc(vediff), TSX_HOST, opts, res)
     niter = res%niter
     reason = res%reason

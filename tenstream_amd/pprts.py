@@ -149,7 +149,7 @@ class PprtsSolver:
             o = _lib.KspOpts()
             self.lib.tsx_default_ksp_opts(C.byref(o))
             drt, dat, dmx = self.core.default_tolerances()
-            o.rtol, o.atol, o.maxit, o.pc, o.pc_sweeps = drt, dat, dmx, 3, 9
+            o.rtol, o.atol, o.maxit, o.pc, o.pc_sweeps = drt, dat, dmx, 3, 0
             for k, v in opts.items():
                 setattr(o, k, v)
         r = _lib.KspResult()

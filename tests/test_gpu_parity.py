@@ -478,7 +478,7 @@ def test_scan_preconditioner_equals_the_column_sweep(gpu, monkeypatch, Nx, Ny, N
         s.close()
     for a, b in zip(out["0"], out["1"]):
         assert np.abs(a - b).max() <= 2e-2 * np.abs(a).max()
-    assert abs(out["its0"] - out["its1"]) <= 1
+    assert abs(out["its0"] - out["its1"]) <= max(1, round(0.1 * out["its0"]))   # tight solves: a few dozen iterations
     assert np.abs(out["x0"] - out["x1"]).max() <= 1e-8 * np.abs(out["x0"]).max()
     # against the model: red-black Gauss-Seidel on the exact column blocks, 5 passes
     M, A = _column_block_matrix(P, lay)
@@ -501,3 +501,57 @@ def test_scan_preconditioner_equals_the_column_sweep(gpu, monkeypatch, Nx, Ny, N
         mk = colour == (p_ % 2)
         x[mk] = lu.solve(rhs)[mk]
     assert np.abs(out["1"][2].ravel() - x).max() <= 6e-2 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 16, 12, 9, 2), ("3_10", 10, 6, 5, 0), ("8_16", 8, 6, 5, 1)])
+def test_shared_block_storage_is_lossless(gpu, monkeypatch, solver, Nx, Ny, Nz, n1d):
+    """tsx_dedup.hip: cells with bit-identical transport blocks share one stored copy behind a per-cell index.  Same
+    numbers, same order of operations: the operator apply and the whole preconditioned solve (residual history included)
+    are bit-identical with TSX_DEDUP=0 and 1, on a field where most blocks repeat (a clear-sky background under a few
+    cloudy columns, 1-D layers on top) -- and against the oracle.  A field of all-different blocks is left dense."""
+    P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
+    D = P["D"]
+    coeff = P["coeff"].copy()
+    # homogeneous background: every cell gets the block of cell (0, 0, Nz-1), a few columns keep their own
+    keep = np.zeros((Ny, Nx), dtype=bool)
+    keep[1, 2] = keep[3, 3] = keep[Ny - 1, Nx - 1] = keep[2, 0] = True
+    coeff[~keep] = coeff[0, 0, Nz - 1]
+    fac = 1.0 - 0.01 * np.random.default_rng(9).random((Ny, Nx, Nz, 1))   # the kept columns: a different block in every cell
+    coeff[keep] = (coeff[keep] * fac[keep]).astype(np.float32)
+    lay = O.layout(solver, Nz, Nx, Ny)
+    x = np.random.default_rng(3).standard_normal(P["b"].shape)
+    res = {}
+    monkeypatch.setenv("TSX_SPMV_CPT", "2")   # same cells per thread on both sides: same summation order of the fused dots
+    for dd in ("0", "1"):
+        monkeypatch.setenv("TSX_DEDUP", dd)
+        s = DiffuseSolver(solver, Nz, Nx, Ny)
+        s.set_coeffs(coeff, P["l1d"], P["a11"], P["a12"], P["albedo"])
+        on, nent = s.dedup_info()
+        y = s.apply(x)
+        xs = np.zeros(s.vec_shape)
+        info = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30, pc_sweeps=9)   # (the automatic pass count depends on the storage)
+        res[dd] = (on, nent, y, xs, info)
+        s.close()
+    assert not res["0"][0] and res["1"][0]
+    # distinct blocks: the background, the kept columns' 3-D cells, and one entry standing for all 1-D cells
+    assert res["1"][1] == 1 + int(keep.sum()) * (Nz - n1d) + (1 if n1d else 0) - (1 if keep[0, 0] else 0)
+    assert np.array_equal(res["0"][2], res["1"][2])
+    assert np.array_equal(res["0"][3], res["1"][3]) and res["0"][4].niter == res["1"][4].niter
+    assert np.array_equal(res["0"][4].res_hist, res["1"][4].res_hist)
+    y_ref = _ref_apply(dict(P, coeff=coeff), lay, x)
+    assert np.abs(res["1"][2] - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+    # the default launch geometry with shared blocks (one cell per thread): the same solution to rounding
+    monkeypatch.delenv("TSX_SPMV_CPT")
+    s = DiffuseSolver(solver, Nz, Nx, Ny)
+    s.set_coeffs(coeff, P["l1d"], P["a11"], P["a12"], P["albedo"])
+    xs = np.zeros(s.vec_shape)
+    assert s.solve(P["b"], xs, rtol=1e-10, atol=1e-30).reason == 2
+    assert np.abs(xs - res["0"][3]).max() <= 1e-9 * np.abs(xs).max()
+    s.close()
+    # every block different: the index would only cost, the dense planes stay
+    monkeypatch.setenv("TSX_DEDUP", "1")
+    s = DiffuseSolver(solver, Nz, Nx, Ny)
+    s.set_coeffs(P["coeff"] * (1 + 1e-3 * np.random.default_rng(5).random(P["coeff"].shape)).astype(np.float32), P["l1d"], P["a11"], P["a12"], P["albedo"])
+    on, nent = s.dedup_info()
+    assert not on and nent > 0.5 * Nx * Ny * Nz
+    s.close()
