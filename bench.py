@@ -240,7 +240,7 @@ def main():
 
     out = None
     if rank == 0:
-        r_spmv = roof("tsx_k_spmv_w (y = (I - T) x, fp64 x and y)", spmv_ms, bytes_spmv, ["tsx_k_spmv", ",0,2,double,double"])
+        r_spmv = roof("tsx_k_spmv_w (y = (I - T) x, fp64 x and y)", spmv_ms, bytes_spmv, ["tsx_k_spmv", (",0,1,double,double", ",0,2,double,double")])
         r_iter = roof("one BiCGStab iteration (2 M^-1, 2 SpMV, 3 vector updates)", iter_ms, bytes_iter, None)
         r_pass = None
         if pass_ms is not None:

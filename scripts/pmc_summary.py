@@ -60,21 +60,23 @@ def main():
             "write_bytes_per_launch": wm * 1024.0,
             "traffic_bytes_per_launch": 2.0 * fm * 1024.0 + wm * 1024.0,
         }
-    # one default iteration: 2 applications of M^-1 (pass 0 without neighbours, 7 intermediate, the fp32 pass, the last
-    # pass), 2 operator applies with fused dots, 3 vector updates
-    per_iter = [("tsx_k_pcs_rb", ",false,0", 2), ("tsx_k_pcs_rb", ",true,0", 14), ("tsx_k_pcs_rb", ",true,1", 2),
-                ("tsx_k_pcs_rb", ",true,2", 2), ("tsx_k_spmv_w", ",1,2,float,float", 1), ("tsx_k_spmv_w", ",5,2,float,double", 1),
-                ("tsx_k_pupdate32", "", 1), ("tsx_k_supdate", "", 1), ("tsx_k_xrupdate", "", 1)]
+    # one default iteration: 2 applications of M^-1 (pass 0 without neighbours, P - 3 intermediate, the fp32 pass, the last
+    # pass; P = argv[5], default 14), 2 operator applies with fused dots, 3 vector updates
+    P = int(sys.argv[5]) if len(sys.argv) > 5 else 14
+    per_iter = [(r"tsx_k_pcs_rb<\d+,\d+,\d+,false,0", 2), (r"tsx_k_pcs_rb<\d+,\d+,\d+,true,0", 2 * (P - 3)),
+                (r"tsx_k_pcs_rb<\d+,\d+,\d+,true,1", 2), (r"tsx_k_pcs_rb<\d+,\d+,\d+,true,2", 2),
+                (r"tsx_k_spmv_w<\d+,\d+,\w+,1,\d,float,float", 1), (r"tsx_k_spmv_w<\d+,\d+,\w+,5,\d,float,double", 1),
+                (r"tsx_k_pupdate32", 1), (r"tsx_k_supdate", 1), (r"tsx_k_xrupdate", 1)]
     it_bytes, missing = 0.0, []
-    for base, pat, mult in per_iter:
-        hit = [v for name, v in kernels.items() if name.startswith(base) and pat in name]
+    for pat, mult in per_iter:
+        hit = [v for name, v in kernels.items() if re.match(pat, name)]
         if hit:
             it_bytes += mult * hit[0]["traffic_bytes_per_launch"]
         else:
-            missing.append(base + pat)
+            missing.append(pat)
     doc = {"workload": key, "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950)", "kernels": kernels}
     if not missing:
-        doc["iteration"] = {"traffic_bytes": it_bytes, "composition": [f"{m} x {b}{p}" for b, p, m in per_iter]}
+        doc["iteration"] = {"traffic_bytes": it_bytes, "passes_per_application": P, "composition": [f"{m} x {p}" for p, m in per_iter]}
     json.dump(doc, open(out, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k[:70]:70s} n={v['launches']:5d} traffic={v['traffic_bytes_per_launch'] / 1e6:10.1f} MB")
