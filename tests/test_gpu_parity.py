@@ -194,9 +194,11 @@ def test_default_solver_on_awkward_shapes(gpu, solver, Nx, Ny, Nz, n1d):
     s.close()
 
 
-def test_stop_rule_reason_codes_like_MyKSPConverged(gpu):
+def test_stop_rule_reason_codes_like_MyKSPConverged(gpu, monkeypatch):
     """Diverged reasons of MyKSPConverged (src/pprts.F90:4437-4486): -3 iteration limit, -9 NaN; the oracle's restatement
-    of KSPFBCGS gives the same reason and iteration count for the bare operator."""
+    of KSPFBCGS gives the same reason and iteration count for the bare operator.  (TSX_NO_RETRY: look at the first
+    attempt only; the second-solver path has its own test below.)"""
+    monkeypatch.setenv("TSX_NO_RETRY", "1")
     P = synthetic.make_problem("3_10", Nx=12, Ny=10, Nz=8)
     s = DiffuseSolver("3_10", 8, 12, 10)
     s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
@@ -212,6 +214,36 @@ def test_stop_rule_reason_codes_like_MyKSPConverged(gpu):
     x = np.zeros(s.vec_shape)
     info = s.solve(b, x, pc=2)
     assert info.reason == -9
+    s.close()
+
+
+def test_failed_solve_is_retried_from_zero_with_the_conservative_solver(gpu, monkeypatch):
+    """src/pprts.F90:4277-4302: a solve that ends with a non-positive reason is repeated once from a zero initial guess
+    with a second solver; only a second failure is reported.  A poisoned initial guess (NaN) makes the first attempt end
+    with -9; the retry (exact fp64 blocks and directions, zebra-ordered column solves) converges to the oracle's solution.
+    A right-hand side that is itself NaN fails twice and reports -9."""
+    import scipy.sparse.linalg as spla
+
+    P = synthetic.make_problem("3_10", Nx=12, Ny=10, Nz=8, n1d=1)
+    lay = O.layout("3_10", 8, 12, 10)
+    A = O.assemble_csr(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x_ref = spla.spsolve(A.tocsc(), P["b"].ravel()).reshape(P["b"].shape)
+    s = DiffuseSolver("3_10", 8, 12, 10)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x = np.zeros(s.vec_shape)
+    x[3, 4, 2, 1] = np.nan
+    info = s.solve(P["b"], x, rtol=1e-10, atol=1e-30)
+    assert info.reason == 2 and np.isfinite(x).all()
+    assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    monkeypatch.setenv("TSX_NO_RETRY", "1")
+    x = np.zeros(s.vec_shape)
+    x[3, 4, 2, 1] = np.nan
+    assert s.solve(P["b"], x, rtol=1e-10, atol=1e-30).reason == -9
+    monkeypatch.delenv("TSX_NO_RETRY")
+    b = P["b"].copy()
+    b[0, 0, 0, 0] = np.nan
+    x = np.zeros(s.vec_shape)
+    assert s.solve(b, x).reason == -9
     s.close()
 
 
