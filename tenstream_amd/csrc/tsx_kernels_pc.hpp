@@ -18,61 +18,6 @@
 //                   G = (I - Rdu A_{k+1})^-1, Gw = G (rd_{k+1} + Rdu B_{k+1}), GT = G Tdd
 //   downward sweep: V_{k+1} = Gw + GT V_k ; U_k = A_k V_k + B_k ; side dst = r + c(up->d) U_{k+1} + c(dn->d) V_k
 // One thread per column, lanes along x: every plane access is a coalesced 256/512-byte span.
-template <int H>
-struct TsxSm {  // tiny dense helpers, fully unrolled
-  static __device__ __forceinline__ void matvec(const double (&M)[H][H], const double (&v)[H], double (&o)[H]) {
-#pragma unroll
-    for (int a = 0; a < H; ++a) {
-      double t = 0.0;
-#pragma unroll
-      for (int b = 0; b < H; ++b) t += M[a][b] * v[b];
-      o[a] = t;
-    }
-  }
-  static __device__ __forceinline__ void matmul(const double (&X)[H][H], const double (&Y)[H][H], double (&O)[H][H]) {
-#pragma unroll
-    for (int a = 0; a < H; ++a)
-#pragma unroll
-      for (int b = 0; b < H; ++b) {
-        double t = 0.0;
-#pragma unroll
-        for (int c = 0; c < H; ++c) t += X[a][c] * Y[c][b];
-        O[a][b] = t;
-      }
-  }
-  // O = (I - X)^-1 by Gauss-Jordan without pivoting (I - Rdu*A is strictly diagonally dominant: entries of
-  // Rdu*A are products of energy-conserving transfer coefficients, row sums < 1)
-  static __device__ __forceinline__ void inv_i_minus(const double (&X)[H][H], double (&O)[H][H]) {
-    double W[H][H];
-#pragma unroll
-    for (int a = 0; a < H; ++a)
-#pragma unroll
-      for (int b = 0; b < H; ++b) {
-        W[a][b] = (a == b ? 1.0 : 0.0) - X[a][b];
-        O[a][b] = (a == b ? 1.0 : 0.0);
-      }
-#pragma unroll
-    for (int c = 0; c < H; ++c) {
-      const double piv = 1.0 / W[c][c];
-#pragma unroll
-      for (int b = 0; b < H; ++b) {
-        W[c][b] *= piv;
-        O[c][b] *= piv;
-      }
-#pragma unroll
-      for (int a = 0; a < H; ++a) {
-        if (a == c) continue;
-        const double f = W[a][c];
-#pragma unroll
-        for (int b = 0; b < H; ++b) {
-          W[a][b] -= f * W[c][b];
-          O[a][b] -= f * O[c][b];
-        }
-      }
-    }
-  }
-};
-
 // temp planes per cell: [Gw: H][GT: H*H][A: H*H][B: H]
 template <int NTOP>
 __host__ __device__ constexpr int tsx_pc_ntmp() { return (NTOP / 2) * 2 * ((NTOP / 2) + 1); }

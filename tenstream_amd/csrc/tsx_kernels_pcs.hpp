@@ -421,3 +421,491 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
     V = Vn;
   }
 }
+
+// =====================================================================================================================
+// 8_16: the same scan with H = 4 up/down pairs.  U, V, B are 4-vectors, the matrix-only quantities 4 x 4 blocks:
+//     G = (I - Rdu A_{k+1})^-1,  GT = G Tdd,  H = G Rdu,  F = Tuu A_{k+1} G,  E = Tuu + F Rdu,  A_k = Rud + F Tdd
+//     upward    B_k     = (ru + F rd) + E B_{k+1}            downward  V_{k+1} = (G rd + H B_{k+1}) + GT V_k
+// A segment's summary is (4-vector, 4 x 4 product); the threads re-run their levels with the true inflow (cheaper than
+// keeping a cumulative product per level).  Packed layout "S16H", 16-byte records:
+//   per cell, P[grp * Nc + cell] (fp16 4 x 4 row-major, two records each): 0,1 E | 2,3 F | 4,5 G - I | 6,7 H | 8,9 GT |
+//     10,11 A_{k+1} | 12,13 A_k
+//   per block, PB[grp * stride + (cell | entry)]: 0,1 c(y_q -> t), byte 4 t + q (fp8) | 2,3 c(x_q -> t) |
+//     4..11 c(src 0..7 -> side dst 8 + dd) (fp16) | 12,13 c(y_q -> 8 + dd), byte 4 dd + q | 14,15 c(x_q -> 8 + dd)
+//   (y_q = src 12 + q, x_q = src 8 + q; t = top dst 0..7).  1-D layers: matrices from a11 / a12, block records zero.
+constexpr int TSX_S16H_CELL = 14, TSX_S16H_BLOCK = 16;
+
+__device__ __forceinline__ uint4 tsx_pack_rows2(const double (&M)[4][4], int r0, double sub_diag) {
+  auto v = [&](int a, int b) { return (float)(M[a][b] - (a == b ? sub_diag : 0.0)); };
+  return make_uint4(tsx_to_h2(v(r0, 0), v(r0, 1)), tsx_to_h2(v(r0, 2), v(r0, 3)), tsx_to_h2(v(r0 + 1, 0), v(r0 + 1, 1)),
+                    tsx_to_h2(v(r0 + 1, 2), v(r0 + 1, 3)));
+}
+
+template <typename CT>
+__global__ __launch_bounds__(64) void tsx_k_pcsh_pack_col(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
+                                                          const double *__restrict__ a11, const double *__restrict__ a12,
+                                                          const double *__restrict__ albedo, uint4 *__restrict__ P) {
+  constexpr int D = 16, H = 4;
+  using SM = TsxSm<H>;
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= g.ncol) return;
+  const long long Nc = g.Nc;
+  const long long sp = tsx_split_col(col % g.xm, col / g.xm, g.xm);
+  double A[H][H];
+#pragma unroll
+  for (int a = 0; a < H; ++a)
+#pragma unroll
+    for (int b = 0; b < H; ++b) A[a][b] = albedo[col] / (double)H;  // assembled surface row: albedo / streams on every pair
+  for (int k = g.Nz - 1; k >= 0; --k) {
+    const size_t c = (size_t)k * g.ncol + col;
+    double Tuu[H][H], Rud[H][H], Rdu[H][H], Tdd[H][H];
+    const bool one = l1d[k] != 0;
+    const double t11 = one ? a11[c] : 0.0, t12 = one ? a12[c] : 0.0;
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+#pragma unroll
+      for (int b = 0; b < H; ++b) {
+        const double dg = a == b ? 1.0 : 0.0;
+        Tuu[a][b] = one ? dg * t11 : (double)C[(size_t)((2 * a) * D + 2 * b) * Nc + c];
+        Rud[a][b] = one ? dg * t12 : (double)C[(size_t)((2 * a) * D + 2 * b + 1) * Nc + c];
+        Rdu[a][b] = one ? dg * t12 : (double)C[(size_t)((2 * a + 1) * D + 2 * b) * Nc + c];
+        Tdd[a][b] = one ? dg * t11 : (double)C[(size_t)((2 * a + 1) * D + 2 * b + 1) * Nc + c];
+      }
+    double RA[H][H], G[H][H], GT[H][H], Hm[H][H], TA[H][H], F[H][H], FR[H][H], E[H][H], FT[H][H], Ao[H][H];
+    SM::matmul(Rdu, A, RA);
+    SM::inv_i_minus(RA, G);
+    SM::matmul(G, Tdd, GT);
+    SM::matmul(G, Rdu, Hm);
+    SM::matmul(Tuu, A, TA);
+    SM::matmul(TA, G, F);
+    SM::matmul(F, Rdu, FR);
+    SM::matmul(F, Tdd, FT);
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+#pragma unroll
+      for (int b = 0; b < H; ++b) {
+        E[a][b] = Tuu[a][b] + FR[a][b];
+        Ao[a][b] = Rud[a][b] + FT[a][b];
+      }
+    const size_t o = (size_t)k * g.ncol + sp;
+    P[(size_t)0 * Nc + o] = tsx_pack_rows2(E, 0, 0.0);
+    P[(size_t)1 * Nc + o] = tsx_pack_rows2(E, 2, 0.0);
+    P[(size_t)2 * Nc + o] = tsx_pack_rows2(F, 0, 0.0);
+    P[(size_t)3 * Nc + o] = tsx_pack_rows2(F, 2, 0.0);
+    P[(size_t)4 * Nc + o] = tsx_pack_rows2(G, 0, 1.0);
+    P[(size_t)5 * Nc + o] = tsx_pack_rows2(G, 2, 1.0);
+    P[(size_t)6 * Nc + o] = tsx_pack_rows2(Hm, 0, 0.0);
+    P[(size_t)7 * Nc + o] = tsx_pack_rows2(Hm, 2, 0.0);
+    P[(size_t)8 * Nc + o] = tsx_pack_rows2(GT, 0, 0.0);
+    P[(size_t)9 * Nc + o] = tsx_pack_rows2(GT, 2, 0.0);
+    P[(size_t)10 * Nc + o] = tsx_pack_rows2(A, 0, 0.0);
+    P[(size_t)11 * Nc + o] = tsx_pack_rows2(A, 2, 0.0);
+    P[(size_t)12 * Nc + o] = tsx_pack_rows2(Ao, 0, 0.0);
+    P[(size_t)13 * Nc + o] = tsx_pack_rows2(Ao, 2, 0.0);
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+#pragma unroll
+      for (int b = 0; b < H; ++b) A[a][b] = Ao[a][b];
+  }
+}
+
+// block records from planes over `n` blocks (cells in colour-split order when split_xm > 0, or distinct-block entries);
+// kof: layer of block q (cell: q / ncol; entry: its representative cell's layer)
+template <typename CT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcsh_pack_block(TsxGeo g, long long n, const CT *__restrict__ C,
+                                                                   const int *__restrict__ ent_cell, const uint8_t *__restrict__ l1d,
+                                                                   uint4 *__restrict__ PB) {
+  constexpr int D = 16;
+  const long long tot = n * TSX_S16H_BLOCK;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < tot; q += (long long)gridDim.x * TSX_BLOCK) {
+    const int grp = (int)(q / n);
+    const long long e = q - (long long)grp * n;
+    const long long cell = ent_cell ? ent_cell[e] : e;
+    const int k = (int)(cell / g.ncol);
+    auto cf = [&](int dst, int src) { return (float)C[(size_t)(dst * D + src) * n + e]; };
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!l1d[k]) {
+      if (grp < 4) {  // couplings into the top streams: word t = the four side sources of top dst t
+        const int s0 = grp < 2 ? 12 : 8, t0 = 4 * (grp & 1);
+        v.x = tsx_to_fp8x4(cf(t0 + 0, s0), cf(t0 + 0, s0 + 1), cf(t0 + 0, s0 + 2), cf(t0 + 0, s0 + 3));
+        v.y = tsx_to_fp8x4(cf(t0 + 1, s0), cf(t0 + 1, s0 + 1), cf(t0 + 1, s0 + 2), cf(t0 + 1, s0 + 3));
+        v.z = tsx_to_fp8x4(cf(t0 + 2, s0), cf(t0 + 2, s0 + 1), cf(t0 + 2, s0 + 2), cf(t0 + 2, s0 + 3));
+        v.w = tsx_to_fp8x4(cf(t0 + 3, s0), cf(t0 + 3, s0 + 1), cf(t0 + 3, s0 + 2), cf(t0 + 3, s0 + 3));
+      } else if (grp < 12) {  // side dst 8 + dd from the eight top sources
+        const int d = 8 + (grp - 4);
+        v.x = tsx_to_h2(cf(d, 0), cf(d, 1));
+        v.y = tsx_to_h2(cf(d, 2), cf(d, 3));
+        v.z = tsx_to_h2(cf(d, 4), cf(d, 5));
+        v.w = tsx_to_h2(cf(d, 6), cf(d, 7));
+      } else {  // side dst from the side sources of the neighbouring columns
+        const int s0 = grp < 14 ? 12 : 8, d0 = 8 + 4 * (grp & 1);
+        v.x = tsx_to_fp8x4(cf(d0 + 0, s0), cf(d0 + 0, s0 + 1), cf(d0 + 0, s0 + 2), cf(d0 + 0, s0 + 3));
+        v.y = tsx_to_fp8x4(cf(d0 + 1, s0), cf(d0 + 1, s0 + 1), cf(d0 + 1, s0 + 2), cf(d0 + 1, s0 + 3));
+        v.z = tsx_to_fp8x4(cf(d0 + 2, s0), cf(d0 + 2, s0 + 1), cf(d0 + 2, s0 + 2), cf(d0 + 2, s0 + 3));
+        v.w = tsx_to_fp8x4(cf(d0 + 3, s0), cf(d0 + 3, s0 + 1), cf(d0 + 3, s0 + 2), cf(d0 + 3, s0 + 3));
+      }
+    }
+    long long o = e;
+    if (!ent_cell) {  // per-cell records live in colour-split order
+      const int i = (int)(e % g.xm);
+      const long long t = e / g.xm;
+      const int j = (int)(t % g.ym), kk = (int)(t / g.ym);
+      o = (long long)kk * g.ncol + tsx_split_col(i, j, g.xm);
+    }
+    PB[(size_t)grp * n + o] = v;
+  }
+}
+
+struct TsxM4 {  // a 4 x 4 block in registers
+  float m[4][4];
+};
+__device__ __forceinline__ TsxM4 tsx_m4(const uint4 &lo, const uint4 &hi, float add_diag) {
+  TsxM4 M;
+  const tsx_h8 a = __builtin_bit_cast(tsx_h8, lo), b = __builtin_bit_cast(tsx_h8, hi);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    M.m[0][q] = (float)a[q] + (q == 0 ? add_diag : 0.0f);
+    M.m[1][q] = (float)a[4 + q] + (q == 1 ? add_diag : 0.0f);
+    M.m[2][q] = (float)b[q] + (q == 2 ? add_diag : 0.0f);
+    M.m[3][q] = (float)b[4 + q] + (q == 3 ? add_diag : 0.0f);
+  }
+  return M;
+}
+__device__ __forceinline__ void tsx_mv4(const TsxM4 &M, const float (&v)[4], float (&o)[4]) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a) o[a] = M.m[a][0] * v[0] + M.m[a][1] * v[1] + M.m[a][2] * v[2] + M.m[a][3] * v[3];
+}
+__device__ __forceinline__ TsxM4 tsx_mm4(const TsxM4 &X, const TsxM4 &Y) {
+  TsxM4 O;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) O.m[a][b] = X.m[a][0] * Y.m[0][b] + X.m[a][1] * Y.m[1][b] + X.m[a][2] * Y.m[2][b] + X.m[a][3] * Y.m[3][b];
+  return O;
+}
+
+#ifndef TSX_PCSH_WAVES
+#define TSX_PCSH_WAVES 2
+#endif
+template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX>
+__global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PCSH_WAVES, TSX_PCSH_WAVES))) void tsx_k_pcsh_rb(TsxGeo g, const uint4 *__restrict__ P, const uint4 *__restrict__ PB,
+                                                          long long bstride, const int *__restrict__ cidx,
+                                                          const float *__restrict__ r, float *__restrict__ z,
+                                                          unsigned *__restrict__ zb, float *__restrict__ zfin,
+                                                          const int *__restrict__ done, int rbc, int nonbr) {
+  constexpr int D = 16, NTOP = 8;
+  constexpr bool FINAL = MODE == 2;
+  __shared__ float4 sS[NSEG][5][CW];  // a segment's summary: 4-vector + 4 x 4 product (reused by both scans)
+  if (done && *done) return;
+  const int h = g.xm >> 1;
+  const int cl = threadIdx.x % CW, sg = threadIdx.x / CW;
+  const int nthr = g.ym * h;
+  int t_ = blockIdx.x * CW + cl;
+  const bool live = t_ < nthr;
+  if (!live) t_ = nthr - 1;
+  const long long Nc = g.Nc;
+  const int Nz = g.Nz, ncol = g.ncol;
+  const int jrow = t_ / h, qh = t_ - jrow * h;
+  const int par = (jrow + rbc) & 1;
+  const int icol = 2 * qh + par;
+  const int col = jrow * g.xm + rbc * h + qh;
+  const long long oc = (long long)(1 - 2 * rbc) * h;
+  const int jn = jrow + 1 < g.ym ? jrow + 1 : (g.wrap_y ? 0 : -1), js = jrow > 0 ? jrow - 1 : (g.wrap_y ? g.ym - 1 : -1);
+  const int qw = par ? qh : (qh > 0 ? qh - 1 : (g.wrap_x ? h - 1 : -1)), qe = par ? (qh + 1 < h ? qh + 1 : (g.wrap_x ? 0 : -1)) : qh;
+  long long offN = jn >= 0 ? (long long)(jn - jrow) * g.xm + oc : 0;
+  long long offS = js >= 0 ? (long long)(js - jrow) * g.xm + oc : 0;
+  long long offE = qe >= 0 ? oc + (qe - qh) : 0;
+  long long offW = qw >= 0 ? oc + (qw - qh) : 0;
+  if (g.pc_tile_x > 0) {
+    if ((icol + 1) % g.pc_tile_x == 0) offE = 0;
+    if (icol % g.pc_tile_x == 0) offW = 0;
+  }
+  if (g.pc_tile_y > 0) {
+    if ((jrow + 1) % g.pc_tile_y == 0) offN = 0;
+    if (jrow % g.pc_tile_y == 0) offS = 0;
+  }
+  if (nonbr) offN = offS = offE = offW = 0;
+  const int ncp = jrow * g.xm + 2 * qh;
+  auto wpair_if = [&](bool on, float *dst, float mine, float partner) {
+    if (on) *reinterpret_cast<float2 *>(dst) = par ? make_float2(partner, mine) : make_float2(mine, partner);
+  };
+  const float *__restrict__ rt = r + (size_t)D * Nc;
+  float *__restrict__ zt = z + (size_t)D * Nc;
+  float2 *__restrict__ zr = reinterpret_cast<float2 *>(z + (size_t)NTOP * Nc);
+  const int k0 = sg * LSEG;
+  const int nl = Nz - k0 < LSEG ? (Nz - k0 > 0 ? Nz - k0 : 0) : LSEG;
+  auto cell = [&](int l) { return (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + col; };
+  auto brec = [&](int grp, size_t c, int id) { return PB[(size_t)grp * bstride + (IDX ? (size_t)id : c)]; };
+  auto mat = [&](int grp, size_t c, float add_diag) { return tsx_m4(P[(size_t)grp * Nc + c], P[(size_t)(grp + 1) * Nc + c], add_diag); };
+  auto nbr_load = [&](size_t c, uint2(&o)[4]) {
+    const long long off[4] = {offE, offW, offN, offS};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const size_t idx = (size_t)m * Nc + c + off[m];
+      if (MODE == 2) o[m] = *reinterpret_cast<const uint2 *>(zr + idx);
+      else o[m] = make_uint2(zb[idx], 0u);
+    }
+  };
+  auto nbr_vals = [&](const uint2(&n)[4], float(&zx)[4], float(&zy)[4]) {
+    float lo[4], hi[4];
+    const long long off[4] = {offE, offW, offN, offS};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float a = MODE == 2 ? __uint_as_float(n[m].x) : __uint_as_float(n[m].x << 16);
+      const float b = MODE == 2 ? __uint_as_float(n[m].y) : __uint_as_float(n[m].x & 0xffff0000u);
+      lo[m] = off[m] ? a : 0.0f;
+      hi[m] = off[m] ? b : 0.0f;
+    }
+    zx[0] = lo[0]; zx[2] = hi[0]; zx[1] = lo[1]; zx[3] = hi[1];
+    zy[0] = lo[2]; zy[2] = hi[2]; zy[1] = lo[3]; zy[3] = hi[3];
+  };
+  auto put_summary = [&](const float(&v)[4], const TsxM4 &M) {
+    sS[sg][0][cl] = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sS[sg][1 + a][cl] = make_float4(M.m[a][0], M.m[a][1], M.m[a][2], M.m[a][3]);
+  };
+  auto chain = [&](int s2, float(&x)[4]) {  // x <- v(s2) + M(s2) x
+    const float4 v = sS[s2][0][cl];
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float4 m = sS[s2][1 + a][cl];
+      o[a] += m.x * x[0] + m.y * x[1] + m.z * x[2] + m.w * x[3];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) x[a] = o[a];
+  };
+
+  // ---- phase 1: local upward scan with zero inflow; keeps beta, rd + couplings and E of its levels
+  // (E and GT of a level are loaded again where the re-run needs them -- L2 hits -- instead of being held: 32 registers
+  // per level would halve the occupancy)
+  float beta[LSEG][4], rdg[LSEG][4];
+  uint2 nb[LSEG][4];
+  int eid[LSEG];
+  {
+    float Bl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    TsxM4 Pc;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) Pc.m[a][b] = a == b ? 1.0f : 0.0f;
+#pragma unroll
+    for (int l = LSEG - 1; l >= 0; --l) {
+      const size_t c = cell(l);
+      const bool act = l < nl;
+      eid[l] = IDX ? cidx[c] : 0;
+      const TsxM4 F = mat(2, c, 0.0f);
+      float ru[4], rd[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        ru[a] = r[(size_t)(2 * a) * Nc + c];
+        rd[a] = r[(size_t)(2 * a + 1) * Nc + c];
+      }
+      if (GS) {
+        nbr_load(c, nb[l]);
+        float zx[4], zy[4];
+        nbr_vals(nb[l], zx, zy);
+        const uint4 cy0 = brec(0, c, eid[l]), cy1 = brec(1, c, eid[l]), cx0 = brec(2, c, eid[l]), cx1 = brec(3, c, eid[l]);
+        const unsigned wy[8] = {cy0.x, cy0.y, cy0.z, cy0.w, cy1.x, cy1.y, cy1.z, cy1.w};
+        const unsigned wx[8] = {cx0.x, cx0.y, cx0.z, cx0.w, cx1.x, cx1.y, cx1.z, cx1.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          float cq[4], cp[4];
+          tsx_fp8x4(wy[t], cq);
+          tsx_fp8x4(wx[t], cp);
+          const float s8 = cq[0] * zy[0] + cq[1] * zy[1] + cq[2] * zy[2] + cq[3] * zy[3] + cp[0] * zx[0] + cp[1] * zx[1] +
+                           cp[2] * zx[2] + cp[3] * zx[3];
+          if (t & 1) rd[t >> 1] += s8 * (1.0f / TSX_FP8_SCALE);
+          else ru[t >> 1] += s8 * (1.0f / TSX_FP8_SCALE);
+        }
+      }
+      float Fr[4];
+      tsx_mv4(F, rd, Fr);
+      const TsxM4 E = mat(0, c, 0.0f);
+      float EB[4];
+      tsx_mv4(E, Bl, EB);
+      const TsxM4 EP = tsx_mm4(E, Pc);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        beta[l][a] = act ? ru[a] + Fr[a] : 0.0f;
+        rdg[l][a] = rd[a];
+        Bl[a] = act ? beta[l][a] + EB[a] : Bl[a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Pc.m[a][b] = act ? EP.m[a][b] : Pc.m[a][b];
+      }
+    }
+    put_summary(Bl, Pc);
+  }
+  __syncthreads();
+  float Bin[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) Bin[a] = rt[(size_t)(2 * a) * ncol + col];  // B_Nz = ru_Nz
+  for (int s2 = NSEG - 1; s2 > sg; --s2) chain(s2, Bin);
+  // ---- phase 2: the true B of every level (re-run with the true inflow)
+  float Bk[LSEG][4];
+  {
+    float Bc[4] = {Bin[0], Bin[1], Bin[2], Bin[3]};
+#pragma unroll
+    for (int l = LSEG - 1; l >= 0; --l) {
+      const TsxM4 E = mat(0, cell(l), 0.0f);
+      float EB[4];
+      tsx_mv4(E, Bc, EB);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        Bc[a] = l < nl ? beta[l][a] + EB[a] : Bc[a];
+        Bk[l][a] = Bc[a];
+      }
+    }
+  }
+  __syncthreads();  // everybody has read the upward summaries: the buffer is free for the downward ones
+  // ---- phase 3: local downward scan with zero inflow; keeps gamma and GT of its levels
+  float gam[LSEG][4];
+  {
+    float Vl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    TsxM4 Qc;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) Qc.m[a][b] = a == b ? 1.0f : 0.0f;
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) {
+      const size_t c = cell(l);
+      const bool act = l < nl;
+      const TsxM4 G = mat(4, c, 1.0f), Hm = mat(6, c, 0.0f);
+      const TsxM4 GT = mat(8, c, 0.0f);
+      float Bn[4], Gr[4], HB[4], GV[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) Bn[a] = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l][a] : Bin[a];
+      tsx_mv4(G, rdg[l], Gr);
+      tsx_mv4(Hm, Bn, HB);
+      tsx_mv4(GT, Vl, GV);
+      const TsxM4 GQ = tsx_mm4(GT, Qc);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        gam[l][a] = act ? Gr[a] + HB[a] : 0.0f;
+        Vl[a] = act ? gam[l][a] + GV[a] : Vl[a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Qc.m[a][b] = act ? GQ.m[a][b] : Qc.m[a][b];
+      }
+    }
+    put_summary(Vl, Qc);
+  }
+  __syncthreads();
+  float V[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) V[a] = rt[(size_t)(2 * a + 1) * ncol + col];  // V_0 = rd_TOA
+  if (sg == 0) {  // tail rows: the TOA identity rows and the side dummies at level Nz
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (MODE == 1 && live) zt[(size_t)(2 * a + 1) * ncol + col] = V[a];
+      if (FINAL) wpair_if(live, zfin + (size_t)D * Nc + (size_t)(2 * a + 1) * ncol + ncp, V[a], zt[(size_t)(2 * a + 1) * ncol + col + oc]);
+    }
+#pragma unroll
+    for (int d = NTOP; d < D; ++d) {
+      const float v = rt[(size_t)d * ncol + col];
+      if (MODE == 1 && live) zt[(size_t)d * ncol + col] = v;
+      if (FINAL) wpair_if(live, zfin + (size_t)D * Nc + (size_t)d * ncol + ncp, v, zt[(size_t)d * ncol + col + oc]);
+    }
+  }
+  for (int s2 = 0; s2 < sg; ++s2) chain(s2, V);
+  // ---- phase 4: true V, U; side streams; stores
+#pragma unroll
+  for (int l = 0; l < LSEG; ++l) {
+    const bool st = live && l < nl;
+    const size_t c = cell(l);
+    const size_t cn = (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + ncp;
+    const TsxM4 GT = mat(8, c, 0.0f), An = mat(10, c, 0.0f);
+    float Bn[4], GV[4], Vn[4], AV[4], Un[4], U[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) Bn[a] = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l][a] : Bin[a];
+    tsx_mv4(GT, V, GV);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) Vn[a] = gam[l][a] + GV[a];
+    tsx_mv4(An, Vn, AV);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) Un[a] = AV[a] + Bn[a];
+    if (MODE != 0) {
+      const TsxM4 Ao = mat(12, c, 0.0f);
+      float AoV[4];
+      tsx_mv4(Ao, V, AoV);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) U[a] = AoV[a] + Bk[l][a];
+    }
+    float pt[8];
+    float2 ps[4];
+    if (FINAL) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pt[q] = z[(size_t)q * Nc + c + oc];
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2) ps[m2] = zr[(size_t)m2 * Nc + c + oc];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (MODE == 1 && st) {
+        z[(size_t)(2 * a) * Nc + c] = U[a];
+        z[(size_t)(2 * a + 1) * Nc + c] = Vn[a];
+      }
+      if (FINAL) {
+        wpair_if(st, zfin + (size_t)(2 * a) * Nc + cn, U[a], pt[2 * a]);
+        wpair_if(st, zfin + (size_t)(2 * a + 1) * Nc + cn, Vn[a], pt[2 * a + 1]);
+      }
+    }
+    float zx[4], zy[4];
+    uint4 sy[2], sx[2];
+    if (GS) {
+      nbr_vals(nb[l], zx, zy);
+      sy[0] = brec(12, c, eid[l]);
+      sy[1] = brec(13, c, eid[l]);
+      sx[0] = brec(14, c, eid[l]);
+      sx[1] = brec(15, c, eid[l]);
+    }
+    const unsigned uy[8] = {sy[0].x, sy[0].y, sy[0].z, sy[0].w, sy[1].x, sy[1].y, sy[1].z, sy[1].w};
+    const unsigned ux[8] = {sx[0].x, sx[0].y, sx[0].z, sx[0].w, sx[1].x, sx[1].y, sx[1].z, sx[1].w};
+    float zo[8];
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) {
+      const tsx_h8 row = __builtin_bit_cast(tsx_h8, brec(4 + dd, c, eid[l]));
+      float acc = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) acc += (float)row[2 * a] * Un[a] + (float)row[2 * a + 1] * V[a];
+      if (GS) {
+        float cq[4], cp[4];
+        tsx_fp8x4(uy[dd], cq);
+        tsx_fp8x4(ux[dd], cp);
+        const float a8 = cq[0] * zy[0] + cq[1] * zy[1] + cq[2] * zy[2] + cq[3] * zy[3] + cp[0] * zx[0] + cp[1] * zx[1] +
+                         cp[2] * zx[2] + cp[3] * zx[3];
+        acc += a8 * (1.0f / TSX_FP8_SCALE);
+      }
+      zo[dd] = r[(size_t)(NTOP + dd) * Nc + c] + acc;
+    }
+    // records by consumer: side dofs (8,10) (9,11) (12,14) (13,15) = zo[0,2] zo[1,3] zo[4,6] zo[5,7]
+    if (MODE == 0 && st) {
+      zb[(size_t)0 * Nc + c] = tsx_bf16x2(zo[0], zo[2]);
+      zb[(size_t)1 * Nc + c] = tsx_bf16x2(zo[1], zo[3]);
+      zb[(size_t)2 * Nc + c] = tsx_bf16x2(zo[4], zo[6]);
+      zb[(size_t)3 * Nc + c] = tsx_bf16x2(zo[5], zo[7]);
+    }
+    if (MODE == 1 && st) {
+      zr[(size_t)0 * Nc + c] = make_float2(zo[0], zo[2]);
+      zr[(size_t)1 * Nc + c] = make_float2(zo[1], zo[3]);
+      zr[(size_t)2 * Nc + c] = make_float2(zo[4], zo[6]);
+      zr[(size_t)3 * Nc + c] = make_float2(zo[5], zo[7]);
+    }
+    if (FINAL) {
+      const int dofs[8] = {8, 10, 9, 11, 12, 14, 13, 15};
+      const float mine[8] = {zo[0], zo[2], zo[1], zo[3], zo[4], zo[6], zo[5], zo[7]};
+      const float part[8] = {ps[0].x, ps[0].y, ps[1].x, ps[1].y, ps[2].x, ps[2].y, ps[3].x, ps[3].y};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wpair_if(st, zfin + (size_t)dofs[q] * Nc + cn, mine[q], part[q]);
+    }
+    if (k0 + l == Nz - 1) {  // U_Nz = (albedo / streams) sum V_Nz + ru_Nz: the surface rows
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        if (MODE == 1 && live) zt[(size_t)(2 * a) * ncol + col] = Un[a];
+        if (FINAL) wpair_if(live, zfin + (size_t)D * Nc + (size_t)(2 * a) * ncol + ncp, Un[a], zt[(size_t)(2 * a) * ncol + col + oc]);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) V[a] = l < nl ? Vn[a] : V[a];
+  }
+}

@@ -109,7 +109,7 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
         tsx_set_error("preconditioner: red-black ordering needs the colour-split packed blocks (internal state error)");
         return TSX_ERR_STATE;
       }
-      if (NTOP == 2 && s->coef_h_scan) return tsx_pcs_apply(s, (float *)z, done);
+      if (s->coef_h_scan) return tsx_pcs_apply(s, (float *)z, done);
       const int P = s->pc_sweeps + 1;
       float *zs = (float *)s->vw;                                   // fp32 iterate (written by the last pass of colour P % 2)
       unsigned short *zb = (unsigned short *)(zs + (size_t)g.N);   // bf16 neighbour values of the intermediate passes
@@ -220,7 +220,7 @@ static int ensure_pc_buffers_t(tsx_solver *s) {
 // packed fp16 copy of the blocks for the preconditioner (tsx_k_pack_p16), rebuilt when the coefficients changed
 int tsx_pc_ensure_half(tsx_solver *s) {
   const bool h1 = s->geo.ntop == 2;
-  const long long n = (long long)(h1 ? TSX_P16_GROUPS : TSX_P16H_GROUPS) * s->geo.Nc;
+  const long long n = (long long)(h1 ? TSX_P16_GROUPS : 30 /* max(TSX_P16H_GROUPS, 14 + 16 of the scan layout) */) * s->geo.Nc;
   if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
   const bool scan = s->pc_split && tsx_pcs_eligible(s);
   if (scan && (!s->coef_h_valid || !s->coef_h_scan || s->coef_h_dd != (s->dd_on && s->coef_bytes == 4))) {

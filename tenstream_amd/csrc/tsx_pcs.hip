@@ -24,6 +24,16 @@ static PcsCfg pcs_config(const tsx_solver *s) {
       }
   }
   const long long nthr = (long long)g.ym * (g.xm / 2);  // columns per pass
+  if (g.ntop == 8) {  // 8_16: 4 x 4 blocks per level -- registers allow 4 levels per thread (8 for deep columns)
+    if (!c.lseg) {
+      if (g.Nz <= 64) c.lseg = 4, c.nseg = 16;
+      else if (g.Nz <= 128) c.lseg = 8, c.nseg = 16;
+    }
+    if (c.lseg == 16 || (c.lseg == 8 && c.nseg == 8)) c.lseg = c.nseg = 0;  // not instantiated for 8_16
+    if (!c.lseg) return c;
+    c.cw = (e_cw == 32 || e_cw == 16) ? e_cw : (nthr >= 8192 ? 32 : 16);
+    return c;
+  }
   if (!c.lseg) {
     // measured (scripts/pcsbench.py): 8 levels x 8 segments on large passes (>= 16 K columns: fewer, fatter threads),
     // 4 x 16 on small ones (more waves); deeper columns take the smallest pair that holds them
@@ -47,11 +57,38 @@ static PcsCfg pcs_config(const tsx_solver *s) {
 bool tsx_pcs_eligible(const tsx_solver *s) {
   const char *e = getenv("TSX_PC_SCAN");  // TSX_PC_SCAN=0: the one-lane-per-column kernels (A/B knob)
   const int on = e ? atoi(e) : 1;
-  return on && s->geo.ntop == 2 && pcs_config(s).lseg > 0;
+  return on && pcs_config(s).lseg > 0;
+}
+
+static int pcsh_pack(tsx_solver *s) {  // 8_16: 14 matrix records per cell, then 16 block records per cell or per entry
+  const TsxGeo &g = s->geo;
+  uint4 *P = (uint4 *)s->coef_h, *PB = P + (size_t)TSX_S16H_CELL * g.Nc;
+  s->coef_h_dd = false;
+  const int nbc = (g.ncol + 63) / 64;
+  if (s->coef_bytes == 4) {
+    hipLaunchKernelGGL((tsx_k_pcsh_pack_col<float>), dim3(nbc), dim3(64), 0, s->stream, g, (const float *)s->coef, s->l1d, s->a11,
+                       s->a12, s->albedo, P);
+    if (s->dd_on) {
+      hipLaunchKernelGGL((tsx_k_pcsh_pack_block<float>), dim3(grid_for((long long)TSX_S16H_BLOCK * s->dd_nent)), dim3(TSX_BLOCK), 0,
+                         s->stream, g, (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d, PB);
+      s->coef_h_dd = true;
+    } else {
+      hipLaunchKernelGGL((tsx_k_pcsh_pack_block<float>), dim3(grid_for((long long)TSX_S16H_BLOCK * g.Nc)), dim3(TSX_BLOCK), 0,
+                         s->stream, g, g.Nc, (const float *)s->coef, (const int *)nullptr, s->l1d, PB);
+    }
+  } else {
+    hipLaunchKernelGGL((tsx_k_pcsh_pack_col<double>), dim3(nbc), dim3(64), 0, s->stream, g, (const double *)s->coef, s->l1d,
+                       s->a11, s->a12, s->albedo, P);
+    hipLaunchKernelGGL((tsx_k_pcsh_pack_block<double>), dim3(grid_for((long long)TSX_S16H_BLOCK * g.Nc)), dim3(TSX_BLOCK), 0,
+                       s->stream, g, g.Nc, (const double *)s->coef, (const int *)nullptr, s->l1d, PB);
+  }
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
 }
 
 int tsx_pcs_pack(tsx_solver *s) {
   const TsxGeo &g = s->geo;
+  if (g.ntop == 8) return pcsh_pack(s);
   uint4 *P = (uint4 *)s->coef_h;
   s->coef_h_dd = false;
   if (s->dd_on && s->coef_bytes == 4) {
@@ -114,10 +151,47 @@ static void pcs_launch_cw(tsx_solver *s, int cw, bool gs, int mode, int rbc, int
   else pcs_launch<L, S, 16>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done);
 }
 
+template <int L, int S, int CW>
+static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin, const int *done) {
+  const TsxGeo &g = s->geo;
+  const long long nthr = (long long)g.ym * (g.xm / 2);
+  const int nb = (int)((nthr + CW - 1) / CW);
+  const uint4 *P = (const uint4 *)s->coef_h, *PB = P + (size_t)TSX_S16H_CELL * g.Nc;
+  const float *r = (const float *)s->pc_rhs;
+  const bool dd = s->coef_h_dd;
+  const long long bstride = dd ? (long long)s->dd_nent : g.Nc;
+  const int *cidx = (const int *)s->dd_cidx_split;
+#define TSX_PCSH_GO(GSV, MODEV)                                                                                                 \
+  do {                                                                                                                          \
+    if (dd)                                                                                                                     \
+      hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, true>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB, bstride,    \
+                         cidx, r, zs, zb, zfin, done, rbc, nonbr);                                                              \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, false>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB, bstride,   \
+                         (const int *)nullptr, r, zs, zb, zfin, done, rbc, nonbr);                                              \
+  } while (0)
+  if (!gs) TSX_PCSH_GO(false, 0);
+  else if (mode == 0) TSX_PCSH_GO(true, 0);
+  else if (mode == 1) TSX_PCSH_GO(true, 1);
+  else TSX_PCSH_GO(true, 2);
+#undef TSX_PCSH_GO
+}
+
 // one pass: mode as in tsx_k_pcs_rb; first = no neighbour values exist yet
 int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done) {
   const TsxGeo &g = s->geo;
   const PcsCfg c = pcs_config(s);
+  if (g.ntop == 8) {
+    float *zs8 = (float *)s->vw;
+    unsigned *zb8 = (unsigned *)(zs8 + (size_t)g.N);
+    const bool first8 = pass == 0, gs8 = !(first8 && mode == 0);
+    const int nonbr8 = first8 && mode != 0, rbc8 = pass & 1;
+    if (c.lseg == 4 && c.cw == 32) pcsh_launch<4, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done);
+    else if (c.lseg == 4) pcsh_launch<4, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done);
+    else if (c.cw == 32) pcsh_launch<8, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done);
+    else pcsh_launch<8, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done);
+    return TSX_OK;
+  }
   float *zs = (float *)s->vw;                        // fp32 iterate (mode 1 writes, mode 2 reads)
   unsigned *zb = (unsigned *)(zs + (size_t)g.N);     // bf16 side-stream records of the intermediate passes
   const bool first = pass == 0;
