@@ -251,7 +251,8 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->v32, s->p32, s->dsend[0], s->dsend[1], s->dsend[2], s->dsend[3], s->drecv[0], s->drecv[1], s->drecv[2], s->drecv[3],
-                  s->coef_h, s->coef, s->dd_coef, s->dd_cidx, s->dd_cidx_split, s->dd_ent_cell, s->dd_scratch, s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
+                  s->coef_h, s->coef, s->dd_coef, s->dd_cidx, s->dd_cidx_split, s->dd_ent_cell, s->dd_scratch, s->pch_send[0], s->pch_send[1], s->pch_send[2], s->pch_send[3],
+                  s->pch_recv[0], s->pch_recv[1], s->pch_recv[2], s->pch_recv[3], s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,

@@ -149,6 +149,45 @@ __device__ __forceinline__ unsigned tsx_bf16x2(float lo, float hi) {
   return (unsigned)tsx_to_bf16(lo) | ((unsigned)tsx_to_bf16(hi) << 16);
 }
 
+// ---- several ranks: the other colour's boundary columns live on the neighbouring rank.  After every pass the records a
+// neighbour consumes are packed per face (tsx_k_pcs_halo_pack), exchanged like the operator's halo
+// (exchange_diffuse_boundary's pattern, src/pprts_explicit.F90:769-843) and read by the next pass at the rank faces --
+// without it the preconditioner would drop those couplings (block-Jacobi over ranks like the reference's PCBJACOBI) and need
+// 20-40 % more iterations.  Buffers: bf16-pair records [k][j] (W / E faces) and [k][i] (S / N faces); null = no exchange.
+struct TsxPcHalo {
+  const unsigned *W, *E, *S, *N;
+};
+// my W face sends rec 0 (the -x streams of my columns i = 0: the west rank's E input), E face rec 1 of i = xm-1, S face rec 2
+// of j = 0, N face rec 3 of j = ym-1; zb: bf16 records, or zr (float2 records of the fp32 pass) when from_f32
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_pack(TsxGeo g, const unsigned *__restrict__ zb,
+                                                                 const float2 *__restrict__ zr, int from_f32,
+                                                                 unsigned *__restrict__ sW, unsigned *__restrict__ sE,
+                                                                 unsigned *__restrict__ sS, unsigned *__restrict__ sN,
+                                                                 const int *__restrict__ done) {
+  if (done && *done) return;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  const long long Nc = g.Nc;
+  const long long nx = g.wrap_x ? 0 : (long long)Nz * ym, ny = g.wrap_y ? 0 : (long long)Nz * xm;
+  auto rec = [&](int m, int k, int i, int j) {
+    const size_t idx = (size_t)m * Nc + (size_t)k * g.ncol + tsx_split_col(i, j, xm);
+    if (!from_f32) return zb[idx];
+    const float2 v = zr[idx];
+    return (unsigned)tsx_to_bf16(v.x) | ((unsigned)tsx_to_bf16(v.y) << 16);
+  };
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < nx + ny; q += (long long)gridDim.x * TSX_BLOCK) {
+    if (q < nx) {
+      const int j = (int)(q % ym), k = (int)(q / ym);
+      sW[q] = rec(0, k, 0, j);
+      sE[q] = rec(1, k, xm - 1, j);
+    } else {
+      const long long p = q - nx;
+      const int i = (int)(p % xm), k = (int)(p / xm);
+      sS[p] = rec(2, k, i, 0);
+      sN[p] = rec(3, k, i, ym - 1);
+    }
+  }
+}
+
 // ---- one half-grid pass.  rbc = colour of this pass.  GS: the other colour's values enter the right-hand side.
 // MODE 0: intermediate pass -- only the side streams are stored, as bf16 records in zb; neighbours from zb.
 // MODE 1: the last pass of the first colour -- all ten streams in fp32 to z (colour-split; side streams as float2 records);
@@ -163,7 +202,7 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
                                                          float *__restrict__ z, unsigned *__restrict__ zb,
                                                          float *__restrict__ zfin, const int *__restrict__ done, int rbc,
                                                          int nonbr, const int *__restrict__ cidx, long long nent,
-                                                         const uint4 *__restrict__ PE) {
+                                                         const uint4 *__restrict__ PE, TsxPcHalo hal) {
   constexpr int D = 10, NTOP = 2;
   constexpr bool FINAL = MODE == 2;
   __shared__ float2 sB[NSEG][CW], sV[NSEG][CW];
@@ -211,14 +250,23 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
   auto cell = [&](int l) { return (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + col; };
 
   // neighbour records of one level: [E (dofs 2,4), W (3,5), N (6,8), S (7,9)]
+  // rank faces: the neighbour's records come from the exchanged buffers (bf16 pairs), [k][j] resp. [k][i]
+  const bool face[4] = {hal.E && !nonbr && qe < 0, hal.W && !nonbr && qw < 0, hal.N && !nonbr && jn < 0, hal.S && !nonbr && js < 0};
   auto nbr_load = [&](size_t c, uint2 (&o)[4]) {
     const long long off[4] = {offE, offW, offN, offS};
-    const int rec[4] = {0, 1, 2, 3};
+    const unsigned *hp[4] = {hal.E, hal.W, hal.N, hal.S};
+    const int k = (int)(c / (size_t)ncol);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const size_t idx = (size_t)rec[m] * Nc + c + off[m];
-      if (MODE == 2) o[m] = *reinterpret_cast<const uint2 *>(zr + idx);
-      else o[m] = make_uint2(zb[idx], 0u);
+      const size_t idx = (size_t)m * Nc + c + off[m];
+      const size_t hidx = m < 2 ? (size_t)k * g.ym + jrow : (size_t)k * g.xm + icol;
+      if (MODE == 2) {
+        o[m] = *reinterpret_cast<const uint2 *>(zr + idx);
+        const unsigned hv = *(face[m] ? hp[m] + hidx : zb);  // unconditional load from a valid address, then select
+        if (face[m]) o[m].x = hv;
+      } else {
+        o[m] = make_uint2(*(face[m] ? hp[m] + hidx : zb + idx), 0u);
+      }
     }
   };
   // -> values by stream: zx[q] = stream 2+q entering through an x face, zy[q] = stream 6+q through a y face
@@ -227,10 +275,11 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
     const long long off[4] = {offE, offW, offN, offS};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const float a = MODE == 2 ? __uint_as_float(n[m].x) : __uint_as_float(n[m].x << 16);
-      const float b = MODE == 2 ? __uint_as_float(n[m].y) : __uint_as_float(n[m].x & 0xffff0000u);
-      lo[m] = off[m] ? a : 0.0f;  // select: the unused slot may hold NaN
-      hi[m] = off[m] ? b : 0.0f;
+      const bool f32 = MODE == 2 && !face[m];
+      const float a = f32 ? __uint_as_float(n[m].x) : __uint_as_float(n[m].x << 16);
+      const float b = f32 ? __uint_as_float(n[m].y) : __uint_as_float(n[m].x & 0xffff0000u);
+      lo[m] = (off[m] || face[m]) ? a : 0.0f;  // select: the unused slot may hold NaN
+      hi[m] = (off[m] || face[m]) ? b : 0.0f;
     }
     zx[0] = lo[0]; zx[2] = hi[0]; zx[1] = lo[1]; zx[3] = hi[1];
     zy[0] = lo[2]; zy[2] = hi[2]; zy[1] = lo[3]; zy[3] = hi[3];
@@ -592,7 +641,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
                                                           long long bstride, const int *__restrict__ cidx,
                                                           const float *__restrict__ r, float *__restrict__ z,
                                                           unsigned *__restrict__ zb, float *__restrict__ zfin,
-                                                          const int *__restrict__ done, int rbc, int nonbr) {
+                                                          const int *__restrict__ done, int rbc, int nonbr, TsxPcHalo hal) {
   constexpr int D = 16, NTOP = 8;
   constexpr bool FINAL = MODE == 2;
   __shared__ float4 sS[NSEG][5][CW];  // a segment's summary: 4-vector + 4 x 4 product (reused by both scans)
@@ -637,13 +686,23 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   auto cell = [&](int l) { return (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + col; };
   auto brec = [&](int grp, size_t c, int id) { return PB[(size_t)grp * bstride + (IDX ? (size_t)id : c)]; };
   auto mat = [&](int grp, size_t c, float add_diag) { return tsx_m4(P[(size_t)grp * Nc + c], P[(size_t)(grp + 1) * Nc + c], add_diag); };
+  // rank faces: the neighbour's records come from the exchanged buffers (bf16 pairs), [k][j] resp. [k][i]
+  const bool face[4] = {hal.E && !nonbr && qe < 0, hal.W && !nonbr && qw < 0, hal.N && !nonbr && jn < 0, hal.S && !nonbr && js < 0};
   auto nbr_load = [&](size_t c, uint2(&o)[4]) {
     const long long off[4] = {offE, offW, offN, offS};
+    const unsigned *hp[4] = {hal.E, hal.W, hal.N, hal.S};
+    const int k = (int)(c / (size_t)ncol);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const size_t idx = (size_t)m * Nc + c + off[m];
-      if (MODE == 2) o[m] = *reinterpret_cast<const uint2 *>(zr + idx);
-      else o[m] = make_uint2(zb[idx], 0u);
+      const size_t hidx = m < 2 ? (size_t)k * g.ym + jrow : (size_t)k * g.xm + icol;
+      if (MODE == 2) {
+        o[m] = *reinterpret_cast<const uint2 *>(zr + idx);
+        const unsigned hv = *(face[m] ? hp[m] + hidx : zb);  // unconditional load from a valid address, then select
+        if (face[m]) o[m].x = hv;
+      } else {
+        o[m] = make_uint2(*(face[m] ? hp[m] + hidx : zb + idx), 0u);
+      }
     }
   };
   auto nbr_vals = [&](const uint2(&n)[4], float(&zx)[4], float(&zy)[4]) {
@@ -651,10 +710,11 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     const long long off[4] = {offE, offW, offN, offS};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const float a = MODE == 2 ? __uint_as_float(n[m].x) : __uint_as_float(n[m].x << 16);
-      const float b = MODE == 2 ? __uint_as_float(n[m].y) : __uint_as_float(n[m].x & 0xffff0000u);
-      lo[m] = off[m] ? a : 0.0f;
-      hi[m] = off[m] ? b : 0.0f;
+      const bool f32 = MODE == 2 && !face[m];
+      const float a = f32 ? __uint_as_float(n[m].x) : __uint_as_float(n[m].x << 16);
+      const float b = f32 ? __uint_as_float(n[m].y) : __uint_as_float(n[m].x & 0xffff0000u);
+      lo[m] = (off[m] || face[m]) ? a : 0.0f;  // select: the unused slot may hold NaN
+      hi[m] = (off[m] || face[m]) ? b : 0.0f;
     }
     zx[0] = lo[0]; zx[2] = hi[0]; zx[1] = lo[1]; zx[3] = hi[1];
     zy[0] = lo[2]; zy[2] = hi[2]; zy[1] = lo[3]; zy[3] = hi[3];

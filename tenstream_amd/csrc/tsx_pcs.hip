@@ -116,6 +116,62 @@ int tsx_pcs_pack(tsx_solver *s) {
   return TSX_OK;
 }
 
+// ---- preconditioner halo on several ranks (tsx_k_pcs_halo_pack): on when some face of the rank is a real neighbour
+// (or force_halo), both local extents are even (colours then agree across ranks) and TSX_PC_HALO != 0
+static bool pcs_halo_on(const tsx_solver *s) {
+  const TsxGeo &g = s->geo;
+  const char *e = getenv("TSX_PC_HALO");
+  if (e && atoi(e) == 0) return false;
+  return !(g.wrap_x && g.wrap_y) && g.xm % 2 == 0 && g.ym % 2 == 0 && g.pc_tile_x == 0 && g.pc_tile_y == 0;
+}
+static size_t pcs_halo_doubles(const tsx_solver *s, int q) {  // message length in doubles (the exchange's unit), rounded up
+  const TsxGeo &g = s->geo;
+  const size_t n = (size_t)g.Nz * (q < 2 ? g.ym : g.xm);
+  return (n + 1) / 2;
+}
+static int pcs_halo_buffers(tsx_solver *s) {
+  for (int q = 0; q < 4; ++q) {
+    const size_t bytes = pcs_halo_doubles(s, q) * sizeof(double);
+    if (!s->pch_send[q]) {
+      HIPCHK(hipMalloc((void **)&s->pch_send[q], bytes));
+      HIPCHK(hipMemsetAsync(s->pch_send[q], 0, bytes, s->stream));
+    }
+    if (!s->pch_recv[q]) {
+      HIPCHK(hipMalloc((void **)&s->pch_recv[q], bytes));
+      HIPCHK(hipMemsetAsync(s->pch_recv[q], 0, bytes, s->stream));
+    }
+  }
+  return TSX_OK;
+}
+static TsxPcHalo pcs_halo_arg(const tsx_solver *s) {
+  TsxPcHalo h = {nullptr, nullptr, nullptr, nullptr};
+  if (!pcs_halo_on(s) || !s->pch_recv[0]) return h;
+  const TsxGeo &g = s->geo;
+  if (!g.wrap_x) {
+    h.W = s->pch_recv[0];
+    h.E = s->pch_recv[1];
+  }
+  if (!g.wrap_y) {
+    h.S = s->pch_recv[2];
+    h.N = s->pch_recv[3];
+  }
+  return h;
+}
+// after a pass: pack the boundary records and exchange them with the W, E, S, N neighbours
+static int pcs_halo_exchange(tsx_solver *s, bool from_f32, const int *done) {
+  const TsxGeo &g = s->geo;
+  float *zs = (float *)s->vw;
+  const unsigned *zb = (const unsigned *)(zs + (size_t)g.N);
+  const float2 *zr = reinterpret_cast<const float2 *>(zs + (size_t)g.ntop * g.Nc);
+  const long long n = (g.wrap_x ? 0 : (long long)g.Nz * g.ym) + (g.wrap_y ? 0 : (long long)g.Nz * g.xm);
+  hipLaunchKernelGGL(tsx_k_pcs_halo_pack, dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, zb, zr, from_f32 ? 1 : 0,
+                     s->pch_send[0], s->pch_send[1], s->pch_send[2], s->pch_send[3], done);
+  HIPCHK(hipGetLastError());
+  double *const send[4] = {(double *)s->pch_send[0], (double *)s->pch_send[1], (double *)s->pch_send[2], (double *)s->pch_send[3]};
+  double *const recv[4] = {(double *)s->pch_recv[0], (double *)s->pch_recv[1], (double *)s->pch_recv[2], (double *)s->pch_recv[3]};
+  return tsx_face_exchange_bufs(s, s->stream, send, recv, pcs_halo_doubles(s, 0), pcs_halo_doubles(s, 2));
+}
+
 template <int L, int S, int CW>
 static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin, const int *done) {
   const TsxGeo &g = s->geo;
@@ -127,14 +183,15 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   const int *cidx = (const int *)s->dd_cidx_split;
   const long long nent = s->dd_nent;
   const uint4 *PE = P + g.Nc;
+  const TsxPcHalo hal = pcs_halo_arg(s);
 #define TSX_PCS_GO(GSV, MODEV)                                                                                                   \
   do {                                                                                                                           \
     if (dd)                                                                                                                      \
       hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, true>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb, zfin,  \
-                         done, rbc, nonbr, cidx, nent, PE);                                                                      \
+                         done, rbc, nonbr, cidx, nent, PE, hal);                                                                 \
     else                                                                                                                         \
       hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, false>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb, zfin, \
-                         done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr);                                   \
+                         done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr, hal);                              \
   } while (0)
   if (!gs) TSX_PCS_GO(false, 0);
   else if (mode == 0) TSX_PCS_GO(true, 0);
@@ -161,14 +218,15 @@ static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, fl
   const bool dd = s->coef_h_dd;
   const long long bstride = dd ? (long long)s->dd_nent : g.Nc;
   const int *cidx = (const int *)s->dd_cidx_split;
+  const TsxPcHalo hal = pcs_halo_arg(s);
 #define TSX_PCSH_GO(GSV, MODEV)                                                                                                 \
   do {                                                                                                                          \
     if (dd)                                                                                                                     \
       hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, true>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB, bstride,    \
-                         cidx, r, zs, zb, zfin, done, rbc, nonbr);                                                              \
+                         cidx, r, zs, zb, zfin, done, rbc, nonbr, hal);                                                         \
     else                                                                                                                        \
       hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, false>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB, bstride,   \
-                         (const int *)nullptr, r, zs, zb, zfin, done, rbc, nonbr);                                              \
+                         (const int *)nullptr, r, zs, zb, zfin, done, rbc, nonbr, hal);                                         \
   } while (0)
   if (!gs) TSX_PCSH_GO(false, 0);
   else if (mode == 0) TSX_PCSH_GO(true, 0);
@@ -208,10 +266,16 @@ int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done
 // z = M^-1 r (r = s->pc_rhs, fp32, colour-split): pc_sweeps + 1 half-grid passes, colours alternately
 int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
   const int P = s->pc_sweeps + 1;
+  const bool halo = pcs_halo_on(s);
+  if (halo) {
+    int rc = pcs_halo_buffers(s);
+    if (rc) return rc;
+  }
   for (int pass = 0; pass < P; ++pass) {
     const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
     int rc = tsx_pcs_pass(s, pass, mode, z, done);
     if (rc) return rc;
+    if (halo && pass + 1 < P && (rc = pcs_halo_exchange(s, mode == 1, done))) return rc;  // what the next pass reads at the faces
   }
   HIPCHK(hipGetLastError());
   return TSX_OK;

@@ -317,3 +317,30 @@ def test_rccl_transport_with_two_ranks_on_one_device(gpu):
         co = coord.coord(rank, 2, Nx, Ny)
         sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
         assert v[1] == 2 and np.abs(v[3] - x_ref[sl]).max() <= 1e-8 * np.abs(x_ref).max()
+
+
+@pytest.mark.parametrize("solver", ["3_10", "8_16"])
+def test_preconditioner_halo_keeps_the_couplings_across_rank_faces(gpu, monkeypatch, solver):
+    """On several ranks the red-black passes exchange the boundary columns' side-stream records after every pass
+    (tsx_k_pcs_halo_pack + the operator's exchange pattern), so M^-1 keeps the couplings across rank faces.  One rank whose
+    faces are routed through the exchange buffers (force_halo) then preconditions exactly like the periodic rank that reads
+    its neighbours in place: same iteration count, same solution.  With TSX_PC_HALO=0 (couplings across faces dropped,
+    block-Jacobi over ranks like the reference's PCBJACOBI) the small domain needs more iterations."""
+    from tenstream_amd import DiffuseSolver, synthetic
+
+    Nx, Ny, Nz = (24, 16, 12) if solver == "3_10" else (12, 8, 6)
+    P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=1)
+    its, xs = {}, {}
+    for name, fh, env in (("wrap", 0, "1"), ("halo", 1, "1"), ("dropped", 1, "0")):
+        monkeypatch.setenv("TSX_PC_HALO", env)
+        s = DiffuseSolver(solver, Nz, Nx, Ny, force_halo=fh)
+        s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+        x = np.zeros(s.vec_shape)
+        info = s.solve(P["b"], x, rtol=1e-10, atol=1e-30)
+        assert info.reason == 2
+        its[name], xs[name] = info.niter, x
+        s.close()
+    assert abs(its["halo"] - its["wrap"]) <= 1
+    assert its["dropped"] > its["halo"]
+    for name in ("halo", "dropped"):
+        assert np.abs(xs[name] - xs["wrap"]).max() <= 1e-8 * np.abs(xs["wrap"]).max()

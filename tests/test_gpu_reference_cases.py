@@ -160,9 +160,9 @@ def test_config3_local_block_with_halo_faces(gpu):
         out.append((Ax.clone(), sol.clone(), info.niter))
         s.close()
     assert float((out[0][0] - out[1][0]).abs().max()) <= 1e-13 * float(out[1][0].abs().max())   # same operator
-    # the preconditioner drops the couplings across rank faces (block-Jacobi over ranks like PCBJACOBI): a few more
-    # iterations, the same fixed point within the stop rule
-    assert out[0][2] <= out[1][2] + 6
+    # the preconditioner's boundary columns travel through the exchange buffers after every pass (tsx_k_pcs_halo_pack):
+    # the same iteration count as the rank that reads its periodic neighbours in place, the same fixed point
+    assert abs(out[0][2] - out[1][2]) <= 1
     assert float((out[0][1] - out[1][1]).abs().max()) <= 2e-4 * float(out[1][1].abs().max())
 
 
