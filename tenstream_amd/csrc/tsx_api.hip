@@ -369,6 +369,12 @@ int tsx_face_exchange(tsx_solver *s, hipStream_t st) {
   return tsx_face_exchange_bufs(s, st, send, recv, s->halo_x_elems, s->halo_y_elems);
 }
 
+int tsx_face_exchange_elems(tsx_solver *s, hipStream_t st, size_t elem_bytes) {
+  double *const send[4] = {s->sendW, s->sendE, s->sendS, s->sendN};
+  double *const recv[4] = {s->recvW, s->recvE, s->recvS, s->recvN};
+  return tsx_face_exchange_bufs(s, st, send, recv, (s->halo_x_elems * elem_bytes + 7) / 8, (s->halo_y_elems * elem_bytes + 7) / 8);
+}
+
 // reduce partials -> (all-reduce) -> scalar algebra
 static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {
   if (s->allred_cb) {

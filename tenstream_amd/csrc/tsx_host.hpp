@@ -79,6 +79,7 @@ struct TsxDevTmp {
 // ---- cross-unit entry points --------------------------------------------------------------------
 // face exchange on stream st (RCCL / host-staged callbacks / self copies), tsx_api.hip
 int tsx_face_exchange(tsx_solver *s, hipStream_t st);
+int tsx_face_exchange_elems(tsx_solver *s, hipStream_t st, size_t elem_bytes);  // the diffuse halo with elements of that size
 int tsx_face_exchange_bufs(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy);
 
 // operator apply: one translation unit per stream configuration (tsx_spmv_3_10.hip, tsx_spmv_8_16.hip).

@@ -32,8 +32,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
     TsxGeo g, const CT *__restrict__ C, const int *__restrict__ cidx, long long nent, const uint8_t *__restrict__ l1d,
     const double *__restrict__ a11,
     const double *__restrict__ a12, const double *__restrict__ albedo, const XT *__restrict__ x,
-    double *__restrict__ y, const double *__restrict__ hW, const double *__restrict__ hE,
-    const double *__restrict__ hS, const double *__restrict__ hN, const WT *__restrict__ w,
+    double *__restrict__ y, const XT *__restrict__ hW, const XT *__restrict__ hE,
+    const XT *__restrict__ hS, const XT *__restrict__ hN, const WT *__restrict__ w,
     double *__restrict__ partials, const int *__restrict__ done, int part) {
   constexpr int D = NTOP + 2 * NSIDE;
   using V = TsxVec<CPT>;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
         const long long off = edge ? (wrapx ? (long long)(xm - 1) : 0) : -1;
         double e = (double)x[(size_t)d * Nc + c + off];
         if (HALO) {
-          const double h = hW[((size_t)slot * Nz + k) * ym + j];
+          const double h = (double)hW[((size_t)slot * Nz + k) * ym + j];
           e = (edge && !wrapx) ? h : e;
         }
         xs[d][0] = e;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
         const long long off = edge ? (wrapx ? (long long)CPT - xm : 0) : CPT;
         double e = (double)x[(size_t)d * Nc + c + off];
         if (HALO) {
-          const double h = hE[((size_t)slot * Nz + k) * ym + j];
+          const double h = (double)hE[((size_t)slot * Nz + k) * ym + j];
           e = (edge && !wrapx) ? h : e;
         }
         xs[d][CPT - 1] = e;
@@ -277,14 +277,15 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
   if (FUSE) tsx_block_reduce_store<3>(sum, partials);
 }
 
-// SpMV halo pack (exchange_diffuse_boundary, src/pprts_explicit.F90:769-800, in dst-owned storage):
+// SpMV halo pack (exchange_diffuse_boundary, src/pprts_explicit.F90:769-800, in dst-owned storage); the messages carry
+// the vector's own precision (fp32 for the preconditioned directions: half the bytes):
 //   sendE = +x streams of my cells i = xm-1   (east rank reads them as its west halo)
 //   sendW = -x streams of my cells i = 0
 //   sendN = +y streams of my cells j = ym-1 ; sendS = -y streams of my cells j = 0
 template <int NTOP, int NSIDE, typename XT>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_halo_pack(TsxGeo g, const XT *__restrict__ v,
-                                                             double *__restrict__ sendW, double *__restrict__ sendE,
-                                                             double *__restrict__ sendS, double *__restrict__ sendN,
+                                                             XT *__restrict__ sendW, XT *__restrict__ sendE,
+                                                             XT *__restrict__ sendS, XT *__restrict__ sendN,
                                                              const int *__restrict__ done) {
   if (done && *done) return;
   const int xm = g.xm, ym = g.ym, Nz = g.Nz;
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_halo_pack(TsxGeo g, const XT 
       const int slot = (int)(q / ((long long)ym * Nz));
       const size_t row = ((size_t)k * ym + j) * xm;
       if (!g.wrap_x) {
-        sendE[q] = (double)v[(size_t)(NTOP + 2 * slot + 1) * Nc + row + (xm - 1)];
-        sendW[q] = (double)v[(size_t)(NTOP + 2 * slot) * Nc + row];
+        sendE[q] = v[(size_t)(NTOP + 2 * slot + 1) * Nc + row + (xm - 1)];
+        sendW[q] = v[(size_t)(NTOP + 2 * slot) * Nc + row];
       }
     } else {
       const long long p = q - nx;
@@ -306,8 +307,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_halo_pack(TsxGeo g, const XT 
       const int k = (int)((p / xm) % Nz);
       const int slot = (int)(p / ((long long)xm * Nz));
       if (!g.wrap_y) {
-        sendN[p] = (double)v[(size_t)(NTOP + NSIDE + 2 * slot + 1) * Nc + ((size_t)k * ym + (ym - 1)) * xm + i];
-        sendS[p] = (double)v[(size_t)(NTOP + NSIDE + 2 * slot) * Nc + (size_t)k * ym * xm + i];
+        sendN[p] = v[(size_t)(NTOP + NSIDE + 2 * slot + 1) * Nc + ((size_t)k * ym + (ym - 1)) * xm + i];
+        sendS[p] = v[(size_t)(NTOP + NSIDE + 2 * slot) * Nc + (size_t)k * ym * xm + i];
       }
     }
   }

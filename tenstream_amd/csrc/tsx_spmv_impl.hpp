@@ -10,9 +10,9 @@ static int halo_update_t(tsx_solver *s, const XT *v, bool in_solve) {
   const TsxGeo &g = s->geo;
   if (g.wrap_x && g.wrap_y) return TSX_OK;
   const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
-  hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE, XT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, v, s->sendW,
-                     s->sendE, s->sendS, s->sendN, in_solve ? &s->scal->done : (const int *)nullptr);
-  return tsx_face_exchange(s, s->stream);
+  hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE, XT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, v, (XT *)s->sendW,
+                     (XT *)s->sendE, (XT *)s->sendS, (XT *)s->sendN, in_solve ? &s->scal->done : (const int *)nullptr);
+  return tsx_face_exchange_elems(s, s->stream, sizeof(XT));
 }
 
 // part 0: whole grid; 1: interior (no halo reads); 2: frame, partial sums behind those of part 1
@@ -25,14 +25,15 @@ static void launch_spmv_variant(tsx_solver *s, const XT *x, double *y, const WT 
     if (s->dd_on) {  // shared storage of identical blocks (tsx_dedup.hip)
       hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, float, FUSE, CPT, XT, WT, HALO, HAS1D, true>), dim3(nb), dim3(TSX_BLOCK), 0,
                          s->stream, g, (const float *)s->dd_coef, (const int *)s->dd_cidx, (long long)s->dd_nent, s->l1d, s->a11,
-                         s->a12, s->albedo, x, y, s->recvW, s->recvE, s->recvS, s->recvN, w,
-                         s->partials + (part == 2 ? nbmain : 0), done, part);
+                         s->a12, s->albedo, x, y, (const XT *)s->recvW, (const XT *)s->recvE, (const XT *)s->recvS,
+                         (const XT *)s->recvN, w, s->partials + (part == 2 ? nbmain : 0), done, part);
       return;
     }
   }
   hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT, XT, WT, HALO, HAS1D>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
-                     (const CT *)s->coef, (const int *)nullptr, 0ll, s->l1d, s->a11, s->a12, s->albedo, x, y, s->recvW, s->recvE,
-                     s->recvS, s->recvN, w, s->partials + (part == 2 ? nbmain : 0), done, part);
+                     (const CT *)s->coef, (const int *)nullptr, 0ll, s->l1d, s->a11, s->a12, s->albedo, x, y, (const XT *)s->recvW,
+                     (const XT *)s->recvE, (const XT *)s->recvS, (const XT *)s->recvN, w, s->partials + (part == 2 ? nbmain : 0),
+                     done, part);
 }
 
 template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT>
@@ -70,13 +71,13 @@ static int launch_spmv_t(tsx_solver *s, const XT *x, double *y, const WT *w, boo
   // overlap: pack -> [exchange on comm_stream || interior cells on stream] -> frame cells
   const TsxGeo &g = s->geo;
   const long long n = (long long)s->halo_x_elems + (long long)s->halo_y_elems;
-  hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE, XT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, x, s->sendW,
-                     s->sendE, s->sendS, s->sendN, done);
+  hipLaunchKernelGGL((tsx_k_halo_pack<NTOP, NSIDE, XT>), dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, x, (XT *)s->sendW,
+                     (XT *)s->sendE, (XT *)s->sendS, (XT *)s->sendN, done);
   HIPCHK(hipEventRecord(s->ev_pack, s->stream));
   HIPCHK(hipStreamWaitEvent(s->comm_stream, s->ev_pack, 0));
   launch(1);  // queued before the (possibly host-synchronous) exchange so that it runs underneath it
   HIPCHK(hipGetLastError());
-  int rc = tsx_face_exchange(s, s->comm_stream);
+  int rc = tsx_face_exchange_elems(s, s->comm_stream, sizeof(XT));
   if (rc) return rc;
   HIPCHK(hipEventRecord(s->ev_recv, s->comm_stream));
   HIPCHK(hipStreamWaitEvent(s->stream, s->ev_recv, 0));

@@ -57,6 +57,17 @@ def _ptr(a, dtype):
     return C.c_void_p(a.ctypes.data), TSX_HOST
 
 
+_LIVE = None  # solvers still holding a device handle: destroyed at interpreter exit *before* HIP / RCCL unload
+
+
+def _close_all():
+    for s in list(_LIVE or ()):
+        try:
+            s.close()
+        except Exception:
+            pass
+
+
 class DiffuseSolver:
     """One diffuse system (I - T) x = b on one rank/GPU."""
 
@@ -74,6 +85,14 @@ class DiffuseSolver:
         _lib.check(self.lib.tsx_create(C.byref(self.grid), C.byref(h)))
         self.h = h
         self._keep = []
+        global _LIVE
+        if _LIVE is None:
+            import atexit
+            import weakref
+
+            _LIVE = weakref.WeakSet()
+            atexit.register(_close_all)
+        _LIVE.add(self)
 
     # -- shapes ------------------------------------------------------------------------------------
     @property

@@ -328,6 +328,11 @@ def test_rccl_transport_with_one_rank_communicator(gpu):
     info = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30, pc=1, pc_sweeps=1)
     x_ref, _ = O.solve_matfree(lay, c64, P["l1d"], P["a11"], P["a12"], P["albedo"], P["b"], rtol=1e-12, atol=1e-30)
     assert info.reason == 2 and np.abs(xs - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    # the default preconditioner too: its boundary columns travel over the same communicator after every pass
+    xs2 = np.zeros(s.vec_shape)
+    info2 = s.solve(P["b"], xs2, rtol=1e-10, atol=1e-30)
+    assert info2.reason == 2 and np.abs(xs2 - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    s.close()   # destroy the communicator now, not at interpreter exit (RCCL's own teardown runs there)
 
 
 def test_fortran_shim_driver(gpu):
