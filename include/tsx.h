@@ -248,10 +248,13 @@ int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int 
 /* ---- measurement helpers (bench.py): time `reps` launches of the dominant kernel with HIP events on
  *      the solver's stream.  kernel: 0 = SpMV (diffuse operator apply), 1 = one full BiCGStab iteration,
  *      2 = one application of the default preconditioner (pc_sweeps + 1 half-grid passes), 3 = one intermediate
- *      Gauss-Seidel pass of it (3_10 scan kernels) */
+ *      Gauss-Seidel pass of it (scan kernels) */
 int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_ms);
-/* algorithmic bytes per launch of that kernel (Nc*D^2*sc + 2*N*sv for the SpMV; the preconditioner passes:
- * packed records + fp32 right-hand side + neighbour records + stores, 200 B per cell of the pass's colour) */
+/* algorithmic bytes per launch of that kernel *in the storage format in use* (with shared storage of identical blocks:
+ * every distinct block once + a 4-byte index per cell + the vectors; the preconditioner passes: packed records + fp32
+ * right-hand side + neighbour records + stores, see the table in tsx_api.hip).  kernel 10 / 11: SURVEY 8(d)'s literal
+ * figures for every cell's block stored, Nc*D^2*sc + 2*N*sv for the SpMV and 2*B_spmv + 16*N*sv for an iteration
+ * (kernel 1 reports the same literal figure: the reference's estimate of an iteration without a preconditioner) */
 int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes);
 /* shared storage of bit-identical transport blocks (lossless; tsx_dedup.hip): how many distinct blocks the current
  * coefficients hold and whether the operator apply / preconditioner read them through the per-cell index (they do when

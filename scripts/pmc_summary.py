@@ -11,7 +11,7 @@ HBM bytes per launch = 2 * FETCH_SIZE * 1024  +  WRITE_SIZE * 1024
 The two counters are collected in separate passes (they do not fit one pass).
 Launches that exit at once (the Krylov loop enqueues up to check_every iterations ahead of the host's convergence check;
 those kernels return on the `done` flag) are excluded: only launches with at least half of the kernel's largest counter
-value are averaged.  "iteration" = the sum over the kernels of one default BiCGStab iteration (3_10, red-black, 10 passes).
+value are averaged.  "iteration" = the sum over the kernels of one default BiCGStab iteration (red-black, argv[5] passes per application).
 """
 import csv
 import json
@@ -63,8 +63,8 @@ def main():
     # one default iteration: 2 applications of M^-1 (pass 0 without neighbours, P - 3 intermediate, the fp32 pass, the last
     # pass; P = argv[5], default 14), 2 operator applies with fused dots, 3 vector updates
     P = int(sys.argv[5]) if len(sys.argv) > 5 else 14
-    per_iter = [(r"tsx_k_pcs_rb<\d+,\d+,\d+,false,0", 2), (r"tsx_k_pcs_rb<\d+,\d+,\d+,true,0", 2 * (P - 3)),
-                (r"tsx_k_pcs_rb<\d+,\d+,\d+,true,1", 2), (r"tsx_k_pcs_rb<\d+,\d+,\d+,true,2", 2),
+    per_iter = [(r"tsx_k_pcsh?_rb<\d+,\d+,\d+,false,0", 2), (r"tsx_k_pcsh?_rb<\d+,\d+,\d+,true,0", 2 * (P - 3)),
+                (r"tsx_k_pcsh?_rb<\d+,\d+,\d+,true,1", 2), (r"tsx_k_pcsh?_rb<\d+,\d+,\d+,true,2", 2),
                 (r"tsx_k_spmv_w<\d+,\d+,\w+,1,\d,float,float", 1), (r"tsx_k_spmv_w<\d+,\d+,\w+,5,\d,float,double", 1),
                 (r"tsx_k_pupdate32", 1), (r"tsx_k_supdate", 1), (r"tsx_k_xrupdate", 1)]
     it_bytes, missing = 0.0, []

@@ -1,9 +1,14 @@
+# usage (on the GPU box): bash scripts/profile_bench.sh [tag [bench.py arguments ...]]
+# default bench line, rocprofv3 kernel trace, and the two PMC passes of the same command -> gpurun_out/r02/<tag>_*
 set -x
-mkdir -p gpurun_out/r02
-cd /tmp && export TMPDIR=/tmp
+TAG=${1:-bench}
+shift
 R=$GRAFT_REPO_ROOT
-python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/r02/bench_line.json 2> $R/gpurun_out/r02/bench_err.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02/kt -- python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 1 > $R/gpurun_out/r02/kt_line.json 2> $R/gpurun_out/r02/kt_err.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r02/fetch -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --kernel-reps 4 > /dev/null 2> $R/gpurun_out/r02/fetch_err.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r02/write -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --kernel-reps 4 > /dev/null 2> $R/gpurun_out/r02/write_err.log
-ls -R $R/gpurun_out/r02 | head -40
+O=$R/gpurun_out/r02
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --steps 20 --warmup 5 "$@" > $O/${TAG}_line.json 2> $O/${TAG}_err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt -- python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 1 "$@" > $O/${TAG}_kt_line.json 2> $O/${TAG}_kt_err.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_fetch -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --kernel-reps 4 "$@" > /dev/null 2> $O/${TAG}_fetch_err.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_write -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --kernel-reps 4 "$@" > /dev/null 2> $O/${TAG}_write_err.log
+find $O -name "*.csv" | head -40

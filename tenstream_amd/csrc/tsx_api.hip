@@ -1082,20 +1082,37 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
   ARGCHK(s && bytes, "tsx_algorithmic_bytes: null");
   const TsxGeo &g = s->geo;
   const double sc = s->coef_bytes ? s->coef_bytes : 4, sv = 8;
-  // B_spmv = Nc*D^2*sc + 2*N*sv ; B_iter = 2*B_spmv + 16*N*sv
-  const double bspmv = (double)g.Nc * g.D * g.D * sc + 2.0 * (double)g.N * sv;
+  const double Nc = (double)g.Nc, N = (double)g.N, nent = (double)s->dd_nent;
+  const bool dd = s->dd_on;
+  // B_spmv = Nc*D^2*sc + 2*N*sv ; B_iter = 2*B_spmv + 16*N*sv (every cell's block stored: kernels 10, 11).
+  // With shared storage of identical blocks (tsx_dedup.hip) the operator's least traffic is every distinct block once, a
+  // 4-byte index per cell and the two vectors: kernel 0 reports the bytes of the storage format in use.
+  const double bspmv_full = Nc * g.D * g.D * sc + 2.0 * N * sv;
+  const double bspmv = dd ? nent * g.D * g.D * 4.0 + Nc * 4.0 + 2.0 * N * sv : bspmv_full;
   if (kernel == 0) *bytes = bspmv;
-  else if (kernel == 1) *bytes = 2.0 * bspmv + 16.0 * (double)g.N * sv;
+  else if (kernel == 10) *bytes = bspmv_full;
+  else if (kernel == 1 || kernel == 11) *bytes = 2.0 * bspmv_full + 16.0 * N * sv;
   else if (kernel == 3 || kernel == 2) {
-    // the red-black passes of 3_10 on the packed blocks (tsx_kernels_pcs.hpp), per cell of the pass's colour:
-    //   Gauss-Seidel pass: 8 records x 16 B + rhs 10 x 4 B + 4 neighbour records x 4 B (bf16 pairs) + 4 x 4 B stored = 200 B
-    //   first pass (no neighbours): 3 records + rhs + stores = 104 B;  fp32 pass of the first colour: 224 B;
-    //   last pass (fp32 neighbours, the row partner's 10 values, both colours' result in the Krylov layout): 320 B
-    const double half = 0.5 * (double)g.Nc;
-    const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : 10;
-    *bytes = kernel == 3 ? 200.0 * half : (104.0 + 200.0 * (P > 3 ? P - 3 : 0) + 224.0 + 320.0) * half;
+    // the red-black passes on the packed blocks (tsx_kernels_pcs.hpp), bytes per cell of the pass's colour {Gauss-Seidel
+    // pass, first pass (no neighbours), fp32 pass of the first colour, last pass (both colours' result in the Krylov
+    // layout)} and per distinct block per pass when the per-block records are shared:
+    //   3_10, every cell's records: 8 records x 16 B + rhs 10 x 4 B + 4 neighbour records x 4 B (bf16 pairs) + 4 x 4 B
+    //         stored = 200;  first: 3 records + rhs + stores = 104;  fp32 pass 224;  last 320
+    //   3_10, shared: record 0 (the column recurrence) stays per cell, records 1..7 per distinct block behind the index:
+    //         16 + 4 + 40 + 16 + 16 = 92 (+112 per block);  first 76 (+32);  fp32 116;  last 212
+    //   8_16, every cell's records: 12 recurrence records (14 in the fp32 passes) + 16 block records (8 in the first pass)
+    //         + rhs 16 x 4 B + 4 neighbour records + 4 stored = 544;  first 400;  fp32 624;  last 768
+    //   8_16, shared: the 16 block records per distinct block: 292 (+256);  first 276 (+128);  fp32 372;  last 516
+    const bool h = g.ntop == 8;
+    const double cell[2][2][4] = {{{200, 104, 224, 320}, {92, 76, 116, 212}}, {{544, 400, 624, 768}, {292, 276, 372, 516}}};
+    const double ent[2][2] = {{112, 32}, {256, 128}};
+    const double *c = cell[h][dd];
+    const double half = 0.5 * Nc, e_gs = dd ? nent * ent[h][0] : 0.0, e_first = dd ? nent * ent[h][1] : 0.0;
+    const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : (dd && !h ? 14 : 10);
+    const double ngs = P > 3 ? P - 3 : 0;
+    *bytes = kernel == 3 ? c[0] * half + e_gs : (c[1] + c[0] * ngs + c[2] + c[3]) * half + e_first + (ngs + 2.0) * e_gs;
   } else {
-    tsx_set_error("tsx_algorithmic_bytes: kernel must be 0..3");
+    tsx_set_error("tsx_algorithmic_bytes: kernel must be 0..3, 10 or 11");
     return TSX_ERR_ARG;
   }
   return TSX_OK;

@@ -36,7 +36,9 @@ def test_bench_one_gpu_line_has_the_contract_keys(gpu):
     assert "tsx_k_pcs_rb" in out["roofline"]["kernel"] and out["roofline"]["frac"] > 0
     # the metric names the solver that ran
     out8 = _line(_run(["--nx", "16", "--ny", "12", "--solver", "8_16"] + SMALL))
-    assert out8["metric"].startswith("pprts 8_16") and "tsx_k_spmv" in out8["roofline"]["kernel"]
+    assert out8["metric"].startswith("pprts 8_16") and "tsx_k_pcsh_rb" in out8["roofline"]["kernel"]
+    for r in (out["roofline"], out["roofline_spmv"], out8["roofline"], out8["roofline_spmv"]):
+        assert 0 < r["frac"] < 1, r   # bytes of the storage format in use: never above the peak
 
 
 @pytest.mark.parametrize("extra,glob,local,scaling", [

@@ -127,6 +127,38 @@ def test_solve_default_tolerances_and_warm_start(gpu):
     assert info2.niter < info.niter and info2.reason in (2, 3)
 
 
+@pytest.mark.parametrize("solver", ["3_10", "8_16"])
+def test_repeated_coefficient_updates_and_solves_leak_no_device_memory(gpu, solver):
+    """A spectral loop hands over new blocks and solves hundreds of times per call (src/pprts.F90:2281-2300 per g-point):
+    50 rounds of host-path set_coeffs + solve on 64 x 64 x 32 leave the free device memory where it was after the first
+    rounds (every per-call temporary, event and packed-block buffer is reused or released)."""
+    import torch
+
+    P = synthetic.make_problem(solver, Nx=64, Ny=64, Nz=32, n1d=2)
+    s = DiffuseSolver(solver, 32, 64, 64)
+    x = np.zeros(s.vec_shape)
+
+    def round_(q):
+        c = P["coeff"] if q % 2 == 0 else P["coeff"] * np.float32(0.999)   # a new coefficient set every round
+        s.set_coeffs(c, P["l1d"], P["a11"], P["a12"], P["albedo"])
+        x[...] = 0
+        info = s.solve(P["b"], x)
+        assert info.reason in (2, 3)
+
+    for q in range(3):   # first rounds allocate the persistent buffers (packed blocks, shared-block table, scratch)
+        round_(q)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for q in range(50):
+        round_(q)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 <= (2 << 20), f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 50 rounds"
+    s.close()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0   # destroy returns everything the solver held
+
+
 @pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 8, 6, 6, 1), ("3_10", 6, 8, 5, 0), ("3_10", 12, 4, 7, 0),
                                                   ("8_16", 6, 4, 5, 1), ("8_16", 4, 6, 4, 0)])
 @pytest.mark.parametrize("sweeps", [1, 2, 3, 5])
