@@ -94,7 +94,9 @@ typedef struct {
                                  of the transport blocks (fp16; for 3_10 the couplings to neighbouring columns fp8 e4m3) and
                                  keeps its sweep temporaries in fp32 -- the preconditioner is an approximation anyway; the
                                  operator itself always uses the exact blocks.  0: exact blocks in the preconditioner too */
-  int32_t reserved_;
+  int32_t skip_complete_initial_run; /* tsx_pprts_solve only.  0 (default): the first solve of a solution uid runs with tolerances
+                                 at least as tight as tsx_determine_ksp_tolerances gives (-ksp_complete_initial_run,
+                                 src/pprts.F90:4245-4256); the caller's looser values apply to the warm-started ones */
 } tsx_ksp_opts;
 
 /* what `solve` stores on the solution: Niter_diff, diff_ksp_residual_history(100)

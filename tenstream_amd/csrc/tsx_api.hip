@@ -137,7 +137,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->check_every = 4;
   o->fp32_directions = 1;
   o->pc_coeff_fp16 = 1;
-  o->reserved_ = 0;
+  o->skip_complete_initial_run = 0;
 }
 
 extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstrained_fraction, double *rtol,

@@ -43,7 +43,7 @@ module m_pprts_hip
     integer(c_int32_t) :: check_every
     integer(c_int32_t) :: fp32_directions
     integer(c_int32_t) :: pc_coeff_fp16
-    integer(c_int32_t) :: reserved_
+    integer(c_int32_t) :: skip_complete_initial_run   ! 0 (default): -ksp_complete_initial_run semantics, src/pprts.F90:4245-4256
   end type
 
   type, bind(C) :: t_tsx_ksp_result

@@ -215,6 +215,32 @@ def test_reference_c_abi_end_to_end(gpu, tmp_path):
 
 
 @pytest.mark.gpu
+def test_first_solve_of_a_uid_completes_to_the_default_tolerances(gpu):
+    """-ksp_complete_initial_run (on by default, src/pprts.F90:4245-4256): the first solve of a solution uid uses
+    min(caller's, determine_ksp_tolerances') tolerances; the caller's looser ones only apply to the warm-started solves
+    that follow.  A new uid, or the other kind of radiation under the same uid, is a first solve again."""
+    P, I = _setup(12, 10, 8, 200.0, 40.0)
+    planck = np.full((10, 12, 9), 30.0)
+    P.set_optical_properties(0.1, I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck)
+    rt, at, _ = P.core.default_tolerances()
+    first = P.solve(1000.0, uid=1, rtol=1e-1)
+    assert first.reason in (2, 3) and (first.rnorm <= rt * first.rnorm0 or first.rnorm <= at)
+    # other optical properties, same uid: a warm start that stops at the caller's loose tolerance
+    P.set_optical_properties(0.1, 1.5 * I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck)
+    warm = P.solve(1000.0, uid=1, rtol=1e-1)
+    assert warm.reason in (2, 3) and warm.niter < first.niter and warm.rnorm > rt * warm.rnorm0
+    # uid 2 starts from uid 1's solution (a foreign guess): complete again
+    other = P.solve(1000.0, uid=2, rtol=1e-1)
+    assert other.rnorm <= rt * other.res_hist[0] or other.rnorm <= at
+    # thermal under uid 2: the solar solution is dropped (src/pprts.F90:2585-2590) -> first solve
+    th = P.solve(0.0, uid=2, rtol=1e-1)
+    assert th.rnorm <= rt * th.rnorm0 or th.rnorm <= at
+    # the switch: with skip_complete_initial_run the loose tolerance applies from the start
+    loose = P.solve(1000.0, uid=7, rtol=1e-1, skip_complete_initial_run=1)
+    assert loose.rnorm > rt * loose.rnorm0 and loose.niter <= first.niter
+
+
+@pytest.mark.gpu
 def test_spectral_loop_script_runs(gpu):
     """bench_specint.py (config 4: many g-points through the whole device pipeline, a merged column with thick 1-D
     background layers, one solution uid per g-point, two radiation calls) on a tiny domain"""
