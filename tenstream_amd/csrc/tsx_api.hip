@@ -1110,7 +1110,14 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
     const double half = 0.5 * Nc, e_gs = dd ? nent * ent[h][0] : 0.0, e_first = dd ? nent * ent[h][1] : 0.0;
     const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : (dd && !h ? 14 : 10);
     const double ngs = P > 3 ? P - 3 : 0;
-    *bytes = kernel == 3 ? c[0] * half + e_gs : (c[1] + c[0] * ngs + c[2] + c[3]) * half + e_first + (ngs + 2.0) * e_gs;
+    // bf16 right-hand side of the intermediate passes (tsx_k_pcs_rb RQ): a colour's first visit leaves 5 words (+20 B), the
+    // later intermediate visits read 20 B instead of 40 B
+    const bool r16 = tsx_pcs_rhs16(s) && P >= 6;
+    const double w16 = h ? 32.0 : 20.0;  // the bf16-pair words of a cell
+    const double gs_b = r16 ? c[0] - w16 : c[0];
+    if (kernel == 3) *bytes = gs_b * half + e_gs;
+    else if (r16) *bytes = ((c[1] + w16) + (c[0] + w16) + gs_b * (ngs - 1.0) + c[2] + c[3]) * half + e_first + (ngs + 2.0) * e_gs;
+    else *bytes = (c[1] + c[0] * ngs + c[2] + c[3]) * half + e_first + (ngs + 2.0) * e_gs;
   } else {
     tsx_set_error("tsx_algorithmic_bytes: kernel must be 0..3, 10 or 11");
     return TSX_ERR_ARG;
@@ -1142,7 +1149,7 @@ static int bench_kernel_t(tsx_solver *s, int kernel, int reps, float *avg_ms) {
     HIPCHK(hipEventRecord(s->ev0, s->stream));
     for (int q = 0; q < reps; ++q) {
       if (kernel == 2) rc = tsx_pc_apply(s, s->vp, s->vph, true, false);
-      else rc = tsx_pcs_pass(s, 2 + (q & 1), 0, (float *)s->vph, nullptr);
+      else rc = tsx_pcs_pass(s, 2 + (q & 1), 0, (float *)s->vph, nullptr, tsx_pcs_rhs16(s) ? 2 : 0);
       if (rc) return rc;
     }
     HIPCHK(hipEventRecord(s->ev1, s->stream));

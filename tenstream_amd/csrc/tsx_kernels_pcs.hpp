@@ -197,12 +197,18 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_pack(TsxGeo g, const
 // nonbr: run a GS kernel without neighbours (first pass of a short sequence).
 // IDX: groups 1..7 are stored per distinct block: PE[(grp - 1) * nent + cidx[cell]] (cidx in colour-split order); group 0
 // (the column recurrences) stays per cell.
-template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false>
+// RQ (MODE 0 only): what an intermediate pass produces is bf16 anyway, so from a colour's second visit on it reads its
+// right-hand side as five bf16-pair words per cell, rb[w * Nc + cell] = (ru, rd), (rs0, rs1) .. (rs6, rs7): 20 B instead of
+// 40 B.  RQ 1: the colour's first visit reads fp32 and leaves those words; RQ 2: reads them; RQ 0: fp32 only.  (Measured:
+// rounding the intermediate passes' right-hand side to bf16 changes no iteration count, 8 / 13 at rtol 1e-5 / 1e-8.)
+template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false, int RQ = 0>
 __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *__restrict__ P, const float *__restrict__ r,
                                                          float *__restrict__ z, unsigned *__restrict__ zb,
                                                          float *__restrict__ zfin, const int *__restrict__ done, int rbc,
                                                          int nonbr, const int *__restrict__ cidx, long long nent,
-                                                         const uint4 *__restrict__ PE, TsxPcHalo hal) {
+                                                         const uint4 *__restrict__ PE, TsxPcHalo hal,
+                                                         unsigned *__restrict__ rb) {
+  static_assert(RQ == 0 || MODE == 0, "bf16 right-hand side only in the intermediate passes");
   constexpr int D = 10, NTOP = 2;
   constexpr bool FINAL = MODE == 2;
   __shared__ float2 sB[NSEG][CW], sV[NSEG][CW];
@@ -296,8 +302,15 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
     const size_t c = cell(l);
     eid[l] = IDX ? cidx[c] : 0;
     r0[l] = P[c];
-    ru[l] = r[c];
-    rd[l] = r[(size_t)Nc + c];
+    if (RQ == 2) {
+      const unsigned w = rb[c];
+      ru[l] = __uint_as_float(w << 16);
+      rd[l] = __uint_as_float(w & 0xffff0000u);
+    } else {
+      ru[l] = r[c];
+      rd[l] = r[(size_t)Nc + c];
+      if (RQ == 1 && live && l < nl) rb[c] = tsx_bf16x2(ru[l], rd[l]);
+    }
     if (GS) {
       r1[l] = rec(1, c, eid[l]);
       nbr_load(c, nb[l]);
@@ -399,8 +412,21 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
       wx[1] = rec(7, c, eid[l]);
     }
     float rs[8];
+    if (RQ == 2) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+      for (int q = 0; q < 4; ++q) {
+        const unsigned w = rb[(size_t)(1 + q) * Nc + c];
+        rs[2 * q] = __uint_as_float(w << 16);
+        rs[2 * q + 1] = __uint_as_float(w & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+      if (RQ == 1 && st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rb[(size_t)(1 + q) * Nc + c] = tsx_bf16x2(rs[2 * q], rs[2 * q + 1]);
+      }
+    }
     float pt[2];
     float2 ps[4];
     if (FINAL) {
@@ -636,12 +662,15 @@ __device__ __forceinline__ TsxM4 tsx_mm4(const TsxM4 &X, const TsxM4 &Y) {
 #ifndef TSX_PCSH_WAVES
 #define TSX_PCSH_WAVES 2
 #endif
-template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX>
+template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false, int RQ = 0>
 __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PCSH_WAVES, TSX_PCSH_WAVES))) void tsx_k_pcsh_rb(TsxGeo g, const uint4 *__restrict__ P, const uint4 *__restrict__ PB,
                                                           long long bstride, const int *__restrict__ cidx,
                                                           const float *__restrict__ r, float *__restrict__ z,
                                                           unsigned *__restrict__ zb, float *__restrict__ zfin,
-                                                          const int *__restrict__ done, int rbc, int nonbr, TsxPcHalo hal) {
+                                                          const int *__restrict__ done, int rbc, int nonbr, TsxPcHalo hal,
+                                                          unsigned *__restrict__ rb) {
+  // RQ as in tsx_k_pcs_rb: eight bf16-pair words per cell, rb[w * Nc + cell] = (ru_a, rd_a), a = 0..3, then (rs_2q, rs_2q+1)
+  static_assert(RQ == 0 || MODE == 0, "bf16 right-hand side only in the intermediate passes");
   constexpr int D = 16, NTOP = 8;
   constexpr bool FINAL = MODE == 2;
   __shared__ float4 sS[NSEG][5][CW];  // a segment's summary: 4-vector + 4 x 4 product (reused by both scans)
@@ -758,8 +787,15 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       float ru[4], rd[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        ru[a] = r[(size_t)(2 * a) * Nc + c];
-        rd[a] = r[(size_t)(2 * a + 1) * Nc + c];
+        if (RQ == 2) {
+          const unsigned w = rb[(size_t)a * Nc + c];
+          ru[a] = __uint_as_float(w << 16);
+          rd[a] = __uint_as_float(w & 0xffff0000u);
+        } else {
+          ru[a] = r[(size_t)(2 * a) * Nc + c];
+          rd[a] = r[(size_t)(2 * a + 1) * Nc + c];
+          if (RQ == 1 && live && act) rb[(size_t)a * Nc + c] = tsx_bf16x2(ru[a], rd[a]);
+        }
       }
       if (GS) {
         nbr_load(c, nb[l]);
@@ -921,6 +957,22 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     }
     const unsigned uy[8] = {sy[0].x, sy[0].y, sy[0].z, sy[0].w, sy[1].x, sy[1].y, sy[1].z, sy[1].w};
     const unsigned ux[8] = {sx[0].x, sx[0].y, sx[0].z, sx[0].w, sx[1].x, sx[1].y, sx[1].z, sx[1].w};
+    float rs[8];
+    if (RQ == 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned w = rb[(size_t)(4 + q) * Nc + c];
+        rs[2 * q] = __uint_as_float(w << 16);
+        rs[2 * q + 1] = __uint_as_float(w & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+      if (RQ == 1 && st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rb[(size_t)(4 + q) * Nc + c] = tsx_bf16x2(rs[2 * q], rs[2 * q + 1]);
+      }
+    }
     float zo[8];
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd) {
@@ -936,7 +988,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
                          cp[2] * zx[2] + cp[3] * zx[3];
         acc += a8 * (1.0f / TSX_FP8_SCALE);
       }
-      zo[dd] = r[(size_t)(NTOP + dd) * Nc + c] + acc;
+      zo[dd] = rs[dd] + acc;
     }
     // records by consumer: side dofs (8,10) (9,11) (12,14) (13,15) = zo[0,2] zo[1,3] zo[4,6] zo[5,7]
     if (MODE == 0 && st) {

@@ -172,8 +172,10 @@ static int pcs_halo_exchange(tsx_solver *s, bool from_f32, const int *done) {
   return tsx_face_exchange_bufs(s, s->stream, send, recv, pcs_halo_doubles(s, 0), pcs_halo_doubles(s, 2));
 }
 
+// rq: 0 = fp32 right-hand side, 1 = fp32 + leave the bf16-pair words, 2 = read the bf16-pair words (mode 0 only)
 template <int L, int S, int CW>
-static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin, const int *done) {
+static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin, const int *done,
+                       int rq) {
   const TsxGeo &g = s->geo;
   const long long nthr = (long long)g.ym * (g.xm / 2);
   const int nb = (int)((nthr + CW - 1) / CW);
@@ -184,32 +186,39 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   const long long nent = s->dd_nent;
   const uint4 *PE = P + g.Nc;
   const TsxPcHalo hal = pcs_halo_arg(s);
-#define TSX_PCS_GO(GSV, MODEV)                                                                                                   \
+  unsigned *rb = zb + (size_t)4 * g.Nc;  // behind the iterate's bf16 records in s->vw
+#define TSX_PCS_GO(GSV, MODEV, RQV)                                                                                              \
   do {                                                                                                                           \
     if (dd)                                                                                                                      \
-      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, true>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb, zfin,  \
-                         done, rbc, nonbr, cidx, nent, PE, hal);                                                                 \
+      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, true, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb,   \
+                         zfin, done, rbc, nonbr, cidx, nent, PE, hal, rb);                                                       \
     else                                                                                                                         \
-      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, false>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb, zfin, \
-                         done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr, hal);                              \
+      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, false, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb,  \
+                         zfin, done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr, hal, rb);                    \
   } while (0)
-  if (!gs) TSX_PCS_GO(false, 0);
-  else if (mode == 0) TSX_PCS_GO(true, 0);
-  else if (mode == 1) TSX_PCS_GO(true, 1);
-  else TSX_PCS_GO(true, 2);
+  if (!gs) {
+    if (rq == 1) TSX_PCS_GO(false, 0, 1);
+    else TSX_PCS_GO(false, 0, 0);
+  } else if (mode == 0) {
+    if (rq == 2) TSX_PCS_GO(true, 0, 2);
+    else if (rq == 1) TSX_PCS_GO(true, 0, 1);
+    else TSX_PCS_GO(true, 0, 0);
+  } else if (mode == 1) TSX_PCS_GO(true, 1, 0);
+  else TSX_PCS_GO(true, 2, 0);
 #undef TSX_PCS_GO
 }
 
 template <int L, int S>
 static void pcs_launch_cw(tsx_solver *s, int cw, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin,
-                          const int *done) {
-  if (cw == 64) pcs_launch<L, S, 64>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done);
-  else if (cw == 32) pcs_launch<L, S, 32>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done);
-  else pcs_launch<L, S, 16>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done);
+                          const int *done, int rq) {
+  if (cw == 64) pcs_launch<L, S, 64>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
+  else if (cw == 32) pcs_launch<L, S, 32>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
+  else pcs_launch<L, S, 16>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
 }
 
 template <int L, int S, int CW>
-static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin, const int *done) {
+static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin, const int *done,
+                        int rq) {
   const TsxGeo &g = s->geo;
   const long long nthr = (long long)g.ym * (g.xm / 2);
   const int nb = (int)((nthr + CW - 1) / CW);
@@ -219,24 +228,39 @@ static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, fl
   const long long bstride = dd ? (long long)s->dd_nent : g.Nc;
   const int *cidx = (const int *)s->dd_cidx_split;
   const TsxPcHalo hal = pcs_halo_arg(s);
-#define TSX_PCSH_GO(GSV, MODEV)                                                                                                 \
+  unsigned *rb = zb + (size_t)4 * g.Nc;
+#define TSX_PCSH_GO(GSV, MODEV, RQV)                                                                                            \
   do {                                                                                                                          \
     if (dd)                                                                                                                     \
-      hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, true>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB, bstride,    \
-                         cidx, r, zs, zb, zfin, done, rbc, nonbr, hal);                                                         \
+      hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, true, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB,        \
+                         bstride, cidx, r, zs, zb, zfin, done, rbc, nonbr, hal, rb);                                            \
     else                                                                                                                        \
-      hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, false>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB, bstride,   \
-                         (const int *)nullptr, r, zs, zb, zfin, done, rbc, nonbr, hal);                                         \
+      hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, false, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB,       \
+                         bstride, (const int *)nullptr, r, zs, zb, zfin, done, rbc, nonbr, hal, rb);                            \
   } while (0)
-  if (!gs) TSX_PCSH_GO(false, 0);
-  else if (mode == 0) TSX_PCSH_GO(true, 0);
-  else if (mode == 1) TSX_PCSH_GO(true, 1);
-  else TSX_PCSH_GO(true, 2);
+  if (!gs) {
+    if (rq == 1) TSX_PCSH_GO(false, 0, 1);
+    else TSX_PCSH_GO(false, 0, 0);
+  } else if (mode == 0) {
+    if (rq == 2) TSX_PCSH_GO(true, 0, 2);
+    else if (rq == 1) TSX_PCSH_GO(true, 0, 1);
+    else TSX_PCSH_GO(true, 0, 0);
+  } else if (mode == 1) TSX_PCSH_GO(true, 1, 0);
+  else TSX_PCSH_GO(true, 2, 0);
 #undef TSX_PCSH_GO
 }
 
 // one pass: mode as in tsx_k_pcs_rb; first = no neighbour values exist yet
-int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done) {
+// intermediate passes read their right-hand side as bf16 pairs: default for 3_10 (14 passes: pass 43.6 -> 36.5 us, M^-1 0.675
+// -> 0.635 ms, same iteration counts); 8_16 with its 10 passes gains nothing (pass 168 -> 162 us, M^-1 1.82 -> 1.83 ms: the two
+// passes that leave the words cost what the four that read them save).  TSX_PC_RHS16 = 0: never, 2: 8_16 too
+bool tsx_pcs_rhs16(const tsx_solver *s) {
+  static const int mode = getenv("TSX_PC_RHS16") ? atoi(getenv("TSX_PC_RHS16")) : 1;
+  return mode == 2 || (mode == 1 && s->geo.ntop == 2);
+}
+
+// rq: right-hand side of an intermediate pass, see tsx_k_pcs_rb (RQ)
+int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done, int rq) {
   const TsxGeo &g = s->geo;
   const PcsCfg c = pcs_config(s);
   if (g.ntop == 8) {
@@ -244,10 +268,11 @@ int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done
     unsigned *zb8 = (unsigned *)(zs8 + (size_t)g.N);
     const bool first8 = pass == 0, gs8 = !(first8 && mode == 0);
     const int nonbr8 = first8 && mode != 0, rbc8 = pass & 1;
-    if (c.lseg == 4 && c.cw == 32) pcsh_launch<4, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done);
-    else if (c.lseg == 4) pcsh_launch<4, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done);
-    else if (c.cw == 32) pcsh_launch<8, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done);
-    else pcsh_launch<8, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done);
+    if (mode != 0) rq = 0;
+    if (c.lseg == 4 && c.cw == 32) pcsh_launch<4, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq);
+    else if (c.lseg == 4) pcsh_launch<4, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq);
+    else if (c.cw == 32) pcsh_launch<8, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq);
+    else pcsh_launch<8, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq);
     return TSX_OK;
   }
   float *zs = (float *)s->vw;                        // fp32 iterate (mode 1 writes, mode 2 reads)
@@ -256,10 +281,11 @@ int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done
   const bool gs = !(first && mode == 0);
   const int nonbr = first && mode != 0;
   const int rbc = pass & 1;
-  if (c.lseg == 4) pcs_launch_cw<4, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done);
-  else if (c.lseg == 8 && c.nseg == 8) pcs_launch_cw<8, 8>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done);
-  else if (c.lseg == 8) pcs_launch_cw<8, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done);
-  else pcs_launch_cw<16, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done);
+  if (mode != 0) rq = 0;
+  if (c.lseg == 4) pcs_launch_cw<4, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
+  else if (c.lseg == 8 && c.nseg == 8) pcs_launch_cw<8, 8>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
+  else if (c.lseg == 8) pcs_launch_cw<8, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
+  else pcs_launch_cw<16, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
   return TSX_OK;
 }
 
@@ -271,9 +297,13 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
     int rc = pcs_halo_buffers(s);
     if (rc) return rc;
   }
+  const bool rhs16 = tsx_pcs_rhs16(s);
   for (int pass = 0; pass < P; ++pass) {
     const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
-    int rc = tsx_pcs_pass(s, pass, mode, z, done);
+    // a colour's intermediate visits are passes c, c + 2, ... < P - 2: the first leaves the bf16 right-hand side if another
+    // one follows, the later ones read it
+    const int rq = !rhs16 || mode != 0 ? 0 : (pass >= 2 ? 2 : (pass + 2 < P - 2 ? 1 : 0));
+    int rc = tsx_pcs_pass(s, pass, mode, z, done, rq);
     if (rc) return rc;
     if (halo && pass + 1 < P && (rc = pcs_halo_exchange(s, mode == 1, done))) return rc;  // what the next pass reads at the faces
   }
