@@ -222,13 +222,10 @@ def main():
     bytes_iter = s.algorithmic_bytes(1)
     pc_ms = pass_ms = None
     dd_on, dd_nent = s.dedup_info()
-    sweeps = args.pc_sweeps if args.pc_sweeps > 0 else ((13 if (dd_on and solver == "3_10") else 9) if args.pc in (2, 3) else 1)
-    if args.pc == 3 and args.pc_sweeps == 0:
-        try:
-            pc_ms = s.bench_kernel(2, args.kernel_reps)
-            pass_ms = s.bench_kernel(3, 4 * args.kernel_reps)
-        except Exception:  # 8_16 / odd grids: no scan kernels (pass_ms stays None)
-            pass
+    pc_ran, sweeps, scan = s.pc_info()   # what the solves above actually ran (automatic pass count, zebra on odd grids)
+    if scan and args.pc_sweeps == 0:
+        pc_ms = s.bench_kernel(2, args.kernel_reps)
+        pass_ms = s.bench_kernel(3, 4 * args.kernel_reps)
     copy_gbps = s.probe_copy_bandwidth(1 << 30, 10)
 
     def roof(kernel, ms, nbytes, patterns, full_storage_bytes=None):
@@ -291,7 +288,7 @@ def main():
                                          "disables); the rooflines count the bytes of this format"),
                 "coeff_setup_ms": t_setup * 1e3,
                 "preconditioner": {0: "none", 1: "column-jacobi", 2: f"column-zebra({sweeps + 1} passes)",
-                                   3: f"column-red-black({sweeps + 1} passes)"}.get(args.pc, str(args.pc)),
+                                   3: f"column-red-black({sweeps + 1} passes)"}.get(pc_ran, str(pc_ran)),
                 "iterations": info.niter,
                 "reason": info.reason,
                 "rel_residual": info.rnorm / info.rnorm0,

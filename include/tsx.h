@@ -84,8 +84,8 @@ typedef struct {
   double rtol, atol, dtol;
   int32_t maxit;
   int32_t pc;                 /* TSX_PC_* */
-  int32_t pc_sweeps;          /* ZEBRA / REDBLACK: pc_sweeps + 1 half-grid passes per application; COLUMN: Jacobi sweeps (1..16);
-                                 0 (default) = automatic: 13 where most blocks are shared (tsx_dedup_info), else 9 */
+  int32_t pc_sweeps;          /* ZEBRA / REDBLACK: pc_sweeps + 1 half-grid passes per application; COLUMN: Jacobi sweeps (1..32);
+                                 0 (default) = automatic: 19 (20 passes) where the scan kernels run, else 9 */
   int32_t check_every;        /* host looks at the device convergence flag every n iterations */
   int32_t fp32_directions;    /* 1 (default): the directions p, p-hat, s-hat and the shadow residual are stored in fp32 --
                                  flexible BiCGStab accepts any direction: x and r are updated consistently with A p-hat,
@@ -262,6 +262,9 @@ int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes);
  * coefficients hold and whether the operator apply / preconditioner read them through the per-cell index (they do when
  * at most half of the cells need a block of their own; TSX_DEDUP=0 switches it off) */
 int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent);
+/* the preconditioner the last solve / tsx_bench_kernel actually ran (after the automatic choices: red-black -> zebra rows
+ * on odd grids, pc_sweeps 0 -> 19 or 9): TSX_PC_*, pc_sweeps, and whether the passes run as scan kernels */
+int tsx_pc_info(const tsx_solver *s, int32_t *pc, int32_t *pc_sweeps, int32_t *scan);
 /* device STREAM-like copy bandwidth probe (GB/s) for reporting against the measured peak */
 int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps);
 

@@ -133,7 +133,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->dtol = 1e4;    // PETSc KSP default divergence tolerance
   o->maxit = 1000;  // src/pprts_base.F90:1118
   o->pc = TSX_PC_REDBLACK;  // this back-end's default preconditioner: 10 half-grid passes
-  o->pc_sweeps = 0;  // automatic (prepare_ksp): 13 where the blocks are shared (a pass costs half), else 9
+  o->pc_sweeps = 0;  // automatic (prepare_ksp): 19 with the scan kernels, else 9
   o->check_every = 4;
   o->fp32_directions = 1;
   o->pc_coeff_fp16 = 1;
@@ -975,7 +975,7 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   else tsx_default_ksp_opts(o);
   ARGCHK(o->maxit >= 1, "solve: maxit < 1");
   ARGCHK(o->pc >= TSX_PC_NONE && o->pc <= TSX_PC_REDBLACK, "solve: unsupported preconditioner");
-  ARGCHK(o->pc_sweeps >= 0 && o->pc_sweeps <= 16, "solve: pc_sweeps out of range");
+  ARGCHK(o->pc_sweeps >= 0 && o->pc_sweeps <= 32, "solve: pc_sweeps out of range");
   HIPCHK(hipSetDevice(s->device));
   s->pc = o->pc;
   s->pc_sweeps = o->pc_sweeps;
@@ -997,10 +997,12 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
     if (rc) return rc;
   }
   if (o->pc_sweeps == 0) {
-    // pass count of the Gauss-Seidel orderings, measured on the metric domain, config 2 and config 4's 252 g-points
-    // (scripts/pcbench.py, scripts/sweeps_study.py): 10 passes / 10 iterations when a pass streams every cell's own
-    // blocks, 14 passes / 8 iterations when most blocks are shared and a pass moves half the bytes
-    o->pc_sweeps = (o->pc == TSX_PC_REDBLACK || o->pc == TSX_PC_ZEBRA) ? (s->dd_on && s->geo.ntop == 2 ? 13 : 9) : 1;
+    // pass count of the Gauss-Seidel orderings, measured on the metric domain, config 2, config 5 and config 4's 252
+    // g-points (scripts/ab_env.sh, scripts/sweeps_study.py): 20 passes where the scan kernels run -- a
+    // pass (36 us on 256 x 256 x 64) is cheap next to the operator and the vector updates of an iteration (1.3 ms), and 20
+    // passes need 6 iterations where 10 need 10 -- and 10 passes with the one-lane-per-column kernels (zebra rows, odd grids)
+    const bool scan = s->pc == TSX_PC_REDBLACK && tsx_pcs_eligible(s);
+    o->pc_sweeps = (s->pc == TSX_PC_REDBLACK || s->pc == TSX_PC_ZEBRA) ? (scan ? 19 : 9) : 1;
     s->pc_sweeps = o->pc_sweeps;
   }
   if (o->pc != TSX_PC_NONE) {
@@ -1056,7 +1058,7 @@ static int pc_apply_t(tsx_solver *s, const double *v, double *z, int where, bool
 
 extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int pc, int pc_sweeps, int mixed) {
   ARGCHK(s && v && z, "tsx_diff_pc_apply: null argument");
-  ARGCHK(pc >= TSX_PC_COLUMN && pc <= TSX_PC_REDBLACK && pc_sweeps >= 1 && pc_sweeps <= 16, "tsx_diff_pc_apply: bad preconditioner");
+  ARGCHK(pc >= TSX_PC_COLUMN && pc <= TSX_PC_REDBLACK && pc_sweeps >= 1 && pc_sweeps <= 32, "tsx_diff_pc_apply: bad preconditioner");
   if (!s->have_coeffs) {
     tsx_set_error("tsx_diff_pc_apply: call tsx_diff_set_coeffs first");
     return TSX_ERR_STATE;
@@ -1108,7 +1110,7 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
     const double ent[2][2] = {{112, 32}, {256, 128}};
     const double *c = cell[h][dd];
     const double half = 0.5 * Nc, e_gs = dd ? nent * ent[h][0] : 0.0, e_first = dd ? nent * ent[h][1] : 0.0;
-    const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : (dd && !h ? 14 : 10);
+    const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : 20;
     const double ngs = P > 3 ? P - 3 : 0;
     // bf16 right-hand side of the intermediate passes (tsx_k_pcs_rb RQ): a colour's first visit leaves 5 words (+20 B), the
     // later intermediate visits read 20 B instead of 40 B
@@ -1198,6 +1200,14 @@ extern "C" int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent) {
   if (rc) return rc;
   *on = s->dd_on ? 1 : 0;
   *nent = s->dd_nent;
+  return TSX_OK;
+}
+
+extern "C" int tsx_pc_info(const tsx_solver *s, int32_t *pc, int32_t *pc_sweeps, int32_t *scan) {
+  ARGCHK(s && pc && pc_sweeps && scan, "tsx_pc_info: null");
+  *pc = s->pc;
+  *pc_sweeps = s->pc_sweeps;
+  *scan = s->coef_h_scan ? 1 : 0;
   return TSX_OK;
 }
 

@@ -251,12 +251,13 @@ static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, fl
 }
 
 // one pass: mode as in tsx_k_pcs_rb; first = no neighbour values exist yet
-// intermediate passes read their right-hand side as bf16 pairs: default for 3_10 (14 passes: pass 43.6 -> 36.5 us, M^-1 0.675
-// -> 0.635 ms, same iteration counts); 8_16 with its 10 passes gains nothing (pass 168 -> 162 us, M^-1 1.82 -> 1.83 ms: the two
-// passes that leave the words cost what the four that read them save).  TSX_PC_RHS16 = 0: never, 2: 8_16 too
+// intermediate passes read their right-hand side as bf16 pairs (TSX_PC_RHS16=0: fp32 throughout).  Measured: 3_10 pass
+// 43.6 -> 36.5 us; 8_16 pass 168 -> 162 us, which pays from about 14 passes on (the two passes that leave the words cost what
+// four reading passes save); same iteration counts
 bool tsx_pcs_rhs16(const tsx_solver *s) {
-  static const int mode = getenv("TSX_PC_RHS16") ? atoi(getenv("TSX_PC_RHS16")) : 1;
-  return mode == 2 || (mode == 1 && s->geo.ntop == 2);
+  static const bool on = !(getenv("TSX_PC_RHS16") && atoi(getenv("TSX_PC_RHS16")) == 0);
+  (void)s;
+  return on;
 }
 
 // rq: right-hand side of an intermediate pass, see tsx_k_pcs_rb (RQ)

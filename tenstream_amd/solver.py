@@ -301,6 +301,12 @@ class DiffuseSolver:
         _lib.check(self.lib.tsx_dedup_info(self.h, C.byref(on), C.byref(n)))
         return bool(on.value), int(n.value)
 
+    def pc_info(self):
+        """(TSX_PC_* id, pc_sweeps, scan kernels?) of the preconditioner the last solve actually ran"""
+        pc, sw, scan = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.tsx_pc_info(self.h, C.byref(pc), C.byref(sw), C.byref(scan)))
+        return int(pc.value), int(sw.value), bool(scan.value)
+
     def bench_kernel(self, kernel: int, reps: int) -> float:
         ms = C.c_float()
         _lib.check(self.lib.tsx_bench_kernel(self.h, kernel, reps, C.byref(ms)))
