@@ -403,11 +403,16 @@ static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// workgroups of the layout conversion: one per tile of TSX_CV_TI columns x TSX_CV_TK levels of one row (grid-stride above 2^20)
+static int convert_grid(const TsxGeo &g) {
+  const long long nt = (long long)((g.xm + TSX_CV_TI - 1) / TSX_CV_TI) * g.ym * ((g.Nz + 1 + TSX_CV_TK - 1) / TSX_CV_TK);
+  return (int)(nt < (1ll << 20) ? nt : (1ll << 20));
+}
+
 template <int NTOP, int NSIDE>
 static int import_vec(tsx_solver *s, const double *ref_dev, double *v) {
   const TsxGeo &g = s->geo;
-  const long long total = (long long)(g.Nz + 1) * g.ncol;
-  hipLaunchKernelGGL((tsx_k_convert_vec<NTOP, NSIDE, false>), dim3(grid_for(total)), dim3(TSX_BLOCK), 0, s->stream, g,
+  hipLaunchKernelGGL((tsx_k_convert_vec<NTOP, NSIDE, false>), dim3(convert_grid(g)), dim3(TSX_BLOCK), 0, s->stream, g,
                      const_cast<double *>(ref_dev), v, s->sendW, s->sendS);
   HIPCHK(hipGetLastError());
   if (!(g.wrap_x && g.wrap_y)) {
@@ -431,8 +436,7 @@ static int export_vec(tsx_solver *s, const double *v, double *ref_dev) {
   const TsxGeo &g = s->geo;
   int rc = halo_update<NTOP, NSIDE>(s, v, false);
   if (rc) return rc;
-  const long long total = (long long)(g.Nz + 1) * g.ncol;
-  hipLaunchKernelGGL((tsx_k_convert_vec<NTOP, NSIDE, true>), dim3(grid_for(total)), dim3(TSX_BLOCK), 0, s->stream, g,
+  hipLaunchKernelGGL((tsx_k_convert_vec<NTOP, NSIDE, true>), dim3(convert_grid(g)), dim3(TSX_BLOCK), 0, s->stream, g,
                      ref_dev, const_cast<double *>(v), s->recvW, s->recvS);
   HIPCHK(hipGetLastError());
   return TSX_OK;

@@ -219,53 +219,81 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
 }
 
 // ------------------------------------------------------------------------------------------------
-// Layout conversion reference <-> internal (see tsx_internal.hpp).  One thread per (level, i, j).
+// Layout conversion reference <-> internal (see tsx_internal.hpp) as a transpose through LDS.  The reference vector is
+// (dof fastest, level, i, j): one column is a contiguous run of D x (Nz + 1) doubles; the internal planes run along i.
+// A workgroup moves a tile of TI columns of one row x TK levels: on the reference side the lanes walk the contiguous
+// (dof, level) runs of each column, on the internal side they walk along i (one thread per (level, i, j) read the reference
+// side in 80-byte pieces: 2 TB/s).
 // Streams that leave the *neighbouring* cell across the low x / low y face of the owned block belong to
 // the neighbour rank's cell: they are routed through the halo buffers.
 //   import: ref value of +x stream at face i=0  -> sendW (west rank stores it at its cell xm-1)
 //           ref value of +y stream at face j=0  -> sendS
 //   export: ref value of +x stream at face i=0  <- recvW (== SpMV halo of x), same for y
+constexpr int TSX_CV_TI = 32, TSX_CV_TK = 8;
 template <int NTOP, int NSIDE, bool EXPORT>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_convert_vec(TsxGeo g, double *__restrict__ ref,
                                                                double *__restrict__ v, double *__restrict__ bufW,
                                                                double *__restrict__ bufS) {
-  constexpr int D = NTOP + 2 * NSIDE;
+  constexpr int D = NTOP + 2 * NSIDE, TI = TSX_CV_TI, TK = TSX_CV_TK, ROWS = TK * D;
+  __shared__ double sm[ROWS][TI + 1];
   const int L = g.Nz + 1, xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
   const long long Nc = g.Nc;
-  const long long total = (long long)L * ncol;
-  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < total; q += (long long)gridDim.x * TSX_BLOCK) {
-    // q enumerates (i fastest, j, k) so that internal accesses coalesce
-    const int i = (int)(q % xm);
-    const long long t = q / xm;
-    const int j = (int)(t % ym);
-    const int k = (int)(t / ym);
-    const int col = j * xm + i;
-    double *__restrict__ rp = ref + (size_t)D * ((size_t)k + (size_t)L * ((size_t)i + (size_t)xm * j));
-    double *__restrict__ vt = v + (size_t)D * Nc;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      double *loc = nullptr;  // internal location of ref (d,k,i,j)
+  const int nti = (xm + TI - 1) / TI, ntk = (L + TK - 1) / TK;
+  const long long ntile = (long long)nti * ym * ntk;
+  double *__restrict__ vt = v + (size_t)D * Nc;
+  for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int ti = (int)(tile % nti);
+    const long long t2 = tile / nti;
+    const int j = (int)(t2 % ym), tk = (int)(t2 / ym);
+    const int i0 = ti * TI, k0 = tk * TK;
+    const int ni = xm - i0 < TI ? xm - i0 : TI, nk = L - k0 < TK ? L - k0 : TK;
+    // internal location of ref (d, k, i, j)
+    auto internal = [&](int d, int k, int i) -> double * {
+      const int col = j * xm + i;
       if (d < NTOP) {
-        if (tsx_inward(d)) loc = k >= 1 ? v + (size_t)d * Nc + ((size_t)(k - 1) * ym + j) * xm + i : vt + (size_t)d * ncol + col;
-        else loc = k < Nz ? v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + i : vt + (size_t)d * ncol + col;
-      } else if (k == Nz) {
-        loc = vt + (size_t)d * ncol + col;
-      } else if (d < NTOP + NSIDE) {
-        const int qd = d - NTOP;
-        if (!tsx_inward(qd)) loc = v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + i;
-        else if (i > 0) loc = v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + (i - 1);
-        else if (g.wrap_x) loc = v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + (xm - 1);
-        else loc = bufW + ((size_t)(qd >> 1) * Nz + k) * ym + j;
-      } else {
-        const int qd = d - NTOP - NSIDE;
-        if (!tsx_inward(qd)) loc = v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + i;
-        else if (j > 0) loc = v + (size_t)d * Nc + ((size_t)k * ym + (j - 1)) * xm + i;
-        else if (g.wrap_y) loc = v + (size_t)d * Nc + ((size_t)k * ym + (ym - 1)) * xm + i;
-        else loc = bufS + ((size_t)(qd >> 1) * Nz + k) * xm + i;
+        if (tsx_inward(d)) return k >= 1 ? v + (size_t)d * Nc + ((size_t)(k - 1) * ym + j) * xm + i : vt + (size_t)d * ncol + col;
+        return k < Nz ? v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + i : vt + (size_t)d * ncol + col;
       }
-      if (EXPORT) rp[d] = *loc;
-      else *loc = rp[d];
+      if (k == Nz) return vt + (size_t)d * ncol + col;
+      if (d < NTOP + NSIDE) {
+        const int qd = d - NTOP;
+        if (!tsx_inward(qd)) return v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + i;
+        if (i > 0) return v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + (i - 1);
+        if (g.wrap_x) return v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + (xm - 1);
+        return bufW + ((size_t)(qd >> 1) * Nz + k) * ym + j;
+      }
+      const int qd = d - NTOP - NSIDE;
+      if (!tsx_inward(qd)) return v + (size_t)d * Nc + ((size_t)k * ym + j) * xm + i;
+      if (j > 0) return v + (size_t)d * Nc + ((size_t)k * ym + (j - 1)) * xm + i;
+      if (g.wrap_y) return v + (size_t)d * Nc + ((size_t)k * ym + (ym - 1)) * xm + i;
+      return bufS + ((size_t)(qd >> 1) * Nz + k) * xm + i;
+    };
+    // reference side: column ii is the run ref[D * (k0 + L * (i0 + ii + xm * j)) + 0 .. nk * D)
+    auto refp = [&](int ii, int rem) { return ref + (size_t)D * ((size_t)k0 + (size_t)L * ((size_t)(i0 + ii) + (size_t)xm * j)) + rem; };
+    if (!EXPORT) {
+      for (int e = threadIdx.x; e < TI * ROWS; e += TSX_BLOCK) {
+        const int ii = e / ROWS, rem = e - ii * ROWS;
+        if (ii < ni && rem < nk * D) sm[rem][ii] = *refp(ii, rem);
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < TI * ROWS; e += TSX_BLOCK) {
+        const int rem = e / TI, ii = e - rem * TI;
+        const int kk = rem / D, d = rem - kk * D;
+        if (ii < ni && kk < nk) *internal(d, k0 + kk, i0 + ii) = sm[rem][ii];
+      }
+    } else {
+      for (int e = threadIdx.x; e < TI * ROWS; e += TSX_BLOCK) {
+        const int rem = e / TI, ii = e - rem * TI;
+        const int kk = rem / D, d = rem - kk * D;
+        if (ii < ni && kk < nk) sm[rem][ii] = *internal(d, k0 + kk, i0 + ii);
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < TI * ROWS; e += TSX_BLOCK) {
+        const int ii = e / ROWS, rem = e - ii * ROWS;
+        if (ii < ni && rem < nk * D) *refp(ii, rem) = sm[rem][ii];
+      }
     }
+    __syncthreads();
   }
 }
 
