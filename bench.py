@@ -251,8 +251,8 @@ def main():
         r_pass = None
         if pass_ms is not None:
             kname = "tsx_k_pcs_rb" if solver == "3_10" else "tsx_k_pcsh_rb"
-            r_pass = roof(f"{kname}<..., GS, MODE 0> (one intermediate red-black pass of M^-1)", pass_ms,
-                          s.algorithmic_bytes(3), [kname, (",true,0>", ",true,0,")])
+            r_pass = roof(f"{kname}<..., GS, MODE 0, RQ 2> (one intermediate red-black pass of M^-1)", pass_ms,
+                          s.algorithmic_bytes(3), [kname, (",true,0,true,2>", ",true,0,false,2>")])
         r_pc = None
         if pc_ms is not None:
             r_pc = {"kernel": f"M^-1: {sweeps + 1} half-grid passes", "ms_per_application": pc_ms,

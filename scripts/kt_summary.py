@@ -13,6 +13,7 @@ from collections import defaultdict
 
 
 def main():
+    assert sys.argv[1].endswith(".csv") and (len(sys.argv) < 3 or sys.argv[2].endswith(".json")), __doc__
     acc = defaultdict(list)
     with open(sys.argv[1], newline="") as f:
         for r in csv.DictReader(f):

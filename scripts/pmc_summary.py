@@ -43,6 +43,7 @@ def collect(path, counter):
 
 def main():
     key, out, fcsv, wcsv = sys.argv[1:5]
+    assert out.endswith(".json") and fcsv.endswith(".csv") and wcsv.endswith(".csv"), "usage: key out.json fetch.csv write.csv [passes]"
     F, W = collect(fcsv, "FETCH_SIZE"), collect(wcsv, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(F) | set(W)):
@@ -62,11 +63,17 @@ def main():
         }
     # one default iteration: 2 applications of M^-1 (pass 0 without neighbours, P - 3 intermediate, the fp32 pass, the last
     # pass; P = argv[5], default 14), 2 operator applies with fused dots, 3 vector updates
-    P = int(sys.argv[5]) if len(sys.argv) > 5 else 14
-    per_iter = [(r"tsx_k_pcsh?_rb<\d+,\d+,\d+,false,0", 2), (r"tsx_k_pcsh?_rb<\d+,\d+,\d+,true,0", 2 * (P - 3)),
-                (r"tsx_k_pcsh?_rb<\d+,\d+,\d+,true,1", 2), (r"tsx_k_pcsh?_rb<\d+,\d+,\d+,true,2", 2),
-                (r"tsx_k_spmv_w<\d+,\d+,\w+,1,\d,float,float", 1), (r"tsx_k_spmv_w<\d+,\d+,\w+,5,\d,float,double", 1),
-                (r"tsx_k_pupdate32", 1), (r"tsx_k_supdate", 1), (r"tsx_k_xrupdate", 1)]
+    P = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+    rb = r"tsx_k_pcsh?_rb<\d+,\d+,\d+,"
+    if any(re.match(rb + r"true,0,\w+,2", k) for k in kernels):
+        # bf16 right-hand side words: per application pass 0 (no neighbours, leaves the words), pass 1 (leaves the words),
+        # P - 4 passes that read them, the fp32 pass, the last pass
+        passes = [(rb + r"false,0,\w+,1", 2), (rb + r"true,0,\w+,1", 2), (rb + r"true,0,\w+,2", 2 * (P - 4)),
+                  (rb + r"true,1", 2), (rb + r"true,2", 2)]
+    else:
+        passes = [(rb + r"false,0", 2), (rb + r"true,0", 2 * (P - 3)), (rb + r"true,1", 2), (rb + r"true,2", 2)]
+    per_iter = passes + [(r"tsx_k_spmv_w<\d+,\d+,\w+,1,\d,float,float", 1), (r"tsx_k_spmv_w<\d+,\d+,\w+,5,\d,float,double", 1),
+                         (r"tsx_k_pupdate32", 1), (r"tsx_k_supdate", 1), (r"tsx_k_xrupdate", 1)]
     it_bytes, missing = 0.0, []
     for pat, mult in per_iter:
         hit = [v for name, v in kernels.items() if re.match(pat, name)]
