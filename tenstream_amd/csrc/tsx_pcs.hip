@@ -299,6 +299,8 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
     if (rc) return rc;
   }
   const bool rhs16 = tsx_pcs_rhs16(s);
+  static const int every_env = getenv("TSX_PC_HALO_EVERY") ? atoi(getenv("TSX_PC_HALO_EVERY")) : 1;
+  const int every = every_env > 0 ? every_env : 1;
   for (int pass = 0; pass < P; ++pass) {
     const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
     // a colour's intermediate visits are passes c, c + 2, ... < P - 2: the first leaves the bf16 right-hand side if another
@@ -306,7 +308,9 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
     const int rq = !rhs16 || mode != 0 ? 0 : (pass >= 2 ? 2 : (pass + 2 < P - 2 ? 1 : 0));
     int rc = tsx_pcs_pass(s, pass, mode, z, done, rq);
     if (rc) return rc;
-    if (halo && pass + 1 < P && (rc = pcs_halo_exchange(s, mode == 1, done))) return rc;  // what the next pass reads at the faces
+    // what the next passes read at the rank faces; TSX_PC_HALO_EVERY = n exchanges after passes 0, n, 2n, ... only (the
+    // passes in between see the neighbour rank's boundary columns n - 1 passes late at most)
+    if (halo && pass + 1 < P && pass % every == 0 && (rc = pcs_halo_exchange(s, mode == 1, done))) return rc;
   }
   HIPCHK(hipGetLastError());
   return TSX_OK;
