@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--pc", type=int, default=3,
                     help="0 none, 1 column-block Jacobi, 2 zebra line-GS over column blocks, 3 red-black GS over column blocks")
     ap.add_argument("--pc-sweeps", type=int, default=0, help="half-grid passes - 1; 0 = the library's choice")
+    ap.add_argument("--explicit", action="store_true", help="the explicit (stationary) solver instead of flexible BiCGStab "
+                    "(-solar_diff_explicit, src/pprts.F90:2799); a side measurement, the headline is the Krylov solve")
     ap.add_argument("--check-every", type=int, default=None, help="host looks at the convergence flag every n iterations (library default 4)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,12 +196,12 @@ def main():
     infos = []
     for _ in range(args.warmup):
         x.zero_()
-        s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every)
+        s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every, explicit_solver=int(args.explicit), maxit=10000 if args.explicit else None)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x.zero_()
-        infos.append(s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every))
+        infos.append(s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every, explicit_solver=int(args.explicit), maxit=10000 if args.explicit else None))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -212,8 +214,8 @@ def main():
     # SURVEY 8(d) also asks for a tight run (rtol 1e-8, atol 1e-30 as in tests/test_pprts_symmetry/tenstream.options) and
     # a warm start (previous solution as initial guess, default tolerances): reported in `config`, never part of `value`
     x.zero_()
-    tight = s.solve(b, x, rtol=1e-8, atol=1e-30, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every)
-    warm = s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every)
+    tight = s.solve(b, x, rtol=1e-8, atol=1e-30, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every, explicit_solver=int(args.explicit), maxit=10000 if args.explicit else None)
+    warm = s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every, explicit_solver=int(args.explicit), maxit=10000 if args.explicit else None)
 
     # ---- rooflines, HIP events on the solver's stream (tsx_bench_kernel): the operator apply, one whole iteration, and
     # the preconditioner (one application = pc_sweeps + 1 half-grid passes; one intermediate pass of the scan kernels)
@@ -263,7 +265,7 @@ def main():
         # scan kernels run, else the operator apply
         dominant = r_pass if r_pass is not None else r_spmv
         out = {
-            "metric": f"pprts {solver} diffuse-solve cells/s",
+            "metric": f"pprts {solver} diffuse-solve cells/s" + (" (explicit solver)" if args.explicit else ""),
             "value": value,
             "unit": "cells/s",
             "n_gpus": world,

@@ -97,6 +97,11 @@ typedef struct {
   int32_t skip_complete_initial_run; /* tsx_pprts_solve only.  0 (default): the first solve of a solution uid runs with tolerances
                                  at least as tight as tsx_determine_ksp_tolerances gives (-ksp_complete_initial_run,
                                  src/pprts.F90:4245-4256); the caller's looser values apply to the warm-started ones */
+  int32_t explicit_solver;    /* 0 (default): flexible BiCGStab.  1: the explicit (stationary) solver, -<prefix>explicit of
+                                 src/pprts.F90:2799 / explicit_ediff (src/pprts_explicit.F90:461-713): x += M^-1 (b - A x) with the
+                                 red-black sweeps (pc_sweeps + 1 half-grid passes per outer iteration = -pc_sub_it) until the
+                                 2-norm of the change (mean over ranks) is < atol or < rtol times the first iteration's; the
+                                 result's res_hist holds those norms, rnorm0 = residual(1); maxit as given */
 } tsx_ksp_opts;
 
 /* what `solve` stores on the solution: Niter_diff, diff_ksp_residual_history(100)

@@ -138,6 +138,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->fp32_directions = 1;
   o->pc_coeff_fp16 = 1;
   o->skip_complete_initial_run = 0;
+  o->explicit_solver = 0;
 }
 
 extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstrained_fraction, double *rtol,
@@ -894,8 +895,60 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
 // a zero initial guess with a second, more conservative solver (there: GMRES on the same preconditioner); only if that
 // fails too the negative reason is reported (and the caller aborts).  Here the second solver is the same flexible
 // BiCGStab on exact fp64 blocks and fp64 directions with the zebra-ordered exact column solves -- nothing reduced.
+// The explicit (stationary) solver on the internal vectors: x += M^-1 (b - A x) until the change of the iterate meets
+// explicit_ediff's stop rule (see tsx_k_defect / TSX_STAGE_EXPLICIT).  One outer iteration = one operator apply, one
+// application of the sweeps (pc_sweeps + 1 half-grid passes: the reference's -pc_sub_it), one update.
+template <int NTOP, int NSIDE, bool MIX>
+static int explicit_run_t(tsx_solver *s, const tsx_ksp_opts *o) {
+  using PT = typename std::conditional<MIX, float, double>::type;
+  const TsxGeo &g = s->geo;
+  int rc;
+  if (s->pc == TSX_PC_NONE) {
+    tsx_set_error("explicit solver: needs the sweeps (pc != TSX_PC_NONE)");
+    return TSX_ERR_ARG;
+  }
+  HIPCHK(hipEventRecord(s->ev0, s->stream));
+  TsxScalars init;
+  memset(&init, 0, sizeof(init));
+  init.rtol = o->rtol;
+  init.atol = o->atol;
+  init.dtol = o->dtol;
+  init.maxit = o->maxit;
+  init.nranks = s->grid.nranks > 1 ? s->grid.nranks : 1;
+  *s->scal_host = init;
+  HIPCHK(hipMemcpyAsync(s->scal, s->scal_host, sizeof(TsxScalars), hipMemcpyHostToDevice, s->stream));
+  const int nbv = grid_for(g.N);
+  const int chunk = o->check_every > 0 ? o->check_every : 2;
+  PT *z = (PT *)s->vph;
+  int enq = 0;
+  bool done = false;
+  while (!done) {
+    const int todo = (o->maxit - enq) < chunk ? (o->maxit - enq) : chunk;
+    for (int q = 0; q < todo; ++q, ++enq) {
+      if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vx, s->vt, (const double *)nullptr, true))) return rc;
+      if (MIX) {
+        hipLaunchKernelGGL(tsx_k_defect<float>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->scal, s->vb, s->vt, s->p32, g,
+                           (int)s->pc_split);
+        s->pc_rhs = s->p32;
+      } else {
+        hipLaunchKernelGGL(tsx_k_defect<double>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->scal, s->vb, s->vt, s->vp, g, 0);
+      }
+      if ((rc = tsx_pc_apply(s, s->vp, z, MIX, true))) return rc;
+      hipLaunchKernelGGL(tsx_k_xplus<PT>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->scal, s->vx, (const PT *)z, s->partials);
+      if ((rc = scalar_stage(s, nbv, 1, TSX_STAGE_EXPLICIT))) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(s->scal_host, s->scal, sizeof(TsxScalars), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    done = s->scal_host->done != 0 || enq >= o->maxit;
+  }
+  HIPCHK(hipEventRecord(s->ev1, s->stream));
+  return TSX_OK;
+}
+
 template <int NTOP, int NSIDE>
 static int krylov_run_with_retry(tsx_solver *s, tsx_ksp_opts *o) {
+  if (o->explicit_solver)
+    return s->mixed ? explicit_run_t<NTOP, NSIDE, true>(s, o) : explicit_run_t<NTOP, NSIDE, false>(s, o);
   int rc = krylov_run<NTOP, NSIDE>(s, o);
   if (rc) return rc;
   const int reason = s->scal_host->done ? s->scal_host->reason : -3;

@@ -47,6 +47,7 @@ struct TsxScalars {
   int done;
   int nhist;
   int restart;   // set by the host before a breakdown restart: INIT keeps its / history / rnorm0
+  int nranks;    // explicit solver: its residual is the mean over ranks of the local norms
   double hist[100];
 };
 

@@ -125,10 +125,36 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xrupdate(long long n2, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The explicit (stationary) solver, explicit_ediff of src/pprts_explicit.F90:461-713 on the device: sweeps until the change
+// of the iterate is small.  One outer iteration is a defect correction, x += M^-1 (b - A x), with M^-1 = the red-black passes
+// of the preconditioner -- for a stationary method, continuing the sweeps from x and sweeping on the defect from zero are the
+// same iterate.  d = b - y (y = A x), in the layout / precision the sweeps read their right-hand side in
+template <typename DT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_defect(long long n, const TsxScalars *__restrict__ sc, const double *__restrict__ b,
+                                                          const double *__restrict__ y, DT *__restrict__ d, TsxGeo g, int split) {
+  if (sc->done) return;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK)
+    d[split ? tsx_split_pos(q, g) : q] = (DT)(b[q] - y[q]);
+}
+// x += z; slot0 = (z, z): the change of the iterate, which is what the reference's stop rule measures (:616-617)
+template <typename ZT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xplus(long long n, const TsxScalars *__restrict__ sc, double *__restrict__ x,
+                                                         const ZT *__restrict__ z, double *__restrict__ partials) {
+  if (sc->done) return;
+  double sum[1] = {0.0};
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double zz = (double)z[q];
+    x[q] += zz;
+    sum[0] += zz * zz;
+  }
+  tsx_block_reduce_store<1>(sum, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Scalar stage: one block.  mode bit0: reduce the per-block partials into sc->red (fixed order);
 // mode bit1: run the stage's scalar algebra (after the all-reduce when ranks > 1).
 // Stop rule restates MyKSPConverged (src/pprts.F90:4437-4486).
-enum { TSX_STAGE_INIT = 0, TSX_STAGE_ALPHA = 1, TSX_STAGE_OMEGA = 2, TSX_STAGE_RHO = 3 };
+enum { TSX_STAGE_INIT = 0, TSX_STAGE_ALPHA = 1, TSX_STAGE_OMEGA = 2, TSX_STAGE_RHO = 3, TSX_STAGE_EXPLICIT = 4 };
 
 __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc, const double *__restrict__ partials,
                                                      int nblocks, int nslots, int stage, int mode) {
@@ -149,6 +175,9 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
         for (int q = 0; q < 16; ++q) v += sm[s][q];
         sc->red[s] = v;
       }
+      // the explicit solver's residual is the *mean over ranks of the local norms* of the change (imp_allreduce_mean,
+      // src/pprts_explicit.F90:620): take the root before the sum over ranks
+      if (stage == TSX_STAGE_EXPLICIT) sc->red[0] = sqrt(sc->red[0]) / (double)(sc->nranks > 0 ? sc->nranks : 1);
     }
     __syncthreads();
   }
@@ -213,6 +242,24 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
         sc->done = 1;
       } else {
         sc->beta = (sc->rho / sc->rho_old) * (sc->alpha / sc->omega);
+      }
+    } break;
+    case TSX_STAGE_EXPLICIT: {  // stop rule of explicit_ediff (src/pprts_explicit.F90:616-650)
+      const double res = sc->red[0];  // residual(iter) = |x_new - x_old|_2, mean over ranks
+      sc->its += 1;
+      if (sc->its == 1) sc->rnorm0 = res;  // residual(1)
+      sc->rnorm = res;
+      sc->hist[(sc->its < 100 ? sc->its : 100) - 1] = res;
+      sc->nhist = sc->its < 100 ? sc->its : 100;
+      const double rel = sc->rnorm0 <= 1.4916681462400413e-154 ? 0.0 : res / sc->rnorm0;  // sqrt(tiny)
+      int reason = 0;
+      if (res < sc->atol) reason = 3;        // CONVERGED_ATOL is tested (and reported) first
+      else if (rel < sc->rtol) reason = 2;
+      else if (res != res) reason = -9;
+      else if (sc->its >= sc->maxit) reason = -3;  // "did not converge"
+      if (reason) {
+        sc->reason = reason;
+        sc->done = 1;
       }
     } break;
   }

@@ -44,6 +44,7 @@ module m_pprts_hip
     integer(c_int32_t) :: fp32_directions
     integer(c_int32_t) :: pc_coeff_fp16
     integer(c_int32_t) :: skip_complete_initial_run   ! 0 (default): -ksp_complete_initial_run semantics, src/pprts.F90:4245-4256
+    integer(c_int32_t) :: explicit_solver             ! 1: explicit_ediff's stationary iteration instead of the Krylov solve
   end type
 
   type, bind(C) :: t_tsx_ksp_result

@@ -272,8 +272,9 @@ class DiffuseSolver:
         return rtol.value, atol.value, maxit.value
 
     def solve(self, b, x, *, rtol=None, atol=None, maxit=None, dtol=None, pc=None, pc_sweeps=None,
-              check_every=None, fp32_directions=None, pc_coeff_fp16=None) -> KspInfo:
-        """Solve in place: x holds the initial guess on entry (src/pprts.F90:4343) and the solution on exit."""
+              check_every=None, fp32_directions=None, pc_coeff_fp16=None, explicit_solver=None) -> KspInfo:
+        """Solve in place: x holds the initial guess on entry (src/pprts.F90:4343) and the solution on exit.
+        explicit_solver=1: explicit_ediff's stationary iteration (-<prefix>explicit, src/pprts.F90:2799) instead of FBCGS."""
         if tuple(b.shape) != self.vec_shape or tuple(x.shape) != self.vec_shape:
             raise ValueError("b/x shape mismatch")
         o = _lib.KspOpts()
@@ -282,7 +283,7 @@ class DiffuseSolver:
         o.rtol, o.atol, o.maxit = drt, dat, dmx
         for name, val in (("rtol", rtol), ("atol", atol), ("maxit", maxit), ("dtol", dtol), ("pc", pc),
                           ("pc_sweeps", pc_sweeps), ("check_every", check_every), ("fp32_directions", fp32_directions),
-                          ("pc_coeff_fp16", pc_coeff_fp16)):
+                          ("pc_coeff_fp16", pc_coeff_fp16), ("explicit_solver", explicit_solver)):
             if val is not None:
                 setattr(o, name, val)
         bp, where = _ptr(b, np.float64)

@@ -137,6 +137,17 @@ def _worker(rank, world, port, solver, Nx, Ny, Nz, ret):
         info2 = s.solve(np.ascontiguousarray(P["b"][sl]), x2, rtol=1e-10, atol=1e-30)
         e_solve = max(e_solve, float(np.abs(x2 - x_ref[sl]).max() / np.abs(x_ref).max()))
         assert info2.reason == 2, info2
+        # the explicit (stationary) solver on several ranks: same fixed point; its residual is the mean over ranks of the
+        # local change norms (imp_allreduce_mean, src/pprts_explicit.F90:620), so every rank reports the same history
+        x3 = np.zeros(s.vec_shape)
+        info3 = s.solve(np.ascontiguousarray(P["b"][sl]), x3, explicit_solver=1, rtol=1e-11, atol=1e-30, maxit=3000, pc_sweeps=5)
+        assert info3.reason == 2, info3
+        e_solve = max(e_solve, float(np.abs(x3 - x_ref[sl]).max() / np.abs(x_ref).max()))
+        h3 = torch.tensor([float(info3.res_hist[0]), float(info3.niter)], dtype=torch.float64)
+        hmax, hmin = h3.clone(), h3.clone()
+        dist.all_reduce(hmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(hmin, op=dist.ReduceOp.MIN)
+        assert torch.equal(hmax, hmin), (hmax, hmin)
         ret[rank] = (e_apply, e_solve, info.reason, info.niter, float(info.res_hist[0]), float(np.linalg.norm(P["b"])))
         s.close()
     finally:

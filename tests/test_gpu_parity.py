@@ -127,6 +127,46 @@ def test_solve_default_tolerances_and_warm_start(gpu):
     assert info2.niter < info.niter and info2.reason in (2, 3)
 
 
+@pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d,mixed", [("3_10", 12, 10, 8, 0, 1), ("3_10", 7, 5, 6, 2, 1), ("3_10", 16, 8, 20, 3, 0),
+                                                        ("8_16", 8, 6, 5, 1, 1)])
+def test_explicit_solver_shares_the_fixed_point_and_the_stop_rule_of_explicit_ediff(gpu, solver, Nx, Ny, Nz, n1d, mixed):
+    """-<prefix>explicit (src/pprts.F90:2799): explicit_ediff (src/pprts_explicit.F90:461-713) sweeps until the 2-norm of the
+    iterate's change is < atol or < rtol x the first iteration's.  The device's sweeps are the red-black column-block passes
+    (a different sweep order than the reference's cell-by-cell SOR, so the iterates differ), the fixed point A x = b and the
+    stop rule are the reference's: converged tightly it equals the oracle's explicit solver and the Krylov solve; the history
+    holds the change norms and the rule is the strict '<' on them."""
+    P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
+    lay = O.layout(solver, Nz, Nx, Ny)
+    s = DiffuseSolver(solver, Nz, Nx, Ny)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x = np.zeros(s.vec_shape)
+    info = s.solve(P["b"], x, explicit_solver=1, rtol=1e-11, atol=1e-30, maxit=2000, pc_sweeps=3, fp32_directions=mixed)
+    assert info.reason == 2 and info.niter > 3
+    h = info.res_hist
+    assert info.rnorm0 == h[0] and len(h) == min(info.niter, 100)
+    assert h[-1] / h[0] < 1e-11 if info.niter <= 100 else True
+    if info.niter <= 100:   # strict '<' on the change norms: the iteration before the last did not satisfy it
+        assert h[-2] / h[0] >= 1e-11
+    assert np.all(np.diff(h[: min(len(h), 30)]) < 0)   # a contraction: the change shrinks monotonically
+    xk = np.zeros(s.vec_shape)
+    ik = s.solve(P["b"], xk, rtol=1e-12, atol=1e-30, maxit=3000)
+    assert ik.reason == 2
+    assert np.abs(x - xk).max() <= 1e-8 * np.abs(xk).max()
+    if solver == "3_10":   # the oracle's restatement of the reference's explicit solver (3_10 sweep)
+        c64 = P["coeff"].astype(np.float64)
+        xo, io = O.solve_sor(lay, c64, P["l1d"], P["a11"], P["a12"], P["albedo"], P["b"], rtol=1e-11, atol=1e-30, maxit=10000)
+        assert io["converged"]
+        assert np.abs(x - xo).max() <= 1e-8 * np.abs(xo).max()
+    # atol is tested first and reported as reason 3; maxit exhausted is -3 (CHKERR 'did not converge' in the reference)
+    x2 = np.zeros(s.vec_shape)
+    i2 = s.solve(P["b"], x2, explicit_solver=1, rtol=1e-30, atol=1e-3 * h[0], maxit=2000, pc_sweeps=3, fp32_directions=mixed)
+    assert i2.reason == 3 and i2.res_hist[-1] < 1e-3 * h[0] <= i2.res_hist[-2]
+    x3 = np.zeros(s.vec_shape)
+    i3 = s.solve(P["b"], x3, explicit_solver=1, rtol=1e-30, atol=1e-300, maxit=3, pc_sweeps=3, fp32_directions=mixed)
+    assert i3.reason == -3 and i3.niter == 3
+    s.close()
+
+
 @pytest.mark.parametrize("solver", ["3_10", "8_16"])
 def test_repeated_coefficient_updates_and_solves_leak_no_device_memory(gpu, solver):
     """A spectral loop hands over new blocks and solves hundreds of times per call (src/pprts.F90:2281-2300 per g-point):
