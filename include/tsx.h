@@ -125,7 +125,8 @@ int tsx_device_count(void);
 int tsx_create(const tsx_grid *grid, tsx_solver **out);
 int tsx_destroy(tsx_solver *s);
 void tsx_default_ksp_opts(tsx_ksp_opts *o);
-/* determine_ksp_tolerances (src/pprts_base.F90:1097-1142): rtol 1e-5, atol max(1e-8, 1e-4*Nx*Ny*(Nz+1)*f) */
+/* determine_ksp_tolerances (src/pprts_base.F90:1097-1142): rtol 1e-5, atol max(1e-8, 1e-4*Nx*Ny*(Nz+1)*f);
+ * f = unconstrained_fraction (share of layers that are not 1-D, src/pprts.F90:716-724); f < 0: the solver's own count */
 int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstrained_fraction, double *rtol,
                                  double *atol, int32_t *maxit);
 /* run on an existing HIP stream (hipStream_t as void*), e.g. the caller's current stream; NULL = own stream */
@@ -200,6 +201,10 @@ int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int where, const t
  * (:184), setup_b needs no exchange in dst-owned storage, and the flux divergence reads one halo update of the solution. */
 /* set_angles (src/pprts.F90:1100-1183): sun azimuth phi0 / zenith theta0 in degrees as pprts_f2c_init takes them */
 int tsx_pprts_set_angles(tsx_solver *s, double phi0, double theta0);
+/* stop rule of the direct sweep (explicit_edir reads -solar_dir_ksp_rtol / _atol / _max_it, src/pprts_explicit.F90:94-121);
+ * a value <= 0 keeps the default of determine_ksp_tolerances / default_max_it; a uid's first solve never runs looser than
+ * the defaults (-ksp_complete_initial_run) */
+int tsx_pprts_set_direct_tolerances(tsx_solver *s, double rtol, double atol, int32_t maxit);
 /* direct tables Tdir (S*S per entry) and Sdir (S*D per entry; S = 3 / 8 for 3_10 / 8_16), 6 axes [tau, w0, aspect_zx, g, phi, theta]
  * (src/optprop_base.F90:228-240); same payload layout as the diffuse table */
 int tsx_lut_set_direct(tsx_solver *s, const float *Tdir, const float *Sdir, int64_t nentries, int32_t ndim,

@@ -18,6 +18,10 @@
  * 310 (3_10) or 816 (8_16);
  * collapseindex must be <= 1; look-up tables are read from $LUT_BASENAME (src/tenstream_options.F90:103-105)
  * in `.mmap4` form (src/mmap.F90), file names as gen_lut_basename builds them (src/optprop_LUT.F90:364-374).
+ * Options: like the reference's options database (src/options_database.F90:60-100) the library reads ./tenstream.options
+ * and then $PETSC_OPTIONS ("-key [value]", later overrides earlier) and acts on the keys of this path:
+ * -solar_diff_ksp_rtol / _atol / _max_it, -thermal_diff_ksp_*, -solar_dir_ksp_*, -solar_diff_explicit,
+ * -thermal_diff_explicit, -accept_incomplete_solve; everything else is ignored.
  */
 #ifndef TSX_F2C_H
 #define TSX_F2C_H

@@ -53,7 +53,7 @@ SYMBOLS = (
     "tsx_diff_set_coeffs", "tsx_lut_set_diffuse", "tsx_lut_load_diffuse_mmap4", "tsx_diff_set_optprop",
     "tsx_diff_get_coeffs", "tsx_pprts_set_angles", "tsx_lut_set_direct", "tsx_lut_load_direct_mmap4", "tsx_pprts_set_optprop", "tsx_pprts_set_optical_properties", "tsx_pprts_solve",
     "tsx_pprts_zero_guess", "tsx_pprts_get_result", "tsx_pprts_get_field", "tsx_diff_apply", "tsx_diff_solve", "tsx_diff_pc_apply", "tsx_bench_kernel", "tsx_algorithmic_bytes",
-    "tsx_probe_copy_bandwidth", "tsx_opp_get_coeff", "tsx_opp_get_info", "tsx_pprts_select_solution", "tsx_dedup_info", "tsx_pc_info",
+    "tsx_probe_copy_bandwidth", "tsx_opp_get_coeff", "tsx_opp_get_info", "tsx_pprts_select_solution", "tsx_dedup_info", "tsx_pc_info", "tsx_pprts_set_direct_tolerances",
 )
 
 _lib = None
@@ -105,6 +105,7 @@ def load():
     lib.tsx_probe_copy_bandwidth.argtypes = [vp, C.c_size_t, ip, dp]
     lib.tsx_opp_get_coeff.argtypes = [vp] + [C.c_float] * 6 + [ip, ip, ip, ip, vp]
     lib.tsx_dedup_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    lib.tsx_pprts_set_direct_tolerances.argtypes = [vp, C.c_double, C.c_double, C.c_int32]
     lib.tsx_pc_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.tsx_opp_get_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
     _lib = lib

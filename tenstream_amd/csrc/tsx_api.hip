@@ -147,6 +147,8 @@ extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstr
   // src/pprts_base.F90:1126-1131 with C = C_diff: glob_zm = Nz + 1
   *maxit = 1000;
   *rtol = 1e-5;
+  if (unconstrained_fraction < 0.0)  // the solver's own count of 1-D layers (after tsx_pprts_set_optical_properties)
+    unconstrained_fraction = s->geo.Nz > 0 ? 1.0 - (double)s->n1d / (double)s->geo.Nz : 1.0;
   double a = 1e-4 * (double)s->grid.glob_xm * (double)s->grid.glob_ym * (double)(s->grid.Nz + 1) * unconstrained_fraction;
   *atol = a > 1e-8 ? a : 1e-8;
   return TSX_OK;

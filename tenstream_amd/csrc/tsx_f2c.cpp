@@ -2,6 +2,7 @@
 // conversion (float32 -> ireals, minimal_dimension tiling, dz from hhl), the rank-0 scatter / gather semantics of the
 // reference wrapper, and the coefficient probe, around the device pipeline tsx_pprts_*; delta scaling, 1-D layer
 // detection and the Eddington coefficients run on the device (tsx_pprts_set_optical_properties).
+#include <ctype.h>
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
@@ -65,6 +66,77 @@ void bcast0(double *v, size_t n) {
   allsum(v, n);
 }
 
+// ---- the options the reference reads from its options database on this path (src/options_database.F90:60-100: later
+// sources override earlier ones; a library has no command line, so: ./tenstream.options, then $PETSC_OPTIONS).  "-key
+// [value]" pairs, '#' and '!' start comments.  Only the keys this back-end acts on are looked up:
+//   -<solar|thermal>_diff_ksp_rtol / _ksp_atol / _ksp_max_it   (KSPSetFromOptions, src/pprts.F90:4258-4260)
+//   -<solar|thermal>_diff_explicit                               (src/pprts.F90:2795-2801)
+//   -solar_dir_ksp_rtol / _ksp_atol / _ksp_max_it                (explicit_edir, src/pprts_explicit.F90:94-112)
+//   -accept_incomplete_solve                                     (src/pprts.F90:4271-4273)
+struct Opt {
+  std::string key, val;
+};
+std::vector<Opt> g_opts;
+bool g_opts_loaded = false;
+
+void opts_insert_string(const std::string &text) {
+  std::vector<std::string> tok;
+  size_t i = 0;
+  while (i < text.size()) {
+    while (i < text.size() && isspace((unsigned char)text[i])) ++i;
+    size_t j = i;
+    while (j < text.size() && !isspace((unsigned char)text[j])) ++j;
+    if (j > i) tok.push_back(text.substr(i, j - i));
+    i = j;
+  }
+  auto is_key = [](const std::string &t) { return t.size() >= 2 && t[0] == '-' && !(isdigit((unsigned char)t[1]) || t[1] == '.'); };
+  for (size_t q = 0; q < tok.size(); ++q) {
+    if (!is_key(tok[q])) continue;
+    Opt o{tok[q].substr(1), ""};
+    if (q + 1 < tok.size() && !is_key(tok[q + 1])) o.val = tok[++q];
+    bool found = false;
+    for (Opt &e : g_opts)
+      if (e.key == o.key) {
+        e.val = o.val;
+        found = true;
+      }
+    if (!found) g_opts.push_back(o);
+  }
+}
+void opts_load() {
+  if (g_opts_loaded) return;
+  g_opts_loaded = true;
+  if (FILE *f = fopen("tenstream.options", "r")) {
+    char line[4096];
+    while (fgets(line, sizeof(line), f)) {
+      std::string l(line);
+      const size_t c = l.find_first_of("#!");
+      if (c != std::string::npos) l.resize(c);
+      opts_insert_string(l);
+    }
+    fclose(f);
+  }
+  if (const char *e = getenv("PETSC_OPTIONS")) opts_insert_string(e);
+}
+const Opt *opt_find(const std::string &key) {
+  opts_load();
+  for (const Opt &e : g_opts)
+    if (e.key == key) return &e;
+  return nullptr;
+}
+bool opt_real(const std::string &key, double *v) {
+  const Opt *o = opt_find(key);
+  if (!o || o->val.empty()) return false;
+  *v = atof(o->val.c_str());
+  return true;
+}
+bool opt_bool(const std::string &key, bool dflt) {  // PetscOptionsGetBool: a bare key means true
+  const Opt *o = opt_find(key);
+  if (!o) return dflt;
+  const std::string &v = o->val;
+  return v.empty() || v == "1" || v == "true" || v == "TRUE" || v == "yes" || v == "on" || v == ".true.";
+}
+
 // setup_coord_native (src/pprts_base.F90:721-828): dims = MPI_Dims_create(nranks, 2) = [nyp, nxp] with nyp >= nxp, ranks
 // x-fastest, even split xs = (xi * Nx) / nxp, periodic neighbours
 void decompose(int nranks, int *nxp, int *nyp) {
@@ -116,6 +188,8 @@ extern "C" void pprts_f2c_init(int fcomm, int *solver_id, int *Nz, int *Nx, int 
       die("seems you changed the solver type id in between calls... you must destroy the solver first");
     return;
   }
+  g_opts.clear();  // a new solver reads the options anew (the reference reads them once per PetscInitialize)
+  g_opts_loaded = false;
   // rank 0's values reach every rank and overwrite the caller's (imp_bcast, f2c_pprts.F90:189-230)
   double head[9] = {(double)*solver_id, (double)*Nz, (double)*Nx, (double)*Ny, *dx, *dy, (double)*phi0, (double)*theta0,
                     (double)*collapseindex};
@@ -248,8 +322,28 @@ extern "C" void pprts_f2c_solve(int fcomm, float edirTOA) {
   bcast0(&e, 1);
   const int lsolar = e > 0;  // lthermal = .not. lsolar, f2c_pprts.F90:340-341
   tsx_ksp_result res;
-  chk(tsx_pprts_solve(g_st.h, e, lsolar, nullptr, &res), "tsx_pprts_solve");
-  if (res.reason <= 0)  // src/pprts.F90:4298-4302
+  // tolerances and solver choice as the options database gives them (defaults: determine_ksp_tolerances, FBCGS)
+  const std::string pre = lsolar ? "solar_diff_" : "thermal_diff_";
+  tsx_ksp_opts o;
+  tsx_default_ksp_opts(&o);
+  int32_t mx;
+  chk(tsx_determine_ksp_tolerances(g_st.h, -1.0, &o.rtol, &o.atol, &mx), "tsx_determine_ksp_tolerances");
+  o.maxit = mx;
+  double v;
+  if (opt_real(pre + "ksp_rtol", &v)) o.rtol = v;
+  if (opt_real(pre + "ksp_atol", &v)) o.atol = v;
+  if (opt_real(pre + "ksp_max_it", &v)) o.maxit = (int32_t)v;
+  o.explicit_solver = opt_bool(pre + "explicit", false) ? 1 : 0;
+  if (o.explicit_solver && !opt_find(pre + "ksp_max_it")) o.maxit = 10000;  // default_max_it, src/pprts_explicit.F90:474
+  if (lsolar) {
+    double rt = -1, at = -1, mi = -1;
+    opt_real("solar_dir_ksp_rtol", &rt);
+    opt_real("solar_dir_ksp_atol", &at);
+    opt_real("solar_dir_ksp_max_it", &mi);
+    chk(tsx_pprts_set_direct_tolerances(g_st.h, rt, at, (int32_t)mi), "tsx_pprts_set_direct_tolerances");
+  }
+  chk(tsx_pprts_solve(g_st.h, e, lsolar, &o, &res), "tsx_pprts_solve");
+  if (res.reason <= 0 && !opt_bool("accept_incomplete_solve", false))  // src/pprts.F90:4271-4273, 4298-4302
     die("***** SOLVER did NOT converge :( -- KSP reason " + std::to_string(res.reason));
 }
 

@@ -143,6 +143,8 @@ struct tsx_solver {
   int cur_uid;         // which uid the working vectors vx / edir_a belong to
   bool guess_foreign;  // the working vectors hold another uid's solution as initial guess (any kind of radiation)
   int niter_dir;
+  double dir_rtol = -1.0, dir_atol = -1.0;  // direct sweep: caller's -solar_dir_ksp_rtol / _atol / _max_it (< 0: defaults)
+  int dir_maxit = -1;
 
   void *nccl_comm;     // ncclComm_t when nranks > 1 (or force_halo with comm)
   bool comm_ready;

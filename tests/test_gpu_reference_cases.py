@@ -85,6 +85,81 @@ def test_config1_pprts_ex1_through_the_reference_c_abi(gpu, tmp_path, monkeypatc
     assert abs(edir[0, 0, 0] - 1.0) < 1e-6 and edir[0, 0, -1] < edir[0, 0, 0]
 
 
+def test_f2c_reads_the_options_of_this_path(gpu, tmp_path, monkeypatch):
+    """The reference takes tolerances and the solver choice from its options database (./tenstream.options, then
+    $PETSC_OPTIONS, src/options_database.F90:60-100).  With the option file of tests/test_pprts_symmetry (rtol 1e-8, atol
+    1e-30 for the direct and the diffuse solve) the C-ABI result equals a tightly converged oracle pipeline to real32
+    precision, which the default tolerances (rtol 1e-5) do not reach; -solar_diff_explicit from $PETSC_OPTIONS selects the
+    explicit solver and arrives at the same fluxes."""
+    from test_gpu_pipeline import _oracle_pipeline
+
+    Nx, Ny, Nz = 6, 4, 10
+    dx, dz, Ag, S0, phi0, theta0 = 100.0, 50.0, 0.15, 1000.0, 200.0, 40.0
+    base, dims, dax, Tdir, Sdir = _write_luts(tmp_path)
+    monkeypatch.setenv("LUT_BASENAME", base)
+    monkeypatch.setenv("TSX_LUT_DIRECT_DIMS", dims)
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(5)
+    kabs = (1e-4 * rng.lognormal(0.0, 0.5, (Ny, Nx, Nz))).astype(np.float32)
+    ksca = (2e-3 * rng.lognormal(0.0, 1.0, (Ny, Nx, Nz))).astype(np.float32)
+    g = np.full((Ny, Nx, Nz), 0.5, dtype=np.float32)
+    hhl = (np.float32(dz) * (Nz - np.arange(Nz + 1))).astype(np.float32)
+    f2c = C.CDLL(os.path.join(ROOT, "tenstream_amd", "lib", "libtsx_f2c.so"))
+    f2c.pprts_f2c_solve.argtypes = [C.c_int, C.c_float]
+    f2c.pprts_f2c_destroy.argtypes = [C.c_int]
+    i32 = lambda v: C.byref(C.c_int(v))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+
+    def run():
+        f2c.pprts_f2c_init(0, i32(310), i32(Nz), i32(Nx), i32(Ny), C.byref(C.c_double(dx)), C.byref(C.c_double(dx)), fp(hhl),
+                           C.byref(C.c_float(phi0)), C.byref(C.c_float(theta0)), i32(1))
+        alb = C.c_float(Ag)
+        f2c.pprts_f2c_set_global_optical_properties(Nz, Nx, Ny, C.byref(alb), fp(kabs), fp(ksca), fp(g), None)
+        f2c.pprts_f2c_solve(0, S0)
+        edn, eup, edir = (np.zeros((Ny, Nx, Nz + 1), dtype=np.float32) for _ in range(3))
+        abso = np.zeros((Ny, Nx, Nz), dtype=np.float32)
+        f2c.pprts_f2c_get_result(Nz, Nx, Ny, fp(edn), fp(eup), fp(abso), fp(edir))
+        f2c.pprts_f2c_destroy(0)
+        return dict(edn=edn, eup=eup, redir=edir, abso=abso)
+
+    # reference: the oracle pipeline with a hard-converged direct beam and a tight diffuse solve
+    P = PprtsSolver(Nz, Nx, Ny, dx, dx, phi0, theta0)
+    P.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
+    P.set_lut_direct(Tdir, Sdir, dax)
+    dzf = np.broadcast_to(hhl[:-1].astype(np.float64) - hhl[1:].astype(np.float64), (Ny, Nx, Nz))
+    P.set_optical_properties(float(np.float32(Ag)), kabs.astype(np.float64), ksca.astype(np.float64), g.astype(np.float64), dzf)
+    F = P.fields
+    lay, dlay, sun = O.layout("3_10", Nz, Nx, Ny), O.dir_layout("3_10"), O.suninfo(phi0, theta0)
+    Ld = O.make_lut(lut.diffuse_axes("3_10"), lut.synthetic_diffuse_table("3_10"))
+    c = O.alloc_coeff_diff2diff(Ld, F["kabs"], F["ksca"], F["g"], F["dz"], dx, P.l1d)
+    LT, LS = O.make_lut(dax, Tdir), O.make_lut(dax, Sdir)
+    t = O.alloc_coeff_dir(LT, True, F["kabs"], F["ksca"], F["g"], F["dz"], dx, sun, P.l1d)
+    sd = O.alloc_coeff_dir(LS, False, F["kabs"], F["ksca"], F["g"], F["dz"], dx, sun, P.l1d)
+    edir, di = O.explicit_edir(lay, dlay, sun, t, P.l1d, F["a33"], S0, dx, dx, rtol=1e-13, atol=1e-30, maxit=2000)
+    b = O.setup_b_solar(lay, dlay, sun, sd, P.l1d, F["a13"], F["a23"], F["albedo"], edir)
+    x, info = O.solve_ilu(lay, c, P.l1d, F["a11"], F["a12"], F["albedo"], b, rtol=1e-12, atol=1e-30, maxit=3000)
+    ediff = O.scale_diff(lay, F["dz"], dx, dx, True, x)
+    edirw = O.scale_dir(lay, dlay, F["dz"], dx, dx, True, edir)
+    abso = O.calc_flx_div(lay, dlay, sun, t, sd, c, P.l1d, F["a11"], F["a12"], F["kabs"], F["dz"], dx, dx, edir, x, None)
+    redn, reup, rabso, redir = O.get_result(lay, dlay, sun, True, edirw, ediff, abso)
+    ref = dict(edn=redn, eup=reup, abso=rabso, redir=redir)
+    P.close()
+
+    def err(res):
+        return max(np.abs(res[k] - ref[k]).max() / np.abs(ref[k]).max() for k in ("edn", "eup", "abso", "redir"))
+
+    monkeypatch.delenv("PETSC_OPTIONS", raising=False)
+    e_default = err(run())
+    (tmp_path / "tenstream.options").write_text(
+        "# as tests/test_pprts_symmetry/tenstream.options\n-solar_dir_ksp_rtol 1e-8\n-solar_diff_ksp_rtol 1e-8\n"
+        "-solar_dir_ksp_atol 1e-30   ! comment\n-solar_diff_ksp_atol 1e-30\n-diff_ksp_monitor\n")
+    e_tight = err(run())
+    assert e_tight <= 2e-6 and e_default > 3.0 * e_tight, (e_default, e_tight)
+    monkeypatch.setenv("PETSC_OPTIONS", "-solar_diff_explicit -solar_diff_ksp_rtol 1e-9")   # overrides the file's 1e-8
+    e_explicit = err(run())
+    assert e_explicit <= 2e-6, e_explicit
+
+
 @pytest.mark.parametrize("phi_a,phi_b", [(10.0, 190.0), (100.0, 280.0)])
 def test_pprts_symmetry_ex1(gpu, phi_a, phi_b):
     """tests/test_pprts_symmetry/test_pprts_symmetry.F90:394-516: 5x5x5 box (dx = dy = dz = 100, albedo 0, S0 = 1000,
