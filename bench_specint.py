@@ -46,6 +46,8 @@ def parse(argv=None):
     ap.add_argument("--ny", type=int, default=256)
     ap.add_argument("--nz", type=int, default=64)
     ap.add_argument("--nz-background", type=int, default=16, help="thick background layers on top of the dynamics grid (1-D rows)")
+    ap.add_argument("--streams", type=int, default=4, help="solver instances (HIP streams + host threads) working on different "
+                    "g-points at the same time")
     ap.add_argument("--calls", type=int, default=2, help="radiation calls (time steps); the first one is cold")
     ap.add_argument("--pc-sweeps", type=int, default=0, help="0 = library default")
     ap.add_argument("--phi0", type=float, default=180.0)
@@ -91,11 +93,19 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
     T = torch.linspace(220.0, 288.0, Nz + 1, dtype=torch.float64, device=dev)
     planck0 = (5.670374419e-8 * T**4 / np.pi).expand(Ny, Nx, Nz + 1).contiguous()
 
-    P = PprtsSolver(Nz, Nx, Ny, dx, dx, args.phi0, args.theta0, device=dev.index)
-    P.set_lut_diffuse(LUT.synthetic_diffuse_table("3_10"), LUT.diffuse_axes("3_10"))
+    # --streams K: K solver instances, each with its own HIP stream and host thread, work on different g-points at the same
+    # time (the library is re-entrant per instance; ctypes calls release the GIL).  On 256 x 256 columns one g-point fills the
+    # chip; on small domains several in flight do
+    K = max(1, args.streams)
     dax = LUT.direct_axes()
     Tdir, Sdir = LUT.synthetic_direct_tables(dax)
-    P.set_lut_direct(Tdir, Sdir, dax)
+    Ps = []
+    for _ in range(K):
+        Pk = PprtsSolver(Nz, Nx, Ny, dx, dx, args.phi0, args.theta0, device=dev.index)
+        Pk.set_lut_diffuse(LUT.synthetic_diffuse_table("3_10"), LUT.diffuse_axes("3_10"))
+        Pk.set_lut_direct(Tdir, Sdir, dax)
+        Ps.append(Pk)
+    P = Ps[0]
 
     rng = np.random.default_rng(7)
     ng = args.sw + args.lw
@@ -105,13 +115,17 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
     mine = list(range(lo, hi))
 
     L = Nz + 1
-    acc = [torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev), torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev),
-           torch.zeros((Ny, Nx, Nz), dtype=torch.float64, device=dev), torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev)]
-    tmp = [torch.empty_like(a) for a in acc]
+    new_acc = lambda: [torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev), torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev),
+                       torch.zeros((Ny, Nx, Nz), dtype=torch.float64, device=dev), torch.zeros((Ny, Nx, L), dtype=torch.float64, device=dev)]
+    acc = new_acc()
+    accs = [acc] + [new_acc() for _ in range(K - 1)]          # one accumulator and one scratch set per instance
+    tmps = [[torch.empty_like(a) for a in acc] for _ in range(K)]
+    tstreams = [torch.cuda.Stream(device=dev) for _ in range(K)] if K > 1 else [None]
     mu0 = float(np.cos(np.deg2rad(args.theta0)))
     shift = {"n": 0}
 
-    def run(q):
+    def run(q, w=0):
+        P, tmp, acc = Ps[w], tmps[w], accs[w]
         f = float(factors[q])
         lsolar = q < args.sw
         roll = lambda a: torch.roll(a, shifts=shift["n"], dims=1) if shift["n"] else a
@@ -134,15 +148,33 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
         torch.cuda.synchronize()
 
     calls = []
-    P.set_optical_properties(alb, kabs0, ksca0, g0, dz_d)   # allocations and first touch outside the timed loop
+    for Pk in Ps:
+        Pk.set_optical_properties(alb, kabs0, ksca0, g0, dz_d)   # allocations and first touch outside the timed loop
     n1d = int(P.l1d.sum())
     for call in range(args.calls):
         shift["n"] = call
-        for a in acc:
-            a.zero_()
+        for ac in accs:
+            for a in ac:
+                a.zero_()
         sync()
         t0 = time.perf_counter()
-        out = [run(q) for q in mine]
+        if K == 1:
+            out = [run(q) for q in mine]
+        else:
+            import concurrent.futures as cf
+
+            def work(w):   # a contiguous block of g-points per instance: the guess of uid - 1 stays with it
+                blk = mine[(w * len(mine)) // K:((w + 1) * len(mine)) // K]
+                with torch.cuda.stream(tstreams[w]):
+                    r = [run(q, w) for q in blk]
+                    tstreams[w].synchronize()
+                return r
+
+            with cf.ThreadPoolExecutor(K) as ex:
+                out = [o for part in ex.map(work, range(K)) for o in part]
+            for other in accs[1:]:
+                for a, t in zip(acc, other):
+                    a += t
         if all_reduce is not None:
             for a in acc:
                 all_reduce(a)
@@ -154,7 +186,8 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
                           reasons=sorted({int(i.reason) for i in infos}), diffuse_solve_ms_total=float(sum(i.solve_ms for i in infos)),
                           energy_balance_max=float(max((o[1] for o in out), default=0.0)),
                           toa_net_down_Wm2=float((acc[0][:, :, 0] + acc[3][:, :, 0] - acc[1][:, :, 0]).mean())))
-    P.close()
+    for Pk in Ps:
+        Pk.close()
     return dict(ng=ng, rank_gpoints=len(mine), n1d_layers=n1d, calls=calls, mu0=mu0)
 
 
@@ -185,7 +218,7 @@ def main():
             "seconds": secs[last], "higher_is_better": True, "scaling": "strong", "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.sw} SW + {args.lw} LW g-points on {Nx}x{Ny}x{Nz} ({R['n1d_layers']} thick background layers "
                                    f"as 1-D rows), whole pipeline per g-point on the device, one solution uid per g-point, "
-                                   f"g-points dealt in blocks to the GPUs, results all-reduced once; value = radiation call {last + 1} "
+                                   f"g-points dealt in blocks to the GPUs" + (f" and to {args.streams} concurrent solver instances per GPU" if args.streams > 1 else "") + ", results all-reduced once; value = radiation call {last + 1} "
                                    f"of {len(secs)} (call 1 is cold: guess from the previous g-point)",
                        "cells_gpoints_per_s": ng * Nx * Ny * Nz / secs[last], "rank0_gpoints": R["rank_gpoints"],
                        "calls": [dict(c, seconds=s_, gpoints_per_s=ng / s_) for c, s_ in zip(R["calls"], secs)]}}))
