@@ -1160,12 +1160,13 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
     //   3_10, every cell's records: 8 records x 16 B + rhs 10 x 4 B + 4 neighbour records x 4 B (bf16 pairs) + 4 x 4 B
     //         stored = 200;  first: 3 records + rhs + stores = 104;  fp32 pass 224;  last 320
     //   3_10, shared: record 0 (the column recurrence) stays per cell, records 1..7 per distinct block behind the index:
-    //         16 + 4 + 40 + 16 + 16 = 92 (+112 per block);  first 76 (+32);  fp32 116;  last 212
+    //         16 (the intermediate passes' copy carries the block index in the word of A_k, which they never use) + 40 + 16
+    //         + 16 = 88 (+112 per block);  first 72 (+32);  fp32 pass 16 + 4 + ... = 116;  last 212
     //   8_16, every cell's records: 12 recurrence records (14 in the fp32 passes) + 16 block records (8 in the first pass)
     //         + rhs 16 x 4 B + 4 neighbour records + 4 stored = 544;  first 400;  fp32 624;  last 768
     //   8_16, shared: the 16 block records per distinct block: 292 (+256);  first 276 (+128);  fp32 372;  last 516
     const bool h = g.ntop == 8;
-    const double cell[2][2][4] = {{{200, 104, 224, 320}, {92, 76, 116, 212}}, {{544, 400, 624, 768}, {292, 276, 372, 516}}};
+    const double cell[2][2][4] = {{{200, 104, 224, 320}, {88, 72, 116, 212}}, {{544, 400, 624, 768}, {292, 276, 372, 516}}};
     const double ent[2][2] = {{112, 32}, {256, 128}};
     const double *c = cell[h][dd];
     const double half = 0.5 * Nc, e_gs = dd ? nent * ent[h][0] : 0.0, e_first = dd ? nent * ent[h][1] : 0.0;

@@ -145,6 +145,17 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent(int ncol, long l
   }
 }
 
+// ---- record 0 for the intermediate passes where the blocks are shared: they never use A_k (the last fp16 of record 0), so a
+// second copy carries the cell's block index in that word -- one 16-byte load instead of record 0 + index (20 B)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_r0g(long long Nc, const uint4 *__restrict__ P0,
+                                                                const int *__restrict__ cidx_split, uint4 *__restrict__ P0G) {
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    uint4 v = P0[c];
+    v.w = (unsigned)cidx_split[c];
+    P0G[c] = v;
+  }
+}
+
 __device__ __forceinline__ unsigned tsx_bf16x2(float lo, float hi) {
   return (unsigned)tsx_to_bf16(lo) | ((unsigned)tsx_to_bf16(hi) << 16);
 }
@@ -300,8 +311,13 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
 #pragma unroll
   for (int l = 0; l < LSEG; ++l) {
     const size_t c = cell(l);
-    eid[l] = IDX ? cidx[c] : 0;
-    r0[l] = P[c];
+    if (IDX && MODE == 0) {  // record 0 with the block index in place of A_k (tsx_k_pcs_pack_r0g)
+      r0[l] = P[(size_t)7 * Nc + c];
+      eid[l] = (int)r0[l].w;
+    } else {
+      eid[l] = IDX ? cidx[c] : 0;
+      r0[l] = P[c];
+    }
     if (RQ == 2) {
       const unsigned w = rb[c];
       ru[l] = __uint_as_float(w << 16);

@@ -97,6 +97,10 @@ int tsx_pcs_pack(tsx_solver *s) {
                        s->l1d, s->a11, s->a12, s->albedo, P);
     hipLaunchKernelGGL(tsx_k_pcs_pack_ent, dim3(grid_for(7ll * s->dd_nent)), dim3(TSX_BLOCK), 0, s->stream, g.ncol,
                        (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d, P + g.Nc);
+    // the intermediate passes' copy of record 0 (block index in the word of A_k) in the last group's slot: the entries
+    // fill at most 3.5 of the 7 groups behind record 0 (sharing is on only where 2 * nent <= Nc)
+    hipLaunchKernelGGL(tsx_k_pcs_pack_r0g, dim3(grid_for(g.Nc)), dim3(TSX_BLOCK), 0, s->stream, (long long)g.Nc, (const uint4 *)P,
+                       (const int *)s->dd_cidx_split, P + (size_t)7 * g.Nc);
     HIPCHK(hipGetLastError());
     s->coef_h_dd = true;
     return TSX_OK;
