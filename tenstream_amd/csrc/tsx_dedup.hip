@@ -188,12 +188,16 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_index(TsxGeo g, const int 
     if (r == (int)c) ent_cell[id] = (int)c;
   }
 }
+// Cd: plane-major [D*D][nent] (what the preconditioner's pack kernels read); Ce: entry-major [nent][D*D] (the operator)
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_compact(long long Nc, int DD, long long nent, const float *__restrict__ C,
-                                                              const int *__restrict__ ent_cell, float *__restrict__ Cd) {
+                                                              const int *__restrict__ ent_cell, float *__restrict__ Cd,
+                                                              float *__restrict__ Ce) {
   const long long n = nent * DD;
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
     const long long pl = q / nent, id = q - pl * nent;
-    Cd[q] = C[(size_t)pl * Nc + ent_cell[id]];
+    const float v = C[(size_t)pl * Nc + ent_cell[id]];
+    Cd[q] = v;
+    Ce[(size_t)id * DD + pl] = v;
   }
 }
 
@@ -267,7 +271,7 @@ int tsx_dedup_ensure(tsx_solver *s) {
     if (s->dd_ent_cell) HIPCHK(hipFree(s->dd_ent_cell));
     s->dd_coef = nullptr;
     s->dd_ent_cell = nullptr;
-    HIPCHK(hipMalloc((void **)&s->dd_coef, sizeof(float) * (size_t)DD * nent));
+    HIPCHK(hipMalloc((void **)&s->dd_coef, sizeof(float) * (size_t)DD * nent * 2));  // plane-major, then entry-major
     HIPCHK(hipMalloc((void **)&s->dd_ent_cell, sizeof(int) * (size_t)nent));
     s->dd_cap = nent;
   }
@@ -275,7 +279,8 @@ int tsx_dedup_ensure(tsx_solver *s) {
   hipLaunchKernelGGL(tsx_k_dd_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, trep.as<int>(), tpos.as<int>(), s->dd_cidx,
                      split ? s->dd_cidx_split : (int *)nullptr, s->dd_ent_cell);
   hipLaunchKernelGGL(tsx_k_dd_compact, dim3(grid_for((long long)nent * DD, 8192)), dim3(TSX_BLOCK), 0, s->stream, Nc, DD,
-                     (long long)nent, C, s->dd_ent_cell, s->dd_coef);
+                     (long long)nent, C, s->dd_ent_cell, s->dd_coef, s->dd_coef + (size_t)DD * s->dd_cap);
+  s->dd_coef_e = s->dd_coef + (size_t)DD * s->dd_cap;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
   s->dd_on = true;

@@ -90,7 +90,8 @@ struct tsx_solver {
   // shared storage of bit-identical blocks (tsx_dedup.hip): planes over entries + per-cell entry index
   bool dd_valid, dd_on;
   int dd_nent, dd_cap;
-  float *dd_coef;          // [D*D][dd_nent]
+  float *dd_coef;          // [D*D][dd_nent] plane-major (preconditioner packing)
+  float *dd_coef_e = nullptr;  // [dd_nent][D*D] entry-major copy behind it (operator apply)
   int *dd_cidx;            // [Nc] natural cell order
   int *dd_cidx_split;      // [Nc] colour-split order (the preconditioner's)
   int *dd_ent_cell;        // [dd_nent] representative cell of every entry

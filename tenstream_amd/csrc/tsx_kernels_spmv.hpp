@@ -13,10 +13,22 @@
 // IDX: the blocks are stored once per *distinct* block (tsx_dedup.hip): C holds planes over nent entries and cidx[c] is
 // the entry of cell c.  Cells that share an entry read the same addresses (one cache line per wave instruction), runs of
 // unique cells have consecutive entries; same numbers, same order of operations as the dense planes.
+// shared blocks are stored entry-major for the operator, Ce[id * D*D + dst * D + src]: a cell's row of D coefficients is one
+// contiguous run (D / 2 eight-byte loads), and every byte of a fetched line belongs to the cell that fetched it -- with
+// plane-major storage a cloudy cell touched D*D lines that it shared with its neighbours in the table, and those lines were
+// fetched about three times over (L2 does not hold them between the workgroups of adjacent rows)
 template <int CPT> struct TsxIdx;
 template <> struct TsxIdx<1> {
   static __device__ __forceinline__ void ids(const int *p, int (&o)[1]) { o[0] = p[0]; }
-  static __device__ __forceinline__ float ld(const float *pl, const int (&id)[1]) { return pl[id[0]]; }
+  template <int D> static __device__ __forceinline__ void ld_row(const float *Ce, const int (&id)[1], int d, float (&cf)[D]) {
+    const float2 *r = reinterpret_cast<const float2 *>(Ce + (size_t)id[0] * (D * D) + d * D);
+#pragma unroll
+    for (int h = 0; h < D / 2; ++h) {
+      const float2 v = r[h];
+      cf[2 * h] = v.x;
+      cf[2 * h + 1] = v.y;
+    }
+  }
 };
 template <> struct TsxIdx<2> {
   static __device__ __forceinline__ void ids(const int *p, int (&o)[2]) {
@@ -24,7 +36,16 @@ template <> struct TsxIdx<2> {
     o[0] = v.x;
     o[1] = v.y;
   }
-  static __device__ __forceinline__ float2 ld(const float *pl, const int (&id)[2]) { return make_float2(pl[id[0]], pl[id[1]]); }
+  template <int D> static __device__ __forceinline__ void ld_row(const float *Ce, const int (&id)[2], int d, float2 (&cf)[D]) {
+    const float2 *r0 = reinterpret_cast<const float2 *>(Ce + (size_t)id[0] * (D * D) + d * D);
+    const float2 *r1 = reinterpret_cast<const float2 *>(Ce + (size_t)id[1] * (D * D) + d * D);
+#pragma unroll
+    for (int h = 0; h < D / 2; ++h) {
+      const float2 a = r0[h], b = r1[h];
+      cf[2 * h] = make_float2(a.x, b.x);
+      cf[2 * h + 1] = make_float2(a.y, b.y);
+    }
+  }
 };
 
 template <int NTOP, int NSIDE, typename CT, int FUSE, int CPT, typename XT, typename WT, bool HALO, bool HAS1D, bool IDX = false>
@@ -175,11 +196,14 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
       XV xoc, xon;
       WV wc, wn;
       auto issue_row = [&](int d, CH(&cf)[D], XV &xo_, WV &w_) {
+        if constexpr (UNI) {
 #pragma unroll
-        for (int s2 = 0; s2 < D; ++s2) {
-          if constexpr (UNI) cf[s2] = C[(size_t)(d * D + s2) * nent + id0];
-          else if constexpr (IDX) cf[s2] = TsxIdx<CPT>::ld(C + (size_t)(d * D + s2) * nent, eid);
-          else cf[s2] = TsxRaw<CT, CPT>::ld(C + (size_t)(d * D + s2) * Nc + c);
+          for (int s2 = 0; s2 < D; ++s2) cf[s2] = C[(size_t)id0 * (D * D) + d * D + s2];
+        } else if constexpr (IDX) {
+          TsxIdx<CPT>::template ld_row<D>(C, eid, d, cf);
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < D; ++s2) cf[s2] = TsxRaw<CT, CPT>::ld(C + (size_t)(d * D + s2) * Nc + c);
         }
         xo_ = TsxRaw<XT, CPT>::ld(x + (size_t)d * Nc + c);
         if (FUSE & 1) w_ = TsxRaw<WT, CPT>::ld(w + (size_t)d * Nc + c);

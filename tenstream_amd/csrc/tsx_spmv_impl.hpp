@@ -24,7 +24,7 @@ static void launch_spmv_variant(tsx_solver *s, const XT *x, double *y, const WT 
   if constexpr (std::is_same<CT, float>::value) {
     if (s->dd_on) {  // shared storage of identical blocks (tsx_dedup.hip)
       hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, float, FUSE, CPT, XT, WT, HALO, HAS1D, true>), dim3(nb), dim3(TSX_BLOCK), 0,
-                         s->stream, g, (const float *)s->dd_coef, (const int *)s->dd_cidx, (long long)s->dd_nent, s->l1d, s->a11,
+                         s->stream, g, (const float *)s->dd_coef_e, (const int *)s->dd_cidx, (long long)s->dd_nent, s->l1d, s->a11,
                          s->a12, s->albedo, x, y, (const XT *)s->recvW, (const XT *)s->recvE, (const XT *)s->recvS,
                          (const XT *)s->recvN, w, s->partials + (part == 2 ? nbmain : 0), done, part);
       return;
