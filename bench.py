@@ -247,15 +247,18 @@ def main():
     out = None
     if rank == 0:
         r_spmv = roof("tsx_k_spmv_w (y = (I - T) x, fp64 x and y)", spmv_ms, bytes_spmv,
-                      ["tsx_k_spmv", (",0,1,double,double", ",0,2,double,double")], s.algorithmic_bytes(10))
+                      ["tsx_k_spmv", (",0,1,double,double", ",0,2,double,double"), ",true>" if dd_on else ",false>"],
+                      s.algorithmic_bytes(10))
         r_iter = roof("one BiCGStab iteration (2 M^-1, 2 SpMV, 3 vector updates)", iter_ms, bytes_iter, None)
+        if not dd_on:   # the committed PMC profile is of the shared-block kernels
+            r_iter["traffic"] = r_iter["traffic_GBps"] = r_iter["traffic_source"] = None
         r_iter["basis"] = ("SURVEY 8(d)'s 2*B_spmv + 16*N*sv: the reference's iteration without M^-1, every cell's block "
                            "stored; this iteration also runs M^-1 twice and shares identical blocks, see `traffic`")
         r_pass = None
         if pass_ms is not None:
             kname = "tsx_k_pcs_rb" if solver == "3_10" else "tsx_k_pcsh_rb"
             r_pass = roof(f"{kname}<..., GS, MODE 0, RQ 2> (one intermediate red-black pass of M^-1)", pass_ms,
-                          s.algorithmic_bytes(3), [kname, (",true,0,true,2>", ",true,0,false,2>")])
+                          s.algorithmic_bytes(3), [kname, ",true,0,true,2>" if dd_on else ",true,0,false,2>"])
         r_pc = None
         if pc_ms is not None:
             r_pc = {"kernel": f"M^-1: {sweeps + 1} half-grid passes", "ms_per_application": pc_ms,
