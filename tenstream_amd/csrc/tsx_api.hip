@@ -132,7 +132,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->atol = 1e-8;
   o->dtol = 1e4;    // PETSc KSP default divergence tolerance
   o->maxit = 1000;  // src/pprts_base.F90:1118
-  o->pc = TSX_PC_REDBLACK;  // this back-end's default preconditioner: 10 half-grid passes
+  o->pc = TSX_PC_REDBLACK;  // this back-end's default preconditioner
   o->pc_sweeps = 0;  // automatic (prepare_ksp): 19 with the scan kernels, else 9
   o->check_every = 2;  // at most one iteration enqueued in vain; measured 1 / 2 / 3 / 4 / 6: 19.44 / 19.24 / 19.37 / 19.68 / 19.26 ms, warm start 3.40 / 3.47 / 3.58 / 3.69 / 3.82 ms
   o->fp32_directions = 1;
