@@ -199,6 +199,27 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_pack(TsxGeo g, const
   }
 }
 
+// ---- parts of a pass on several ranks (overlap of the boundary-record exchange with the pass, tsx_pcs_apply):
+// part 0 = every column of the colour; 1 = the same launch with the columns on a rank face idle (their neighbours' records
+// are still in flight); 2 = only the columns on a rank face.  Frame columns of colour rbc, enumerated: the rows j = 0 and
+// j = ym - 1 entirely (if the rank does not wrap onto itself in y), then of every other row the one column at i = 0 or
+// i = xm - 1 that has the colour (if it does not wrap in x; xm is even, so exactly one of the two has it).
+__device__ __forceinline__ int tsx_pcs_nframe(const TsxGeo &g) {
+  const int h = g.xm >> 1;
+  const int rows = g.wrap_y ? 0 : (g.ym >= 2 ? 2 : 1);
+  return rows * h + (g.wrap_x ? 0 : g.ym - rows);
+}
+__device__ __forceinline__ int tsx_pcs_frame_thread(const TsxGeo &g, int rbc, int f) {  // -> jrow * h + qh
+  const int h = g.xm >> 1;
+  const int rows = g.wrap_y ? 0 : (g.ym >= 2 ? 2 : 1);
+  if (f < rows * h) return (f < h ? 0 : g.ym - 1) * h + (f % h);
+  const int jrow = (f - rows * h) + (rows ? 1 : 0);
+  return jrow * h + (((jrow + rbc) & 1) ? h - 1 : 0);
+}
+__device__ __forceinline__ bool tsx_pcs_on_frame(const TsxGeo &g, int jrow, int icol) {
+  return (!g.wrap_y && (jrow == 0 || jrow == g.ym - 1)) || (!g.wrap_x && (icol == 0 || icol == g.xm - 1));
+}
+
 // ---- one half-grid pass.  rbc = colour of this pass.  GS: the other colour's values enter the right-hand side.
 // MODE 0: intermediate pass -- only the side streams are stored, as bf16 records in zb; neighbours from zb.
 // MODE 1: the last pass of the first colour -- all ten streams in fp32 to z (colour-split; side streams as float2 records);
@@ -218,7 +239,7 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
                                                          float *__restrict__ zfin, const int *__restrict__ done, int rbc,
                                                          int nonbr, const int *__restrict__ cidx, long long nent,
                                                          const uint4 *__restrict__ PE, TsxPcHalo hal,
-                                                         unsigned *__restrict__ rb) {
+                                                         unsigned *__restrict__ rb, int part) {
   static_assert(RQ == 0 || MODE == 0, "bf16 right-hand side only in the intermediate passes");
   constexpr int D = 10, NTOP = 2;
   constexpr bool FINAL = MODE == 2;
@@ -226,15 +247,17 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
   if (done && *done) return;
   const int h = g.xm >> 1;
   const int cl = threadIdx.x % CW, sg = threadIdx.x / CW;
-  const int nthr = g.ym * h;
+  const int nthr = part == 2 ? tsx_pcs_nframe(g) : g.ym * h;
   int t_ = blockIdx.x * CW + cl;
-  const bool live = t_ < nthr;  // dead lanes shadow the last column (loads stay valid, nothing is stored)
+  bool live = t_ < nthr;  // dead lanes shadow the last column (loads stay valid, nothing is stored)
   if (!live) t_ = nthr - 1;
+  if (part == 2) t_ = tsx_pcs_frame_thread(g, rbc, t_);
   const long long Nc = g.Nc;
   const int Nz = g.Nz, ncol = g.ncol;
   const int jrow = t_ / h, qh = t_ - jrow * h;
   const int par = (jrow + rbc) & 1;
   const int icol = 2 * qh + par;
+  if (part == 1 && tsx_pcs_on_frame(g, jrow, icol)) live = false;
   const int col = jrow * g.xm + rbc * h + qh;  // colour-split column index (P, r, z, zb)
   // neighbours (other colour) in split space; 0 = no neighbour (rank face / tile edge)
   const long long oc = (long long)(1 - 2 * rbc) * h;
@@ -684,7 +707,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
                                                           const float *__restrict__ r, float *__restrict__ z,
                                                           unsigned *__restrict__ zb, float *__restrict__ zfin,
                                                           const int *__restrict__ done, int rbc, int nonbr, TsxPcHalo hal,
-                                                          unsigned *__restrict__ rb) {
+                                                          unsigned *__restrict__ rb, int part) {
   // RQ as in tsx_k_pcs_rb: eight bf16-pair words per cell, rb[w * Nc + cell] = (ru_a, rd_a), a = 0..3, then (rs_2q, rs_2q+1)
   static_assert(RQ == 0 || MODE == 0, "bf16 right-hand side only in the intermediate passes");
   constexpr int D = 16, NTOP = 8;
@@ -693,15 +716,17 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   if (done && *done) return;
   const int h = g.xm >> 1;
   const int cl = threadIdx.x % CW, sg = threadIdx.x / CW;
-  const int nthr = g.ym * h;
+  const int nthr = part == 2 ? tsx_pcs_nframe(g) : g.ym * h;
   int t_ = blockIdx.x * CW + cl;
-  const bool live = t_ < nthr;
+  bool live = t_ < nthr;
   if (!live) t_ = nthr - 1;
+  if (part == 2) t_ = tsx_pcs_frame_thread(g, rbc, t_);
   const long long Nc = g.Nc;
   const int Nz = g.Nz, ncol = g.ncol;
   const int jrow = t_ / h, qh = t_ - jrow * h;
   const int par = (jrow + rbc) & 1;
   const int icol = 2 * qh + par;
+  if (part == 1 && tsx_pcs_on_frame(g, jrow, icol)) live = false;
   const int col = jrow * g.xm + rbc * h + qh;
   const long long oc = (long long)(1 - 2 * rbc) * h;
   const int jn = jrow + 1 < g.ym ? jrow + 1 : (g.wrap_y ? 0 : -1), js = jrow > 0 ? jrow - 1 : (g.wrap_y ? g.ym - 1 : -1);

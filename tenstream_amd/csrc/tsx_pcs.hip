@@ -161,8 +161,14 @@ static TsxPcHalo pcs_halo_arg(const tsx_solver *s) {
   }
   return h;
 }
-// after a pass: pack the boundary records and exchange them with the W, E, S, N neighbours
-static int pcs_halo_exchange(tsx_solver *s, bool from_f32, const int *done) {
+static long long pcs_nframe(const TsxGeo &g) {  // host mirror of tsx_pcs_nframe
+  const int h = g.xm >> 1;
+  const int rows = g.wrap_y ? 0 : (g.ym >= 2 ? 2 : 1);
+  return (long long)rows * h + (g.wrap_x ? 0 : g.ym - rows);
+}
+// after a pass: pack the boundary records (on the solver stream) and exchange them with the W, E, S, N neighbours -- on the
+// solver stream, or (overlap) on comm_stream behind ev_pack, with ev_recv recorded after it
+static int pcs_halo_exchange(tsx_solver *s, bool from_f32, const int *done, bool overlap) {
   const TsxGeo &g = s->geo;
   float *zs = (float *)s->vw;
   const unsigned *zb = (const unsigned *)(zs + (size_t)g.N);
@@ -173,15 +179,27 @@ static int pcs_halo_exchange(tsx_solver *s, bool from_f32, const int *done) {
   HIPCHK(hipGetLastError());
   double *const send[4] = {(double *)s->pch_send[0], (double *)s->pch_send[1], (double *)s->pch_send[2], (double *)s->pch_send[3]};
   double *const recv[4] = {(double *)s->pch_recv[0], (double *)s->pch_recv[1], (double *)s->pch_recv[2], (double *)s->pch_recv[3]};
-  return tsx_face_exchange_bufs(s, s->stream, send, recv, pcs_halo_doubles(s, 0), pcs_halo_doubles(s, 2));
+  if (!overlap) return tsx_face_exchange_bufs(s, s->stream, send, recv, pcs_halo_doubles(s, 0), pcs_halo_doubles(s, 2));
+  HIPCHK(hipEventRecord(s->ev_pack, s->stream));
+  HIPCHK(hipStreamWaitEvent(s->comm_stream, s->ev_pack, 0));
+  return TSX_OK;  // the caller queues the next pass's interior part first, then calls pcs_halo_exchange_finish
+}
+static int pcs_halo_exchange_finish(tsx_solver *s) {
+  double *const send[4] = {(double *)s->pch_send[0], (double *)s->pch_send[1], (double *)s->pch_send[2], (double *)s->pch_send[3]};
+  double *const recv[4] = {(double *)s->pch_recv[0], (double *)s->pch_recv[1], (double *)s->pch_recv[2], (double *)s->pch_recv[3]};
+  int rc = tsx_face_exchange_bufs(s, s->comm_stream, send, recv, pcs_halo_doubles(s, 0), pcs_halo_doubles(s, 2));
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(s->ev_recv, s->comm_stream));
+  HIPCHK(hipStreamWaitEvent(s->stream, s->ev_recv, 0));
+  return TSX_OK;
 }
 
 // rq: 0 = fp32 right-hand side, 1 = fp32 + leave the bf16-pair words, 2 = read the bf16-pair words (mode 0 only)
 template <int L, int S, int CW>
 static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin, const int *done,
-                       int rq) {
+                       int rq, int part) {
   const TsxGeo &g = s->geo;
-  const long long nthr = (long long)g.ym * (g.xm / 2);
+  const long long nthr = part == 2 ? pcs_nframe(g) : (long long)g.ym * (g.xm / 2);
   const int nb = (int)((nthr + CW - 1) / CW);
   const uint4 *P = (const uint4 *)s->coef_h;
   const float *r = (const float *)s->pc_rhs;
@@ -195,10 +213,10 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   do {                                                                                                                           \
     if (dd)                                                                                                                      \
       hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, true, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb,   \
-                         zfin, done, rbc, nonbr, cidx, nent, PE, hal, rb);                                                       \
+                         zfin, done, rbc, nonbr, cidx, nent, PE, hal, rb, part);                                                 \
     else                                                                                                                         \
       hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, false, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb,  \
-                         zfin, done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr, hal, rb);                    \
+                         zfin, done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr, hal, rb, part);              \
   } while (0)
   if (!gs) {
     if (rq == 1) TSX_PCS_GO(false, 0, 1);
@@ -214,17 +232,17 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
 
 template <int L, int S>
 static void pcs_launch_cw(tsx_solver *s, int cw, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin,
-                          const int *done, int rq) {
-  if (cw == 64) pcs_launch<L, S, 64>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
-  else if (cw == 32) pcs_launch<L, S, 32>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
-  else pcs_launch<L, S, 16>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
+                          const int *done, int rq, int part) {
+  if (cw == 64) pcs_launch<L, S, 64>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq, part);
+  else if (cw == 32) pcs_launch<L, S, 32>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq, part);
+  else pcs_launch<L, S, 16>(s, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq, part);
 }
 
 template <int L, int S, int CW>
 static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, float *zs, unsigned *zb, float *zfin, const int *done,
-                        int rq) {
+                        int rq, int part) {
   const TsxGeo &g = s->geo;
-  const long long nthr = (long long)g.ym * (g.xm / 2);
+  const long long nthr = part == 2 ? pcs_nframe(g) : (long long)g.ym * (g.xm / 2);
   const int nb = (int)((nthr + CW - 1) / CW);
   const uint4 *P = (const uint4 *)s->coef_h, *PB = P + (size_t)TSX_S16H_CELL * g.Nc;
   const float *r = (const float *)s->pc_rhs;
@@ -237,10 +255,10 @@ static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, fl
   do {                                                                                                                          \
     if (dd)                                                                                                                     \
       hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, true, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB,        \
-                         bstride, cidx, r, zs, zb, zfin, done, rbc, nonbr, hal, rb);                                            \
+                         bstride, cidx, r, zs, zb, zfin, done, rbc, nonbr, hal, rb, part);                                      \
     else                                                                                                                        \
       hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, false, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB,       \
-                         bstride, (const int *)nullptr, r, zs, zb, zfin, done, rbc, nonbr, hal, rb);                            \
+                         bstride, (const int *)nullptr, r, zs, zb, zfin, done, rbc, nonbr, hal, rb, part);                      \
   } while (0)
   if (!gs) {
     if (rq == 1) TSX_PCSH_GO(false, 0, 1);
@@ -265,7 +283,7 @@ bool tsx_pcs_rhs16(const tsx_solver *s) {
 }
 
 // rq: right-hand side of an intermediate pass, see tsx_k_pcs_rb (RQ)
-int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done, int rq) {
+int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done, int rq, int part) {
   const TsxGeo &g = s->geo;
   const PcsCfg c = pcs_config(s);
   if (g.ntop == 8) {
@@ -274,10 +292,10 @@ int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done
     const bool first8 = pass == 0, gs8 = !(first8 && mode == 0);
     const int nonbr8 = first8 && mode != 0, rbc8 = pass & 1;
     if (mode != 0) rq = 0;
-    if (c.lseg == 4 && c.cw == 32) pcsh_launch<4, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq);
-    else if (c.lseg == 4) pcsh_launch<4, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq);
-    else if (c.cw == 32) pcsh_launch<8, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq);
-    else pcsh_launch<8, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq);
+    if (c.lseg == 4 && c.cw == 32) pcsh_launch<4, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);
+    else if (c.lseg == 4) pcsh_launch<4, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);
+    else if (c.cw == 32) pcsh_launch<8, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);
+    else pcsh_launch<8, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);
     return TSX_OK;
   }
   float *zs = (float *)s->vw;                        // fp32 iterate (mode 1 writes, mode 2 reads)
@@ -287,10 +305,10 @@ int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done
   const int nonbr = first && mode != 0;
   const int rbc = pass & 1;
   if (mode != 0) rq = 0;
-  if (c.lseg == 4) pcs_launch_cw<4, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
-  else if (c.lseg == 8 && c.nseg == 8) pcs_launch_cw<8, 8>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
-  else if (c.lseg == 8) pcs_launch_cw<8, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
-  else pcs_launch_cw<16, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq);
+  if (c.lseg == 4) pcs_launch_cw<4, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq, part);
+  else if (c.lseg == 8 && c.nseg == 8) pcs_launch_cw<8, 8>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq, part);
+  else if (c.lseg == 8) pcs_launch_cw<8, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq, part);
+  else pcs_launch_cw<16, 16>(s, c.cw, gs, mode, rbc, nonbr, zs, zb, zfin, done, rq, part);
   return TSX_OK;
 }
 
@@ -305,16 +323,32 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
   const bool rhs16 = tsx_pcs_rhs16(s);
   static const int every_env = getenv("TSX_PC_HALO_EVERY") ? atoi(getenv("TSX_PC_HALO_EVERY")) : 1;
   const int every = every_env > 0 ? every_env : 1;
+  // Overlap (TSX_PC_OVERLAP != 0, several ranks): the exchange of pass p's boundary records runs on comm_stream while pass
+  // p + 1 already works on the columns that touch no rank face (part 1, queued *before* the possibly host-synchronous
+  // exchange so that it runs underneath it); the columns on a face follow once the records have arrived (part 2).
+  static const bool overlap_env = !(getenv("TSX_PC_OVERLAP") && atoi(getenv("TSX_PC_OVERLAP")) == 0);
+  const bool overlap = halo && overlap_env && s->overlap && s->comm_stream != nullptr;  // s->overlap: TSX_OVERLAP, as for the operator
+  bool in_flight = false;  // an exchange has been packed and handed to comm_stream (ev_pack) but not issued yet
   for (int pass = 0; pass < P; ++pass) {
     const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
     // a colour's intermediate visits are passes c, c + 2, ... < P - 2: the first leaves the bf16 right-hand side if another
     // one follows, the later ones read it
     const int rq = !rhs16 || mode != 0 ? 0 : (pass >= 2 ? 2 : (pass + 2 < P - 2 ? 1 : 0));
-    int rc = tsx_pcs_pass(s, pass, mode, z, done, rq);
-    if (rc) return rc;
+    int rc;
+    if (in_flight) {
+      if ((rc = tsx_pcs_pass(s, pass, mode, z, done, rq, 1))) return rc;  // interior, under the exchange
+      if ((rc = pcs_halo_exchange_finish(s))) return rc;
+      if ((rc = tsx_pcs_pass(s, pass, mode, z, done, rq, 2))) return rc;  // the columns on the rank faces
+      in_flight = false;
+    } else if ((rc = tsx_pcs_pass(s, pass, mode, z, done, rq, 0))) {
+      return rc;
+    }
     // what the next passes read at the rank faces; TSX_PC_HALO_EVERY = n exchanges after passes 0, n, 2n, ... only (the
     // passes in between see the neighbour rank's boundary columns n - 1 passes late at most)
-    if (halo && pass + 1 < P && pass % every == 0 && (rc = pcs_halo_exchange(s, mode == 1, done))) return rc;
+    if (halo && pass + 1 < P && pass % every == 0) {
+      if ((rc = pcs_halo_exchange(s, mode == 1, done, overlap))) return rc;
+      in_flight = overlap;
+    }
   }
   HIPCHK(hipGetLastError());
   return TSX_OK;
