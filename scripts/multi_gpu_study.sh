@@ -27,4 +27,4 @@ for n in 1 2 4 8; do
     run "strong N=$n, preconditioner halo every 2nd pass" TSX_PC_HALO_EVERY=2 -- --gpus $n --scaling strong
   fi
 done
-[ $MAXN -ge 8 ] && run "config 3: 512x512x64 on 2x4" A=1 -- --gpus 8 --global-nx 512 --global-ny 512
+if [ $MAXN -ge 8 ]; then run "config 3: 512x512x64 on 2x4" A=1 -- --gpus 8 --global-nx 512 --global-ny 512; fi
