@@ -254,7 +254,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->v32, s->p32, s->dsend[0], s->dsend[1], s->dsend[2], s->dsend[3], s->drecv[0], s->drecv[1], s->drecv[2], s->drecv[3],
-                  s->coef_h, s->coef, s->dd_coef, s->dd_cidx, s->dd_cidx_split, s->dd_ent_cell, s->dd_scratch, s->pch_send[0], s->pch_send[1], s->pch_send[2], s->pch_send[3],
+                  s->coef_h, s->coef, s->dd_coef, s->dd_cidx, s->dd_cidx_split, s->dd_ent_cell, s->dd_scratch, s->pcr_idx, s->pcr_ent, s->pcr_tab, s->pch_send[0], s->pch_send[1], s->pch_send[2], s->pch_send[3],
                   s->pch_recv[0], s->pch_recv[1], s->pch_recv[2], s->pch_recv[3], s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
@@ -1165,11 +1165,26 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
     //   8_16, every cell's records: 12 recurrence records (14 in the fp32 passes) + 16 block records (8 in the first pass)
     //         + rhs 16 x 4 B + 4 neighbour records + 4 stored = 544;  first 400;  fp32 624;  last 768
     //   8_16, shared: the 16 block records per distinct block: 292 (+256);  first 276 (+128);  fp32 372;  last 516
+    //   recurrence records shared too (tsx_records_share; npid distinct ones): a cell reads a 4-byte index instead of them
+    //         3_10 intermediate passes: record 0 (16 B) -> 4 B (+16 per distinct record and pass);
+    //         8_16 all passes: 12 (14) records -> 4 B (+192 / 224 per distinct set and pass)
     const bool h = g.ntop == 8;
     const double cell[2][2][4] = {{{200, 104, 224, 320}, {88, 72, 116, 212}}, {{544, 400, 624, 768}, {292, 276, 372, 516}}};
     const double ent[2][2] = {{112, 32}, {256, 128}};
-    const double *c = cell[h][dd];
-    const double half = 0.5 * Nc, e_gs = dd ? nent * ent[h][0] : 0.0, e_first = dd ? nent * ent[h][1] : 0.0;
+    double c[4] = {cell[h][dd][0], cell[h][dd][1], cell[h][dd][2], cell[h][dd][3]};
+    const double half = 0.5 * Nc, e_gs0 = dd ? nent * ent[h][0] : 0.0, e_first0 = dd ? nent * ent[h][1] : 0.0;
+    double r_gs = 0.0, r_f32 = 0.0;  // bytes of the shared recurrence table per pass
+    if (dd && s->pcr_on) {
+      const double np = (double)s->pcr_n;
+      if (h) {
+        c[0] -= 188.0, c[1] -= 188.0, c[2] -= 220.0, c[3] -= 220.0;
+        r_gs = np * 192.0, r_f32 = np * 224.0;
+      } else {
+        c[0] -= 12.0, c[1] -= 12.0;
+        r_gs = np * 16.0;
+      }
+    }
+    const double e_gs = e_gs0 + r_gs, e_first = e_first0 + r_gs, e_f32 = e_gs0 + r_f32;
     const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : 20;
     const double ngs = P > 3 ? P - 3 : 0;
     // bf16 right-hand side of the intermediate passes (tsx_k_pcs_rb RQ): a colour's first visit leaves 5 words (+20 B), the
@@ -1178,8 +1193,8 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
     const double w16 = h ? 32.0 : 20.0;  // the bf16-pair words of a cell
     const double gs_b = r16 ? c[0] - w16 : c[0];
     if (kernel == 3) *bytes = gs_b * half + e_gs;
-    else if (r16) *bytes = ((c[1] + w16) + (c[0] + w16) + gs_b * (ngs - 1.0) + c[2] + c[3]) * half + e_first + (ngs + 2.0) * e_gs;
-    else *bytes = (c[1] + c[0] * ngs + c[2] + c[3]) * half + e_first + (ngs + 2.0) * e_gs;
+    else if (r16) *bytes = ((c[1] + w16) + (c[0] + w16) + gs_b * (ngs - 1.0) + c[2] + c[3]) * half + e_first + ngs * e_gs + 2.0 * e_f32;
+    else *bytes = (c[1] + c[0] * ngs + c[2] + c[3]) * half + e_first + ngs * e_gs + 2.0 * e_f32;
   } else {
     tsx_set_error("tsx_algorithmic_bytes: kernel must be 0..3, 10 or 11");
     return TSX_ERR_ARG;

@@ -206,6 +206,40 @@ struct TsxDdSlice {  // a piece of the solver's scratch allocation
   template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
+// scratch kept with the solver (one allocation; hipMalloc / hipFree per g-point cost more than the kernels): hashes, table
+// keys, table owners, representative, flag, position, per-chunk sums, total
+struct TsxDdScratch {
+  TsxDdSlice th, tk, to, trep, tflag, tpos, tsum, ttot;
+  unsigned long long tsz;
+  int nsb;
+};
+static int dd_scratch(tsx_solver *s, long long Nc, TsxDdScratch *w) {
+  unsigned long long tsz = 1;
+  while (tsz < (unsigned long long)(2 * Nc)) tsz <<= 1;
+  const int nsb = (int)((Nc + TSX_SCAN_CHUNK - 1) / TSX_SCAN_CHUNK);
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t sz[8] = {al(sizeof(unsigned long long) * (size_t)Nc), al(sizeof(unsigned long long) * (size_t)tsz),
+                        al(sizeof(int) * (size_t)tsz), al(sizeof(int) * (size_t)Nc), al(sizeof(int) * (size_t)Nc),
+                        al(sizeof(int) * (size_t)Nc), al(sizeof(int) * (size_t)nsb), 256};
+  size_t tot = 0;
+  for (size_t v : sz) tot += v;
+  if (s->dd_scratch_bytes < tot) {
+    if (s->dd_scratch) HIPCHK(hipFree(s->dd_scratch));
+    s->dd_scratch = nullptr;
+    HIPCHK(hipMalloc(&s->dd_scratch, tot));
+    s->dd_scratch_bytes = tot;
+  }
+  TsxDdSlice *d[8] = {&w->th, &w->tk, &w->to, &w->trep, &w->tflag, &w->tpos, &w->tsum, &w->ttot};
+  size_t off = 0;
+  for (int q = 0; q < 8; ++q) {
+    d[q]->p = (char *)s->dd_scratch + off;
+    off += sz[q];
+  }
+  w->tsz = tsz;
+  w->nsb = nsb;
+  return TSX_OK;
+}
+
 static bool dedup_enabled() {
   const char *e = getenv("TSX_DEDUP");  // TSX_DEDUP=0: always the dense planes (A/B knob)
   return e ? atoi(e) != 0 : true;
@@ -221,31 +255,14 @@ int tsx_dedup_ensure(tsx_solver *s) {
   if (g.Nc >= (1ll << 31)) return TSX_OK;
   const int DD = g.D * g.D;
   const long long Nc = g.Nc;
-  unsigned long long tsz = 1;
-  while (tsz < (unsigned long long)(2 * Nc)) tsz <<= 1;
-  // scratch kept with the solver (one allocation; hipMalloc / hipFree per g-point cost more than the kernels)
-  const int nsb = (int)((Nc + TSX_SCAN_CHUNK - 1) / TSX_SCAN_CHUNK);
-  TsxDdSlice th, tk, to, trep, tflag, tpos, tsum, ttot;
+  TsxDdScratch w;
   {
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t sz[8] = {al(sizeof(unsigned long long) * (size_t)Nc), al(sizeof(unsigned long long) * (size_t)tsz),
-                          al(sizeof(int) * (size_t)tsz), al(sizeof(int) * (size_t)Nc), al(sizeof(int) * (size_t)Nc),
-                          al(sizeof(int) * (size_t)Nc), al(sizeof(int) * (size_t)nsb), 256};
-    size_t tot = 0;
-    for (size_t v : sz) tot += v;
-    if (s->dd_scratch_bytes < tot) {
-      if (s->dd_scratch) HIPCHK(hipFree(s->dd_scratch));
-      s->dd_scratch = nullptr;
-      HIPCHK(hipMalloc(&s->dd_scratch, tot));
-      s->dd_scratch_bytes = tot;
-    }
-    TsxDdSlice *d[8] = {&th, &tk, &to, &trep, &tflag, &tpos, &tsum, &ttot};
-    size_t off = 0;
-    for (int q = 0; q < 8; ++q) {
-      d[q]->p = (char *)s->dd_scratch + off;
-      off += sz[q];
-    }
+    int rc = dd_scratch(s, Nc, &w);
+    if (rc) return rc;
   }
+  const unsigned long long tsz = w.tsz;
+  const int nsb = w.nsb;
+  TsxDdSlice &th = w.th, &tk = w.tk, &to = w.to, &trep = w.trep, &tflag = w.tflag, &tpos = w.tpos, &tsum = w.tsum, &ttot = w.ttot;
   HIPCHK(hipMemsetAsync(tk.p, 0, sizeof(unsigned long long) * (size_t)tsz, s->stream));
   HIPCHK(hipMemsetAsync(to.p, 0x7f, sizeof(int) * (size_t)tsz, s->stream));
   const float *C = (const float *)s->coef;
@@ -284,5 +301,113 @@ int tsx_dedup_ensure(tsx_solver *s) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
   s->dd_on = true;
+  return TSX_OK;
+}
+
+
+// =====================================================================================================================
+// Shared storage of identical *packed records* (the preconditioner's per-cell recurrence records, tsx_kernels_pcs.hpp).
+// The column recurrences depend on everything between a cell and the surface; below the lowest cloud of a column -- and in
+// every clear column -- they are the same at a given level for all columns (83 % of the cells of the benchmark field).  Same
+// pipeline as for the blocks: hash the R records of a cell, table with the smallest cell as owner, exact comparison, scan,
+// compact.  Cells are taken in the order the records are stored in (colour-split).  Lossless.
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_rec_hash(long long Nc, int R, const uint4 *__restrict__ P,
+                                                            unsigned long long *__restrict__ h) {
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    unsigned long long v = 0x13198a2e03707344ull;
+    for (int r = 0; r < R; ++r) {
+      const uint4 q = P[(size_t)r * Nc + c];
+      v = tsx_mix64(v, ((unsigned long long)q.x << 32) | q.y);
+      v = tsx_mix64(v, ((unsigned long long)q.z << 32) | q.w);
+    }
+    if (v == TSX_DD_EMPTY) v = 0x5555555555555555ull;
+    h[c] = v;
+  }
+}
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_rec_resolve(long long Nc, int R, const uint4 *__restrict__ P, unsigned long long mask,
+                                                               const unsigned long long *__restrict__ h,
+                                                               const unsigned long long *__restrict__ keys,
+                                                               const int *__restrict__ owner, int *__restrict__ rep,
+                                                               int *__restrict__ flag) {
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const unsigned long long hv = h[c];
+    unsigned long long slot = hv & mask;
+    while (keys[slot] != hv) slot = (slot + 1) & mask;
+    const int o = owner[slot];
+    bool same = true;
+    if (o != (int)c) {
+      for (int r = 0; r < R; ++r) {
+        const uint4 a = P[(size_t)r * Nc + c], b = P[(size_t)r * Nc + o];
+        same &= a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+      }
+    }
+    const int rr = same ? o : (int)c;
+    rep[c] = rr;
+    flag[c] = rr == (int)c;
+  }
+}
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_rec_index(long long Nc, const int *__restrict__ rep, const int *__restrict__ pos,
+                                                             int *__restrict__ pidx, int *__restrict__ ent_cell) {
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int r = rep[c], id = pos[r];
+    pidx[c] = id;
+    if (r == (int)c) ent_cell[id] = (int)c;
+  }
+}
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_rec_compact(long long Nc, int R, long long n, const uint4 *__restrict__ P,
+                                                               const int *__restrict__ ent_cell, uint4 *__restrict__ PT) {
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n * R; q += (long long)gridDim.x * TSX_BLOCK) {
+    const long long r = q / n, id = q - r * n;
+    PT[q] = P[(size_t)r * Nc + ent_cell[id]];
+  }
+}
+
+// P: R planes of Nc records.  On success with sharing worth it (2 n <= Nc): s->pcr_idx[c], s->pcr_tab[r * n + id], s->pcr_n = n
+// and returns with s->pcr_on = true; else s->pcr_on = false.  TSX_PC_RECSHARE=0 switches it off.
+int tsx_records_share(tsx_solver *s, int R, const uint4 *P) {
+  s->pcr_on = false;
+  s->pcr_n = 0;
+  static const bool enabled = !(getenv("TSX_PC_RECSHARE") && atoi(getenv("TSX_PC_RECSHARE")) == 0);
+  const long long Nc = s->geo.Nc;
+  if (!enabled || Nc >= (1ll << 31)) return TSX_OK;
+  TsxDdScratch w;
+  {
+    int rc = dd_scratch(s, Nc, &w);
+    if (rc) return rc;
+  }
+  HIPCHK(hipMemsetAsync(w.tk.p, 0, sizeof(unsigned long long) * (size_t)w.tsz, s->stream));
+  HIPCHK(hipMemsetAsync(w.to.p, 0x7f, sizeof(int) * (size_t)w.tsz, s->stream));
+  const int nb = grid_for(Nc, 8192);
+  hipLaunchKernelGGL(tsx_k_rec_hash, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, R, P, w.th.as<unsigned long long>());
+  hipLaunchKernelGGL(tsx_k_dd_insert, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, w.tsz - 1, w.th.as<unsigned long long>(),
+                     w.tk.as<unsigned long long>(), w.to.as<int>());
+  hipLaunchKernelGGL(tsx_k_rec_resolve, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, R, P, w.tsz - 1, w.th.as<unsigned long long>(),
+                     w.tk.as<unsigned long long>(), w.to.as<int>(), w.trep.as<int>(), w.tflag.as<int>());
+  hipLaunchKernelGGL(tsx_k_scan_sums, dim3(w.nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, w.tflag.as<int>(), w.tsum.as<int>());
+  hipLaunchKernelGGL(tsx_k_scan_top, dim3(1), dim3(1024), 0, s->stream, w.nsb, w.tsum.as<int>(), w.ttot.as<int>());
+  hipLaunchKernelGGL(tsx_k_scan_write, dim3(w.nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, w.tflag.as<int>(), w.tsum.as<int>(),
+                     w.tpos.as<int>());
+  HIPCHK(hipGetLastError());
+  int n = 0;
+  HIPCHK(hipMemcpyAsync(&n, w.ttot.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  s->pcr_n = n;
+  if ((long long)n * 2 > Nc) return TSX_OK;
+  if (!s->pcr_idx) HIPCHK(hipMalloc((void **)&s->pcr_idx, sizeof(int) * (size_t)Nc));
+  if (s->pcr_cap < (long long)n * R) {
+    if (s->pcr_tab) HIPCHK(hipFree(s->pcr_tab));
+    if (s->pcr_ent) HIPCHK(hipFree(s->pcr_ent));
+    s->pcr_tab = nullptr;
+    s->pcr_ent = nullptr;
+    HIPCHK(hipMalloc((void **)&s->pcr_tab, sizeof(uint4) * (size_t)n * R));
+    HIPCHK(hipMalloc((void **)&s->pcr_ent, sizeof(int) * (size_t)n));
+    s->pcr_cap = (long long)n * R;
+  }
+  hipLaunchKernelGGL(tsx_k_rec_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, w.trep.as<int>(), w.tpos.as<int>(), s->pcr_idx,
+                     s->pcr_ent);
+  hipLaunchKernelGGL(tsx_k_rec_compact, dim3(grid_for((long long)n * R, 8192)), dim3(TSX_BLOCK), 0, s->stream, Nc, R, (long long)n, P,
+                     s->pcr_ent, (uint4 *)s->pcr_tab);
+  HIPCHK(hipGetLastError());
+  s->pcr_on = true;
   return TSX_OK;
 }

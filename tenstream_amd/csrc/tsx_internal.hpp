@@ -96,6 +96,11 @@ struct tsx_solver {
   int *dd_cidx_split;      // [Nc] colour-split order (the preconditioner's)
   int *dd_ent_cell;        // [dd_nent] representative cell of every entry
   unsigned *pch_send[4], *pch_recv[4];  // preconditioner halo (bf16-pair records of the boundary columns), W E S N
+  // shared storage of identical packed preconditioner records (tsx_records_share): per-cell index, table, capacity (records)
+  bool pcr_on = false;
+  int *pcr_idx = nullptr, *pcr_ent = nullptr;
+  void *pcr_tab = nullptr;
+  long long pcr_n = 0, pcr_cap = 0;
   void *dd_scratch;        // work space of the build (hashes, table, scan)
   size_t dd_scratch_bytes;
   int n1d;             // number of 1-D layers (unconstrained_fraction = 1 - n1d/Nz, src/pprts.F90:721-723)

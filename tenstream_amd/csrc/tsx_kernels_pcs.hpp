@@ -239,7 +239,10 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
                                                          float *__restrict__ zfin, const int *__restrict__ done, int rbc,
                                                          int nonbr, const int *__restrict__ cidx, long long nent,
                                                          const uint4 *__restrict__ PE, TsxPcHalo hal,
-                                                         unsigned *__restrict__ rb, int part) {
+                                                         unsigned *__restrict__ rb, int part, const int *__restrict__ pidx,
+                                                         const uint4 *__restrict__ PT) {
+  // pidx != null (intermediate passes with shared blocks): the cell's record 0 (with its block index) is entry pidx[cell] of
+  // the table PT of distinct records (tsx_records_share)
   static_assert(RQ == 0 || MODE == 0, "bf16 right-hand side only in the intermediate passes");
   constexpr int D = 10, NTOP = 2;
   constexpr bool FINAL = MODE == 2;
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
   for (int l = 0; l < LSEG; ++l) {
     const size_t c = cell(l);
     if (IDX && MODE == 0) {  // record 0 with the block index in place of A_k (tsx_k_pcs_pack_r0g)
-      r0[l] = P[(size_t)7 * Nc + c];
+      r0[l] = pidx ? PT[pidx[c]] : P[(size_t)7 * Nc + c];
       eid[l] = (int)r0[l].w;
     } else {
       eid[l] = IDX ? cidx[c] : 0;
@@ -707,7 +710,10 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
                                                           const float *__restrict__ r, float *__restrict__ z,
                                                           unsigned *__restrict__ zb, float *__restrict__ zfin,
                                                           const int *__restrict__ done, int rbc, int nonbr, TsxPcHalo hal,
-                                                          unsigned *__restrict__ rb, int part) {
+                                                          unsigned *__restrict__ rb, int part, const int *__restrict__ pidx,
+                                                          long long pstride) {
+  // pidx != null: the 14 recurrence records are shared between cells with identical ones (tsx_records_share): P is the table
+  // P[grp * pstride + pidx[cell]]; else P[grp * Nc + cell], pstride = Nc
   // RQ as in tsx_k_pcs_rb: eight bf16-pair words per cell, rb[w * Nc + cell] = (ru_a, rd_a), a = 0..3, then (rs_2q, rs_2q+1)
   static_assert(RQ == 0 || MODE == 0, "bf16 right-hand side only in the intermediate passes");
   constexpr int D = 16, NTOP = 8;
@@ -755,7 +761,10 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   const int nl = Nz - k0 < LSEG ? (Nz - k0 > 0 ? Nz - k0 : 0) : LSEG;
   auto cell = [&](int l) { return (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + col; };
   auto brec = [&](int grp, size_t c, int id) { return PB[(size_t)grp * bstride + (IDX ? (size_t)id : c)]; };
-  auto mat = [&](int grp, size_t c, float add_diag) { return tsx_m4(P[(size_t)grp * Nc + c], P[(size_t)(grp + 1) * Nc + c], add_diag); };
+  auto prow = [&](size_t c) { return pidx ? (size_t)pidx[c] : c; };
+  auto mat = [&](int grp, size_t pr, float add_diag) {
+    return tsx_m4(P[(size_t)grp * pstride + pr], P[(size_t)(grp + 1) * pstride + pr], add_diag);
+  };
   // rank faces: the neighbour's records come from the exchanged buffers (bf16 pairs), [k][j] resp. [k][i]
   const bool face[4] = {hal.E && !nonbr && qe < 0, hal.W && !nonbr && qw < 0, hal.N && !nonbr && jn < 0, hal.S && !nonbr && js < 0};
   auto nbr_load = [&](size_t c, uint2(&o)[4]) {
@@ -812,6 +821,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   float beta[LSEG][4], rdg[LSEG][4];
   uint2 nb[LSEG][4];
   int eid[LSEG];
+  unsigned pr[LSEG];  // row of the level's recurrence records (the cell, or its entry of the shared table)
   {
     float Bl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     TsxM4 Pc;
@@ -824,7 +834,8 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       const size_t c = cell(l);
       const bool act = l < nl;
       eid[l] = IDX ? cidx[c] : 0;
-      const TsxM4 F = mat(2, c, 0.0f);
+      pr[l] = (unsigned)prow(c);
+      const TsxM4 F = mat(2, pr[l], 0.0f);
       float ru[4], rd[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -858,7 +869,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       }
       float Fr[4];
       tsx_mv4(F, rd, Fr);
-      const TsxM4 E = mat(0, c, 0.0f);
+      const TsxM4 E = mat(0, pr[l], 0.0f);
       float EB[4];
       tsx_mv4(E, Bl, EB);
       const TsxM4 EP = tsx_mm4(E, Pc);
@@ -884,7 +895,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     float Bc[4] = {Bin[0], Bin[1], Bin[2], Bin[3]};
 #pragma unroll
     for (int l = LSEG - 1; l >= 0; --l) {
-      const TsxM4 E = mat(0, cell(l), 0.0f);
+      const TsxM4 E = mat(0, pr[l], 0.0f);
       float EB[4];
       tsx_mv4(E, Bc, EB);
 #pragma unroll
@@ -906,10 +917,9 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       for (int b = 0; b < 4; ++b) Qc.m[a][b] = a == b ? 1.0f : 0.0f;
 #pragma unroll
     for (int l = 0; l < LSEG; ++l) {
-      const size_t c = cell(l);
       const bool act = l < nl;
-      const TsxM4 G = mat(4, c, 1.0f), Hm = mat(6, c, 0.0f);
-      const TsxM4 GT = mat(8, c, 0.0f);
+      const TsxM4 G = mat(4, pr[l], 1.0f), Hm = mat(6, pr[l], 0.0f);
+      const TsxM4 GT = mat(8, pr[l], 0.0f);
       float Bn[4], Gr[4], HB[4], GV[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) Bn[a] = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l][a] : Bin[a];
@@ -951,7 +961,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     const bool st = live && l < nl;
     const size_t c = cell(l);
     const size_t cn = (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + ncp;
-    const TsxM4 GT = mat(8, c, 0.0f), An = mat(10, c, 0.0f);
+    const TsxM4 GT = mat(8, pr[l], 0.0f), An = mat(10, pr[l], 0.0f);
     float Bn[4], GV[4], Vn[4], AV[4], Un[4], U[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) Bn[a] = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l][a] : Bin[a];
@@ -962,7 +972,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
 #pragma unroll
     for (int a = 0; a < 4; ++a) Un[a] = AV[a] + Bn[a];
     if (MODE != 0) {
-      const TsxM4 Ao = mat(12, c, 0.0f);
+      const TsxM4 Ao = mat(12, pr[l], 0.0f);
       float AoV[4];
       tsx_mv4(Ao, V, AoV);
 #pragma unroll

@@ -72,6 +72,9 @@ static int pcsh_pack(tsx_solver *s) {  // 8_16: 14 matrix records per cell, then
       hipLaunchKernelGGL((tsx_k_pcsh_pack_block<float>), dim3(grid_for((long long)TSX_S16H_BLOCK * s->dd_nent)), dim3(TSX_BLOCK), 0,
                          s->stream, g, (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d, PB);
       s->coef_h_dd = true;
+      // where blocks repeat, so do the column recurrences below the lowest cloud of a column: share the 14 records too
+      int rc = tsx_records_share(s, TSX_S16H_CELL, P);
+      if (rc) return rc;
     } else {
       hipLaunchKernelGGL((tsx_k_pcsh_pack_block<float>), dim3(grid_for((long long)TSX_S16H_BLOCK * g.Nc)), dim3(TSX_BLOCK), 0,
                          s->stream, g, g.Nc, (const float *)s->coef, (const int *)nullptr, s->l1d, PB);
@@ -88,6 +91,7 @@ static int pcsh_pack(tsx_solver *s) {  // 8_16: 14 matrix records per cell, then
 
 int tsx_pcs_pack(tsx_solver *s) {
   const TsxGeo &g = s->geo;
+  s->pcr_on = false;
   if (g.ntop == 8) return pcsh_pack(s);
   uint4 *P = (uint4 *)s->coef_h;
   s->coef_h_dd = false;
@@ -103,7 +107,11 @@ int tsx_pcs_pack(tsx_solver *s) {
                        (const int *)s->dd_cidx_split, P + (size_t)7 * g.Nc);
     HIPCHK(hipGetLastError());
     s->coef_h_dd = true;
-    return TSX_OK;
+    // below the lowest cloud of a column -- and in every clear column -- that record is the same for all columns of a level.
+    // It costs one more dependent load per level (index -> record -> block records): worth it where a pass is bound by bytes
+    // (512 x 256 columns: 85.8 -> 78.0 us, 256 x 256: 35.2 -> 32.8 us), not where it is bound by latency (128 x 128: 12.0 -> 12.5 us)
+    if ((long long)g.ym * (g.xm / 2) < 16384) return TSX_OK;
+    return tsx_records_share(s, 1, P + (size_t)7 * g.Nc);
   }
   if (s->coef_bytes == 4) {
     hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->coef,
@@ -209,14 +217,17 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   const uint4 *PE = P + g.Nc;
   const TsxPcHalo hal = pcs_halo_arg(s);
   unsigned *rb = zb + (size_t)4 * g.Nc;  // behind the iterate's bf16 records in s->vw
+  const int *pidx = dd && s->pcr_on ? (const int *)s->pcr_idx : (const int *)nullptr;  // shared record 0 of the intermediate passes
+  const uint4 *PT = (const uint4 *)s->pcr_tab;
 #define TSX_PCS_GO(GSV, MODEV, RQV)                                                                                              \
   do {                                                                                                                           \
     if (dd)                                                                                                                      \
       hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, true, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb,   \
-                         zfin, done, rbc, nonbr, cidx, nent, PE, hal, rb, part);                                                 \
+                         zfin, done, rbc, nonbr, cidx, nent, PE, hal, rb, part, pidx, PT);                                       \
     else                                                                                                                         \
       hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, false, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb,  \
-                         zfin, done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr, hal, rb, part);              \
+                         zfin, done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr, hal, rb, part,               \
+                         (const int *)nullptr, (const uint4 *)nullptr);                                                          \
   } while (0)
   if (!gs) {
     if (rq == 1) TSX_PCS_GO(false, 0, 1);
@@ -244,7 +255,11 @@ static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, fl
   const TsxGeo &g = s->geo;
   const long long nthr = part == 2 ? pcs_nframe(g) : (long long)g.ym * (g.xm / 2);
   const int nb = (int)((nthr + CW - 1) / CW);
-  const uint4 *P = (const uint4 *)s->coef_h, *PB = P + (size_t)TSX_S16H_CELL * g.Nc;
+  const uint4 *Pcell = (const uint4 *)s->coef_h, *PB = Pcell + (size_t)TSX_S16H_CELL * g.Nc;
+  // recurrence records: per cell, or the shared table behind the per-cell index (tsx_records_share)
+  const uint4 *P = s->pcr_on ? (const uint4 *)s->pcr_tab : Pcell;
+  const int *pidx = s->pcr_on ? (const int *)s->pcr_idx : (const int *)nullptr;
+  const long long pstride = s->pcr_on ? s->pcr_n : (long long)g.Nc;
   const float *r = (const float *)s->pc_rhs;
   const bool dd = s->coef_h_dd;
   const long long bstride = dd ? (long long)s->dd_nent : g.Nc;
@@ -255,10 +270,10 @@ static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, fl
   do {                                                                                                                          \
     if (dd)                                                                                                                     \
       hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, true, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB,        \
-                         bstride, cidx, r, zs, zb, zfin, done, rbc, nonbr, hal, rb, part);                                      \
+                         bstride, cidx, r, zs, zb, zfin, done, rbc, nonbr, hal, rb, part, pidx, pstride);                       \
     else                                                                                                                        \
       hipLaunchKernelGGL((tsx_k_pcsh_rb<L, S, CW, GSV, MODEV, false, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, PB,       \
-                         bstride, (const int *)nullptr, r, zs, zb, zfin, done, rbc, nonbr, hal, rb, part);                      \
+                         bstride, (const int *)nullptr, r, zs, zb, zfin, done, rbc, nonbr, hal, rb, part, pidx, pstride);       \
   } while (0)
   if (!gs) {
     if (rq == 1) TSX_PCSH_GO(false, 0, 1);

@@ -277,8 +277,8 @@ def test_spectral_loop_full_size_energy_balance_and_uid_warm_start(gpu):
     for c in (cold, warm):
         assert set(c["reasons"]) <= {2, 3}
         assert c["energy_balance_max"] < 2e-3
-    assert sum(warm["iterations_min_med_max"]) < sum(cold["iterations_min_med_max"])
-    assert warm["diffuse_solve_ms_total"] < cold["diffuse_solve_ms_total"]
+    assert sum(warm["iterations_min_med_max"]) < sum(cold["iterations_min_med_max"])   # (no timing assertion: several g-points
+    # are in flight on separate streams and their per-solve event times overlap)
 
 
 def _abso_by_flux_divergence(P, edir, ediff, lsolar):
