@@ -188,16 +188,32 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_index(TsxGeo g, const int 
     if (r == (int)c) ent_cell[id] = (int)c;
   }
 }
-// Cd: plane-major [D*D][nent] (what the preconditioner's pack kernels read); Ce: entry-major [nent][D*D] (the operator)
-__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_compact(long long Nc, int DD, long long nent, const float *__restrict__ C,
+// Cd: plane-major [D*D][nent] (what the preconditioner's pack kernels read); Ce: entry-major [nent][D*D] (the operator).
+// A workgroup moves a tile of 32 entries: plane by plane the lanes read 32 consecutive entries (their representative cells
+// ascend, so clouds read nearly contiguously) and write Cd; the tile goes through LDS and leaves as one contiguous run of Ce
+// (writing Ce straight from the plane-major loop scattered 4-byte stores 4 * D*D bytes apart: 0.57 ms instead of 0.07).
+template <int DD>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_compact(long long Nc, long long nent, const float *__restrict__ C,
                                                               const int *__restrict__ ent_cell, float *__restrict__ Cd,
                                                               float *__restrict__ Ce) {
-  const long long n = nent * DD;
-  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
-    const long long pl = q / nent, id = q - pl * nent;
-    const float v = C[(size_t)pl * Nc + ent_cell[id]];
-    Cd[q] = v;
-    Ce[(size_t)id * DD + pl] = v;
+  constexpr int T = 32;
+  __shared__ float sm[T][DD + 1];
+  const int lane = threadIdx.x % T, grp = threadIdx.x / T;  // 8 groups of 32 lanes walk the planes
+  const long long ntile = (nent + T - 1) / T;
+  for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long long id = tile * T + lane;
+    const bool live = id < nent;
+    const long long cell = live ? (long long)ent_cell[id] : 0;
+    for (int pl = grp; pl < DD; pl += TSX_BLOCK / T) {
+      const float v = live ? C[(size_t)pl * Nc + cell] : 0.0f;
+      if (live) Cd[(size_t)pl * nent + id] = v;
+      sm[lane][pl] = v;
+    }
+    __syncthreads();
+    const long long n = (nent - tile * T < T ? nent - tile * T : T) * DD;
+    float *out = Ce + (size_t)tile * T * DD;
+    for (long long q = threadIdx.x; q < n; q += TSX_BLOCK) out[q] = sm[q / DD][q % DD];
+    __syncthreads();
   }
 }
 
@@ -295,8 +311,16 @@ int tsx_dedup_ensure(tsx_solver *s) {
   const bool split = g.xm % 2 == 0;
   hipLaunchKernelGGL(tsx_k_dd_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, trep.as<int>(), tpos.as<int>(), s->dd_cidx,
                      split ? s->dd_cidx_split : (int *)nullptr, s->dd_ent_cell);
-  hipLaunchKernelGGL(tsx_k_dd_compact, dim3(grid_for((long long)nent * DD, 8192)), dim3(TSX_BLOCK), 0, s->stream, Nc, DD,
-                     (long long)nent, C, s->dd_ent_cell, s->dd_coef, s->dd_coef + (size_t)DD * s->dd_cap);
+  {
+    const int nbt = (int)(((long long)nent + 31) / 32 < 65536 ? ((long long)nent + 31) / 32 : 65536);
+    float *Cd = s->dd_coef, *Ce = s->dd_coef + (size_t)DD * s->dd_cap;
+    if (DD == 100)
+      hipLaunchKernelGGL(tsx_k_dd_compact<100>, dim3(nbt > 0 ? nbt : 1), dim3(TSX_BLOCK), 0, s->stream, Nc, (long long)nent, C,
+                         s->dd_ent_cell, Cd, Ce);
+    else
+      hipLaunchKernelGGL(tsx_k_dd_compact<256>, dim3(nbt > 0 ? nbt : 1), dim3(TSX_BLOCK), 0, s->stream, Nc, (long long)nent, C,
+                         s->dd_ent_cell, Cd, Ce);
+  }
   s->dd_coef_e = s->dd_coef + (size_t)DD * s->dd_cap;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
