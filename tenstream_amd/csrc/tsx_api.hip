@@ -554,6 +554,7 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
   s->coef_h_valid = false;
   s->dd_valid = false;
   s->dd_on = false;
+  s->dd_hash_ready = false;  // imported blocks: tsx_dedup.hip hashes them itself
   return TSX_OK;
 }
 
@@ -646,8 +647,13 @@ extern "C" int tsx_lut_load_diffuse_mmap4(tsx_solver *s, const char *path) {
 }
 
 // alloc_coeff_diff2diff on the device: kabs/ksca/g/dz are device pointers in the reference layout
-static void lut_diffuse_launch(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz, double dx) {
+static int lut_diffuse_launch(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz, double dx) {
   const TsxGeo &gm = s->geo;
+  unsigned long long *hash = nullptr;  // the kernel leaves the blocks' hashes for the shared storage (tsx_dedup.hip)
+  {
+    int rc = tsx_dedup_hash_buffer(s, &hash);
+    if (rc) return rc;
+  }
   TsxLutDev L;
   memset(&L, 0, sizeof(L));
   const TsxLutHost &H = s->lut_diff;
@@ -667,10 +673,12 @@ static void lut_diffuse_launch(tsx_solver *s, const double *kabs, const double *
   const int nbk = grid_for(gm.Nc, 8192);
   if (gm.D == 10)
     hipLaunchKernelGGL((tsx_k_lut_diff2diff<100>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, kabs, ksca, g, dz, dx,
-                       s->l1d, (float *)s->coef);
+                       s->l1d, (float *)s->coef, hash);
   else
     hipLaunchKernelGGL((tsx_k_lut_diff2diff<256>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, kabs, ksca, g, dz, dx,
-                       s->l1d, (float *)s->coef);
+                       s->l1d, (float *)s->coef, hash);
+  s->dd_hash_ready = hash != nullptr;
+  return TSX_OK;
 }
 
 extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const double *ksca, const double *g,
@@ -697,7 +705,7 @@ extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const dou
       p[q] = tmp[q].as<double>();
     }
   }
-  lut_diffuse_launch(s, p[0], p[1], p[2], p[3], dx);
+  if ((rc = lut_diffuse_launch(s, p[0], p[1], p[2], p[3], dx))) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
   s->have_coeffs = true;

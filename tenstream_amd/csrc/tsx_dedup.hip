@@ -15,27 +15,18 @@
 // Used only when it pays (Nent <= Nc / 2); the dense planes stay (setup_b thermal, flux divergence, export read them).
 #include "tsx_host.hpp"
 
-__device__ __forceinline__ unsigned long long tsx_mix64(unsigned long long h, unsigned long long v) {
-  h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
-  h *= 0xff51afd7ed558ccdull;
-  h ^= h >> 33;
-  return h;
-}
-
-constexpr unsigned long long TSX_DD_EMPTY = 0ull;
-constexpr unsigned long long TSX_DD_H1D = 0x1d1d1d1d1d1d1d1dull;
 
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_hash(TsxGeo g, int DD, const float *__restrict__ C,
                                                            const uint8_t *__restrict__ l1d, unsigned long long *__restrict__ h) {
   const long long Nc = g.Nc;
   for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
     const int k = (int)(c / g.ncol);
-    unsigned long long v = 0x243f6a8885a308d3ull;
+    unsigned long long v = TSX_DD_SEED;
     if (l1d[k]) {
       v = TSX_DD_H1D;
     } else {
-      for (int q = 0; q < DD; ++q) v = tsx_mix64(v, (unsigned long long)__float_as_uint(C[(size_t)q * Nc + c]) + ((unsigned long long)q << 32));
-      if (v == TSX_DD_EMPTY || v == TSX_DD_H1D) v ^= 0x5555555555555555ull;
+      for (int q = 0; q < DD; ++q) v = tsx_dd_hash_step(v, q, C[(size_t)q * Nc + c]);
+      v = tsx_dd_hash_final(v);
     }
     h[c] = v;
   }
@@ -256,6 +247,19 @@ static int dd_scratch(tsx_solver *s, long long Nc, TsxDdScratch *w) {
   return TSX_OK;
 }
 
+static bool dedup_enabled();
+// where a kernel that produces the blocks can leave their hashes (same function as tsx_k_dd_hash): null if sharing is off
+int tsx_dedup_hash_buffer(tsx_solver *s, unsigned long long **h) {
+  *h = nullptr;
+  s->dd_hash_ready = false;
+  if (!dedup_enabled() || s->geo.Nc >= (1ll << 31)) return TSX_OK;
+  TsxDdScratch w;
+  int rc = dd_scratch(s, s->geo.Nc, &w);
+  if (rc) return rc;
+  *h = w.th.as<unsigned long long>();
+  return TSX_OK;
+}
+
 static bool dedup_enabled() {
   const char *e = getenv("TSX_DEDUP");  // TSX_DEDUP=0: always the dense planes (A/B knob)
   return e ? atoi(e) != 0 : true;
@@ -283,7 +287,9 @@ int tsx_dedup_ensure(tsx_solver *s) {
   HIPCHK(hipMemsetAsync(to.p, 0x7f, sizeof(int) * (size_t)tsz, s->stream));
   const float *C = (const float *)s->coef;
   const int nb = grid_for(Nc, 8192);
-  hipLaunchKernelGGL(tsx_k_dd_hash, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, th.as<unsigned long long>());
+  if (!s->dd_hash_ready)  // else tsx_k_lut_diff2diff has left the hashes of the blocks it produced (tsx_dedup_hash_buffer)
+    hipLaunchKernelGGL(tsx_k_dd_hash, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, th.as<unsigned long long>());
+  s->dd_hash_ready = false;
   hipLaunchKernelGGL(tsx_k_dd_insert, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, tsz - 1, th.as<unsigned long long>(),
                      tk.as<unsigned long long>(), to.as<int>());
   hipLaunchKernelGGL(tsx_k_dd_resolve, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, tsz - 1,

@@ -140,3 +140,21 @@ __device__ __forceinline__ long long tsx_split_pos(long long idx, const TsxGeo &
   const int col = (int)(t - d * g.ncol);
   return body + d * g.ncol + tsx_split_col(col % g.xm, col / g.xm, g.xm);
 }
+
+// ---- 64-bit hash of a transport block (shared storage of identical blocks, tsx_dedup.hip): fed coefficient by coefficient,
+// by tsx_k_dd_hash from the stored planes or by the kernel that produces the block while it still has it in registers
+constexpr unsigned long long TSX_DD_EMPTY = 0ull;
+constexpr unsigned long long TSX_DD_H1D = 0x1d1d1d1d1d1d1d1dull;  // all cells of 1-D layers (their blocks are never read)
+constexpr unsigned long long TSX_DD_SEED = 0x243f6a8885a308d3ull;
+__device__ __forceinline__ unsigned long long tsx_mix64(unsigned long long h, unsigned long long v) {
+  h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  return h;
+}
+__device__ __forceinline__ unsigned long long tsx_dd_hash_step(unsigned long long h, int q, float coeff) {
+  return tsx_mix64(h, (unsigned long long)__float_as_uint(coeff) + ((unsigned long long)q << 32));
+}
+__device__ __forceinline__ unsigned long long tsx_dd_hash_final(unsigned long long h) {
+  return (h == TSX_DD_EMPTY || h == TSX_DD_H1D) ? h ^ 0x5555555555555555ull : h;
+}

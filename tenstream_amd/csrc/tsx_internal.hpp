@@ -102,6 +102,7 @@ struct tsx_solver {
   void *pcr_tab = nullptr;
   long long pcr_n = 0, pcr_cap = 0;
   void *dd_scratch;        // work space of the build (hashes, table, scan)
+  bool dd_hash_ready = false;  // the hashes of the current blocks already sit in dd_scratch (left by tsx_k_lut_diff2diff)
   size_t dd_scratch_bytes;
   int n1d;             // number of 1-D layers (unconstrained_fraction = 1 - n1d/Nz, src/pprts.F90:721-723)
   TsxLutHost lut_diff;

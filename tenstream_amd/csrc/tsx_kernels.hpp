@@ -437,7 +437,10 @@ template <int DD>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_diff2diff(TsxGeo g, TsxLutDev L, const double *__restrict__ kabs,
                                                                  const double *__restrict__ ksca, const double *__restrict__ gg,
                                                                  const double *__restrict__ dz, double dx,
-                                                                 const uint8_t *__restrict__ l1d, float *__restrict__ C) {
+                                                                 const uint8_t *__restrict__ l1d, float *__restrict__ C,
+                                                                 unsigned long long *__restrict__ hash) {
+  // hash (nullable): the block's 64-bit hash for the shared storage, taken while the block is in registers (tsx_dedup.hip
+  // would otherwise read all planes again for it)
   const int xm = g.xm, ym = g.ym, Nz = g.Nz;
   const long long Nc = g.Nc;
   for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
@@ -445,7 +448,10 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_diff2diff(TsxGeo g, TsxLu
     const long long t = c / xm;
     const int j = (int)(t % ym);
     const int k = (int)(t / ym);
-    if (l1d[k]) continue;
+    if (l1d[k]) {
+      if (hash) hash[c] = TSX_DD_H1D;
+      continue;
+    }
     const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
     const double ka = kabs[r], ks = ksca[r], dzz = dz[r];
     // src/pprts_base.F90:1517-1533
@@ -488,6 +494,12 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_diff2diff(TsxGeo g, TsxLu
     }
 #pragma unroll
     for (int q = 0; q < DD; ++q) C[(size_t)q * Nc + c] = acc[q];
+    if (hash) {
+      unsigned long long hv = TSX_DD_SEED;
+#pragma unroll
+      for (int q = 0; q < DD; ++q) hv = tsx_dd_hash_step(hv, q, acc[q]);
+      hash[c] = tsx_dd_hash_final(hv);
+    }
   }
 }
 
