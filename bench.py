@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--pc-sweeps", type=int, default=0, help="half-grid passes - 1; 0 = the library's choice")
     ap.add_argument("--explicit", action="store_true", help="the explicit (stationary) solver instead of flexible BiCGStab "
                     "(-solar_diff_explicit, src/pprts.F90:2799); a side measurement, the headline is the Krylov solve")
+    ap.add_argument("--seed", type=int, default=20240611, help="seed of the synthetic cloud field (the headline uses the default)")
+    ap.add_argument("--cover", type=float, default=0.3, help="cloud cover of the synthetic field (the headline uses 0.3)")
     ap.add_argument("--check-every", type=int, default=None, help="host looks at the convergence flag every n iterations (library default 4)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,7 +150,7 @@ def main():
     # ---- synthetic optical properties for the owned block (same seed on all ranks -> one global field).  Only the cloud
     # mask is generated globally; delta scaling and the source term are evaluated on the owned block plus one periodic
     # halo column/row (the source of a side stream comes from the neighbouring column), so set-up cost does not grow with N
-    kabs, ksca, g = S.cloud_field(Nx, Ny, Nz, seed=20240611)
+    kabs, ksca, g = S.cloud_field(Nx, Ny, Nz, seed=args.seed, cover=args.cover)
     jj = np.arange(co.ys - 1, co.ys + co.ym + 1) % Ny
     ii = np.arange(co.xs - 1, co.xs + co.xm + 1) % Nx
     kabs, ksca, g = (np.ascontiguousarray(a[np.ix_(jj, ii)]) for a in (kabs, ksca, g))
