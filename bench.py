@@ -227,7 +227,7 @@ def main():
     bytes_iter = s.algorithmic_bytes(1)
     pc_ms = pass_ms = None
     dd_on, dd_nent = s.dedup_info()
-    pc_ran, sweeps, scan = s.pc_info()   # what the solves above actually ran (automatic pass count, zebra on odd grids)
+    pc_ran, sweeps, scan, rec_shared = s.pc_info()   # what the solves above actually ran (automatic pass count, zebra on odd grids)
     if scan and args.pc_sweeps == 0:
         pc_ms = s.bench_kernel(2, args.kernel_reps)
         pass_ms = s.bench_kernel(3, 4 * args.kernel_reps)
@@ -294,6 +294,7 @@ def main():
                 "coeff_dedup": dict(in_use=dd_on, distinct_blocks=dd_nent, cells_local=co.xm * co.ym * Nz,
                                     note="bit-identical blocks are stored once behind a per-cell index (lossless; TSX_DEDUP=0 "
                                          "disables); the rooflines count the bytes of this format"),
+                "preconditioner_records_shared": rec_shared,
                 "coeff_setup_ms": t_setup * 1e3,
                 "preconditioner": {0: "none", 1: "column-jacobi", 2: f"column-zebra({sweeps + 1} passes)",
                                    3: f"column-red-black({sweeps + 1} passes)"}.get(pc_ran, str(pc_ran)),

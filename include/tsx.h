@@ -273,7 +273,8 @@ int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes);
  * at most half of the cells need a block of their own; TSX_DEDUP=0 switches it off) */
 int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent);
 /* the preconditioner the last solve / tsx_bench_kernel actually ran (after the automatic choices: red-black -> zebra rows
- * on odd grids, pc_sweeps 0 -> 19 or 9): TSX_PC_*, pc_sweeps, and whether the passes run as scan kernels */
+ * on odd grids, pc_sweeps 0 -> 19 or 9): TSX_PC_*, pc_sweeps, and scan: 0 = one-lane-per-column kernels, 1 = scan kernels,
+ * 3 = scan kernels reading identical recurrence records through a shared table */
 int tsx_pc_info(const tsx_solver *s, int32_t *pc, int32_t *pc_sweeps, int32_t *scan);
 /* device STREAM-like copy bandwidth probe (GB/s) for reporting against the measured peak */
 int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps);

@@ -1290,7 +1290,7 @@ extern "C" int tsx_pc_info(const tsx_solver *s, int32_t *pc, int32_t *pc_sweeps,
   ARGCHK(s && pc && pc_sweeps && scan, "tsx_pc_info: null");
   *pc = s->pc;
   *pc_sweeps = s->pc_sweeps;
-  *scan = s->coef_h_scan ? 1 : 0;
+  *scan = s->coef_h_scan ? (s->pcr_on ? 3 : 1) : 0;  // bit 1: identical recurrence records are stored once (tsx_records_share)
   return TSX_OK;
 }
 

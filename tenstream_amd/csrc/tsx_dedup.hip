@@ -397,7 +397,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_rec_compact(long long Nc, int
 int tsx_records_share(tsx_solver *s, int R, const uint4 *P) {
   s->pcr_on = false;
   s->pcr_n = 0;
-  static const bool enabled = !(getenv("TSX_PC_RECSHARE") && atoi(getenv("TSX_PC_RECSHARE")) == 0);
+  const bool enabled = !(getenv("TSX_PC_RECSHARE") && atoi(getenv("TSX_PC_RECSHARE")) == 0);  // read per call: tests switch it
   const long long Nc = s->geo.Nc;
   if (!enabled || Nc >= (1ll << 31)) return TSX_OK;
   TsxDdScratch w;

@@ -303,10 +303,11 @@ class DiffuseSolver:
         return bool(on.value), int(n.value)
 
     def pc_info(self):
-        """(TSX_PC_* id, pc_sweeps, scan kernels?) of the preconditioner the last solve actually ran"""
+        """(TSX_PC_* id, pc_sweeps, scan kernels?, identical recurrence records shared?) of the preconditioner the last
+        solve actually ran"""
         pc, sw, scan = C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self.lib.tsx_pc_info(self.h, C.byref(pc), C.byref(sw), C.byref(scan)))
-        return int(pc.value), int(sw.value), bool(scan.value)
+        return int(pc.value), int(sw.value), bool(scan.value & 1), bool(scan.value & 2)
 
     def bench_kernel(self, kernel: int, reps: int) -> float:
         ms = C.c_float()

@@ -265,7 +265,7 @@ def test_default_solver_on_awkward_shapes(gpu, solver, Nx, Ny, Nz, n1d):
     assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
     # what the automatic choices resolved to (tsx_pc_info): red-black with 20 passes on the scan kernels where the grid has an
     # even number of columns per row (and of rows, the rank wrapping onto itself) and Nz <= 256; else zebra rows, 10 passes
-    pc, sweeps, scan = s.pc_info()
+    pc, sweeps, scan, _ = s.pc_info()
     redblack = Nx % 2 == 0 and Ny % 2 == 0
     assert pc == (3 if redblack else 2) and scan == redblack and sweeps == (19 if redblack else 9), (pc, sweeps, scan)
     s.close()
@@ -615,6 +615,37 @@ def test_scan_preconditioner_equals_the_column_sweep(gpu, monkeypatch, Nx, Ny, N
         mk = colour == (p_ % 2)
         x[mk] = lu.solve(rhs)[mk]
     assert np.abs(out["1"][2].ravel() - x).max() <= 6e-2 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("solver,Nx,Ny,Nz", [("3_10", 256, 128, 6), ("8_16", 16, 12, 9)])
+def test_shared_recurrence_records_are_lossless(gpu, monkeypatch, solver, Nx, Ny, Nz):
+    """tsx_records_share: the preconditioner's column recurrence records repeat wherever the column is the same from the cell
+    down to the surface (every clear column, every cloudy column below its lowest cloud); they are stored once behind a second
+    per-cell index (3_10: on passes of >= 16 K columns; 8_16: always).  Same numbers in the same order: the solve -- residual
+    history included -- is bit-identical with TSX_PC_RECSHARE=0 and 1."""
+    P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=0)
+    coeff = P["coeff"].copy()
+    keep = np.zeros((Ny, Nx), dtype=bool)
+    keep[1, 2] = keep[Ny // 2, Nx // 3] = keep[Ny - 1, Nx - 1] = True
+    coeff[~keep] = coeff[0, 0, Nz - 1]                       # one block everywhere ...
+    top = slice(0, Nz // 2)                                  # ... but a "cloud" in the upper half of three columns
+    fac = 1.0 - 0.01 * np.random.default_rng(5).random((int(keep.sum()), Nz // 2, 1))
+    cl = coeff[keep]
+    cl[:, top] = (cl[:, top] * fac).astype(np.float32)
+    cl[:, Nz // 2:] = coeff[0, 0, Nz - 1]                    # below the cloud those columns are like the clear ones
+    coeff[keep] = cl
+    res = {}
+    for share in ("0", "1"):
+        monkeypatch.setenv("TSX_PC_RECSHARE", share)
+        s = DiffuseSolver(solver, Nz, Nx, Ny)
+        s.set_coeffs(coeff, P["l1d"], P["a11"], P["a12"], P["albedo"])
+        xs = np.zeros(s.vec_shape)
+        info = s.solve(P["b"], xs, rtol=1e-9, atol=1e-30)
+        res[share] = (s.pc_info(), xs, info)
+        s.close()
+    assert res["0"][0][2] and not res["0"][0][3] and res["1"][0][3], (res["0"][0], res["1"][0])
+    assert res["0"][2].reason == 2 and res["0"][2].niter == res["1"][2].niter
+    assert np.array_equal(res["0"][2].res_hist, res["1"][2].res_hist) and np.array_equal(res["0"][1], res["1"][1])
 
 
 @pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 16, 12, 9, 2), ("3_10", 10, 6, 5, 0), ("8_16", 8, 6, 5, 1)])
