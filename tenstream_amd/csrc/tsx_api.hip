@@ -413,10 +413,10 @@ static int convert_grid(const TsxGeo &g) {
 }
 
 template <int NTOP, int NSIDE>
-static int import_vec(tsx_solver *s, const double *ref_dev, double *v) {
+static int import_vec(tsx_solver *s, const double *ref_dev, double *v, int *nzflag = nullptr) {
   const TsxGeo &g = s->geo;
   hipLaunchKernelGGL((tsx_k_convert_vec<NTOP, NSIDE, false>), dim3(convert_grid(g)), dim3(TSX_BLOCK), 0, s->stream, g,
-                     const_cast<double *>(ref_dev), v, s->sendW, s->sendS);
+                     const_cast<double *>(ref_dev), v, s->sendW, s->sendS, nzflag);
   HIPCHK(hipGetLastError());
   if (!(g.wrap_x && g.wrap_y)) {
     // only the W-ward / S-ward messages carry data; E/N-ward buffers travel as they are (ignored)
@@ -440,7 +440,7 @@ static int export_vec(tsx_solver *s, const double *v, double *ref_dev) {
   int rc = halo_update<NTOP, NSIDE>(s, v, false);
   if (rc) return rc;
   hipLaunchKernelGGL((tsx_k_convert_vec<NTOP, NSIDE, true>), dim3(convert_grid(g)), dim3(TSX_BLOCK), 0, s->stream, g,
-                     ref_dev, const_cast<double *>(v), s->recvW, s->recvS);
+                     ref_dev, const_cast<double *>(v), s->recvW, s->recvS, (int *)nullptr);
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
@@ -853,15 +853,19 @@ static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o, bool restart = fal
     s->scal_host->restart = 1;
   }
   HIPCHK(hipMemcpyAsync(s->scal, s->scal_host, sizeof(TsxScalars), hipMemcpyHostToDevice, s->stream));
-  // r = b - A x0 (nonzero initial guess, src/pprts.F90:4343); rhat = p = r
-  if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vx, s->vt, (const double *)nullptr, false))) return rc;
+  // r = b - A x0 (nonzero initial guess, src/pprts.F90:4343); rhat = p = r.  A guess known to be zero on every rank (a cold
+  // start) spares the operator apply: r = b
+  const int yzero = s->x_is_zero && !restart ? 1 : 0;
+  if (!yzero && (rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vx, s->vt, (const double *)nullptr, false))) return rc;
+  s->x_is_zero = false;  // from here on x is the iterate
   const int nbv = grid_for(g.N);
   if (s->mixed)
     hipLaunchKernelGGL(tsx_k_residual0<float>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr,
-                       (float *)s->vrhat, s->vp, s->pc != TSX_PC_NONE ? s->p32 : (float *)nullptr, s->partials, g, (int)s->pc_split);
+                       (float *)s->vrhat, s->vp, s->pc != TSX_PC_NONE ? s->p32 : (float *)nullptr, s->partials, g, (int)s->pc_split,
+                       yzero);
   else
     hipLaunchKernelGGL(tsx_k_residual0<double>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr, s->vrhat,
-                       s->vp, (float *)nullptr, s->partials, g, 0);
+                       s->vp, (float *)nullptr, s->partials, g, 0, yzero);
   if ((rc = scalar_stage(s, nbv, 2, TSX_STAGE_INIT))) return rc;
   return TSX_OK;
 }
@@ -972,6 +976,7 @@ static int krylov_run_with_retry(tsx_solver *s, tsx_ksp_opts *o) {
   tsx_ksp_opts o3;
   if ((rc = prepare_ksp(s, &o2, &o3))) return rc;
   HIPCHK(hipMemsetAsync(s->vx, 0, sizeof(double) * (size_t)s->geo.N, s->stream));
+  s->x_is_zero = true;
   hipEvent_t keep0 = s->ev0;  // solve_ms covers both attempts: keep the first start event
   hipEvent_t tmp;
   HIPCHK(hipEventCreate(&tmp));
@@ -998,6 +1003,8 @@ static int fill_result(tsx_solver *s, tsx_ksp_result *res) {
   return TSX_OK;
 }
 
+static int allreduce_host(tsx_solver *s, double *v, int n);  // tsx_pipeline_api.inc
+
 template <int NTOP, int NSIDE>
 static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, const tsx_ksp_opts *o,
                         tsx_ksp_result *res) {
@@ -1016,7 +1023,17 @@ static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, co
   }
   HIPCHK(hipEventRecord(e_imp0, s->stream));
   if ((rc = import_vec<NTOP, NSIDE>(s, bd, s->vb))) return rc;
-  if ((rc = import_vec<NTOP, NSIDE>(s, xd, s->vx))) return rc;
+  {  // the import of the guess also tells whether it is zero
+    int *nzflag = &s->scal->aux_flag;
+    HIPCHK(hipMemsetAsync(nzflag, 0, sizeof(int), s->stream));
+    if ((rc = import_vec<NTOP, NSIDE>(s, xd, s->vx, nzflag))) return rc;
+    int nz = 1;
+    HIPCHK(hipMemcpyAsync(&nz, nzflag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    double anynz = nz;
+    if (s->grid.nranks > 1 && (rc = allreduce_host(s, &anynz, 1))) return rc;  // zero only if zero on every rank
+    s->x_is_zero = anynz == 0.0;
+  }
   HIPCHK(hipEventRecord(e_imp1, s->stream));
 
   {

@@ -48,6 +48,7 @@ struct TsxScalars {
   int nhist;
   int restart;   // set by the host before a breakdown restart: INIT keeps its / history / rnorm0
   int nranks;    // explicit solver: its residual is the mean over ranks of the local norms
+  int aux_flag;  // scratch flag for kernels outside the loop (import: is the guess nonzero?)
   double hist[100];
 };
 
@@ -102,6 +103,7 @@ struct tsx_solver {
   void *pcr_tab = nullptr;
   long long pcr_n = 0, pcr_cap = 0;
   void *dd_scratch;        // work space of the build (hashes, table, scan)
+  bool x_is_zero = false;      // the initial guess in vx is known to be zero on every rank (krylov_begin then skips A x0)
   bool dd_hash_ready = false;  // the hashes of the current blocks already sit in dd_scratch (left by tsx_k_lut_diff2diff)
   size_t dd_scratch_bytes;
   int n1d;             // number of 1-D layers (unconstrained_fraction = 1 - n1d/Nz, src/pprts.F90:721-723)

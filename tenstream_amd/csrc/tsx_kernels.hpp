@@ -12,10 +12,11 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_residual0(long long n, const 
                                                              const double *__restrict__ y, double *__restrict__ r,
                                                              RT *__restrict__ rhat, double *__restrict__ p,
                                                              float *__restrict__ p32, double *__restrict__ partials, TsxGeo g,
-                                                             int split) {
+                                                             int split, int yzero) {
+  // yzero: the initial guess is known to be zero -- y = A x0 was not computed and is not read: r = b
   double sum[2] = {0.0, 0.0};  // slot0 = (rhat, r) with rhat as stored, slot1 = (r, r)
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
-    const double v = b[q] - y[q];
+    const double v = yzero ? b[q] : b[q] - y[q];
     r[q] = v;
     rhat[q] = (RT)v;
     if (p32) p32[split ? tsx_split_pos(q, g) : q] = (float)v;  // fp32 directions with a preconditioner: p lives in fp32 only
@@ -280,7 +281,9 @@ constexpr int TSX_CV_TI = 32, TSX_CV_TK = 8;
 template <int NTOP, int NSIDE, bool EXPORT>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_convert_vec(TsxGeo g, double *__restrict__ ref,
                                                                double *__restrict__ v, double *__restrict__ bufW,
-                                                               double *__restrict__ bufS) {
+                                                               double *__restrict__ bufS, int *__restrict__ nzflag) {
+  // nzflag (import only, nullable): set to 1 if any imported value is nonzero (a zero initial guess spares the solve A x0)
+  bool nz = false;
   constexpr int D = NTOP + 2 * NSIDE, TI = TSX_CV_TI, TK = TSX_CV_TK, ROWS = TK * D;
   __shared__ double sm[ROWS][TI + 1];
   const int L = g.Nz + 1, xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
@@ -320,7 +323,11 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_convert_vec(TsxGeo g, double 
     if (!EXPORT) {
       for (int e = threadIdx.x; e < TI * ROWS; e += TSX_BLOCK) {
         const int ii = e / ROWS, rem = e - ii * ROWS;
-        if (ii < ni && rem < nk * D) sm[rem][ii] = *refp(ii, rem);
+        if (ii < ni && rem < nk * D) {
+          const double val = *refp(ii, rem);
+          sm[rem][ii] = val;
+          nz |= val != 0.0;
+        }
       }
       __syncthreads();
       for (int e = threadIdx.x; e < TI * ROWS; e += TSX_BLOCK) {
@@ -342,6 +349,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_convert_vec(TsxGeo g, double 
     }
     __syncthreads();
   }
+  if (!EXPORT && nzflag && nz) *nzflag = 1;  // benign race: every writer stores 1
 }
 
 // after an import exchange: +x streams received from the east rank (its face i=0) land on my cells xm-1,
