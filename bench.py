@@ -55,6 +55,12 @@ def parse():
                     "(-solar_diff_explicit, src/pprts.F90:2799); a side measurement, the headline is the Krylov solve")
     ap.add_argument("--seed", type=int, default=20240611, help="seed of the synthetic cloud field (the headline uses the default)")
     ap.add_argument("--cover", type=float, default=0.3, help="cloud cover of the synthetic field (the headline uses 0.3)")
+    ap.add_argument("--field", choices=("clouds", "heterogeneous"), default="clouds",
+                    help="clouds: SURVEY 8(d)'s field (homogeneous clear-sky background + cloud layer; the headline). "
+                         "heterogeneous: every cell its own kabs / ksca (log-normal noise on background and clouds), so no two "
+                         "cells share a transport block")
+    ap.add_argument("--skip-no-sharing", action="store_true",
+                    help="skip the second (reported, never `value`) leg that repeats the solves with every block stored per cell")
     ap.add_argument("--check-every", type=int, default=None, help="host looks at the convergence flag every n iterations (library default 4)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,7 +156,7 @@ def main():
     # ---- synthetic optical properties for the owned block (same seed on all ranks -> one global field).  Only the cloud
     # mask is generated globally; delta scaling and the source term are evaluated on the owned block plus one periodic
     # halo column/row (the source of a side stream comes from the neighbouring column), so set-up cost does not grow with N
-    kabs, ksca, g = S.cloud_field(Nx, Ny, Nz, seed=args.seed, cover=args.cover)
+    kabs, ksca, g = S.cloud_field(Nx, Ny, Nz, seed=args.seed, cover=args.cover, heterogeneous=args.field == "heterogeneous")
     jj = np.arange(co.ys - 1, co.ys + co.ym + 1) % Ny
     ii = np.arange(co.xs - 1, co.xs + co.xm + 1) % Nx
     kabs, ksca, g = (np.ascontiguousarray(a[np.ix_(jj, ii)]) for a in (kabs, ksca, g))
@@ -183,7 +189,8 @@ def main():
     dz_l = torch.full((co.ym, co.xm, Nz), dz, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     t_setup = time.perf_counter()
-    s.set_optprop(dev_f(kabs_l), dev_f(ksca_l), dev_f(g_l), dz_l, dx, l1d, a11, a12, alb)
+    optprop = (dev_f(kabs_l), dev_f(ksca_l), dev_f(g_l), dz_l, dx, l1d, a11, a12, alb)
+    s.set_optprop(*optprop)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
     torch.cuda.empty_cache()
@@ -195,29 +202,37 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warm-up + timed steps -------------------------------------------------------------------------
-    infos = []
-    for _ in range(args.warmup):
-        x.zero_()
-        s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every, explicit_solver=int(args.explicit), maxit=10000 if args.explicit else None)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        x.zero_()
-        infos.append(s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every, explicit_solver=int(args.explicit), maxit=10000 if args.explicit else None))
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if transport == "rccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    kw = dict(pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every, explicit_solver=int(args.explicit),
+              maxit=10000 if args.explicit else None)
+
+    def timed_steps():
+        """W untimed + K timed solves from a zero guess, barrier + synchronize on both sides, max over ranks"""
+        got = []
+        for _ in range(args.warmup):
+            x.zero_()
+            s.solve(b, x, **kw)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            x.zero_()
+            got.append(s.solve(b, x, **kw))
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev if transport == "rccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, got
+
+    dt, infos = timed_steps()
     cells_total = Nx * Ny * Nz
     value = cells_total * args.steps / dt
     info = infos[-1]
     # SURVEY 8(d) also asks for a tight run (rtol 1e-8, atol 1e-30 as in tests/test_pprts_symmetry/tenstream.options) and
     # a warm start (previous solution as initial guess, default tolerances): reported in `config`, never part of `value`
     x.zero_()
-    tight = s.solve(b, x, rtol=1e-8, atol=1e-30, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every, explicit_solver=int(args.explicit), maxit=10000 if args.explicit else None)
-    warm = s.solve(b, x, pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every, explicit_solver=int(args.explicit), maxit=10000 if args.explicit else None)
+    tight = s.solve(b, x, rtol=1e-8, atol=1e-30, **kw)
+    warm = s.solve(b, x, **kw)
 
     # ---- rooflines, HIP events on the solver's stream (tsx_bench_kernel): the operator apply, one whole iteration, and
     # the preconditioner (one application = pc_sweeps + 1 half-grid passes; one intermediate pass of the scan kernels)
@@ -232,6 +247,33 @@ def main():
         pc_ms = s.bench_kernel(2, args.kernel_reps)
         pass_ms = s.bench_kernel(3, 4 * args.kernel_reps)
     copy_gbps = s.probe_copy_bandwidth(1 << 30, 10)
+
+    # ---- second leg, reported under config.no_sharing and never part of `value`: the same solves with every cell's block
+    # stored (TSX_DEDUP=0 / TSX_PC_RECSHARE=0: what any field whose cells all differ gets, e.g. --field heterogeneous)
+    no_sharing = None
+    if dd_on and not args.skip_no_sharing and not args.explicit:
+        keep = {k: os.environ.get(k) for k in ("TSX_DEDUP", "TSX_PC_RECSHARE")}
+        os.environ["TSX_DEDUP"] = "0"
+        os.environ["TSX_PC_RECSHARE"] = "0"
+        s.set_optprop(*optprop)
+        dt_ns, infos_ns = timed_steps()
+        it_ns = s.bench_kernel(1, max(4, args.kernel_reps // 4))
+        pass_ns = s.bench_kernel(3, 4 * args.kernel_reps) if scan and args.pc_sweeps == 0 else None
+        spmv_ns = s.bench_kernel(0, args.kernel_reps)
+        b_it = s.algorithmic_bytes(1)
+        no_sharing = {"cells_per_s": cells_total * args.steps / dt_ns, "ms_per_step": dt_ns / args.steps * 1e3,
+                      "iterations": infos_ns[-1].niter, "reason": infos_ns[-1].reason, "iter_ms": it_ns,
+                      "iter_frac_of_B_iter": b_it / (it_ns * 1e-3) / 1e9 / 8000.0, "B_iter_bytes": b_it,
+                      "spmv_ms": spmv_ns, "spmv_frac": s.algorithmic_bytes(0) / (spmv_ns * 1e-3) / 1e9 / 8000.0,
+                      "pass_ms": pass_ns,
+                      "pass_frac": None if pass_ns is None else s.algorithmic_bytes(3) / (pass_ns * 1e-3) / 1e9 / 8000.0,
+                      "how": "TSX_DEDUP=0 TSX_PC_RECSHARE=0, same field, same solves"}
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        s.set_optprop(*optprop)   # back to the default storage for what follows
 
     def roof(kernel, ms, nbytes, patterns, full_storage_bytes=None):
         ach = nbytes / (ms * 1e-3) / 1e9
@@ -309,6 +351,9 @@ def main():
                 "warm_start": {"iterations": warm.niter, "reason": warm.reason, "solve_ms": warm.solve_ms},
                 "iter_GBps": bytes_iter / (iter_ms * 1e-3) / 1e9,
                 "copy_GBps_measured": copy_gbps,
+                "field": args.field,
+                "no_sharing": no_sharing,
+                "baseline_config": baseline_config(solver, Nx, Ny, Nz, world, npx, npy, scaling),
             },
             "roofline": dominant,
             "roofline_spmv": r_spmv,
@@ -316,7 +361,7 @@ def main():
             "roofline_pc": r_pc,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, solver, dx, dz, albedo)
+            out["cpu_baseline"] = cpu_baseline(args, solver, dx, dz, albedo, s, b, x, Nx, Ny, kw)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -371,10 +416,27 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(args, solver, dx, dz, albedo):
+def baseline_config(solver, Nx, Ny, Nz, world, npx, npy, scaling):
+    """Which line of BASELINE.json `configs` / `metric` this run is (None: a workload BASELINE.json does not list)."""
+    if solver == "3_10" and (Nx, Ny, Nz) == (256, 256, 64):
+        return f"metric: pprts 3_10 diffuse-solve cells/s on 256x256x64 at {world} GPU" + ("s" if world > 1 else "")
+    if solver == "3_10" and (Nx, Ny, Nz) == (128, 128, 64) and world == 1:
+        return "configs[1]: pprts 3_10, 128x128x64 single solar g-point, 1xMI355X"
+    if solver == "3_10" and (Nx, Ny, Nz) == (512, 512, 64) and world == 8 and (npx, npy) == (2, 4):
+        return "configs[2]: pprts 3_10, 512x512x64 domain-decomposed 2x4 across 8xMI355X"
+    if solver == "8_16" and (Nx, Ny, Nz) == (256, 256, 64) and world == 1:
+        return "configs[4]: pprts 8_16 higher-order streams, 256x256x64, 1xMI355X"
+    return None
+
+
+def cpu_baseline(args, solver, dx, dz, albedo, dev_solver=None, dev_b=None, dev_x=None, Nx=0, Ny=0, solve_kw=None):
     """The reference's default CPU path as restated by the oracle, timed on this box's host cores on a bounded sample of
     the same generator: assembled AIJ + KSPFBCGS + PCBJACOBI/ILU(0), one subdomain per core like one MPI rank per core
-    (src/pprts.F90:4342-4371, 4415-4425).  With one thread this is the 1-rank default (plain ILU(0))."""
+    (src/pprts.F90:4342-4371, 4415-4425).  With one thread this is the 1-rank default (plain ILU(0)).
+
+    When the sample IS the benchmark domain (>= 16 usable cores), the CPU solves the very system the device solved -- the
+    coefficient blocks are read back from the device (tsx_diff_get_coeffs), same b -- and `parity_check` compares the two
+    converged solutions (both tightened to ~1e-10; outside every timed region)."""
     from oracle import oracle as O
     from tenstream_amd import synthetic as S
     from tenstream_amd.coord import decompose
@@ -383,11 +445,40 @@ def cpu_baseline(args, solver, dx, dz, albedo):
     threads = args.cpu_threads if args.cpu_threads > 0 else min(cores, 128)
     n = args.cpu_sample if args.cpu_sample > 0 else (256 if threads >= 16 else 112)
     npx, npy = decompose(threads)
-    P = S.make_problem(solver, Nx=n, Ny=n, Nz=args.nz, dx=dx, dz=dz, albedo=albedo)
     lay = O.layout(solver, args.nz, n, n)
     rt, at, mx = O.default_tolerances(n, n, args.nz + 1)
-    x, info = O.solve_bjacobi_ilu_mt(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"],
-                                     P["b"], npx, npy, rtol=rt, atol=at, maxit=mx)
+    same = dev_solver is not None and n == Nx and n == Ny and args.nz == dev_solver.Nz
+    parity = None
+    if same:
+        coeff = dev_solver.get_coeffs()
+        bh = dev_b.cpu().numpy()
+        Pz = dict(l1d=np.zeros(args.nz, dtype=np.uint8), a11=np.zeros((n, n, args.nz)), a12=np.zeros((n, n, args.nz)),
+                  albedo=np.full((n, n), albedo))
+        x, info = O.solve_bjacobi_ilu_mt(lay, coeff, Pz["l1d"], Pz["a11"], Pz["a12"], Pz["albedo"], bh, npx, npy, rtol=rt,
+                                         atol=at, maxit=mx, tighten=(1e-6, 1e-30, 2000))
+        del coeff
+        dev_x.zero_()
+        di = dev_solver.solve(dev_b, dev_x, **dict(solve_kw or {}, rtol=1e-10, atol=1e-30))
+        xd = dev_x.cpu().numpy()
+        xt = info["x_tight"]
+        scale = float(np.abs(xt).max())
+        dev_x.zero_()
+        dd = dev_solver.solve(dev_b, dev_x, **(solve_kw or {}))
+        xdd = dev_x.cpu().numpy()
+        parity = {"max_rel_err": float(np.abs(xd - xt).max() / scale),
+                  "device": {"rtol": 1e-10, "its": di.niter, "reason": di.reason},
+                  "cpu": {"its": info["niter"] + info["niter_tight"], "reason": info["reason_tight"],
+                          "how": "the timed default-tolerance solve continued to 1e-6 of its final residual with the same factors"},
+                  "default_tolerance_max_rel_err": {"device_vs_tight": float(np.abs(xdd - xt).max() / scale),
+                                                    "cpu_vs_tight": float(np.abs(x - xt).max() / scale)},
+                  "system": "identical: the device's coefficient blocks (tsx_diff_get_coeffs) and right-hand side",
+                  "norm": "max |x_device - x_cpu| / max |x_cpu| over all unknowns"}
+        sample_desc = f"{n}x{n}x{args.nz}: the benchmark domain itself (the device's blocks and right-hand side)"
+    else:
+        P = S.make_problem(solver, Nx=n, Ny=n, Nz=args.nz, dx=dx, dz=dz, albedo=albedo)
+        x, info = O.solve_bjacobi_ilu_mt(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"],
+                                         P["b"], npx, npy, rtol=rt, atol=at, maxit=mx)
+        sample_desc = f"{n}x{n}x{args.nz} periodic domain of the same generator"
     cells = n * n * args.nz
     # SURVEY 8(d) B2 / B3 beside it, one core each on a smaller sample of the same generator (both are serial codes in the
     # oracle: the matrix-free FBCGS without preconditioner -- the algorithm of the GPU path minus M^-1 --, and the
@@ -414,9 +505,10 @@ def cpu_baseline(args, solver, dx, dz, albedo):
         "unit": "cells/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{n}x{n}x{args.nz} periodic domain of the same generator; assembled CSR + FBCGS + block-Jacobi/ILU(0) on "
+        "sample": f"{sample_desc}; assembled CSR + FBCGS + block-Jacobi/ILU(0) on "
                   f"{npx}x{npy} subdomains (one thread each), {info['niter']} its, reason {info['reason']}, solve "
                   f"{info['t_solve']:.2f}s (assembly {info['t_assemble']:.2f}s, factor {info['t_factor']:.2f}s not counted)",
+        "parity_check": parity,
         "host_cores_available": cores,
         "host_cores_logical": os.cpu_count(),
     }

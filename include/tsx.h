@@ -102,6 +102,10 @@ typedef struct {
                                  red-black sweeps (pc_sweeps + 1 half-grid passes per outer iteration = -pc_sub_it) until the
                                  2-norm of the change (mean over ranks) is < atol or < rtol times the first iteration's; the
                                  result's res_hist holds those norms, rnorm0 = residual(1); maxit as given */
+  int32_t accept_incomplete_solve; /* 0 (default): a solve that ends with reason <= 0 is repeated once from a zero guess with the
+                                 conservative solver (src/pprts.F90:4277-4302).  1: -accept_incomplete_solve (:4271-4273) -- the
+                                 reference returns BEFORE that retry; the (warm-started) partial iterate and the negative
+                                 reason are the result, e.g. with -<prefix>ksp_max_it N as a fixed work budget per call */
 } tsx_ksp_opts;
 
 /* what `solve` stores on the solution: Niter_diff, diff_ksp_residual_history(100)

@@ -190,9 +190,10 @@ def solve_ilu(lay, coeff, l1d, a11, a12, albedo, b, x0=None, rtol=1e-5, atol=1e-
 
 
 def solve_bjacobi_ilu_mt(lay, coeff, l1d, a11, a12, albedo, b, npx, npy, x0=None, rtol=1e-5, atol=1e-8, maxit=1000,
-                         dtol=1e4):
+                         dtol=1e4, tighten=None):
     """The reference's default on npx*npy ranks (FBCGS + PCBJACOBI/ILU(0), pprts.F90:4415-4425), one host thread per
-    subdomain (pprts_oracle_mt.c)."""
+    subdomain (pprts_oracle_mt.c).  tighten=(rtol2, atol2, maxit2): a second solve continues from the first solution with
+    the same factors; its result is info['x_tight'] (reason_tight, niter_tight, t_solve_tight)."""
     coeff, l1d, a11, a12, albedo = _chk(lay, coeff, l1d, a11, a12, albedo)
     b = np.ascontiguousarray(b, dtype=np.float64)
     x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64, order="C", copy=True)
@@ -200,12 +201,24 @@ def solve_bjacobi_ilu_mt(lay, coeff, l1d, a11, a12, albedo, b, npx, npy, x0=None
     nit = C.c_int()
     hist = np.full(maxit + 2, -1.0)
     ta, tf, ts = C.c_double(), C.c_double(), C.c_double()
-    reason = lib().orc_diff_solve_bjacobi_ilu_mt(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12),
-                                                 _p(albedo), _p(b), _p(x), C.byref(tol), int(npx), int(npy),
-                                                 C.byref(nit), _p(hist), len(hist), C.byref(ta), C.byref(tf),
-                                                 C.byref(ts))
+    if tighten is None:
+        reason = lib().orc_diff_solve_bjacobi_ilu_mt(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12),
+                                                     _p(albedo), _p(b), _p(x), C.byref(tol), int(npx), int(npy),
+                                                     C.byref(nit), _p(hist), len(hist), C.byref(ta), C.byref(tf),
+                                                     C.byref(ts))
+        extra = {}
+    else:
+        tol2 = KspTol(tighten[0], tighten[1], dtol, tighten[2])
+        x2 = np.zeros_like(b)
+        nit2, r2, ts2 = C.c_int(), C.c_int(), C.c_double()
+        reason = lib().orc_diff_solve_bjacobi_ilu_mt2(C.byref(lay), _p(coeff), _p(l1d, C.c_uint8), _p(a11), _p(a12),
+                                                      _p(albedo), _p(b), _p(x), C.byref(tol), int(npx), int(npy),
+                                                      C.byref(nit), _p(hist), len(hist), C.byref(ta), C.byref(tf),
+                                                      C.byref(ts), C.byref(tol2), _p(x2), C.byref(nit2), C.byref(r2),
+                                                      C.byref(ts2))
+        extra = dict(x_tight=x2, reason_tight=r2.value, niter_tight=nit2.value, t_solve_tight=ts2.value)
     return x, dict(reason=reason, niter=nit.value, res_hist=hist[: nit.value + 1], t_assemble=ta.value,
-                   t_factor=tf.value, t_solve=ts.value)
+                   t_factor=tf.value, t_solve=ts.value, **extra)
 
 
 def solve_sor(lay, coeff, l1d, a11, a12, albedo, b, x0=None, rtol=1e-5, atol=1e-8, maxit=10000, omega=1.0,
@@ -341,6 +354,13 @@ def suninfo(phi, theta):
 
 def _c64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dir_coeff_symmetry(coeff, is_dir2dir, S, D, east, north):
+    """src/optprop.F90:1009-1045, 1186-1240, 1268-1302 on one coefficient vector (flat dst*S + src); returns a copy."""
+    v = np.array(coeff, dtype=np.float32, order="C")
+    lib().orc_dir_coeff_symmetry(int(is_dir2dir), int(S), int(D), int(east), int(north), _p(v, C.c_float))
+    return v
 
 
 def alloc_coeff_dir(lut_, is_dir2dir, kabs, ksca, g, dz, dx, sun, l1d, S=3, D=10):

@@ -39,10 +39,11 @@ void orc_layout_8_16(orc_layout *l, int Nz, int xm, int ym) {
 int orc_D(const orc_layout *l) { return l->ntop + 2 * l->nside; }
 
 /* inv_dof: pprts_shell.F90:527-540 (same in pprts.F90:5739-5752, pprts_explicit.F90:1001-1014) */
-static int inv_dof(const orc_layout *l, int dof) {
+int orc_inv_dof(const orc_layout *l, int dof) {
   int inc = l->top_inward[0] ? 1 : -1;
   return l->top_inward[dof] ? dof + inc : dof - inc;
 }
+#define inv_dof orc_inv_dof
 
 /* ghosted index helper: (d, k, i, j) with i,j in [-1, xm] / [-1, ym] */
 #define GIDX(D, L, gxm, d, k, i, j) \

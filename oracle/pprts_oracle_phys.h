@@ -80,6 +80,11 @@ typedef struct {
 } orc_suninfo;
 void orc_setup_suninfo(double phi, double theta, orc_suninfo *sun);
 
+/* dir2dir / dir2diff stream relabelling for a sun in the east / north half, in place on one coefficient vector
+ * (flat dst * S + src): src/optprop.F90:1009-1045 (3_10 dir2diff), :1186-1240 (8_16 dir2diff), :1268-1302 (8_16 dir2dir),
+ * :1256-1266 (3_10 dir2dir: none).  Only the dst blocks the reference assigns are touched. */
+void orc_dir_coeff_symmetry(int is_dir2dir, int S, int D, int lswitch_east, int lswitch_north, float *coeff);
+
 /* get_coeff, direct branch (src/pprts_base.F90:1517-1542 -> src/optprop.F90:568-582 -> LUT_get_dir2dir /
  * LUT_get_dir2diff src/optprop_LUT.F90), sample order [tauz, w0, aspect, g, phi, theta]; for 3_10 dir2dir has no
  * symmetry swap, dir2diff uses dir3_to_diff10_coeff_symmetry (src/optprop.F90:1009-1045). */

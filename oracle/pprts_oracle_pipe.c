@@ -49,6 +49,48 @@ void orc_setup_suninfo(double phi, double theta, orc_suninfo *sun) {
   sun->yinc = cos(deg2rad(phi)) < 0.0 ? 1 : 0;
 }
 
+/* The stream relabelling for a sun in the east / north half (get_coeff_cube, src/optprop.F90:571-576), statement by
+   statement as the reference's routines assign it -- `coeff(dst block) = newcoeff(src permutation + other dst block)`,
+   east first, then north.  A dst block without an (uncommented) assignment in the reference keeps its values,
+   source order included.  Pinned to tests/golden/coeff_symmetry.json (the reference's text, interpreted).
+     3_10 dir2dir : dir2dir_coeff_symmetry_none        (:1256-1266)   nothing
+     3_10 dir2diff: dir3_to_diff10_coeff_symmetry      (:1009-1045)   east: dst 3<->4, 5<->6; north: 7<->8, 9<->10
+     8_16 dir2dir : dir2dir8_coeff_symmetry            (:1268-1302)   all 8 dst blocks assigned, src [2,1,4,3,..] / [3,4,1,2,..]
+     8_16 dir2diff: dir8_to_diff16_coeff_symmetry      (:1186-1240)   east: dst 3,4,7,8,9..12 assigned; north: 1,2,5,6,13..16 */
+void orc_dir_coeff_symmetry(int is_dir2dir, int S, int D, int lswitch_east, int lswitch_north, float *coeff) {
+  if (S == 3) {
+    if (is_dir2dir || D != 10) return;
+    /* from[b] = 1-based block read for dst block b+1; 0 = no assignment */
+    static const int e3[10] = {0, 0, 4, 3, 6, 5, 0, 0, 0, 0}, n3[10] = {0, 0, 0, 0, 0, 0, 8, 7, 10, 9};
+    float nw[30];
+    for (int pass = 0; pass < 2; ++pass) {
+      if (!(pass == 0 ? lswitch_east : lswitch_north)) continue;
+      const int *from = pass == 0 ? e3 : n3;
+      memcpy(nw, coeff, sizeof(nw));
+      for (int b = 0; b < 10; ++b)
+        if (from[b])
+          for (int q = 0; q < 3; ++q) coeff[b * 3 + q] = nw[(from[b] - 1) * 3 + q];
+    }
+    return;
+  }
+  if (S != 8) return;
+  const int nb = is_dir2dir ? 8 : 16;
+  static const int src_e[8] = {2, 1, 4, 3, 5, 6, 7, 8}, src_n[8] = {3, 4, 1, 2, 5, 6, 7, 8};
+  static const int t_e[8] = {2, 1, 4, 3, 5, 6, 7, 8}, t_n[8] = {3, 4, 1, 2, 5, 6, 7, 8};
+  static const int s_e[16] = {0, 0, 7, 8, 0, 0, 3, 4, 10, 9, 12, 11, 0, 0, 0, 0};
+  static const int s_n[16] = {5, 6, 0, 0, 1, 2, 0, 0, 0, 0, 0, 0, 14, 13, 16, 15};
+  float nw[128];
+  for (int pass = 0; pass < 2; ++pass) {
+    if (!(pass == 0 ? lswitch_east : lswitch_north)) continue;
+    const int *from = is_dir2dir ? (pass == 0 ? t_e : t_n) : (pass == 0 ? s_e : s_n);
+    const int *sp = pass == 0 ? src_e : src_n;
+    memcpy(nw, coeff, sizeof(float) * (size_t)nb * 8);
+    for (int b = 0; b < nb; ++b)
+      if (from[b])
+        for (int q = 0; q < 8; ++q) coeff[b * 8 + q] = nw[(from[b] - 1) * 8 + (sp[q] - 1)];
+  }
+}
+
 /* get_coeff direct branch; clamps on dirconfig dims (src/pprts_base.F90:1521-1526) */
 void orc_get_coeff_dir(const orc_lut *lut, int is_dir2dir, int S, int D, double kabs, double ksca, double g, double dz,
                        double dx, double sym_phi, double theta, int lswitch_east, int lswitch_north, float *out) {
@@ -64,40 +106,7 @@ void orc_get_coeff_dir(const orc_lut *lut, int is_dir2dir, int S, int D, double 
   for (int d = 0; d < 6; ++d) pti[d] = orc_search_sorted_bisection_f32(lut->axis[d], lut->n[d], sample[d]);
   orc_ndarray_offsets(lut->n, 6, offs);
   orc_interp_vec_nd_f32(pti, 6, lut->table, lut->nvec, offs, out);
-  if (!is_dir2dir && S == 3 && D == 10) { /* dir3_to_diff10_coeff_symmetry: swap dst blocks */
-    float tmp[3];
-#define SWAPBLK(a, b)                                  \
-  memcpy(tmp, out + 3 * ((a)-1), sizeof(tmp));         \
-  memcpy(out + 3 * ((a)-1), out + 3 * ((b)-1), sizeof(tmp)); \
-  memcpy(out + 3 * ((b)-1), tmp, sizeof(tmp));
-    if (lswitch_east) {
-      SWAPBLK(3, 4)
-      SWAPBLK(5, 6)
-    }
-    if (lswitch_north) {
-      SWAPBLK(7, 8)
-      SWAPBLK(9, 10)
-    }
-#undef SWAPBLK
-  }
-  if (S == 8) { /* dir2dir8_coeff_symmetry (src/optprop.F90:1268-1302) / dir8_to_diff16_coeff_symmetry (:1186-1240):
-                   coeff(dst block) = newcoeff(src permutation + other dst block), east first, then north */
-    const int nb = is_dir2dir ? 8 : 16;
-    float nw[128];
-    static const int src_e[8] = {1, 0, 3, 2, 4, 5, 6, 7}, src_n[8] = {2, 3, 0, 1, 4, 5, 6, 7};
-    /* from[b] = the old block that becomes new block b (0-based) */
-    static const int t_e[8] = {1, 0, 3, 2, 4, 5, 6, 7}, t_n[8] = {2, 3, 0, 1, 4, 5, 6, 7};
-    static const int s_e[16] = {0, 1, 6, 7, 4, 5, 2, 3, 9, 8, 11, 10, 12, 13, 14, 15};
-    static const int s_n[16] = {4, 5, 2, 3, 0, 1, 6, 7, 8, 9, 10, 11, 13, 12, 15, 14};
-    for (int pass = 0; pass < 2; ++pass) {
-      if (!(pass == 0 ? lswitch_east : lswitch_north)) continue;
-      const int *from = is_dir2dir ? (pass == 0 ? t_e : t_n) : (pass == 0 ? s_e : s_n);
-      const int *sp = pass == 0 ? src_e : src_n;
-      memcpy(nw, out, sizeof(float) * (size_t)nb * 8);
-      for (int b = 0; b < nb; ++b)
-        for (int q = 0; q < 8; ++q) out[b * 8 + q] = nw[from[b] * 8 + sp[q]];
-    }
-  }
+  orc_dir_coeff_symmetry(is_dir2dir, S, D, lswitch_east, lswitch_north, out);
 }
 
 /* alloc_coeff_dir2dir / dir2diff: src/pprts.F90:3129-3184, 3280-3391 */

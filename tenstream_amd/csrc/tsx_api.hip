@@ -139,6 +139,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->pc_coeff_fp16 = 1;
   o->skip_complete_initial_run = 0;
   o->explicit_solver = 0;
+  o->accept_incomplete_solve = 0;
 }
 
 extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstrained_fraction, double *rtol,
@@ -922,6 +923,7 @@ static int explicit_run_t(tsx_solver *s, const tsx_ksp_opts *o) {
     return TSX_ERR_ARG;
   }
   HIPCHK(hipEventRecord(s->ev0, s->stream));
+  s->x_is_zero = false;  // vx becomes the iterate (only krylov_begin consumes the flag; it must not outlive this solve)
   TsxScalars init;
   memset(&init, 0, sizeof(init));
   init.rtol = o->rtol;
@@ -966,7 +968,8 @@ static int krylov_run_with_retry(tsx_solver *s, tsx_ksp_opts *o) {
   int rc = krylov_run<NTOP, NSIDE>(s, o);
   if (rc) return rc;
   const int reason = s->scal_host->done ? s->scal_host->reason : -3;
-  if (reason > 0 || getenv("TSX_NO_RETRY")) return TSX_OK;
+  // -accept_incomplete_solve: the reference returns before its retry (src/pprts.F90:4271-4273) -- the partial iterate stays
+  if (reason > 0 || o->accept_incomplete_solve || getenv("TSX_NO_RETRY")) return TSX_OK;
   const int its_first = s->scal_host->its;
   tsx_ksp_opts o2 = *o;
   o2.fp32_directions = 0;
@@ -1079,6 +1082,7 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   {
     int rc = tsx_dedup_ensure(s);  // shared storage of identical blocks (operator apply and scan preconditioner)
     if (rc) return rc;
+    if ((rc = tsx_pc_global_agree(s))) return rc;  // several ranks: the preconditioner's halo exchange is on everywhere or nowhere
   }
   if (o->pc_sweeps == 0) {
     // pass count of the Gauss-Seidel orderings, measured on the metric domain, config 2, config 5 and config 4's 252
@@ -1155,8 +1159,10 @@ extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int 
     if (!(mixed && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0))) s->pc = TSX_PC_ZEBRA;
   }
   s->pc_split = s->pc == TSX_PC_REDBLACK;
+  s->mixed = mixed != 0;
   int rc = tsx_dedup_ensure(s);
   if (rc) return rc;
+  if ((rc = tsx_pc_global_agree(s))) return rc;
   if ((rc = tsx_pc_ensure_buffers(s))) return rc;
   s->pc_half = false;
   if (mixed && (rc = tsx_pc_ensure_half(s))) return rc;

@@ -32,6 +32,14 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_hash(TsxGeo g, int DD, con
   }
 }
 
+// tsx_k_dd_insert elects one lane per distinct hash with 64-bit ballots and width-64 shuffles: gfx950 runs wave64 (the only
+// target this library is built for); on a device that reports another wave size the shared storage is simply not used
+static bool tsx_dd_wave64(const tsx_solver *s) {
+  int ws = 0;
+  if (hipDeviceGetAttribute(&ws, hipDeviceAttributeWarpSize, s->device) != hipSuccess) return false;
+  return ws == 64;
+}
+
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_insert(long long Nc, unsigned long long mask, const unsigned long long *__restrict__ h,
                                                              unsigned long long *__restrict__ keys, int *__restrict__ owner) {
   // Most cells of a homogeneous background carry the same hash: millions of atomics on one slot would serialise (measured:
@@ -272,7 +280,8 @@ int tsx_dedup_ensure(tsx_solver *s) {
   s->dd_on = false;
   if (!dedup_enabled() || s->coef_bytes != 4 || !s->have_coeffs) return TSX_OK;
   const TsxGeo &g = s->geo;
-  if (g.Nc >= (1ll << 31)) return TSX_OK;
+  // cell indices are ints and the owner table's "no owner yet" value is 0x7f7f7f7f (byte-wise memset): stay below it
+  if (g.Nc >= 0x7f7f7f7fll || !tsx_dd_wave64(s)) return TSX_OK;
   const int DD = g.D * g.D;
   const long long Nc = g.Nc;
   TsxDdScratch w;
@@ -399,7 +408,7 @@ int tsx_records_share(tsx_solver *s, int R, const uint4 *P) {
   s->pcr_n = 0;
   const bool enabled = !(getenv("TSX_PC_RECSHARE") && atoi(getenv("TSX_PC_RECSHARE")) == 0);  // read per call: tests switch it
   const long long Nc = s->geo.Nc;
-  if (!enabled || Nc >= (1ll << 31)) return TSX_OK;
+  if (!enabled || Nc >= 0x7f7f7f7fll || !tsx_dd_wave64(s)) return TSX_OK;
   TsxDdScratch w;
   {
     int rc = dd_scratch(s, Nc, &w);

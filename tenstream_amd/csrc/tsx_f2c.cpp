@@ -334,6 +334,7 @@ extern "C" void pprts_f2c_solve(int fcomm, float edirTOA) {
   if (opt_real(pre + "ksp_atol", &v)) o.atol = v;
   if (opt_real(pre + "ksp_max_it", &v)) o.maxit = (int32_t)v;
   o.explicit_solver = opt_bool(pre + "explicit", false) ? 1 : 0;
+  o.accept_incomplete_solve = opt_bool("accept_incomplete_solve", false) ? 1 : 0;  // no retry from zero then, src/pprts.F90:4271-4273
   if (o.explicit_solver && !opt_find(pre + "ksp_max_it")) o.maxit = 10000;  // default_max_it, src/pprts_explicit.F90:474
   if (lsolar) {
     double rt = -1, at = -1, mi = -1;

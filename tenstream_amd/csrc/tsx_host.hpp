@@ -119,6 +119,8 @@ int tsx_pc_widen(tsx_solver *s, const float *a, double *o);  // o = (double) a o
 int tsx_dedup_ensure(tsx_solver *s);
 // the red-black preconditioner of 3_10 as a segmented scan over the levels (tsx_pcs.hip); packed layout "S16" in s->coef_h
 bool tsx_pcs_eligible(const tsx_solver *s);
+int tsx_pc_global_agree(tsx_solver *s);       // tsx_pcs.hip: collective, see there
+int tsx_allreduce_host(tsx_solver *s, double *v, int n);  // tsx_api.hip (tsx_pipeline_api.inc)
 int tsx_pcs_pack(tsx_solver *s);
 int tsx_pcs_apply(tsx_solver *s, float *z, const int *done);
 int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done, int rq, int part = 0);

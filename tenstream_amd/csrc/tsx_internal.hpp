@@ -97,6 +97,11 @@ struct tsx_solver {
   int *dd_cidx_split;      // [Nc] colour-split order (the preconditioner's)
   int *dd_ent_cell;        // [dd_nent] representative cell of every entry
   unsigned *pch_send[4], *pch_recv[4];  // preconditioner halo (bf16-pair records of the boundary columns), W E S N
+  // several ranks: whether EVERY rank runs the scan red-black passes with the halo exchange (tsx_pc_global_agree); the
+  // exchange is a matched send/recv with the neighbours, so it is on everywhere or nowhere.  pcg_key = the settings the
+  // answer was agreed for (-1: not yet)
+  int pcg_key = -1;
+  bool pcg_halo_ok = false;
   // shared storage of identical packed preconditioner records (tsx_records_share): per-cell index, table, capacity (records)
   bool pcr_on = false;
   int *pcr_idx = nullptr, *pcr_ent = nullptr;

@@ -129,12 +129,34 @@ int tsx_pcs_pack(tsx_solver *s) {
 }
 
 // ---- preconditioner halo on several ranks (tsx_k_pcs_halo_pack): on when some face of the rank is a real neighbour
-// (or force_halo), both local extents are even (colours then agree across ranks) and TSX_PC_HALO != 0
-static bool pcs_halo_on(const tsx_solver *s) {
+// (or force_halo), both local extents are even and TSX_PC_HALO != 0 -- on EVERY rank.  The exchange is a matched send / recv
+// with the four neighbours, so one rank deciding differently (an odd local extent from an uneven split such as
+// xs = (xi * Nx) / nxp with Nx = 7, or zebra rows after the local red-black fallback) would leave its neighbours' messages
+// unmatched or paired with the operator's halo messages.  pcs_halo_local is this rank's vote, tsx_pc_global_agree
+// (called from prepare_ksp / tsx_diff_pc_apply, collective) the all-reduce.  All extents even on all ranks also means
+// xs and ys are even everywhere (sums of even extents), so the local colour (i + j) & 1 is the global colour.
+static bool pcs_halo_local(const tsx_solver *s) {
   const TsxGeo &g = s->geo;
   const char *e = getenv("TSX_PC_HALO");
   if (e && atoi(e) == 0) return false;
   return !(g.wrap_x && g.wrap_y) && g.xm % 2 == 0 && g.ym % 2 == 0 && g.pc_tile_x == 0 && g.pc_tile_y == 0;
+}
+static bool pcs_halo_on(const tsx_solver *s) {
+  if (!pcs_halo_local(s)) return false;
+  return s->grid.nranks <= 1 || s->pcg_halo_ok;  // one rank with force_halo: its own vote is everybody's
+}
+int tsx_pc_global_agree(tsx_solver *s) {
+  if (s->grid.nranks <= 1) return TSX_OK;
+  const int key = (s->pc << 4) | (s->mixed ? 2 : 0) | (s->pc_split ? 1 : 0);
+  if (key == s->pcg_key) return TSX_OK;
+  const bool mine = s->pc == TSX_PC_REDBLACK && s->pc_split && tsx_pcs_eligible(s) && pcs_halo_local(s) && s->grid.xs % 2 == 0 &&
+                    s->grid.ys % 2 == 0;
+  double v = mine ? 0.0 : 1.0;  // number of ranks that cannot take part
+  int rc = tsx_allreduce_host(s, &v, 1);
+  if (rc) return rc;
+  s->pcg_halo_ok = v == 0.0;
+  s->pcg_key = key;
+  return TSX_OK;
 }
 static size_t pcs_halo_doubles(const tsx_solver *s, int q) {  // message length in doubles (the exchange's unit), rounded up
   const TsxGeo &g = s->geo;

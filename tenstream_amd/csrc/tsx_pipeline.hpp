@@ -14,15 +14,19 @@ struct TsxSun {
 
 // Where coefficient q = dst * S + src of the table's entry goes after the sun-quadrant symmetries: the tables only hold
 // phi in [0, 90]; for a sun in the east (xinc == 0) / north (yinc == 0) the streams of the mirrored box are relabelled
-// (get_coeff_cube, src/optprop.F90:571-576): first the east swap, then the north swap, each a pair of involutions on the
-// dst blocks and on the sources:
-//   3_10  dir2dir: none (dir2dir_coeff_symmetry_none);  dir2diff (dir3_to_diff10_coeff_symmetry, :1009-1045):
-//         east: dst 3<->4, 5<->6; north: dst 7<->8, 9<->10 (1-based)
-//   8_16  dir2dir (dir2dir8_coeff_symmetry, :1268-1302): east: dst 1<->2, 3<->4, src [2,1,4,3,5..8];
+// (get_coeff_cube, src/optprop.F90:571-576): first the east routine, then the north routine, each a list of assignments
+// `coeff(dst block) = newcoeff(src permutation + other dst block)`.  Only the dst blocks the reference ASSIGNS change; a block
+// whose line is commented out there keeps its values *and its source order* (pinned by tests/golden/coeff_symmetry.json,
+// which is the reference's text interpreted statement by statement):
+//   3_10  dir2dir: none (dir2dir_coeff_symmetry_none, :1256-1266);  dir2diff (dir3_to_diff10_coeff_symmetry, :1009-1045):
+//         east: dst 3<->4, 5<->6; north: dst 7<->8, 9<->10 (1-based), sources as they are
+//   8_16  dir2dir (dir2dir8_coeff_symmetry, :1268-1302): all 8 dst blocks assigned.  east: dst 1<->2, 3<->4, src [2,1,4,3,5..8];
 //         north: dst 1<->3, 2<->4, src [3,4,1,2,5..8]
-//         dir2diff (dir8_to_diff16_coeff_symmetry, :1186-1240): east: dst 3<->7, 4<->8, 9<->10, 11<->12, src as above;
-//         north: dst 1<->5, 2<->6, 13<->14, 15<->16, src as above
-// new(d, s) = old(pe_d(pn_d(d)), pe_s(pn_s(s))), so old entry (d0, s0) lands at d = pn_d(pe_d(d0)), s = pn_s(pe_s(s0)).
+//         dir2diff (dir8_to_diff16_coeff_symmetry, :1186-1240): east assigns dst 3<->7, 4<->8, 9<->10, 11<->12 with
+//         src [2,1,4,3,5..8] -- dst 1,2,5,6,13..16 untouched; north assigns dst 1<->5, 2<->6, 13<->14, 15<->16 with
+//         src [3,4,1,2,5..8] -- dst 3,4,7..12 untouched
+// The device scatters: the table's entry (d0, s0) is stored at the position the assignments move it to (the block maps and
+// the source permutations are involutions, so "moved to" = "read from").
 template <int NV, int S, bool DIR2DIFF>
 __device__ __forceinline__ int tsx_dir_symmetry(int q, int east, int north) {
   int d = q / S, s = q % S;
@@ -34,24 +38,28 @@ __device__ __forceinline__ int tsx_dir_symmetry(int q, int east, int north) {
   }
   // S == 8
   if (east) {
-    if (s < 4) s ^= 1;  // [2,1,4,3]
+    bool moved = true;
     if (DIR2DIFF) {
       if (d == 2 || d == 3) d += 4;
       else if (d == 6 || d == 7) d -= 4;
       else if (d >= 8 && d <= 11) d ^= 1;
-    } else if (d < 4) {
-      d ^= 1;
+      else moved = false;
+    } else {
+      if (d < 4) d ^= 1;  // dst 5..8 are assigned from themselves, with the source permutation
     }
+    if (moved && s < 4) s ^= 1;  // [2,1,4,3]
   }
   if (north) {
-    if (s < 4) s ^= 2;  // [3,4,1,2]
+    bool moved = true;
     if (DIR2DIFF) {
       if (d == 0 || d == 1) d += 4;
       else if (d == 4 || d == 5) d -= 4;
       else if (d >= 12) d ^= 1;
-    } else if (d < 4) {
-      d ^= 2;
+      else moved = false;
+    } else {
+      if (d < 4) d ^= 2;
     }
+    if (moved && s < 4) s ^= 2;  // [3,4,1,2]
   }
   return d * S + s;
 }

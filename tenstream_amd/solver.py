@@ -272,9 +272,11 @@ class DiffuseSolver:
         return rtol.value, atol.value, maxit.value
 
     def solve(self, b, x, *, rtol=None, atol=None, maxit=None, dtol=None, pc=None, pc_sweeps=None,
-              check_every=None, fp32_directions=None, pc_coeff_fp16=None, explicit_solver=None) -> KspInfo:
+              check_every=None, fp32_directions=None, pc_coeff_fp16=None, explicit_solver=None,
+              accept_incomplete_solve=None) -> KspInfo:
         """Solve in place: x holds the initial guess on entry (src/pprts.F90:4343) and the solution on exit.
-        explicit_solver=1: explicit_ediff's stationary iteration (-<prefix>explicit, src/pprts.F90:2799) instead of FBCGS."""
+        explicit_solver=1: explicit_ediff's stationary iteration (-<prefix>explicit, src/pprts.F90:2799) instead of FBCGS.
+        accept_incomplete_solve=1: -accept_incomplete_solve (src/pprts.F90:4271-4273): no retry from zero after a failed solve."""
         if tuple(b.shape) != self.vec_shape or tuple(x.shape) != self.vec_shape:
             raise ValueError("b/x shape mismatch")
         o = _lib.KspOpts()
@@ -283,7 +285,8 @@ class DiffuseSolver:
         o.rtol, o.atol, o.maxit = drt, dat, dmx
         for name, val in (("rtol", rtol), ("atol", atol), ("maxit", maxit), ("dtol", dtol), ("pc", pc),
                           ("pc_sweeps", pc_sweeps), ("check_every", check_every), ("fp32_directions", fp32_directions),
-                          ("pc_coeff_fp16", pc_coeff_fp16), ("explicit_solver", explicit_solver)):
+                          ("pc_coeff_fp16", pc_coeff_fp16), ("explicit_solver", explicit_solver),
+                          ("accept_incomplete_solve", accept_incomplete_solve)):
             if val is not None:
                 setattr(o, name, val)
         bp, where = _ptr(b, np.float64)

@@ -144,8 +144,12 @@ def delta_scale(kabs, ksca, g, f=None):
     return kabs_o, ksca_o, g_o
 
 
-def cloud_field(Nx, Ny, Nz, seed=20240611, cover=0.3, cld_layers=None, sigma=8.0):
-    """clear sky kabs = ksca = 1e-5, g = 0; thresholded smooth random cloud field."""
+def cloud_field(Nx, Ny, Nz, seed=20240611, cover=0.3, cld_layers=None, sigma=8.0, heterogeneous=False):
+    """clear sky kabs = ksca = 1e-5, g = 0; thresholded smooth random cloud field.
+    heterogeneous=True: every cell gets optical properties of its own -- log-normal "humidity" noise (sigma 0.25, smooth over
+    ~4 cells horizontally and 2 levels, times white noise of 3 %) on the absorption and scattering of the background and the
+    clouds alike, as an LES humidity / aerosol field has it.  No two cells then share a transport block (the general case
+    the shared-block storage does not help with)."""
     from scipy.ndimage import gaussian_filter
 
     rng = np.random.default_rng(seed)
@@ -164,6 +168,12 @@ def cloud_field(Nx, Ny, Nz, seed=20240611, cover=0.3, cld_layers=None, sigma=8.0
         ksca[..., k] = np.where(mask2d, ks, ksca[..., k])
         kabs[..., k] = np.where(mask2d, 1e-6 * ks, kabs[..., k])
         g[..., k] = np.where(mask2d, 0.85, g[..., k])
+    if heterogeneous:
+        rng2 = np.random.default_rng(seed + 1)
+        for a in (kabs, ksca):
+            smooth = gaussian_filter(rng2.standard_normal((Ny, Nx, Nz)), sigma=(4.0, 4.0, 2.0), mode="wrap")
+            smooth *= 0.25 / max(float(smooth.std()), 1e-30)
+            a *= np.exp(smooth + 0.03 * rng2.standard_normal((Ny, Nx, Nz)))
     return kabs, ksca, g
 
 

@@ -128,3 +128,44 @@ def test_solar_gpoint_energy_balance_full_size(gpu):
     assert abs(out_toa + srf + atm - incoming) <= 2e-4 * incoming
     assert atm > 0.01 * incoming and out_toa > 0.01 * incoming
     P.close()
+
+
+@pytest.mark.parametrize("solver,Nx,Ny,Nz", [("3_10", 256, 256, 64), ("3_10", 128, 128, 64), ("8_16", 128, 128, 64)])
+def test_device_solution_equals_the_oracle_at_baseline_sizes(gpu, solver, Nx, Ny, Nz):
+    """The oracle's restatement of the reference's default CPU path (assembled AIJ + KSPFBCGS + PCBJACOBI/ILU(0),
+    src/pprts.F90:4342-4371, 4415-4425; one subdomain per usable core, oracle/pprts_oracle_mt.c) solves the very system the
+    device solved -- the device's own coefficient blocks read back through tsx_diff_get_coeffs, the same right-hand side --
+    on BASELINE.json's metric domain (256x256x64), config 2 (128x128x64) and, for 8_16, the largest domain whose CSR and
+    ILU factors fit comfortably (128x128x64: 0.29 G non-zeros; 256x256x64 would be 1.1 G = 27 GB for matrix + factors).
+    Bar: max |x_device - x_oracle| <= 1e-8 max |x| with both solves tightened to ~1e-10/1e-11."""
+    import sys
+
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    import bench
+    from oracle import oracle as O
+    from tenstream_amd.coord import decompose
+
+    s, b, dev = _solver(solver, Nx, Ny, Nz)
+    import torch
+
+    x = torch.zeros_like(b)
+    info = s.solve(b, x, rtol=1e-10, atol=1e-30)
+    assert info.reason == 2
+    xd = x.cpu().numpy()
+    coeff = s.get_coeffs()
+    s.close()
+    threads = min(bench.usable_cores(), 64)
+    npx, npy = decompose(threads)
+    lay = O.layout(solver, Nz, Nx, Ny)
+    rt, at, mx = O.default_tolerances(Nx, Ny, Nz + 1)
+    z = np.zeros((Ny, Nx, Nz))
+    xo, oi = O.solve_bjacobi_ilu_mt(lay, coeff, np.zeros(Nz, dtype=np.uint8), z, z, np.full((Ny, Nx), ALB), b.cpu().numpy(),
+                                    npx, npy, rtol=rt, atol=at, maxit=mx, tighten=(1e-6, 1e-30, 2000))
+    del coeff
+    assert oi["reason"] in (2, 3) and oi["reason_tight"] == 2, oi
+    xt = oi["x_tight"]
+    scale = np.abs(xt).max()
+    err = np.abs(xd - xt).max() / scale
+    assert err <= 1e-8, (err, info.niter, oi["niter"], oi["niter_tight"])
+    # and the default-tolerance iterate of the oracle (what the CPU baseline times) is the same solution to its own stop rule
+    assert np.abs(xo - xt).max() / scale <= 1e-3

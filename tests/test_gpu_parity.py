@@ -324,6 +324,69 @@ def test_failed_solve_is_retried_from_zero_with_the_conservative_solver(gpu, mon
     s.close()
 
 
+def test_accept_incomplete_solve_keeps_the_partial_iterate(gpu):
+    """-accept_incomplete_solve (src/pprts.F90:4271-4273): the reference returns BEFORE the retry, so a solve limited by
+    -ksp_max_it leaves its (warm-started) partial iterate and the negative reason.  Without the option the same call is
+    retried from zero (reason of the second attempt, iteration counts added)."""
+    import scipy.sparse.linalg as spla
+
+    P = synthetic.make_problem("3_10", Nx=12, Ny=10, Nz=8, n1d=1)
+    lay = O.layout("3_10", 8, 12, 10)
+    A = O.assemble_csr(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x_ref = spla.spsolve(A.tocsc(), P["b"].ravel()).reshape(P["b"].shape)
+    s = DiffuseSolver("3_10", 8, 12, 10)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x = np.zeros(s.vec_shape)
+    errs = []
+    for call in range(4):   # a fixed budget of 2 iterations per call, warm-started: the error keeps falling across calls
+        info = s.solve(P["b"], x, rtol=1e-13, atol=1e-30, maxit=2, pc=0, accept_incomplete_solve=1)   # no M^-1: slow on purpose
+        assert info.reason == -3 and info.niter == 2, info
+        errs.append(np.abs(x - x_ref).max() / np.abs(x_ref).max())
+    assert errs[-1] < 0.3 * errs[0] and errs[-1] > 1e-9, errs
+    # without the option: first attempt fails after 2, the retry starts from zero and fails too -> 4 iterations, still -3,
+    # and the warm start is gone (the error is that of 2 conservative iterations from zero, not of 8 + 2)
+    x2 = x.copy()
+    info = s.solve(P["b"], x2, rtol=1e-13, atol=1e-30, maxit=2, pc=0)
+    assert info.reason == -3 and info.niter == 4
+    x3 = np.zeros(s.vec_shape)
+    s.solve(P["b"], x3, rtol=1e-13, atol=1e-30, maxit=2, pc=0, accept_incomplete_solve=1)
+    e2, e3 = (np.abs(v - x_ref).max() / np.abs(x_ref).max() for v in (x2, x3))
+    assert e2 > errs[-1] and e2 > 0.1 * e3, (e2, e3, errs)
+    s.close()
+
+
+def test_zero_guess_flag_does_not_outlive_the_guess(gpu):
+    """tsx_pprts_zero_guess lets the next Krylov solve skip A x0 -- only while vx really is zero.  Three sequences that wrote
+    vx afterwards (a stored solution selected, an explicit solve, the |b| < atol shortcut) used to leave the flag set: the
+    next warm-started solve then took r = b with x0 != 0 and converged to x0 + A^-1 b."""
+    from test_gpu_pipeline import _setup
+
+    P, I = _setup(8, 6, 8, 200.0, 40.0, 0)
+    P.set_optical_properties(0.15, I["kabs"], I["ksca"], I["g"], I["dz"])
+    tight = dict(rtol=1e-11, atol=1e-30, maxit=500)
+    P.solve(1000.0, uid=1, **tight)
+    x1 = P.get_field("ediff").copy()
+    # (1) select a fresh uid (zeroes the guess, sets the flag), then go back to uid 1 without solving in between
+    import ctypes as C
+    from tenstream_amd import _lib
+    _lib.check(P.lib.tsx_pprts_select_solution(P.h, 7))
+    info = P.solve(1000.0, uid=1, **tight)
+    assert info.reason > 0
+    assert np.abs(P.get_field("ediff") - x1).max() <= 1e-8 * np.abs(x1).max()
+    # (2) zero guess + explicit solve, then a warm-started Krylov solve
+    P.solve(1000.0, zero_guess=True, explicit_solver=1, rtol=1e-4, atol=1e-30, maxit=200, pc_sweeps=5)
+    info = P.solve(1000.0, **tight)
+    assert info.reason > 0
+    assert np.abs(P.get_field("ediff") - x1).max() <= 1e-8 * np.abs(x1).max()
+    # (3) zero guess + a solve that takes the |b|_1 < atol shortcut (ediff = b), then a real solve warm-started from it
+    info = P.solve(1000.0, zero_guess=True, rtol=1e-5, atol=1e30, skip_complete_initial_run=1)
+    assert info.reason == 3 and info.niter == 0
+    info = P.solve(1000.0, **tight)
+    assert info.reason > 0
+    assert np.abs(P.get_field("ediff") - x1).max() <= 1e-8 * np.abs(x1).max()
+    P.close()
+
+
 def _column_block_matrix(P, lay):
     """M = entries of the assembled matrix whose row and column unknowns leave the same cell column
     (dst-owned numbering): the matrix the column preconditioner inverts exactly."""

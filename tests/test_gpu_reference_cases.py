@@ -243,9 +243,12 @@ def test_config3_local_block_with_halo_faces(gpu):
 
 def test_config5_8_16_through_the_reference_c_abi(gpu, tmp_path, monkeypatch):
     """pprts_f2c_init with SOLVER_ID_PPRTS_8_16 = 816 (c_wrapper/f2c_solver_ids.h; f2c_pprts.F90:270-272): tables
-    `_diffuse_16...` / `_direct_8_16...` from $LUT_BASENAME, a cloudy solar g-point; equal to the PprtsSolver-driven
-    pipeline (which tests/test_gpu_pipeline.py pins to the oracle) to float32 rounding."""
-    Nx, Ny, Nz, phi0, theta0 = 6, 5, 10, 200.0, 35.0
+    `_diffuse_16...` / `_direct_8_16...` from $LUT_BASENAME, a cloudy solar g-point with the sun in the north-east
+    quadrant (phi 50: lswitch_east and lswitch_north both on, so dir2dir8 / dir8_to_diff16_coeff_symmetry are in the result);
+    equal to the PprtsSolver-driven pipeline to float32 rounding AND to the oracle's restatement of the pipeline."""
+    from test_gpu_pipeline import _oracle_pipeline
+
+    Nx, Ny, Nz, phi0, theta0 = 6, 5, 10, 50.0, 35.0
     base, dims, dax, Tdir, Sdir = _write_luts(tmp_path, "8_16")
     monkeypatch.setenv("LUT_BASENAME", base)
     monkeypatch.setenv("TSX_LUT_DIRECT_DIMS", dims)
@@ -280,10 +283,18 @@ def test_config5_8_16_through_the_reference_c_abi(gpu, tmp_path, monkeypatch):
     P.set_optical_properties(float(np.float32(0.1)), kabs.astype(np.float64), ksca.astype(np.float64), g.astype(np.float64), dz)
     P.solve(1000.0)
     want = P.get_result()
+    sun = O.suninfo(float(np.float32(phi0)), float(np.float32(theta0)))
+    assert sun.xinc == 0 and sun.yinc == 0
+    ref = _oracle_pipeline(P, dict(dx=100.0, dy=100.0, dax=dax, Tdir=Tdir, Sdir=Sdir, solver="8_16"), 0.1, 1000.0, True)
     P.close()
     for got, w in zip((edn, eup, abso, edir), want):
         assert np.abs(got - w.astype(np.float32)).max() <= 2e-6 * np.abs(w).max() + 1e-30
     assert np.ptp(edir[:, :, -1]) > 10.0   # the clouds cast shadows (W/m2)
+    # against the oracle (diffuse solve at the reference's default rtol 1e-5 on the device, 1e-10 in the oracle)
+    for name, got, w, tol in (("edir", edir, ref["redir"], 2e-4), ("edn", edn, ref["edn"], 5e-4), ("eup", eup, ref["eup"], 5e-4),
+                              ("abso", abso, ref["abso"], 5e-4)):
+        err = np.abs(got - w).max() / np.abs(w).max()
+        assert err <= tol, (name, err)
 
 
 @pytest.mark.parametrize("solver", ["3_10", "8_16"])
