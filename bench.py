@@ -9,8 +9,9 @@ A "step" is one diffuse solve (I - T) x = b with the reference's stop rule (rtol
 g-point; inputs (coefficient blocks, RHS) are resident in HBM before the timed region.  At N > 1 the
 domain is sharded 2-D in x/y exactly like the reference's DMDA (src/pprts_base.F90:747-790, 972-990), one rank
 per GPU, face halos + dot products over RCCL (host-staged gloo when several ranks have to share a device).
-Domain:  --scaling weak (default): every GPU owns --nx x --ny columns (256 x 256 x 64: the BASELINE metric domain per GPU);
-         --scaling strong: the global domain is --nx x --ny whatever N is (256 x 256 x 64 at 1/2/4/8 GPUs);
+Domain:  --scaling strong (the default at N > 1): the global domain is --nx x --ny whatever N is -- BASELINE.json's metric,
+         "256x256x64 at 1/2/4/8 GPU"; config.baseline_config names the BASELINE line a run corresponds to;
+         --scaling weak: every GPU owns --nx x --ny columns (256 x 256 x 64 per GPU);
          --global-nx / --global-ny: an explicit global domain, e.g. config 3 = `--gpus 8 --global-nx 512 --global-ny 512`
          (2 x 4 ranks of 256 x 128 columns).
 Prints ONE JSON line on rank 0.
@@ -41,7 +42,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nx", type=int, default=256, help="columns in x: per GPU (weak scaling) or of the global domain (strong)")
     ap.add_argument("--ny", type=int, default=256, help="columns in y, likewise")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
+                    help="auto = strong: BASELINE.json's metric is the 256x256x64 domain at 1/2/4/8 GPUs (fixed total work)")
     ap.add_argument("--global-nx", type=int, default=0, help="explicit global domain (implies fixed total work)")
     ap.add_argument("--global-ny", type=int, default=0)
     ap.add_argument("--transport", choices=("auto", "rccl", "host"), default="auto",
@@ -145,9 +147,9 @@ def main():
     Nz = args.nz
     if args.global_nx or args.global_ny:
         Nx, Ny, scaling = args.global_nx or args.nx, args.global_ny or args.ny, "strong"
-    elif args.scaling == "strong":
+    elif args.scaling in ("strong", "auto") and world > 1:
         Nx, Ny, scaling = args.nx, args.ny, "strong"
-    else:
+    else:   # one GPU (either reading gives the same domain; the line says "weak" as the contract's example does), or --scaling weak
         Nx, Ny, scaling = args.nx * npx, args.ny * npy, "weak"
     co = decompose.coord(rank, world, Nx, Ny)
     dx, dz, albedo = 100.0, 50.0, 0.1
@@ -247,6 +249,9 @@ def main():
         pc_ms = s.bench_kernel(2, args.kernel_reps)
         pass_ms = s.bench_kernel(3, 4 * args.kernel_reps)
     copy_gbps = s.probe_copy_bandwidth(1 << 30, 10)
+    # the byte counts follow the storage format in use: take them while the solver is in the state that was timed
+    bytes_survey_spmv = s.algorithmic_bytes(10)
+    bytes_pass, bytes_pc = (s.algorithmic_bytes(3), s.algorithmic_bytes(2)) if pass_ms is not None else (None, None)
 
     # ---- second leg, reported under config.no_sharing and never part of `value`: the same solves with every cell's block
     # stored (TSX_DEDUP=0 / TSX_PC_RECSHARE=0: what any field whose cells all differ gets, e.g. --field heterogeneous)
@@ -292,7 +297,7 @@ def main():
     if rank == 0:
         r_spmv = roof("tsx_k_spmv_w (y = (I - T) x, fp64 x and y)", spmv_ms, bytes_spmv,
                       ["tsx_k_spmv", (",0,1,double,double", ",0,2,double,double"), ",true>" if dd_on else ",false>"],
-                      s.algorithmic_bytes(10))
+                      bytes_survey_spmv)
         r_iter = roof("one BiCGStab iteration (2 M^-1, 2 SpMV, 3 vector updates)", iter_ms, bytes_iter, None)
         if not dd_on:   # the committed PMC profile is of the shared-block kernels
             r_iter["traffic"] = r_iter["traffic_GBps"] = r_iter["traffic_source"] = None
@@ -302,12 +307,12 @@ def main():
         if pass_ms is not None:
             kname = "tsx_k_pcs_rb" if solver == "3_10" else "tsx_k_pcsh_rb"
             r_pass = roof(f"{kname}<..., GS, MODE 0, RQ 2> (one intermediate red-black pass of M^-1)", pass_ms,
-                          s.algorithmic_bytes(3), [kname, ",true,0,true,2>" if dd_on else ",true,0,false,2>"])
+                          bytes_pass, [kname, ",true,0,true,2>" if dd_on else ",true,0,false,2>"])
         r_pc = None
         if pc_ms is not None:
             r_pc = {"kernel": f"M^-1: {sweeps + 1} half-grid passes", "ms_per_application": pc_ms,
-                    "bytes_per_application": s.algorithmic_bytes(2),
-                    "achieved": s.algorithmic_bytes(2) / (pc_ms * 1e-3) / 1e9, "unit": "GB/s"}
+                    "bytes_per_application": bytes_pc,
+                    "achieved": bytes_pc / (pc_ms * 1e-3) / 1e9, "unit": "GB/s"}
         # the kernel the solve spends most of its time in: the preconditioner pass (about half of an iteration) when the
         # scan kernels run, else the operator apply
         dominant = r_pass if r_pass is not None else r_spmv

@@ -44,6 +44,41 @@ def write_mmap4(path, table):
         f.write(t.tobytes())
 
 
+def write_mmap4_generated(path, nentries, ncoeff, gen, chunk=1 << 20):
+    """The same container written in pieces: gen(lo, hi) -> (hi - lo, ncoeff) float32 for entries lo..hi-1.  For tables of
+    the reference's full preset size (LUT_direct_3_10 Tdir: 30.9 M entries x 9 = 1.1 GB, Sdir x 30 = 3.7 GB) that should
+    not be held in memory twice."""
+    header = np.zeros(PAGESIZE // 8, dtype=np.uint64)
+    header[0] = 4
+    header[1] = nentries * ncoeff
+    header[2] = 4 * nentries * ncoeff
+    header[3] = ncoeff
+    header[4] = nentries
+    with open(path, "wb") as f:
+        f.write(header.tobytes())
+        for lo in range(0, nentries, chunk):
+            hi = min(nentries, lo + chunk)
+            t = np.ascontiguousarray(gen(lo, hi), dtype=np.float32)
+            assert t.shape == (hi - lo, ncoeff)
+            f.write(t.tobytes())
+
+
+def hashed_table_values(lo, hi, ncoeff, salt=0):
+    """Deterministic pseudo-random float32 values in [0, 1/ncoeff) for entries lo..hi-1 (a stand-in payload for tables of
+    the preset size: values differ from entry to entry and from coefficient to coefficient, sums over a block stay <= 1)."""
+    n = (hi - lo) * ncoeff
+    h = np.arange(n, dtype=np.uint32)
+    h += np.uint32((lo * ncoeff + salt * 0x51ED27) & 0xFFFFFFFF)   # flat index of (entry, coefficient), wrapping
+    h *= np.uint32(2654435761)
+    h ^= h >> np.uint32(15)
+    h *= np.uint32(2246822519)
+    h ^= h >> np.uint32(13)
+    h >>= np.uint32(8)
+    v = h.astype(np.float32)
+    v *= np.float32(1.0 / (1 << 24) / ncoeff)
+    return v.reshape(hi - lo, ncoeff)
+
+
 def read_mmap4(path):
     """Returns a read-only (nentries, ncoeff) float32 memory map of a `.mmap4` table."""
     header = np.fromfile(path, dtype=np.uint64, count=PAGESIZE // 8)

@@ -42,7 +42,7 @@ def test_bench_one_gpu_line_has_the_contract_keys(gpu):
 
 
 @pytest.mark.parametrize("extra,glob,local,scaling", [
-    (["--nx", "32", "--ny", "24"], (32, 48), (32, 24), "weak"),
+    (["--nx", "32", "--ny", "24", "--scaling", "weak"], (32, 48), (32, 24), "weak"),
     (["--nx", "32", "--ny", "24", "--scaling", "strong"], (32, 24), (32, 12), "strong"),
     (["--global-nx", "64", "--global-ny", "32"], (64, 32), (64, 16), "strong"),   # config-3 style: an explicit global domain
 ])
@@ -57,6 +57,24 @@ def test_bench_launches_its_own_ranks(gpu, extra, glob, local, scaling):
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["config"]["process_grid"] == "1x2"
     assert f"{glob[0]}x{glob[1]}x16 cells global ({local[0]}x{local[1]}x16 on rank 0)" in out["config"]["workload"]
     assert out["config"]["reason"] in (2, 3) and out["value"] > 0
+
+
+def test_bench_eight_ranks_on_the_two_by_four_grid(gpu):
+    """`python bench.py --gpus 8` on a 1-GPU box: config 3's 2 x 4 process grid (src/pprts_base.F90:757-763), here on a
+    64 x 64 x 16 domain with the host-staged transport; fixed total work by default at N > 1 (BASELINE's metric reads
+    "256x256x64 at 1/2/4/8 GPU")."""
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--global-nx", "64", "--global-ny", "64",
+                        "--transport", "host"] + SMALL, capture_output=True, text=True, timeout=1200, env=clean, cwd=ROOT)
+    out = _line(p)
+    assert out["n_gpus"] == 8 and out["config"]["process_grid"] == "2x4" and out["scaling"] == "strong"
+    assert "64x64x16 cells global (32x16x16 on rank 0)" in out["config"]["workload"]
+    assert out["config"]["reason"] in (2, 3) and out["value"] > 0
+    # the default at N > 1 is the metric's reading: the same global domain whatever N
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "32", "--ny", "24"] + SMALL,
+                       capture_output=True, text=True, timeout=900, env=clean, cwd=ROOT)
+    out = _line(p)
+    assert out["scaling"] == "strong" and "32x24x16 cells global (32x12x16 on rank 0)" in out["config"]["workload"]
 
 
 def test_bench_refuses_a_rank_count_mismatch(gpu):

@@ -168,6 +168,76 @@ def test_sharded_hip_solve_equals_global_oracle(gpu, world, solver, Nx, Ny):
         assert abs(r0 - bn) <= 1e-12 * bn  # the initial residual is the *global* norm of b
 
 
+# ---- 8 ranks, 2 x 4: config 3's decomposition (src/pprts_base.F90:747-790: dims = [nyp, nxp] = [4, 2], ranks x-fastest) ----
+def _worker8(rank, world, port, Nx, Ny, Nz, ref_path, ret):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from tenstream_amd import DiffuseSolver, coord, hostcomm, synthetic
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ref = np.load(ref_path)
+        P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+        co = coord.coord(rank, world, Nx, Ny)
+        sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
+        s = DiffuseSolver("3_10", Nz, co.xm, co.ym, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank, nranks=world,
+                          neighbors=(co.west, co.east, co.south, co.north), device=0)
+        hostcomm.attach(s, rank)
+        loc = lambda k: np.ascontiguousarray(P[k][sl])
+        s.set_coeffs(loc("coeff"), P["l1d"], loc("a11"), loc("a12"), loc("albedo"))
+        y = s.apply(np.ascontiguousarray(ref["xg"][sl]))
+        e_apply = float(np.abs(y - ref["yg"][sl]).max() / np.abs(ref["yg"]).max())
+        x = np.zeros(s.vec_shape)
+        info = s.solve(np.ascontiguousarray(P["b"][sl]), x, rtol=1e-10, atol=1e-30)   # the library's default preconditioner
+        e_solve = float(np.abs(x - ref["x_ref"][sl]).max() / np.abs(ref["x_ref"]).max())
+        xd = np.zeros(s.vec_shape)
+        infod = s.solve(np.ascontiguousarray(P["b"][sl]), xd)                          # reference default tolerances
+        ret[rank] = (e_apply, e_solve, info.reason, info.niter, infod.niter, (co.nxp, co.nyp, co.xi, co.yi, co.xm, co.ym),
+                     s.pc_info())
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_two_by_four_equal_the_global_oracle(gpu, tmp_path):
+    """Config 3's process grid on one device: 8 rank processes share cuda:0 (host-staged face exchange), a 64 x 64 x 16
+    domain -> 2 x 4 blocks of 32 x 16 columns.  Operator and default solve against the oracle on the global domain; the
+    preconditioner's halo exchange keeps the one-rank iteration count."""
+    from oracle import oracle as O
+    from tenstream_amd import DiffuseSolver, synthetic
+
+    Nx, Ny, Nz = 64, 64, 16
+    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+    lay = O.layout("3_10", Nz, Nx, Ny)
+    c64 = P["coeff"].astype(np.float64)
+    xg = np.random.default_rng(11).standard_normal((Ny, Nx, Nz + 1, 10))
+    yg = O.diff_apply(lay, c64, P["l1d"], P["a11"], P["a12"], P["albedo"], xg)
+    x_ref, oi = O.solve_ilu(lay, c64, P["l1d"], P["a11"], P["a12"], P["albedo"], P["b"], rtol=1e-13, atol=1e-30, maxit=3000)
+    assert oi["reason"] == 2
+    ref_path = str(tmp_path / "ref.npz")
+    np.savez(ref_path, xg=xg, yg=yg, x_ref=x_ref)
+    # one periodic rank for the iteration counts
+    s1 = DiffuseSolver("3_10", Nz, Nx, Ny)
+    s1.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x1 = np.zeros(s1.vec_shape)
+    its1_tight = s1.solve(P["b"], x1, rtol=1e-10, atol=1e-30).niter
+    x1[...] = 0
+    its1 = s1.solve(P["b"], x1).niter
+    s1.close()
+    ret = _spawn(_worker8, 8, (Nx, Ny, Nz, ref_path))
+    grids = set()
+    for rank, (e_apply, e_solve, reason, niter, niter_d, grid, pci) in ret.items():
+        assert e_apply < 1e-13 and reason == 2 and e_solve < 1e-8, (rank, e_apply, e_solve, reason)
+        assert grid[:2] == (2, 4) and grid[2:4] == (rank % 2, rank // 2) and grid[4:] == (32, 16), grid
+        assert abs(niter - its1_tight) <= 1 and abs(niter_d - its1) <= 1, (niter, its1_tight, niter_d, its1)
+        assert pci[0] == 3 and pci[2], pci   # red-black scan passes on every rank
+        grids.add(grid[2:4])
+    assert len(grids) == 8
+
+
 # ---- the whole g-point pipeline on several ranks ------------------------------------------------------------------
 def _pipeline_worker(rank, world, port, Nx, Ny, Nz, phi0, theta0, tall_top, ret):
     sys.path.insert(0, ROOT)

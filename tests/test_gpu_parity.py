@@ -338,20 +338,19 @@ def test_accept_incomplete_solve_keeps_the_partial_iterate(gpu):
     s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
     x = np.zeros(s.vec_shape)
     errs = []
-    for call in range(4):   # a fixed budget of 2 iterations per call, warm-started: the error keeps falling across calls
-        info = s.solve(P["b"], x, rtol=1e-13, atol=1e-30, maxit=2, pc=0, accept_incomplete_solve=1)   # no M^-1: slow on purpose
+    kw = dict(rtol=1e-13, atol=1e-30, maxit=2, pc=1, pc_sweeps=1)   # column block-Jacobi: converges, but not in 2 iterations
+    for call in range(6):   # a fixed budget of 2 iterations per call, warm-started: the error keeps falling across calls
+        info = s.solve(P["b"], x, accept_incomplete_solve=1, **kw)
         assert info.reason == -3 and info.niter == 2, info
         errs.append(np.abs(x - x_ref).max() / np.abs(x_ref).max())
-    assert errs[-1] < 0.3 * errs[0] and errs[-1] > 1e-9, errs
+    assert errs[-1] < 0.1 * errs[0] and errs[-1] > 1e-12, errs
     # without the option: first attempt fails after 2, the retry starts from zero and fails too -> 4 iterations, still -3,
-    # and the warm start is gone (the error is that of 2 conservative iterations from zero, not of 8 + 2)
+    # and the warm start is gone (the error is that of 2 conservative iterations from zero, not of 12 + 2)
     x2 = x.copy()
-    info = s.solve(P["b"], x2, rtol=1e-13, atol=1e-30, maxit=2, pc=0)
+    info = s.solve(P["b"], x2, **kw)
     assert info.reason == -3 and info.niter == 4
-    x3 = np.zeros(s.vec_shape)
-    s.solve(P["b"], x3, rtol=1e-13, atol=1e-30, maxit=2, pc=0, accept_incomplete_solve=1)
-    e2, e3 = (np.abs(v - x_ref).max() / np.abs(x_ref).max() for v in (x2, x3))
-    assert e2 > errs[-1] and e2 > 0.1 * e3, (e2, e3, errs)
+    e2 = np.abs(x2 - x_ref).max() / np.abs(x_ref).max()
+    assert e2 > 3.0 * errs[-1], (e2, errs)
     s.close()
 
 

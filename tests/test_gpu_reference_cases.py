@@ -353,6 +353,89 @@ def test_f2c_opp_coefficient_probe_is_bit_exact(gpu, tmp_path, monkeypatch, solv
     f2c.pprts_f2c_opp_destroy(opp, C.byref(ierr))
 
 
+def test_f2c_preset_size_direct_tables_without_any_sidecar(gpu, tmp_path, monkeypatch):
+    """The branch a real installation takes: `LUT_direct_3_10.tau31.w020.aspect_zx23.g6.phi19.theta19.ds1000.nc.{Tdir,Sdir}.mmap4`
+    (names: src/optprop_LUT.F90:364-374, 505, 1348; header: src/mmap.F90:63-127) of the reference's full preset size
+    (30.9 M entries: Tdir 1.1 GB, Sdir 3.7 GB) and `LUT_diffuse_10...Sdiff.mmap4` under $LUT_BASENAME -- NO TSX_LUT_DIRECT_DIMS and
+    NO `.axes` sidecar, so the axes come from the library's presets (src/optprop_parameters.F90:107-110, 145-154, 194-199, 245;
+    phi19 / theta19 = linspace(0, 90), src/optprop_base.F90:228-235).  pprts_f2c_opp_get_coeff bit-exact against the oracle's
+    interpolation with the axes of tests/golden/lut_presets.json on 200 samples."""
+    import json
+
+    S, D = 3, 10
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "lut_presets.json")))
+    pre = lambda name: np.frombuffer(bytes.fromhex("".join(fx["presets"][name]["f32_hex"])), dtype=np.float32)
+    cfg = fx["configs"]["LUT_3_10"]
+    dax = [pre(d["preset"]) if "preset" in d else np.linspace(d["vrange"][0], d["vrange"][1], d["n"], dtype=np.float32)
+           for d in cfg["dirconfig"]]
+    dfx = [pre(d["preset"]) for d in cfg["diffconfig"]]
+    assert [len(a) for a in dax] == [31, 20, 23, 6, 19, 19]
+    nent = int(np.prod([len(a) for a in dax]))
+    base = str(tmp_path / "LUT")
+    monkeypatch.delenv("TSX_LUT_DIRECT_DIMS", raising=False)
+    monkeypatch.setenv("LUT_BASENAME", base)
+    dims = "tau31.w020.aspect_zx23.g6.phi19.theta19"
+    tpath, spath = (f"{base}_direct_3_10.{dims}.ds1000.nc.{k}.mmap4" for k in ("Tdir", "Sdir"))
+    import torch
+
+    tg = torch.Generator(device="cuda").manual_seed(77)
+
+    def payload(ncoeff):   # pseudo-random float32 in [0, 1/ncoeff): generated on the GPU (the host has few cores to spare)
+        return lambda lo, hi: (torch.rand((hi - lo, ncoeff), generator=tg, device="cuda", dtype=torch.float32) / ncoeff).cpu().numpy()
+
+    lut.write_mmap4_generated(tpath, nent, S * S, payload(S * S), chunk=1 << 22)
+    lut.write_mmap4_generated(spath, nent, S * D, payload(S * D), chunk=1 << 22)
+    assert not os.path.exists(tpath + ".axes")
+    dtab = lut.synthetic_diffuse_table("3_10")
+    lut.write_mmap4(base + "_diffuse_10.tau31.w020.aspect_zx23.g6.ds1000.nc.Sdiff.mmap4", dtab)
+    assert os.path.getsize(tpath) == lut.PAGESIZE + 4 * 9 * nent and os.path.getsize(spath) == lut.PAGESIZE + 4 * 30 * nent
+
+    f2c = C.CDLL(os.path.join(ROOT, "tenstream_amd", "lib", "libtsx_f2c.so"))
+    opp, ierr = C.c_void_p(), C.c_int(-1)
+    f2c.pprts_f2c_opp_init(0, 310, C.byref(opp), C.byref(ierr))
+    assert ierr.value == 0 and opp.value
+    f2c.pprts_f2c_opp_get_coeff.argtypes = [C.c_void_p] + [C.c_float] * 6 + [C.c_int] * 4 + [C.c_void_p, C.POINTER(C.c_int)]
+    nd, nf = C.c_int(), C.c_int()
+    rng = [(C.c_float * 2)() for _ in range(10)]
+    f2c.pprts_f2c_opp_get_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)] + [C.c_void_p] * 10 + [C.POINTER(C.c_int)]
+    f2c.pprts_f2c_opp_get_info(opp, C.byref(nd), C.byref(nf), *rng, C.byref(ierr))
+    assert (nd.value, nf.value) == (S, D)
+    want = [dfx[0], dfx[1], dfx[3], dfx[2], dax[0], dax[1], dax[3], dax[2], dax[4], dax[5]]
+    for r, a in zip(rng, want):
+        assert (r[0], r[1]) == (np.float32(a[0]), np.float32(a[-1]))
+    LT = O.make_lut(dax, lut.read_mmap4(tpath))
+    LS = O.make_lut(dax, lut.read_mmap4(spath))
+    Ld = O.make_lut(dfx, dtab)
+    gen = np.random.default_rng(8)
+    n_checked = 0
+    while n_checked < 200:
+        dz, dx = float(gen.uniform(20, 300)), 100.0
+        ext = 10 ** gen.uniform(-5, -1.5)
+        w = gen.uniform(0, 0.999)
+        kabs, ksca, g = ext * (1 - w), ext * w, float(gen.choice([0.0, 0.2424, 0.85, gen.uniform(0, 0.85)]))
+        phi, theta = float(gen.choice([0.0, 45.0, 90.0, gen.uniform(0, 90)])), float(gen.choice([0.0, 40.0, gen.uniform(0, 90)]))
+        tauz, w0, asp = np.float32((kabs + ksca) * dz), np.float32(ksca / max(kabs + ksca, np.finfo(float).eps)), np.float32(dz / dx)
+        if not (dax[0][0] <= tauz <= dax[0][-1] and dax[1][0] <= w0 <= dax[1][-1]):
+            continue
+        for imode, table, L_ in ((1, S * S, LT), (2, S * D, LS), (3, D * D, Ld)):
+            east, north = int(gen.integers(0, 2)), int(gen.integers(0, 2))
+            out = np.zeros(table, dtype=np.float32)
+            f2c.pprts_f2c_opp_get_coeff(opp, tauz, w0, np.float32(g), asp, np.float32(phi), np.float32(theta), imode, east, north,
+                                        table, out.ctypes.data, C.byref(ierr))
+            assert ierr.value == 0
+            if imode == 3:
+                ref = O.get_coeff_diff2diff(L_, kabs, ksca, g, dz, dx)
+            else:
+                ref = np.zeros(table, dtype=np.float32)
+                O.lib().orc_get_coeff_dir(C.byref(L_), int(imode == 1), S, D, C.c_double(kabs), C.c_double(ksca), C.c_double(g),
+                                          C.c_double(dz), C.c_double(dx), C.c_double(phi), C.c_double(theta), east, north,
+                                          ref.ctypes.data_as(C.POINTER(C.c_float)))
+            assert np.array_equal(out, ref), (imode, east, north, n_checked)
+            assert np.abs(out).max() > 0
+            n_checked += 1
+    f2c.pprts_f2c_opp_destroy(opp, C.byref(ierr))
+
+
 def _f2c_worker(rank, world, port, solver_id, Nx, Ny, Nz, lut_env, lsolar, ret):
     import sys
 

@@ -52,3 +52,14 @@ def test_alloc_coeff_field_skips_1d_layers():
     c = O.alloc_coeff_diff2diff(L, kabs, ksca, g, dz, 100.0, l1d)
     assert np.all(c[:, :, 0] == 0) and np.all(c[:, :, 5] == 0) and np.all(c[:, :, 1:5].sum(axis=-1) > 0)
     assert np.array_equal(c.astype(np.float32).astype(np.float64), c)  # real(v, ireals): fp32-exact
+
+
+def test_mmap4_written_in_pieces_equals_the_single_write(tmp_path):
+    """write_mmap4_generated (tables of the reference's preset size are written chunk by chunk): same bytes as one write,
+    header as src/mmap.F90:63-127 lays it out."""
+    n, nc = 1000, 9
+    full = lut.hashed_table_values(0, n, nc, salt=1)
+    assert full.shape == (n, nc) and full.dtype == np.float32 and 0 <= full.min() and full.max() < 1.0 / nc
+    lut.write_mmap4(tmp_path / "a.mmap4", full)
+    lut.write_mmap4_generated(tmp_path / "b.mmap4", n, nc, lambda lo, hi: lut.hashed_table_values(lo, hi, nc, salt=1), chunk=300)
+    assert (tmp_path / "a.mmap4").read_bytes() == (tmp_path / "b.mmap4").read_bytes()
