@@ -46,8 +46,10 @@ def parse():
                     help="auto = strong: BASELINE.json's metric is the 256x256x64 domain at 1/2/4/8 GPUs (fixed total work)")
     ap.add_argument("--global-nx", type=int, default=0, help="explicit global domain (implies fixed total work)")
     ap.add_argument("--global-ny", type=int, default=0)
-    ap.add_argument("--transport", choices=("auto", "rccl", "host"), default="auto",
-                    help="auto: RCCL when every rank has a device of its own, else host-staged (gloo)")
+    ap.add_argument("--transport", choices=("auto", "rccl", "peer", "host"), default="auto",
+                    help="auto: RCCL when every rank has a device of its own, else host-staged (gloo); peer: the "
+                         "device-resident transport (IPC-mapped mailboxes, tsx_peer.hip) -- works with one device per rank "
+                         "(xGMI) and with ranks sharing a device")
     ap.add_argument("--nz", type=int, default=64)
     ap.add_argument("--solver", default="3_10")
     ap.add_argument("--pc", type=int, default=3,
@@ -103,7 +105,8 @@ def launch_ranks(args):
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
-    sys.stdout.write(out0.decode())
+    for line in out0.decode().splitlines():   # ONE JSON line: libraries (gloo) chat on the ranks' stdout
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return rc
 
@@ -137,10 +140,17 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if transport == "rccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.stdout.flush()
+        keep_fd = os.dup(1)
+        os.dup2(2, 1)   # gloo / RCCL print their banners on stdout: the line contract wants exactly one JSON line there
+        try:
+            if transport == "rccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:   # host-staged exchanges, or only the bootstrap of the peer transport
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        finally:
+            os.dup2(keep_fd, 1)
+            os.close(keep_fd)
 
     # ---- domain -------------------------------------------------------------------------------------
     npx, npy = decompose(world)
@@ -178,6 +188,10 @@ def main():
         uid = [s.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         s.comm_init(uid[0])
+    elif world > 1 and transport == "peer":
+        from tenstream_amd import hostcomm
+
+        hostcomm.attach_peer(s)
     elif world > 1:
         from tenstream_amd import hostcomm
 
@@ -333,7 +347,8 @@ def main():
                 "workload": f"pprts {solver} diffuse solve, {Nx}x{Ny}x{Nz} cells global ({co.xm}x{co.ym}x{Nz} on rank 0), "
                             f"{scaling} scaling, single solar g-point, rtol 1e-5 / reference atol, zero initial guess",
                 "process_grid": f"{npx}x{npy}",
-                "transport": "none (1 rank)" if world == 1 else ("RCCL" if transport == "rccl" else "host-staged (gloo)"),
+                "transport": "none (1 rank)" if world == 1 else {"rccl": "RCCL", "peer": "device-resident peer mailboxes (HIP IPC)",
+                                                                    "host": "host-staged (gloo)"}[transport],
                 "coeff_storage": "fp32 blocks (lossless); x, r, s, v, t fp64; directions p, p-hat, s-hat and shadow residual fp32",
                 "preconditioner_storage": "inside M^-1 only: fp16 column blocks + fp8 couplings, fp32/bf16 iterates; operator, "
                                           "Krylov vectors, dots and stop rule fp64 on the exact blocks",

@@ -143,6 +143,19 @@ int tsx_set_stream(tsx_solver *s, void *hip_stream);
 int tsx_comm_unique_id(void *id128);
 int tsx_comm_init(tsx_solver *s, const void *id128);
 
+/* ---- device-resident peer transport (node-local; replaces MPI_Isend/Irecv of exchange_diffuse_boundary,
+ *      src/pprts_explicit.F90:715-848, and the MPI_Allreduce of the Krylov dots): every rank owns a mailbox in fine-grained
+ *      device memory that its peers map through HIP IPC (xGMI between the GPUs of a node; rank processes sharing one device
+ *      work too).  Halos are written by the sender's kernel straight into the receiver's mailbox and signalled with a
+ *      sequence word; the 3-double all-reduces are all-to-all stores summed in rank order.  Only kernels on the solver's
+ *      streams: no library call and no host round trip per exchange.
+ *      Bootstrap like tsx_comm_unique_id / tsx_comm_init: every rank exports a blob of TSX_PEER_BLOB_BYTES, the host
+ *      all-gathers them in rank order (MPI_Allgather in the reference's world) and hands the nranks blobs to attach.
+ *      Takes precedence over RCCL and over the callbacks once attached.  At most 16 ranks. */
+#define TSX_PEER_BLOB_BYTES 192
+int tsx_comm_peer_export(tsx_solver *s, void *blob);
+int tsx_comm_peer_attach(tsx_solver *s, const void *blobs);
+
 /* Alternative transport: host-staged callbacks, for hosts whose communicator is MPI (TenStream's own
  * solver%comm) without GPU-aware transport, and for multi-process tests on one GPU.  The library copies the
  * four face buffers to pinned host memory, calls `exchange`, and copies the received faces back.

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "tsx_host.hpp"
+#include "tsx_peer.hpp"
 #include "tsx_kernels.hpp"
 #include "tsx_pipeline.hpp"
 
@@ -40,6 +41,7 @@ struct RcclApi {
   int (*GetUniqueId)(tsx_ncclUniqueId *) = nullptr;
   int (*CommInitRank)(tsx_ncclComm_t *, int, tsx_ncclUniqueId, int) = nullptr;
   int (*CommDestroy)(tsx_ncclComm_t) = nullptr;
+  int (*CommSplit)(tsx_ncclComm_t, int, int, tsx_ncclComm_t *, void *) = nullptr;  // optional (RCCL >= 2.18)
   int (*Send)(const void *, size_t, int, int, tsx_ncclComm_t, hipStream_t) = nullptr;
   int (*Recv)(void *, size_t, int, int, tsx_ncclComm_t, hipStream_t) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, tsx_ncclComm_t, hipStream_t) = nullptr;
@@ -80,6 +82,7 @@ static int rccl_load() {
   BIND(GroupEnd, "ncclGroupEnd");
   BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
+  *(void **)(&g_rccl.CommSplit) = dlsym(h, "ncclCommSplit");
   g_rccl.h = h;
   return TSX_OK;
 }
@@ -113,6 +116,14 @@ extern "C" int tsx_comm_init(tsx_solver *s, const void *id128) {
   NCCLCHK(g_rccl.CommInitRank(&comm, s->grid.nranks, id, s->grid.rank));
   s->nccl_comm = comm;
   s->comm_ready = true;
+  // The face exchanges run on comm_stream while the all-reduces run on the solver stream: give each stream a communicator
+  // of its own (two streams driving one communicator concurrently is the classic RCCL hang).  TSX_RCCL_SPLIT=0 keeps one.
+  const char *e = getenv("TSX_RCCL_SPLIT");
+  if (g_rccl.CommSplit && !(e && atoi(e) == 0)) {
+    tsx_ncclComm_t cx = nullptr;
+    NCCLCHK(g_rccl.CommSplit(comm, 0, s->grid.rank, &cx, nullptr));
+    s->nccl_comm_x = cx;
+  }
   return TSX_OK;
 }
 
@@ -272,7 +283,11 @@ extern "C" int tsx_destroy(tsx_solver *s) {
     if (s->host_recv[q]) (void)hipHostFree(s->host_recv[q]);
   }
   slots_free(s);
-  if (s->comm_ready && g_rccl.CommDestroy) g_rccl.CommDestroy(s->nccl_comm);
+  if (s->comm_ready && g_rccl.CommDestroy) {
+    if (s->nccl_comm_x) g_rccl.CommDestroy(s->nccl_comm_x);
+    g_rccl.CommDestroy(s->nccl_comm);
+  }
+  tsx_peer_destroy(s);
   for (hipEvent_t e : {s->ev0, s->ev1, s->ev_imp0, s->ev_imp1, s->ev_exp1, s->ev_pack, s->ev_recv})
     if (e) (void)hipEventDestroy(e);
   if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
@@ -308,6 +323,7 @@ extern "C" int tsx_set_stream(tsx_solver *s, void *hip_stream) {
 int tsx_face_exchange_bufs(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy) {
   const TsxGeo &g = s->geo;
   const size_t bx = cx, by = cy;
+  if (tsx_peer_ready(s)) return tsx_peer_exchange(s, st, send, recv, cx, cy, nullptr);
   if (s->xchg_cb) {
     const tsx_grid &gr = s->grid;
     const size_t count[4] = {g.wrap_x ? 0 : bx, g.wrap_x ? 0 : bx, g.wrap_y ? 0 : by, g.wrap_y ? 0 : by};
@@ -332,7 +348,7 @@ int tsx_face_exchange_bufs(tsx_solver *s, hipStream_t st, double *const send[4],
     return TSX_OK;
   }
   if (s->comm_ready) {
-    tsx_ncclComm_t c = s->nccl_comm;
+    tsx_ncclComm_t c = s->nccl_comm_x ? s->nccl_comm_x : s->nccl_comm;
     const tsx_grid &gr = s->grid;
     NCCLCHK(g_rccl.GroupStart());
     if (!g.wrap_x) {
@@ -381,6 +397,14 @@ int tsx_face_exchange_elems(tsx_solver *s, hipStream_t st, size_t elem_bytes) {
 
 // reduce partials -> (all-reduce) -> scalar algebra
 static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {
+  if (tsx_peer_ready(s) && s->grid.nranks > 1) {  // three small kernels on the solver stream, no library call, no host
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1);
+    int rc = tsx_peer_allreduce(s, s->stream, s->scal->red, TSX_NSLOTS, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 2);
+    HIPCHK(hipGetLastError());
+    return TSX_OK;
+  }
   if (s->allred_cb) {
     hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1);
     HIPCHK(hipMemcpyAsync(s->scal_host->red, s->scal->red, sizeof(double) * TSX_NSLOTS, hipMemcpyDeviceToHost, s->stream));
@@ -993,6 +1017,10 @@ static int krylov_run_with_retry(tsx_solver *s, tsx_ksp_opts *o) {
 }
 
 static int fill_result(tsx_solver *s, tsx_ksp_result *res) {
+  {
+    int rc = tsx_peer_check(s);  // the stream has been synchronised: did a bounded wait of the peer transport expire?
+    if (rc) return rc;
+  }
   if (!res) return TSX_OK;
   const TsxScalars &h = *s->scal_host;
   memset(res, 0, sizeof(*res));

@@ -67,6 +67,8 @@ struct TsxSolSlot {  // one stored solution (initial guess of the next solve wit
   int lsolar;
 };
 
+struct TsxPeer;  // tsx_peer.hip
+
 struct tsx_solver {
   tsx_grid grid;
   TsxGeo geo;
@@ -160,7 +162,10 @@ struct tsx_solver {
   double dir_rtol = -1.0, dir_atol = -1.0;  // direct sweep: caller's -solar_dir_ksp_rtol / _atol / _max_it (< 0: defaults)
   int dir_maxit = -1;
 
-  void *nccl_comm;     // ncclComm_t when nranks > 1 (or force_halo with comm)
+  void *nccl_comm;     // ncclComm_t when nranks > 1 (or force_halo with comm): the all-reduces on the solver stream
+  void *nccl_comm_x = nullptr;  // a second communicator (ncclCommSplit) for the face exchanges on comm_stream: one communicator
+                                // must not be driven from two streams at once; null = none (the exchanges use nccl_comm)
+  TsxPeer *peer = nullptr;      // device-resident peer transport (tsx_peer.hip); takes precedence when attached
   bool comm_ready;
   tsx_exchange_fn xchg_cb;      // host-staged transport (MPI hosts, tests)
   tsx_allreduce_fn allred_cb;

@@ -1,0 +1,446 @@
+// tsx_peer.hip -- device-resident peer transport for the face halos and the dot-product all-reduces.
+//
+// What it replaces: `exchange_diffuse_boundary` / `exchange_direct_boundary` (MPI_Isend / Irecv of the entering side streams,
+// src/pprts_explicit.F90:715-848, 1076-1140) and the MPI_Allreduce of the Krylov dots inside PETSc's KSP.  RCCL's grouped
+// ncclSend / ncclRecv costs a launch of its own per exchange (15-30 us); an iteration of the default solver issues 40 exchanges
+// of 64 KB - 0.5 MB and 3 all-reduces of 3 doubles -- a latency problem, not a bandwidth problem.
+//
+// Here every rank owns one *mailbox*: a fine-grained (uncached) device allocation that the other ranks of the node map into
+// their address space with hipIpcGetMemHandle / hipIpcOpenMemHandle (over xGMI on a node; two rank processes sharing one
+// device work the same way, which is how the 1-GPU test pool executes it).  A message is written by the SENDER's kernel
+// straight into the receiver's mailbox with plain stores, followed by a release store of a sequence number; the receiver's
+// kernel acquires that number, copies the payload out and releases an acknowledgement into the sender's mailbox.  Nothing
+// but kernels on the caller's stream: no host round trip, no library call, no second stream needed.
+//
+//   mailbox of rank r:
+//     seq[q]   q = W, E, S, N: number of messages delivered THROUGH MY FACE q (written by the neighbour behind that face)
+//     ack[q]   number of MY messages sent through my face q that the neighbour has consumed (written by that neighbour)
+//     ar[2][R] all-reduce contributions: {v[TSX_NSLOTS], seq} per rank and parity (written by every rank, also by r itself)
+//     data[q][2][cap]  payload, double-buffered by message parity
+//
+//   send n through face q (tsx_k_peer_send): wait ack[q] >= n - 2 (the slot's previous message was consumed), store the payload
+//     into the neighbour's data[q ^ 1][n & 1], fence, the last workgroup stores the neighbour's seq[q ^ 1] = n.
+//   recv n through face q (tsx_k_peer_recv): wait seq[q] >= n, copy data[q][n & 1] to the caller's buffer, the last workgroup
+//     stores the neighbour's ack[q ^ 1] = n.
+//   all-reduce n (tsx_k_peer_allreduce, one workgroup): lane r stores my partial sums + n into rank r's ar[n & 1][me]; lane r
+//     then waits for ar[n & 1][r] of my own mailbox; lane 0 adds them in rank order -- every rank gets bit-identical sums.
+//     No acknowledgement needed: a rank writes n only after it finished n - 1, which needed every rank's contribution n - 1,
+//     which that rank sent after it had finished reading n - 2.
+//
+// Messages between two ranks are matched by count, per face, like MPI's non-overtaking rule: every rank must issue the same
+// sequence of exchanges (the solver does: the exchanges are part of the collective solve).  With two ranks along a periodic
+// axis the W and E neighbour are the same rank, with distinct faces and therefore distinct counters.
+//
+// Every wait is bounded (TSX_PEER_TIMEOUT_S, default 20 s of the 100 MHz wall clock): on expiry the kernel records an error in
+// the mailbox header and gives up, the host reports TSX_ERR_COMM at the next synchronisation -- a lost rank never hangs the GPU.
+#include <string.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include "tsx_host.hpp"
+#include "tsx_peer.hpp"
+
+namespace {
+
+constexpr int kMaxRanks = TSX_PEER_MAX_RANKS;
+constexpr size_t kHdrBytes = 4096;
+
+struct PeerArSlot {  // 64 bytes: one line per contribution
+  double v[TSX_NSLOTS + 1];
+  unsigned long long seq;
+  unsigned long long pad[8 - (TSX_NSLOTS + 1) - 1];
+};
+static_assert(sizeof(PeerArSlot) == 64, "all-reduce slot is one 64-byte line");
+
+struct PeerHdr {
+  unsigned long long seq[4];
+  unsigned long long ack[4];
+  int error;  // 0 ok; 1 send timed out waiting for an acknowledgement, 2 recv timed out, 3 all-reduce timed out
+  int error_face;
+  unsigned long long error_want, error_have;
+};
+
+struct PeerBlob {  // what tsx_comm_peer_export hands to the host's all-gather (TSX_PEER_BLOB_BYTES)
+  hipIpcMemHandle_t handle;
+  unsigned long long bytes, cap;
+  void *ptr;  // valid in the exporting process only (ranks living in one process use it directly)
+  int pid, device, rank, nranks;
+  char host[32];
+};
+static_assert(sizeof(PeerBlob) <= TSX_PEER_BLOB_BYTES, "blob size");
+
+__device__ __forceinline__ unsigned long long ld_acquire_sys(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_release_sys(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// spin until *p >= want; false after `ticks` of the constant-rate wall clock
+__device__ __forceinline__ bool wait_ge(const unsigned long long *p, unsigned long long want, unsigned long long ticks,
+                                        unsigned long long *have) {
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    const unsigned long long v = ld_acquire_sys(p);
+    if (v >= want) return true;
+    if (wall_clock64() - t0 > ticks) {
+      *have = v;
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+struct PeerXArgs {
+  char *mine;                 // my mailbox
+  char *remote[4];            // mailbox of the neighbour behind face q (W, E, S, N)
+  const char *src[4];         // send: the caller's send buffers;  recv: unused
+  char *dst[4];               // recv: the caller's receive buffers
+  unsigned long long bytes[4];  // payload per face (0: face inactive)
+  unsigned long long n[4];    // sequence number of this message per face
+  unsigned long long cap, data_off, ticks;
+  unsigned int *blkctr;       // [4] workgroups that have finished their slice (local memory)
+  const int *done;            // the solver's convergence flag (nullable): the exchange is skipped once it is set ... on
+                              // every rank alike (the flag follows all-reduced scalars)
+};
+
+__device__ __forceinline__ char *peer_data(char *box, unsigned long long data_off, unsigned long long cap, int face, int parity) {
+  return box + data_off + ((size_t)face * 2 + parity) * cap;
+}
+__device__ __forceinline__ void copy16(char *__restrict__ d, const char *__restrict__ s, unsigned long long bytes, int nblk) {
+  // bytes is a multiple of 8 (doubles); 16-byte pieces, the odd double at the end by lane 0
+  const unsigned long long n16 = bytes >> 4;
+  const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
+  uint4 *d4 = reinterpret_cast<uint4 *>(d);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (unsigned long long)nblk * blockDim.x)
+    d4[i] = s4[i];
+  if ((bytes & 8) && blockIdx.x == 0 && threadIdx.x == 0)
+    *reinterpret_cast<unsigned long long *>(d + (n16 << 4)) = *reinterpret_cast<const unsigned long long *>(s + (n16 << 4));
+}
+__device__ __forceinline__ void peer_fail(char *mine, int code, int face, unsigned long long want, unsigned long long have) {
+  PeerHdr *h = reinterpret_cast<PeerHdr *>(mine);
+  if (atomicCAS(&h->error, 0, code) == 0) {
+    h->error_face = face;
+    h->error_want = want;
+    h->error_have = have;
+  }
+}
+
+// grid (nblk, 4): blockIdx.y = face
+__global__ __launch_bounds__(256) void tsx_k_peer_send(PeerXArgs a) {
+  const int q = blockIdx.y;
+  if (a.bytes[q] == 0) return;
+  if (a.done && *a.done) return;
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    const PeerHdr *h = reinterpret_cast<const PeerHdr *>(a.mine);
+    unsigned long long have = 0;
+    ok = 1;
+    if (a.n[q] > 2 && !wait_ge(&h->ack[q], a.n[q] - 2, a.ticks, &have)) {
+      ok = 0;
+      peer_fail(a.mine, 1, q, a.n[q] - 2, have);
+    }
+  }
+  __syncthreads();
+  if (!ok) return;
+  copy16(peer_data(a.remote[q], a.data_off, a.cap, q ^ 1, (int)(a.n[q] & 1)), a.src[q], a.bytes[q], gridDim.x);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int prev = atomicAdd(&a.blkctr[q], 1u);
+    if (prev + 1 == gridDim.x) {  // every workgroup's stores are fenced: publish
+      a.blkctr[q] = 0;
+      __threadfence_system();
+      st_release_sys(&reinterpret_cast<PeerHdr *>(a.remote[q])->seq[q ^ 1], a.n[q]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tsx_k_peer_recv(PeerXArgs a) {
+  const int q = blockIdx.y;
+  if (a.bytes[q] == 0) return;
+  if (a.done && *a.done) return;
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    const PeerHdr *h = reinterpret_cast<const PeerHdr *>(a.mine);
+    unsigned long long have = 0;
+    ok = 1;
+    if (!wait_ge(&h->seq[q], a.n[q], a.ticks, &have)) {
+      ok = 0;
+      peer_fail(a.mine, 2, q, a.n[q], have);
+    }
+  }
+  __syncthreads();
+  if (!ok) return;
+  copy16(a.dst[q], peer_data(a.mine, a.data_off, a.cap, q, (int)(a.n[q] & 1)), a.bytes[q], gridDim.x);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned int prev = atomicAdd(&a.blkctr[q], 1u);
+    if (prev + 1 == gridDim.x) {
+      a.blkctr[q] = 0;
+      st_release_sys(&reinterpret_cast<PeerHdr *>(a.remote[q])->ack[q ^ 1], a.n[q]);
+    }
+  }
+}
+
+struct PeerArArgs {
+  char *mine;
+  char *box[kMaxRanks];
+  int rank, nranks, nvals;
+  unsigned long long n, ar_off, ticks;
+};
+
+// one workgroup of 64 lanes; v: nvals (<= TSX_NSLOTS + 1) doubles in device memory, summed over the ranks in place
+__global__ __launch_bounds__(64) void tsx_k_peer_allreduce(PeerArArgs a, double *__restrict__ v, const int *__restrict__ done) {
+  if (done && *done) return;
+  const int r = threadIdx.x;
+  const int par = (int)(a.n & 1);
+  __shared__ int bad;
+  if (r == 0) bad = 0;
+  __syncthreads();
+  if (r < a.nranks) {
+    PeerArSlot *slot = reinterpret_cast<PeerArSlot *>(a.box[r] + a.ar_off) + (size_t)par * kMaxRanks + a.rank;
+    for (int k = 0; k < a.nvals; ++k) slot->v[k] = v[k];
+    __threadfence_system();
+    st_release_sys(&slot->seq, a.n);
+    const PeerArSlot *in = reinterpret_cast<const PeerArSlot *>(a.mine + a.ar_off) + (size_t)par * kMaxRanks + r;
+    unsigned long long have = 0;
+    if (!wait_ge(&in->seq, a.n, a.ticks, &have)) {
+      bad = 1;
+      peer_fail(a.mine, 3, r, a.n, have);
+    }
+  }
+  __syncthreads();
+  if (r == 0 && !bad) {
+    const PeerArSlot *in = reinterpret_cast<const PeerArSlot *>(a.mine + a.ar_off) + (size_t)par * kMaxRanks;
+    for (int k = 0; k < a.nvals; ++k) {
+      double sum = 0.0;
+      for (int q = 0; q < a.nranks; ++q) sum += __hip_atomic_load(&in[q].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v[k] = sum;
+    }
+  }
+}
+
+}  // namespace
+
+struct TsxPeer {
+  char *mine = nullptr;
+  size_t bytes = 0, cap = 0, data_off = 0, ar_off = 0;
+  char *box[kMaxRanks] = {nullptr};      // every rank's mailbox in this process's address space (box[rank] == mine)
+  bool opened[kMaxRanks] = {false};      // mapped with hipIpcOpenMemHandle (to be closed)
+  unsigned long long sent[4] = {0, 0, 0, 0}, rcvd[4] = {0, 0, 0, 0}, ar_n = 0;
+  unsigned int *blkctr = nullptr;        // [8]: send 0..3, recv 4..7
+  unsigned long long ticks = 0;
+  bool attached = false;
+};
+
+static size_t peer_capacity(const tsx_solver *s) {
+  // the largest face message any exchange of this solver sends: the diffuse halo (nside / 2 streams x Nz x edge doubles), the
+  // direct beam's (dirside streams x Nz x edge), the preconditioner's records (Nz x edge words)
+  const TsxGeo &g = s->geo;
+  const size_t edge = (size_t)(g.xm > g.ym ? g.xm : g.ym);
+  const size_t streams = 4;  // >= nside / 2 (2) and dirside (1 / 2)
+  size_t b = streams * (size_t)(g.Nz + 1) * edge * sizeof(double);
+  return (b + 255) & ~(size_t)255;
+}
+
+extern "C" int tsx_comm_peer_export(tsx_solver *s, void *blob) {
+  ARGCHK(s && blob, "tsx_comm_peer_export: null");
+  ARGCHK(s->grid.nranks >= 1 && s->grid.nranks <= kMaxRanks, "tsx_comm_peer_export: more ranks than TSX_PEER_MAX_RANKS");
+  HIPCHK(hipSetDevice(s->device));
+  if (!s->peer) {
+    TsxPeer *p = new TsxPeer();
+    p->cap = peer_capacity(s);
+    p->ar_off = kHdrBytes;
+    p->data_off = p->ar_off + sizeof(PeerArSlot) * 2 * kMaxRanks;
+    p->data_off = (p->data_off + 255) & ~(size_t)255;
+    p->bytes = p->data_off + (size_t)4 * 2 * p->cap;
+    void *m = nullptr;
+    // uncached: the counters and payloads are written by other agents while kernels of this rank are running
+    hipError_t e = hipExtMallocWithFlags(&m, p->bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) e = hipExtMallocWithFlags(&m, p->bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+      delete p;
+      tsx_set_error(std::string("tsx_comm_peer_export: fine-grained allocation failed: ") + hipGetErrorString(e));
+      return TSX_ERR_HIP;
+    }
+    p->mine = (char *)m;
+    HIPCHK(hipMemset(p->mine, 0, p->bytes));
+    HIPCHK(hipMalloc((void **)&p->blkctr, sizeof(unsigned int) * 8));
+    HIPCHK(hipMemset(p->blkctr, 0, sizeof(unsigned int) * 8));
+    const char *to = getenv("TSX_PEER_TIMEOUT_S");
+    const double sec = to ? atof(to) : 20.0;
+    p->ticks = (unsigned long long)((sec > 0 ? sec : 20.0) * 1e8);  // wall_clock64: 100 MHz
+    HIPCHK(hipDeviceSynchronize());
+    s->peer = p;
+  }
+  TsxPeer *p = s->peer;
+  PeerBlob b;
+  memset(&b, 0, sizeof(b));
+  HIPCHK(hipIpcGetMemHandle(&b.handle, p->mine));
+  b.bytes = p->bytes;
+  b.cap = p->cap;
+  b.ptr = p->mine;
+  b.pid = (int)getpid();
+  b.device = s->device;
+  b.rank = s->grid.rank;
+  b.nranks = s->grid.nranks;
+  gethostname(b.host, sizeof(b.host) - 1);
+  memset(blob, 0, TSX_PEER_BLOB_BYTES);
+  memcpy(blob, &b, sizeof(b));
+  return TSX_OK;
+}
+
+extern "C" int tsx_comm_peer_attach(tsx_solver *s, const void *blobs) {
+  ARGCHK(s && blobs, "tsx_comm_peer_attach: null");
+  if (!s->peer) {
+    tsx_set_error("tsx_comm_peer_attach: call tsx_comm_peer_export first");
+    return TSX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  TsxPeer *p = s->peer;
+  const int R = s->grid.nranks, me = s->grid.rank;
+  char myhost[32] = {0};
+  gethostname(myhost, sizeof(myhost) - 1);
+  for (int r = 0; r < R; ++r) {
+    PeerBlob b;
+    memcpy(&b, (const char *)blobs + (size_t)r * TSX_PEER_BLOB_BYTES, sizeof(b));
+    if (b.rank != r || b.nranks != R || b.bytes != p->bytes || b.cap != p->cap) {
+      tsx_set_error("tsx_comm_peer_attach: blob " + std::to_string(r) + " does not describe rank " + std::to_string(r) +
+                    " of this job (all ranks need the same Nz and local extents' maximum)");
+      return TSX_ERR_ARG;
+    }
+    if (strncmp(b.host, myhost, sizeof(myhost)) != 0) {
+      tsx_set_error("tsx_comm_peer_attach: rank " + std::to_string(r) + " runs on another host: the peer transport is node-local");
+      return TSX_ERR_COMM;
+    }
+    if (r == me) {
+      p->box[r] = p->mine;
+    } else if (b.pid == (int)getpid()) {
+      p->box[r] = (char *)b.ptr;  // several ranks in one process: the pointer is valid as it is
+      if (b.device != s->device) {
+        int can = 0;
+        HIPCHK(hipDeviceCanAccessPeer(&can, s->device, b.device));
+        if (!can) {
+          tsx_set_error("tsx_comm_peer_attach: no peer access between devices");
+          return TSX_ERR_COMM;
+        }
+        hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHK(e);
+        (void)hipGetLastError();
+      }
+    } else {
+      void *m = nullptr;
+      hipError_t e = hipIpcOpenMemHandle(&m, b.handle, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        tsx_set_error(std::string("tsx_comm_peer_attach: hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
+        (void)hipGetLastError();
+        return TSX_ERR_COMM;
+      }
+      p->box[r] = (char *)m;
+      p->opened[r] = true;
+    }
+  }
+  p->attached = true;
+  return TSX_OK;
+}
+
+bool tsx_peer_ready(const tsx_solver *s) { return s->peer && s->peer->attached; }
+
+void tsx_peer_destroy(tsx_solver *s) {
+  TsxPeer *p = s->peer;
+  if (!p) return;
+  for (int r = 0; r < kMaxRanks; ++r)
+    if (p->opened[r] && p->box[r]) (void)hipIpcCloseMemHandle(p->box[r]);
+  if (p->mine) (void)hipFree(p->mine);
+  if (p->blkctr) (void)hipFree(p->blkctr);
+  delete p;
+  s->peer = nullptr;
+}
+
+// the error a kernel recorded (bounded waits), turned into a host error; call after a stream synchronisation
+int tsx_peer_check(tsx_solver *s) {
+  TsxPeer *p = s->peer;
+  if (!p || !p->attached) return TSX_OK;
+  PeerHdr h;
+  HIPCHK(hipMemcpy(&h, p->mine, sizeof(h), hipMemcpyDeviceToHost));
+  if (h.error == 0) return TSX_OK;
+  static const char *what[] = {"", "send: no acknowledgement from the neighbour", "recv: no message from the neighbour",
+                               "all-reduce: no contribution from a rank"};
+  tsx_set_error(std::string("peer transport timed out -- ") + what[h.error & 3] + " (face / rank " + std::to_string(h.error_face) +
+                ", waiting for " + std::to_string(h.error_want) + ", have " + std::to_string(h.error_have) + ")");
+  return TSX_ERR_COMM;
+}
+
+int tsx_peer_exchange(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy,
+                      const int *done) {
+  TsxPeer *p = s->peer;
+  const TsxGeo &g = s->geo;
+  const tsx_grid &gr = s->grid;
+  const size_t cnt[4] = {g.wrap_x ? 0 : cx, g.wrap_x ? 0 : cx, g.wrap_y ? 0 : cy, g.wrap_y ? 0 : cy};
+  const int nb[4] = {gr.neigh_w, gr.neigh_e, gr.neigh_s, gr.neigh_n};
+  PeerXArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mine = p->mine;
+  a.cap = p->cap;
+  a.data_off = p->data_off;
+  a.ticks = p->ticks;
+  a.done = done;
+  size_t maxb = 0;
+  for (int q = 0; q < 4; ++q) {
+    a.bytes[q] = cnt[q] * sizeof(double);
+    if (a.bytes[q] > p->cap) {
+      tsx_set_error("peer exchange: message larger than the mailbox slots");
+      return TSX_ERR_ARG;
+    }
+    if (a.bytes[q] == 0) continue;
+    if (nb[q] < 0 || nb[q] >= gr.nranks || !p->box[nb[q]]) {
+      tsx_set_error("peer exchange: neighbour rank out of range");
+      return TSX_ERR_ARG;
+    }
+    a.remote[q] = p->box[nb[q]];
+    a.src[q] = (const char *)send[q];
+    a.dst[q] = (char *)recv[q];
+    maxb = a.bytes[q] > maxb ? a.bytes[q] : maxb;
+  }
+  if (maxb == 0) return TSX_OK;
+  // `done` skips an exchange on every rank alike, so the counters advance only when ... they must advance identically on both
+  // sides: an exchange skipped by `done` is skipped by both kernels of both ranks, and the host counts it nowhere -- but the
+  // host cannot see `done`.  The counters therefore count ISSUED exchanges and the kernels of a skipped exchange still publish
+  // their numbers: see below (done is honoured only for the payload copy).
+  for (int q = 0; q < 4; ++q)
+    if (a.bytes[q]) a.n[q] = ++p->sent[q];
+  int nblk = (int)((maxb + 32767) / 32768);
+  nblk = nblk < 1 ? 1 : (nblk > 8 ? 8 : nblk);
+  a.blkctr = p->blkctr;
+  a.done = nullptr;  // see the comment above: sequence numbers must stay in step whatever `done` says
+  hipLaunchKernelGGL(tsx_k_peer_send, dim3(nblk, 4), dim3(256), 0, st, a);
+  for (int q = 0; q < 4; ++q)
+    if (a.bytes[q]) a.n[q] = ++p->rcvd[q];
+  a.blkctr = p->blkctr + 4;
+  hipLaunchKernelGGL(tsx_k_peer_recv, dim3(nblk, 4), dim3(256), 0, st, a);
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+// v: nvals doubles on the device, summed over the ranks in place, on stream st
+int tsx_peer_allreduce(tsx_solver *s, hipStream_t st, double *v, int nvals, const int *done) {
+  TsxPeer *p = s->peer;
+  ARGCHK(nvals >= 1 && nvals <= TSX_NSLOTS + 1, "peer all-reduce: too many values");
+  PeerArArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mine = p->mine;
+  for (int r = 0; r < s->grid.nranks; ++r) a.box[r] = p->box[r];
+  a.rank = s->grid.rank;
+  a.nranks = s->grid.nranks;
+  a.nvals = nvals;
+  a.n = ++p->ar_n;
+  a.ar_off = p->ar_off;
+  a.ticks = p->ticks;
+  (void)done;  // as for the exchange: the sequence stays in step on every rank
+  hipLaunchKernelGGL(tsx_k_peer_allreduce, dim3(1), dim3(64), 0, st, a, v, (const int *)nullptr);
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}

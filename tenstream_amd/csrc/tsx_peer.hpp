@@ -1,0 +1,16 @@
+// tsx_peer.hpp -- device-resident peer transport (tsx_peer.hip): mailboxes in IPC-shared fine-grained device memory
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tsx_internal.hpp"
+
+#define TSX_PEER_MAX_RANKS 16    // node-local: one rank per GPU of a node (8 on MI355X nodes)
+
+bool tsx_peer_ready(const tsx_solver *s);
+void tsx_peer_destroy(tsx_solver *s);
+int tsx_peer_check(tsx_solver *s);  // after a synchronisation: did a bounded wait expire?
+// the four face buffers W, E, S, N (cx / cy doubles per x / y face), entirely on stream st
+int tsx_peer_exchange(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy,
+                      const int *done);
+// nvals (<= TSX_NSLOTS + 1) doubles in device memory, summed over the ranks in place in rank order, on stream st
+int tsx_peer_allreduce(tsx_solver *s, hipStream_t st, double *v, int nvals, const int *done);

@@ -38,3 +38,16 @@ def attach(solver, rank: int):
         dist.all_reduce(torch.from_numpy(buf))
 
     solver.comm_set_callbacks(exchange, allreduce)
+
+
+def attach_peer(solver):
+    """device-resident peer transport (tsx_peer.hip): the mailboxes' IPC handles are all-gathered over the default process
+    group (any backend); after that no exchange touches the host"""
+    import torch.distributed as dist
+
+    def allgather(blob):
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, blob)
+        return out
+
+    solver.comm_peer_init(allgather)

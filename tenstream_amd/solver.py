@@ -79,6 +79,7 @@ class DiffuseSolver:
         self.D = self.ntop + 2 * self.nside
         self.Nz, self.xm, self.ym = int(Nz), int(xm), int(ym)
         w, e, s_, n = neighbors if neighbors is not None else (rank, rank, rank, rank)
+        self.rank, self.nranks = int(rank), int(nranks)
         self.grid = _lib.Grid(sid, Nz, xm, ym, xs, ys, glob_xm or xm, glob_ym or ym, rank, nranks, w, e, s_, n,
                               device, int(force_halo))
         h = C.c_void_p()
@@ -131,6 +132,17 @@ class DiffuseSolver:
     def comm_init(self, uid: bytes):
         buf = C.create_string_buffer(uid, 128)
         _lib.check(self.lib.tsx_comm_init(self.h, buf))
+
+    def comm_peer_init(self, allgather):
+        """Device-resident peer transport (tsx_comm_peer_export / _attach): `allgather(blob: bytes) -> list of every rank's
+        blob in rank order` is the host's all-gather (torch.distributed.all_gather_object, MPI_Allgather ...)."""
+        buf = C.create_string_buffer(_lib.PEER_BLOB_BYTES)
+        _lib.check(self.lib.tsx_comm_peer_export(self.h, buf))
+        blobs = allgather(buf.raw)
+        if len(blobs) != self.nranks or any(len(b) != _lib.PEER_BLOB_BYTES for b in blobs):
+            raise ValueError("comm_peer_init: the all-gather must return one blob per rank")
+        allb = C.create_string_buffer(b"".join(blobs), _lib.PEER_BLOB_BYTES * len(blobs))
+        _lib.check(self.lib.tsx_comm_peer_attach(self.h, allb))
 
     def comm_set_callbacks(self, exchange, allreduce):
         """Host-staged transport.  exchange(send: list of 4 numpy views W,E,S,N, recv: list of 4 writable views,

@@ -65,8 +65,9 @@ def _spawn(fn, world, args):
         return out
 
 
-def _worker(rank, world, port, solver, Nx, Ny, Nz, ret):
+def _worker(rank, world, port, solver, Nx, Ny, Nz, transport, ret):
     sys.path.insert(0, ROOT)
+    os.environ.setdefault("TSX_PEER_TIMEOUT_S", "10")
     import torch
     import torch.distributed as dist
 
@@ -110,7 +111,12 @@ def _worker(rank, world, port, solver, Nx, Ny, Nz, ret):
             t = torch.from_numpy(buf)
             dist.all_reduce(t)
 
-        s.comm_set_callbacks(exchange, allreduce)
+        if transport == "peer":   # device-resident: IPC-mapped mailboxes, no host in any exchange (tsx_peer.hip)
+            from tenstream_amd import hostcomm
+
+            hostcomm.attach_peer(s)
+        else:
+            s.comm_set_callbacks(exchange, allreduce)
         loc = lambda k: np.ascontiguousarray(P[k][sl])
         s.set_coeffs(loc("coeff"), P["l1d"], loc("a11"), loc("a12"), loc("albedo"))
         layg = O.layout(solver, Nz, Nx, Ny)
@@ -159,8 +165,12 @@ def _worker(rank, world, port, solver, Nx, Ny, Nz, ret):
 # on EVERY rank (tsx_pc_global_agree), not just on the odd ones (an even rank's messages would find no partner)
 @pytest.mark.parametrize("world,solver,Nx,Ny", [(2, "3_10", 10, 12), (4, "3_10", 12, 10), (2, "8_16", 6, 8), (2, "3_10", 10, 13),
                                                 (3, "3_10", 8, 8)])
-def test_sharded_hip_solve_equals_global_oracle(gpu, world, solver, Nx, Ny):
-    ret = _spawn(_worker, world, (solver, Nx, Ny, 6))
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_sharded_hip_solve_equals_global_oracle(gpu, world, solver, Nx, Ny, transport):
+    """transport "host": the callbacks (gloo underneath); "peer": the device-resident transport -- halos stored by the sender's
+    kernel into the receiver's IPC-mapped mailbox, all-reduces as all-to-all stores (tsx_peer.hip), the rank processes sharing
+    cuda:0.  Same checks, same iteration counts."""
+    ret = _spawn(_worker, world, (solver, Nx, Ny, 6, transport))
     its = {v[3] for v in ret.values()}
     assert len(its) == 1  # every rank saw the same (all-reduced) scalars
     for e_apply, e_solve, reason, niter, r0, bn in ret.values():
@@ -168,9 +178,37 @@ def test_sharded_hip_solve_equals_global_oracle(gpu, world, solver, Nx, Ny):
         assert abs(r0 - bn) <= 1e-12 * bn  # the initial residual is the *global* norm of b
 
 
+def test_peer_transport_with_self_neighbours_in_one_process(gpu, monkeypatch):
+    """One rank whose four neighbours are itself (force_halo): every face message goes through the rank's own mailbox --
+    send kernel (payload + sequence word), receive kernel (wait, copy out, acknowledge) -- instead of a device-to-device copy.
+    Same arithmetic, so apply and residual history are bit-identical to the copy path; the double-buffered slots and the
+    acknowledgements are exercised by the 40 exchanges per iteration of the default solver."""
+    from tenstream_amd import DiffuseSolver, synthetic
+
+    monkeypatch.setenv("TSX_PEER_TIMEOUT_S", "5")
+    P = synthetic.make_problem("3_10", Nx=12, Ny=10, Nz=8, n1d=1)
+    out = []
+    for peer in (False, True):
+        s = DiffuseSolver("3_10", 8, 12, 10, force_halo=True)
+        if peer:
+            s.comm_peer_init(lambda blob: [blob])
+        s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+        x = np.random.default_rng(2).standard_normal(s.vec_shape)
+        y = s.apply(x)
+        sol = np.zeros(s.vec_shape)
+        info = s.solve(P["b"], sol, rtol=1e-10, atol=1e-30)
+        out.append((y, sol, info))
+        s.close()
+    (y0, x0, i0), (y1, x1, i1) = out
+    assert np.array_equal(y0, y1)
+    assert i0.reason == 2 and i1.reason == 2 and i0.niter == i1.niter
+    assert np.array_equal(i0.res_hist, i1.res_hist) and np.array_equal(x0, x1)
+
+
 # ---- 8 ranks, 2 x 4: config 3's decomposition (src/pprts_base.F90:747-790: dims = [nyp, nxp] = [4, 2], ranks x-fastest) ----
-def _worker8(rank, world, port, Nx, Ny, Nz, ref_path, ret):
+def _worker8(rank, world, port, Nx, Ny, Nz, ref_path, transport, ret):
     sys.path.insert(0, ROOT)
+    os.environ.setdefault("TSX_PEER_TIMEOUT_S", "20")
     import torch.distributed as dist
 
     from tenstream_amd import DiffuseSolver, coord, hostcomm, synthetic
@@ -185,7 +223,10 @@ def _worker8(rank, world, port, Nx, Ny, Nz, ref_path, ret):
         sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
         s = DiffuseSolver("3_10", Nz, co.xm, co.ym, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank, nranks=world,
                           neighbors=(co.west, co.east, co.south, co.north), device=0)
-        hostcomm.attach(s, rank)
+        if transport == "peer":
+            hostcomm.attach_peer(s)
+        else:
+            hostcomm.attach(s, rank)
         loc = lambda k: np.ascontiguousarray(P[k][sl])
         s.set_coeffs(loc("coeff"), P["l1d"], loc("a11"), loc("a12"), loc("albedo"))
         y = s.apply(np.ascontiguousarray(ref["xg"][sl]))
@@ -202,8 +243,10 @@ def _worker8(rank, world, port, Nx, Ny, Nz, ref_path, ret):
         dist.destroy_process_group()
 
 
-def test_eight_ranks_two_by_four_equal_the_global_oracle(gpu, tmp_path):
-    """Config 3's process grid on one device: 8 rank processes share cuda:0 (host-staged face exchange), a 64 x 64 x 16
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_eight_ranks_two_by_four_equal_the_global_oracle(gpu, tmp_path, transport):
+    """Config 3's process grid on one device: 8 rank processes share cuda:0 (host-staged face exchange, or the device-resident
+    peer transport with all 8 mailboxes IPC-mapped into every process), a 64 x 64 x 16
     domain -> 2 x 4 blocks of 32 x 16 columns.  Operator and default solve against the oracle on the global domain; the
     preconditioner's halo exchange keeps the one-rank iteration count."""
     from oracle import oracle as O
@@ -227,7 +270,7 @@ def test_eight_ranks_two_by_four_equal_the_global_oracle(gpu, tmp_path):
     x1[...] = 0
     its1 = s1.solve(P["b"], x1).niter
     s1.close()
-    ret = _spawn(_worker8, 8, (Nx, Ny, Nz, ref_path))
+    ret = _spawn(_worker8, 8, (Nx, Ny, Nz, ref_path, transport))
     grids = set()
     for rank, (e_apply, e_solve, reason, niter, niter_d, grid, pci) in ret.items():
         assert e_apply < 1e-13 and reason == 2 and e_solve < 1e-8, (rank, e_apply, e_solve, reason)
@@ -239,7 +282,7 @@ def test_eight_ranks_two_by_four_equal_the_global_oracle(gpu, tmp_path):
 
 
 # ---- the whole g-point pipeline on several ranks ------------------------------------------------------------------
-def _pipeline_worker(rank, world, port, Nx, Ny, Nz, phi0, theta0, tall_top, ret):
+def _pipeline_worker(rank, world, port, Nx, Ny, Nz, phi0, theta0, tall_top, transport, ret):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -295,7 +338,12 @@ def _pipeline_worker(rank, world, port, Nx, Ny, Nz, phi0, theta0, tall_top, ret)
         def allreduce(buf):
             dist.all_reduce(torch.from_numpy(buf))
 
-        P.core.comm_set_callbacks(exchange, allreduce)
+        if transport == "peer":
+            from tenstream_amd import hostcomm
+
+            hostcomm.attach_peer(P.core)
+        else:
+            P.core.comm_set_callbacks(exchange, allreduce)
         loc = lambda a: np.ascontiguousarray(a[sl])
         out = {}
         for kind in ("solar", "thermal"):
@@ -330,10 +378,11 @@ def _pipeline_worker(rank, world, port, Nx, Ny, Nz, phi0, theta0, tall_top, ret)
 
 @pytest.mark.parametrize("world,Nx,Ny,phi0,theta0,tall_top", [(2, 10, 12, 200.0, 40.0, 0), (4, 12, 10, 30.0, 55.0, 1),
                                                                (4, 10, 12, 300.0, 20.0, 0)])
-def test_sharded_pipeline_equals_one_rank_pipeline(gpu, world, Nx, Ny, phi0, theta0, tall_top):
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_sharded_pipeline_equals_one_rank_pipeline(gpu, world, Nx, Ny, phi0, theta0, tall_top, transport):
     """set_optical_properties -> direct sweep (face exchange per sweep) -> setup_b -> solve -> flux divergence on 2/4
-    ranks against the same g-point on one periodic rank."""
-    ret = _spawn(_pipeline_worker, world, (Nx, Ny, 8, phi0, theta0, tall_top))
+    ranks against the same g-point on one periodic rank; host-staged and device-resident (peer) transport."""
+    ret = _spawn(_pipeline_worker, world, (Nx, Ny, 8, phi0, theta0, tall_top, transport))
     for errs in ret.values():
         reason, _, e = errs["solar"]
         assert reason == 2
