@@ -144,7 +144,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->dtol = 1e4;    // PETSc KSP default divergence tolerance
   o->maxit = 1000;  // src/pprts_base.F90:1118
   o->pc = TSX_PC_REDBLACK;  // this back-end's default preconditioner
-  o->pc_sweeps = 0;  // automatic (prepare_ksp): 19 with the scan kernels, else 9
+  o->pc_sweeps = 0;  // automatic (prepare_ksp): 21 / 19 with the scan kernels of 3_10 / 8_16, else 9
   o->check_every = 2;  // at most one iteration enqueued in vain; measured 1 / 2 / 3 / 4 / 6: 19.44 / 19.24 / 19.37 / 19.68 / 19.26 ms, warm start 3.40 / 3.47 / 3.58 / 3.69 / 3.82 ms
   o->fp32_directions = 1;
   o->pc_coeff_fp16 = 1;
@@ -1118,7 +1118,12 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
     // pass (36 us on 256 x 256 x 64) is cheap next to the operator and the vector updates of an iteration (1.3 ms), and 20
     // passes need 6 iterations where 10 need 10 -- and 10 passes with the one-lane-per-column kernels (zebra rows, odd grids)
     const bool scan = s->pc == TSX_PC_REDBLACK && tsx_pcs_eligible(s);
-    o->pc_sweeps = (s->pc == TSX_PC_REDBLACK || s->pc == TSX_PC_ZEBRA) ? (scan ? 19 : 9) : 1;
+    // round 3: with the side -> top couplings in fp16 (3_10 scan kernels, C16) the residual after 5 iterations of 20 passes
+    // sits at 1.02-1.08e-5 on every measured domain -- 22 passes take it below the reference's rtol 1e-5: 5 iterations instead
+    // of 6 (256 x 256 x 64: 18.7 -> 16.4 ms; 128 x 128: 6.05 -> 5.29 ms; all blocks distinct: 35.7 -> 31.5 ms; 24 / 26 passes:
+    // still 5 iterations, 17.2 / 17.8 ms)
+    const int auto_scan = s->geo.ntop == 2 ? 21 : 19;
+    o->pc_sweeps = (s->pc == TSX_PC_REDBLACK || s->pc == TSX_PC_ZEBRA) ? (scan ? auto_scan : 9) : 1;
     s->pc_sweeps = o->pc_sweeps;
   }
   if (o->pc != TSX_PC_NONE) {
@@ -1229,8 +1234,11 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
     //         8_16 all passes: 12 (14) records -> 4 B (+192 / 224 per distinct set and pass)
     const bool h = g.ntop == 8;
     const double cell[2][2][4] = {{{200, 104, 224, 320}, {88, 72, 116, 212}}, {{544, 400, 624, 768}, {292, 276, 372, 516}}};
-    const double ent[2][2] = {{112, 32}, {256, 128}};
+    // 3_10 with the side -> top couplings in fp16 (C16): one record more per cell / per distinct block in the passes that read them
+    const double c16 = s->coef_h_c16 && !h ? 16.0 : 0.0;
+    const double ent[2][2] = {{112.0 + c16, 32}, {256, 128}};
     double c[4] = {cell[h][dd][0], cell[h][dd][1], cell[h][dd][2], cell[h][dd][3]};
+    if (!dd) c[0] += c16, c[2] += c16, c[3] += c16;  // every pass with neighbours reads the extra record per cell
     const double half = 0.5 * Nc, e_gs0 = dd ? nent * ent[h][0] : 0.0, e_first0 = dd ? nent * ent[h][1] : 0.0;
     double r_gs = 0.0, r_f32 = 0.0;  // bytes of the shared recurrence table per pass
     if (dd && s->pcr_on) {
@@ -1244,7 +1252,7 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
       }
     }
     const double e_gs = e_gs0 + r_gs, e_first = e_first0 + r_gs, e_f32 = e_gs0 + r_f32;
-    const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : 20;
+    const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : (h ? 20 : 22);
     const double ngs = P > 3 ? P - 3 : 0;
     // bf16 right-hand side of the intermediate passes (tsx_k_pcs_rb RQ): a colour's first visit leaves 5 words (+20 B), the
     // later intermediate visits read 20 B instead of 40 B

@@ -82,6 +82,7 @@ struct tsx_solver {
   void *coef_h;        // packed fp16 copy of the blocks for the preconditioner (tsx_k_pack_p16; built in prepare_ksp)
   bool coef_h_valid, pc_half;
   bool coef_h_dd;      // ... with groups 1..7 stored per distinct block (tsx_dedup.hip)
+  bool coef_h_c16 = false;  // ... those in the 12-slot layout with fp16 couplings (tsx_k_pcs_pack_ent16)
   bool coef_h_scan;    // the packed copy is in the scan kernels' layout "S16" (tsx_kernels_pcs.hpp; always colour-split)
   bool coef_h_split;   // layout of the packed copy: colour-split (red-black preconditioner) or natural
   bool pc_split;       // the preconditioner's private arrays (packed blocks, fp32 rhs) are in colour-split order

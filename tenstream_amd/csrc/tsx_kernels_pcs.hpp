@@ -145,6 +145,82 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent(int ncol, long l
   }
 }
 
+// ---- side -> top couplings in fp16 (C16).  tests/studies/quant_study.py: of everything the preconditioner rounds, only the
+// precision of the couplings from the neighbouring columns' side streams INTO the column's top streams (record 1) costs
+// iterations -- they feed the exact column solve, which spreads their error through the whole column: 3 iterations with
+// them exact or fp16 against 4 with fp8 e4m3 on 64 x 64 x 32 (the device: 4), 6 -> 5 on 256 x 256 x 64; the 64 side -> side
+// couplings (records 4..7) can stay fp8.  Record 1 therefore becomes two fp16 records:
+//   1a: c(y_q -> 0) c(y_q -> 1), q = 0..3 (8 halfs)      1b: the same for x_q
+// per cell:  1a in group 1's place, 1b as group 8:  P[8 * Nc + cell]                      (9 records per cell)
+// per block: PE[slot * nent + id], slot 0 = 1a, 1 = 1b, slot g = record g for g = 2..7   (8 records per distinct block)
+__device__ __forceinline__ uint4 tsx_pcs_rec1_h(int half, float (&c0)[4], float (&c1)[4]) {  // c0[q] = c(src_q -> 0), c1: -> 1
+  (void)half;
+  return make_uint4(tsx_to_h2(c0[0], c1[0]), tsx_to_h2(c0[1], c1[1]), tsx_to_h2(c0[2], c1[2]), tsx_to_h2(c0[3], c1[3]));
+}
+template <typename CT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_rec1h(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
+                                                                  uint4 *__restrict__ P) {
+  constexpr int D = 10;
+  const long long Nc = g.Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int i = (int)(c % g.xm);
+    const long long t = c / g.xm;
+    const int j = (int)(t % g.ym), k = (int)(t / g.ym);
+    uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+    if (!l1d[k]) {
+      float y0[4], y1[4], x0[4], x1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        y0[q] = (float)C[(size_t)(0 * D + 6 + q) * Nc + c];
+        y1[q] = (float)C[(size_t)(1 * D + 6 + q) * Nc + c];
+        x0[q] = (float)C[(size_t)(0 * D + 2 + q) * Nc + c];
+        x1[q] = (float)C[(size_t)(1 * D + 2 + q) * Nc + c];
+      }
+      va = tsx_pcs_rec1_h(0, y0, y1);
+      vb = tsx_pcs_rec1_h(1, x0, x1);
+    }
+    const size_t o = (size_t)k * g.ncol + tsx_split_col(i, j, g.xm);
+    P[(size_t)1 * Nc + o] = va;
+    P[(size_t)8 * Nc + o] = vb;
+  }
+}
+constexpr int TSX_PCS_ENT16_SLOTS = 8;
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent16(int ncol, long long nent, const float *__restrict__ Cd,
+                                                                  const int *__restrict__ ent_cell, const uint8_t *__restrict__ l1d,
+                                                                  uint4 *__restrict__ PE) {
+  constexpr int D = 10;
+  const long long n = nent * TSX_PCS_ENT16_SLOTS;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
+    const int slot = (int)(q / nent);
+    const long long id = q - (long long)slot * nent;
+    const int k = ent_cell[id] / ncol;
+    auto cf = [&](int dst, int src) { return Cd[(size_t)(dst * D + src) * nent + id]; };
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!l1d[k]) {
+      if (slot < 2) {
+        const int s0 = slot == 0 ? 6 : 2;
+        v.x = tsx_to_h2(cf(0, s0), cf(1, s0));
+        v.y = tsx_to_h2(cf(0, s0 + 1), cf(1, s0 + 1));
+        v.z = tsx_to_h2(cf(0, s0 + 2), cf(1, s0 + 2));
+        v.w = tsx_to_h2(cf(0, s0 + 3), cf(1, s0 + 3));
+      } else if (slot < 4) {
+        const int sc = slot - 2;
+        v.x = tsx_to_h2(cf(2, sc), cf(3, sc));
+        v.y = tsx_to_h2(cf(4, sc), cf(5, sc));
+        v.z = tsx_to_h2(cf(6, sc), cf(7, sc));
+        v.w = tsx_to_h2(cf(8, sc), cf(9, sc));
+      } else {
+        const int s0 = slot < 6 ? 6 : 2, d0 = 2 + 4 * (slot & 1);
+        v.x = tsx_to_fp8x4(cf(d0 + 0, s0), cf(d0 + 0, s0 + 1), cf(d0 + 0, s0 + 2), cf(d0 + 0, s0 + 3));
+        v.y = tsx_to_fp8x4(cf(d0 + 1, s0), cf(d0 + 1, s0 + 1), cf(d0 + 1, s0 + 2), cf(d0 + 1, s0 + 3));
+        v.z = tsx_to_fp8x4(cf(d0 + 2, s0), cf(d0 + 2, s0 + 1), cf(d0 + 2, s0 + 2), cf(d0 + 2, s0 + 3));
+        v.w = tsx_to_fp8x4(cf(d0 + 3, s0), cf(d0 + 3, s0 + 1), cf(d0 + 3, s0 + 2), cf(d0 + 3, s0 + 3));
+      }
+    }
+    PE[q] = v;
+  }
+}
+
 // ---- record 0 for the intermediate passes where the blocks are shared: they never use A_k (the last fp16 of record 0), so a
 // second copy carries the cell's block index in that word -- one 16-byte load instead of record 0 + index (20 B)
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_r0g(long long Nc, const uint4 *__restrict__ P0,
@@ -233,7 +309,8 @@ __device__ __forceinline__ bool tsx_pcs_on_frame(const TsxGeo &g, int jrow, int 
 // right-hand side as five bf16-pair words per cell, rb[w * Nc + cell] = (ru, rd), (rs0, rs1) .. (rs6, rs7): 20 B instead of
 // 40 B.  RQ 1: the colour's first visit reads fp32 and leaves those words; RQ 2: reads them; RQ 0: fp32 only.  (Measured:
 // rounding the intermediate passes' right-hand side to bf16 changes no iteration count, 8 / 13 at rtol 1e-5 / 1e-8.)
-template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false, int RQ = 0>
+// C16: the side -> top couplings (record 1) are two fp16 records (tsx_k_pcs_pack_rec1h / tsx_k_pcs_pack_ent16).
+template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false, int RQ = 0, bool C16 = false>
 __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *__restrict__ P, const float *__restrict__ r,
                                                          float *__restrict__ z, unsigned *__restrict__ zb,
                                                          float *__restrict__ zfin, const int *__restrict__ done, int rbc,
@@ -246,6 +323,7 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
   static_assert(RQ == 0 || MODE == 0, "bf16 right-hand side only in the intermediate passes");
   constexpr int D = 10, NTOP = 2;
   constexpr bool FINAL = MODE == 2;
+  constexpr float CSC1 = C16 ? 1.0f : 1.0f / TSX_FP8_SCALE;  // the fp8 couplings are stored times TSX_FP8_SCALE
   __shared__ float2 sB[NSEG][CW], sV[NSEG][CW];
   if (done && *done) return;
   const int h = g.xm >> 1;
@@ -329,11 +407,22 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
   };
 
   // ---- phase 1: all loads of the upward scan (independent of each other), then the local scan with zero inflow
-  uint4 r0[LSEG], r1[LSEG];
+  uint4 r0[LSEG], r1[LSEG], r1x[C16 ? LSEG : 1];
   float ru[LSEG], rd[LSEG];
   uint2 nb[LSEG][4];
   int eid[LSEG];
-  auto rec = [&](int grp, size_t c, int id) { return IDX ? PE[(size_t)(grp - 1) * nent + id] : P[(size_t)grp * Nc + c]; };
+  // group g = 1..7 of the layout: per cell P[g * Nc + cell]; per block PE[(g - 1) * nent + id], or with C16 PE[g * nent + id]
+  // (slots 0 and 1 hold record 1's two fp16 halves)
+  auto rec = [&](int grp, size_t c, int id) { return IDX ? PE[(size_t)(C16 ? grp : grp - 1) * nent + id] : P[(size_t)grp * Nc + c]; };
+  // four side -> top couplings as floats: fp8 word w, or the fp16 pair of words (a, b)
+  auto dec4 = [&](unsigned w, unsigned a, unsigned b, float (&o)[4]) {
+    if (C16) {
+      const tsx_h4 h = __builtin_bit_cast(tsx_h4, make_uint2(a, b));
+      o[0] = (float)h[0]; o[1] = (float)h[1]; o[2] = (float)h[2]; o[3] = (float)h[3];
+    } else {
+      tsx_fp8x4(w, o);
+    }
+  };
 #pragma unroll
   for (int l = 0; l < LSEG; ++l) {
     const size_t c = cell(l);
@@ -354,7 +443,12 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
       if (RQ == 1 && live && l < nl) rb[c] = tsx_bf16x2(ru[l], rd[l]);
     }
     if (GS) {
-      r1[l] = rec(1, c, eid[l]);
+      if (C16) {
+        r1[l] = IDX ? PE[eid[l]] : P[(size_t)1 * Nc + c];
+        r1x[l] = IDX ? PE[(size_t)nent + eid[l]] : P[(size_t)8 * Nc + c];
+      } else {
+        r1[l] = rec(1, c, eid[l]);
+      }
       nbr_load(c, nb[l]);
     }
   }
@@ -368,16 +462,17 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
       if (GS) {
         float zx[4], zy[4], cy0[4], cy1[4], cx0[4], cx1[4];
         nbr_vals(nb[l], zx, zy);
-        tsx_fp8x4(r1[l].x, cy0);
-        tsx_fp8x4(r1[l].y, cy1);
-        tsx_fp8x4(r1[l].z, cx0);
-        tsx_fp8x4(r1[l].w, cx1);
+        const uint4 ry = r1[l], rx = C16 ? r1x[l] : r1[l];
+        dec4(ry.x, ry.x, ry.y, cy0);
+        dec4(ry.y, ry.z, ry.w, cy1);
+        dec4(rx.z, rx.x, rx.y, cx0);
+        dec4(rx.w, rx.z, rx.w, cx1);
         float gu8 = cy0[0] * zy[0] + cy0[2] * zy[1] + cy1[0] * zy[2] + cy1[2] * zy[3];
         float gd8 = cy0[1] * zy[0] + cy0[3] * zy[1] + cy1[1] * zy[2] + cy1[3] * zy[3];
         gu8 += cx0[0] * zx[0] + cx0[2] * zx[1] + cx1[0] * zx[2] + cx1[2] * zx[3];
         gd8 += cx0[1] * zx[0] + cx0[3] * zx[1] + cx1[1] * zx[2] + cx1[3] * zx[3];
-        gu = gu8 * (1.0f / TSX_FP8_SCALE);
-        gd = gd8 * (1.0f / TSX_FP8_SCALE);
+        gu = gu8 * CSC1;
+        gd = gd8 * CSC1;
       }
       const bool act = l < nl;
       const float E = act ? (float)m[0] : 1.0f;

@@ -54,6 +54,13 @@ static PcsCfg pcs_config(const tsx_solver *s) {
   return c;
 }
 
+// side -> top couplings (record 1) as two fp16 records instead of one fp8 record (tsx_kernels_pcs.hpp "C16"): a build-time
+// choice (both variants of every pass kernel would double the compile time); measured 6 -> 5 iterations on the metric domain
+#ifndef TSX_PCS_C16
+#define TSX_PCS_C16 1
+#endif
+static constexpr bool pcs_c16() { return TSX_PCS_C16 != 0; }
+
 bool tsx_pcs_eligible(const tsx_solver *s) {
   const char *e = getenv("TSX_PC_SCAN");  // TSX_PC_SCAN=0: the one-lane-per-column kernels (A/B knob)
   const int on = e ? atoi(e) : 1;
@@ -99,8 +106,14 @@ int tsx_pcs_pack(tsx_solver *s) {
     // group 0 per cell, groups 1..7 per distinct block behind it (7 * nent <= 7 * Nc records: the same buffer holds them)
     hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->coef,
                        s->l1d, s->a11, s->a12, s->albedo, P);
-    hipLaunchKernelGGL(tsx_k_pcs_pack_ent, dim3(grid_for(7ll * s->dd_nent)), dim3(TSX_BLOCK), 0, s->stream, g.ncol,
-                       (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d, P + g.Nc);
+    s->coef_h_c16 = pcs_c16();
+    if (s->coef_h_c16)  // side -> top couplings in fp16: 8 records per distinct block
+      hipLaunchKernelGGL(tsx_k_pcs_pack_ent16, dim3(grid_for((long long)TSX_PCS_ENT16_SLOTS * s->dd_nent)), dim3(TSX_BLOCK), 0,
+                         s->stream, g.ncol, (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d,
+                         P + g.Nc);
+    else
+      hipLaunchKernelGGL(tsx_k_pcs_pack_ent, dim3(grid_for(7ll * s->dd_nent)), dim3(TSX_BLOCK), 0, s->stream, g.ncol,
+                         (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d, P + g.Nc);
     // the intermediate passes' copy of record 0 (block index in the word of A_k) in the last group's slot: the entries
     // fill at most 3.5 of the 7 groups behind record 0 (sharing is on only where 2 * nent <= Nc)
     hipLaunchKernelGGL(tsx_k_pcs_pack_r0g, dim3(grid_for(g.Nc)), dim3(TSX_BLOCK), 0, s->stream, (long long)g.Nc, (const uint4 *)P,
@@ -113,16 +126,23 @@ int tsx_pcs_pack(tsx_solver *s) {
     if ((long long)g.ym * (g.xm / 2) < 16384) return TSX_OK;
     return tsx_records_share(s, 1, P + (size_t)7 * g.Nc);
   }
+  s->coef_h_c16 = pcs_c16();
   if (s->coef_bytes == 4) {
     hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->coef,
                        s->l1d, s->a11, s->a12, s->albedo, P);
     hipLaunchKernelGGL((tsx_k_pcs_pack<float>), dim3(grid_for(7 * g.Nc)), dim3(TSX_BLOCK), 0, s->stream, g, (const float *)s->coef,
                        s->l1d, P);
+    if (s->coef_h_c16)
+      hipLaunchKernelGGL((tsx_k_pcs_pack_rec1h<float>), dim3(grid_for(g.Nc)), dim3(TSX_BLOCK), 0, s->stream, g,
+                         (const float *)s->coef, s->l1d, P);
   } else {
     hipLaunchKernelGGL((tsx_k_pcs_pack_col<double>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const double *)s->coef,
                        s->l1d, s->a11, s->a12, s->albedo, P);
     hipLaunchKernelGGL((tsx_k_pcs_pack<double>), dim3(grid_for(7 * g.Nc)), dim3(TSX_BLOCK), 0, s->stream, g,
                        (const double *)s->coef, s->l1d, P);
+    if (s->coef_h_c16)
+      hipLaunchKernelGGL((tsx_k_pcs_pack_rec1h<double>), dim3(grid_for(g.Nc)), dim3(TSX_BLOCK), 0, s->stream, g,
+                         (const double *)s->coef, s->l1d, P);
   }
   HIPCHK(hipGetLastError());
   return TSX_OK;
@@ -241,14 +261,15 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   unsigned *rb = zb + (size_t)4 * g.Nc;  // behind the iterate's bf16 records in s->vw
   const int *pidx = dd && s->pcr_on ? (const int *)s->pcr_idx : (const int *)nullptr;  // shared record 0 of the intermediate passes
   const uint4 *PT = (const uint4 *)s->pcr_tab;
+  constexpr bool C16 = pcs_c16();
 #define TSX_PCS_GO(GSV, MODEV, RQV)                                                                                              \
   do {                                                                                                                           \
     if (dd)                                                                                                                      \
-      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, true, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb,   \
-                         zfin, done, rbc, nonbr, cidx, nent, PE, hal, rb, part, pidx, PT);                                       \
+      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, true, RQV, C16>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs,  \
+                         zb, zfin, done, rbc, nonbr, cidx, nent, PE, hal, rb, part, pidx, PT);                                   \
     else                                                                                                                         \
-      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, false, RQV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, zb,  \
-                         zfin, done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr, hal, rb, part,               \
+      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, false, RQV, C16>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, \
+                         zb, zfin, done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr, hal, rb, part,           \
                          (const int *)nullptr, (const uint4 *)nullptr);                                                          \
   } while (0)
   if (!gs) {

@@ -1,0 +1,173 @@
+"""Offline (CPU, scipy) study: how coarse may the preconditioner's coupling records be?  Red-black column-block Gauss-Seidel
+(P half-grid passes) as M^-1 of flexible BiCGStab; the couplings to OTHER columns (what the device keeps in records 1 and 4..7,
+fp8 e4m3 today) and the top -> side couplings inside the column block (records 2, 3, fp16 today) are quantised in several ways;
+the operator itself stays exact.  Prints iteration counts to rtol 1e-5 / 1e-8."""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import oracle as O
+from tenstream_amd import synthetic
+
+Nx, Ny, Nz = int(os.environ.get("NX", 32)), int(os.environ.get("NY", 32)), int(os.environ.get("NZ", 16))
+P_ = int(os.environ.get("PASSES", 20))
+HET = bool(int(os.environ.get("HET", "1")))
+P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+if HET:   # every cell its own optical properties
+    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, heterogeneous=True)
+    kabs, ksca, g = synthetic.delta_scale(kabs, ksca, g)
+    tau = np.clip(((kabs + ksca) * 50.0).astype(np.float32), synthetic.PRESET_TAU31[0], synthetic.PRESET_TAU31[-1])
+    w0 = np.clip((ksca / np.maximum(kabs + ksca, 1e-300)).astype(np.float32), 0, synthetic.PRESET_W020[-1])
+    P["coeff"] = np.ascontiguousarray(synthetic.diff2diff_surrogate("3_10", tau, w0, 0.5, g.astype(np.float32)).astype(np.float32))
+    P["b"] = synthetic.solar_source("3_10", kabs, ksca, g, 50.0, 100.0, P["albedo"])
+lay = O.layout("3_10", Nz, Nx, Ny)
+A = O.assemble_csr(lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], P["albedo"]).tocsr()
+n = A.shape[0]
+D, L = 10, Nz + 1
+idx = np.arange(n)
+d, k = idx % D, (idx // D) % L
+i, j = (idx // (D * L)) % Nx, idx // (D * L * Nx)
+oi, oj = i.copy(), j.copy()
+qx, qy = d - 2, d - 6
+mx = (qx >= 0) & (qx < 4) & (qx % 2 == 1) & (k < Nz)
+my = (qy >= 0) & (qy < 4) & (qy % 2 == 1) & (k < Nz)
+oi[mx] = (i[mx] - 1) % Nx
+oj[my] = (j[my] - 1) % Ny
+owner = oj * Nx + oi
+Ac = A.tocoo()
+same = owner[Ac.row] == owner[Ac.col]
+b = P["b"].ravel()
+rb = (oi + oj) % 2
+
+
+def e4m3(v, scale=64.0):
+    """round |v| * scale to OCP fp8 e4m3 (3 mantissa bits, min normal 2^-6, subnormals 2^-9), sign kept"""
+    a = np.abs(v) * scale
+    out = np.zeros_like(a)
+    nz = a > 0
+    e = np.floor(np.log2(a[nz]))
+    e = np.maximum(e, -6)
+    q = np.round(a[nz] / 2.0 ** (e - 3)) * 2.0 ** (e - 3)
+    out[nz] = np.minimum(q, 448.0)
+    return np.sign(v) * out / scale
+
+
+def e2m1_block(v, grp):
+    """4-bit e2m1 {0, .5, 1, 1.5, 2, 3, 4, 6} with one power-of-two scale per group `grp` (ids): the largest entry -> <= 6"""
+    a = np.abs(v)
+    mxv = np.zeros(grp.max() + 1)
+    np.maximum.at(mxv, grp, a)
+    sc = 2.0 ** np.ceil(np.log2(np.maximum(mxv, 1e-30) / 6.0))
+    x = a / sc[grp]
+    levels = np.array([0, .5, 1, 1.5, 2, 3, 4, 6])
+    q = levels[np.abs(x[:, None] - levels[None, :]).argmin(axis=1)]
+    return np.sign(v) * q * sc[grp]
+
+
+def log4(v, step=0.5, top=0.0):
+    """4-bit logarithmic: 15 levels 2^(top - step * m), m = 0..14, and zero"""
+    a = np.abs(v)
+    out = np.zeros_like(a)
+    nz = a > 2.0 ** (top - step * 14.5)
+    m = np.clip(np.round((top - np.log2(a[nz])) / step), 0, 14)
+    out[nz] = 2.0 ** (top - step * m)
+    return np.sign(v) * out
+
+
+def build(noff_q=None, mtop_q=None, drop_xy=False, only=None):
+    data = Ac.data.copy()
+    off = ~same
+    rows, cols = Ac.row, Ac.col
+    dr, dc = d[rows], d[cols]
+    if drop_xy:   # side -> side couplings between different axes dropped from the off-column part
+        xs_ = lambda q: (q >= 2) & (q < 6)
+        ys_ = lambda q: q >= 6
+        kill = off & ((xs_(dr) & ys_(dc)) | (ys_(dr) & xs_(dc)))
+        data[kill] = 0.0
+    if noff_q is not None:
+        grp = (owner[rows[off]] * L + k[rows[off]])   # one group per receiving cell (level of the row unknown)
+        q = noff_q(data[off], grp)
+        if only == "top":      # only the couplings into the column's top streams (record 1) are quantised
+            q = np.where(dr[off] < 2, q, data[off])
+        elif only == "side":   # only side -> side (records 4..7)
+            q = np.where(dr[off] >= 2, q, data[off])
+        elif only == "side_conserve":
+            # side -> side quantised, side -> top exact, and what the rounding took from (added to) the total that a source
+            # stream scatters into the receiving cell is given back through its two side -> top couplings (in proportion):
+            # the preconditioner's matrix keeps the operator's column sums, i.e. it conserves energy like the operator
+            q = np.where(dr[off] >= 2, q, data[off])
+            src = cols[off]                      # the source unknown identifies (source stream, receiving cell)
+            err = np.zeros(n)
+            np.add.at(err, src, data[off] - q)   # entries are -c: err = sum(-c_exact + c_q) ... sign carried through
+            topsum = np.zeros(n)
+            top = dr[off] < 2
+            np.add.at(topsum, src[top], data[off][top])
+            scale = np.where(topsum != 0, 1.0 + err / np.where(topsum != 0, topsum, 1.0), 1.0)
+            q = np.where(top, data[off] * scale[src], q)
+        data[off] = q
+    if mtop_q is not None:   # within the column block: top (0, 1) -> side (2..9) couplings of a cell
+        m = same & (dr >= 2) & (dc < 2) & (rows != cols)
+        data[m] = mtop_q(data[m])
+    M = sp.csc_matrix((data[same], (rows[same], cols[same])), shape=A.shape)
+    Noff = sp.csr_matrix((data[off], (rows[off], cols[off])), shape=A.shape)
+    lu = spla.splu(M, permc_spec="NATURAL")
+
+    def apply(v):
+        x = np.zeros(n)
+        for p in range(P_):
+            rhs = v - Noff @ x
+            mk = rb == (p & 1)
+            x[mk] = lu.solve(rhs)[mk]
+        return x
+    return apply
+
+
+def fbcgs(Minv, rtols=(1e-5, 1e-8), maxit=60):
+    x = np.zeros(n); r = b.copy(); rh = r.copy(); p = r.copy()
+    rho = rh @ r; r0 = np.linalg.norm(r)
+    got = {}
+    hist = []
+    for it in range(1, maxit + 1):
+        ph = Minv(p); v = A @ ph; alpha = rho / (rh @ v)
+        s = r - alpha * v; sh = Minv(s); t = A @ sh
+        omega = (t @ s) / (t @ t)
+        x += alpha * ph + omega * sh; r = s - omega * t
+        rel = np.linalg.norm(r) / r0
+        hist.append(rel)
+        for rt in rtols:
+            if rt not in got and rel <= rt:
+                got[rt] = it
+        if len(got) == len(rtols):
+            break
+        rho_new = rh @ r; beta = (rho_new / rho) * (alpha / omega); rho = rho_new
+        p = r + beta * (p - omega * v)
+    return [got.get(rt, maxit) for rt in rtols], hist
+
+
+print("problem", Nx, Ny, Nz, "n", n, "passes", P_, "heterogeneous" if HET else "clouds", flush=True)
+f8 = lambda v, g=None: e4m3(v)
+variants = [
+    ("exact couplings", dict()),
+    ("off-column fp8 e4m3 (today)", dict(noff_q=f8)),
+    ("fp8 only into top (side->side exact)", dict(noff_q=f8, only="top")),
+    ("fp8 only side->side (into top exact)", dict(noff_q=f8, only="side")),
+    ("fp8 side->side, column sums kept", dict(noff_q=f8, only="side_conserve")),
+    ("off-column fp16", dict(noff_q=lambda v, g: v.astype(np.float16).astype(np.float64))),
+    ("off-column e5m10-like 6 mantissa bits", dict(noff_q=lambda v, g: np.ldexp(np.round(np.ldexp(np.frexp(v)[0], 7)), np.frexp(v)[1] - 7))),
+    ("off-column e2m1 + scale per cell", dict(noff_q=e2m1_block)),
+    ("off-column log4 step 1/2", dict(noff_q=lambda v, g: log4(v, 0.5))),
+    ("off-column log4 step 3/4", dict(noff_q=lambda v, g: log4(v, 0.75))),
+    ("off-column fp8, x<->y dropped", dict(noff_q=f8, drop_xy=True)),
+    ("off-column fp8 + top->side fp8", dict(noff_q=f8, mtop_q=lambda v: e4m3(v))),
+    ("off-column log4 1/2 + top->side fp8", dict(noff_q=lambda v, g: log4(v, 0.5), mtop_q=lambda v: e4m3(v))),
+]
+sel = os.environ.get("VARIANTS", "")
+for name, kw in variants:
+    if sel and not any(s_ in name for s_ in sel.split(",")):
+        continue
+    its, hist = fbcgs(build(**kw))
+    print(f"{name:40s} its(1e-5, 1e-8) = {its}  " + " ".join(f"{h:.1e}" for h in hist), flush=True)

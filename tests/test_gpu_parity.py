@@ -263,11 +263,13 @@ def test_default_solver_on_awkward_shapes(gpu, solver, Nx, Ny, Nz, n1d):
     info = s.solve(P["b"], x, rtol=1e-10, atol=1e-30)
     assert info.reason == 2, info
     assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
-    # what the automatic choices resolved to (tsx_pc_info): red-black with 20 passes on the scan kernels where the grid has an
-    # even number of columns per row (and of rows, the rank wrapping onto itself) and Nz <= 256; else zebra rows, 10 passes
+    # what the automatic choices resolved to (tsx_pc_info): red-black with 22 (3_10) / 20 (8_16) passes on the scan kernels where
+    # the grid has an even number of columns per row (and of rows, the rank wrapping onto itself) and Nz <= 256; else zebra
+    # rows, 10 passes
     pc, sweeps, scan, _ = s.pc_info()
     redblack = Nx % 2 == 0 and Ny % 2 == 0
-    assert pc == (3 if redblack else 2) and scan == redblack and sweeps == (19 if redblack else 9), (pc, sweeps, scan)
+    auto = 21 if solver == "3_10" else 19
+    assert pc == (3 if redblack else 2) and scan == redblack and sweeps == (auto if redblack else 9), (pc, sweeps, scan)
     s.close()
 
 
@@ -632,7 +634,8 @@ def test_scan_preconditioner_equals_the_column_sweep(gpu, monkeypatch, Nx, Ny, N
     """tsx_k_pcs_rb (segmented scan over the levels: LSEG x NSEG levels, CW columns per workgroup; ragged last segment,
     idle segments, columns that do not fill a workgroup) computes the same red-black M^-1 as the one-lane-per-column
     sweep tsx_k_pc_column_rb and as the sparse model.  Both run on reduced-precision blocks (roundings differ: the scan
-    stores the matrix-only recurrences in fp16, the sweep the four top coefficients): 2 % of max between them, 6 % of max
+    stores the matrix-only recurrences and the side -> top couplings in fp16, the sweep the four top coefficients in fp16 and
+    every coupling in fp8 e4m3, 2^-4 per coefficient): 6 % of max between them and 6 % of max
     against the exact model, like test_red_black_preconditioner_is_checkerboard_gauss_seidel."""
     import scipy.sparse.linalg as spla
 
@@ -652,9 +655,11 @@ def test_scan_preconditioner_equals_the_column_sweep(gpu, monkeypatch, Nx, Ny, N
         out["its" + scan], out["x" + scan] = info.niter, x
         assert info.reason == 2
         s.close()
-    for a, b in zip(out["0"], out["1"]):
-        assert np.abs(a - b).max() <= 2e-2 * np.abs(a).max()
-    assert abs(out["its0"] - out["its1"]) <= max(1, round(0.1 * out["its0"]))   # tight solves: a few dozen iterations
+    for a, b in zip(out["0"], out["1"]):   # the sweep rounds the side -> top couplings to fp8 (2^-4), the scan to fp16
+        assert np.abs(a - b).max() <= 6e-2 * np.abs(a).max()
+    # tight solves: a few dozen iterations.  The scan never needs more than the sweep; it may need fewer: it keeps the side ->
+    # top couplings in fp16 (tsx_kernels_pcs.hpp C16), the sweep kernels in fp8
+    assert out["its1"] <= out["its0"] + max(1, round(0.1 * out["its0"])) and out["its1"] >= 0.6 * out["its0"], (out["its0"], out["its1"])
     assert np.abs(out["x0"] - out["x1"]).max() <= 1e-8 * np.abs(out["x0"]).max()
     # against the model: red-black Gauss-Seidel on the exact column blocks, 5 passes
     M, A = _column_block_matrix(P, lay)
