@@ -85,7 +85,7 @@ typedef struct {
   int32_t maxit;
   int32_t pc;                 /* TSX_PC_* */
   int32_t pc_sweeps;          /* ZEBRA / REDBLACK: pc_sweeps + 1 half-grid passes per application; COLUMN: Jacobi sweeps (1..32);
-                                 0 (default) = automatic: 21 / 19 (22 / 20 passes) where the scan kernels of 3_10 / 8_16 run, else 9 */
+                                 0 (default) = automatic: 21 (22 passes) where the scan kernels run, else 9 */
   int32_t check_every;        /* host looks at the device convergence flag every n iterations (default 2) */
   int32_t fp32_directions;    /* 1 (default): the directions p, p-hat, s-hat and the shadow residual are stored in fp32 --
                                  flexible BiCGStab accepts any direction: x and r are updated consistently with A p-hat,

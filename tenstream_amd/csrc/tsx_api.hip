@@ -144,7 +144,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->dtol = 1e4;    // PETSc KSP default divergence tolerance
   o->maxit = 1000;  // src/pprts_base.F90:1118
   o->pc = TSX_PC_REDBLACK;  // this back-end's default preconditioner
-  o->pc_sweeps = 0;  // automatic (prepare_ksp): 21 / 19 with the scan kernels of 3_10 / 8_16, else 9
+  o->pc_sweeps = 0;  // automatic (prepare_ksp): 21 (22 passes) with the scan kernels, else 9
   o->check_every = 2;  // at most one iteration enqueued in vain; measured 1 / 2 / 3 / 4 / 6: 19.44 / 19.24 / 19.37 / 19.68 / 19.26 ms, warm start 3.40 / 3.47 / 3.58 / 3.69 / 3.82 ms
   o->fp32_directions = 1;
   o->pc_coeff_fp16 = 1;
@@ -1122,7 +1122,8 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
     // sits at 1.02-1.08e-5 on every measured domain -- 22 passes take it below the reference's rtol 1e-5: 5 iterations instead
     // of 6 (256 x 256 x 64: 18.7 -> 16.4 ms; 128 x 128: 6.05 -> 5.29 ms; all blocks distinct: 35.7 -> 31.5 ms; 24 / 26 passes:
     // still 5 iterations, 17.2 / 17.8 ms)
-    const int auto_scan = s->geo.ntop == 2 ? 21 : 19;
+    // 8_16 likewise: 20 passes 1.15e-5 after 5 iterations, 22 passes: 5 iterations, 47.0 -> 41.7 ms (24 passes: 44.6 ms)
+    const int auto_scan = 21;
     o->pc_sweeps = (s->pc == TSX_PC_REDBLACK || s->pc == TSX_PC_ZEBRA) ? (scan ? auto_scan : 9) : 1;
     s->pc_sweeps = o->pc_sweeps;
   }
@@ -1235,8 +1236,9 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
     const bool h = g.ntop == 8;
     const double cell[2][2][4] = {{{200, 104, 224, 320}, {88, 72, 116, 212}}, {{544, 400, 624, 768}, {292, 276, 372, 516}}};
     // 3_10 with the side -> top couplings in fp16 (C16): one record more per cell / per distinct block in the passes that read them
-    const double c16 = s->coef_h_c16 && !h ? 16.0 : 0.0;
-    const double ent[2][2] = {{112.0 + c16, 32}, {256, 128}};
+    // (8_16: four records more, 64 B)
+    const double c16 = s->coef_h_c16 ? (h ? 64.0 : 16.0) : 0.0;
+    const double ent[2][2] = {{112.0 + c16, 32}, {256.0 + c16, 128}};
     double c[4] = {cell[h][dd][0], cell[h][dd][1], cell[h][dd][2], cell[h][dd][3]};
     if (!dd) c[0] += c16, c[2] += c16, c[3] += c16;  // every pass with neighbours reads the extra record per cell
     const double half = 0.5 * Nc, e_gs0 = dd ? nent * ent[h][0] : 0.0, e_first0 = dd ? nent * ent[h][1] : 0.0;
@@ -1252,7 +1254,7 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
       }
     }
     const double e_gs = e_gs0 + r_gs, e_first = e_first0 + r_gs, e_f32 = e_gs0 + r_f32;
-    const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : (h ? 20 : 22);
+    const int P = s->pc_sweeps > 0 ? s->pc_sweeps + 1 : 22;
     const double ngs = P > 3 ? P - 3 : 0;
     // bf16 right-hand side of the intermediate passes (tsx_k_pcs_rb RQ): a colour's first visit leaves 5 words (+20 B), the
     // later intermediate visits read 20 B instead of 40 B

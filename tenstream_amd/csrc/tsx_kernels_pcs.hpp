@@ -645,7 +645,12 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
 //   per block, PB[grp * stride + (cell | entry)]: 0,1 c(y_q -> t), byte 4 t + q (fp8) | 2,3 c(x_q -> t) |
 //     4..11 c(src 0..7 -> side dst 8 + dd) (fp16) | 12,13 c(y_q -> 8 + dd), byte 4 dd + q | 14,15 c(x_q -> 8 + dd)
 //   (y_q = src 12 + q, x_q = src 8 + q; t = top dst 0..7).  1-D layers: matrices from a11 / a12, block records zero.
-constexpr int TSX_S16H_CELL = 14, TSX_S16H_BLOCK = 16;
+#ifndef TSX_PCS_C16
+#define TSX_PCS_C16 1  // side -> top couplings in fp16 (see tsx_k_pcs_pack_rec1h); 0: fp8 like the side -> side couplings
+#endif
+// With TSX_PCS_C16 the four fp8 records 0..3 of the per-block part become eight fp16 records (two top dsts per record:
+// halfs 4 (t & 1) + q of record t >> 1 for the y sources, of record 4 + (t >> 1) for the x sources) and the others move up by four
+constexpr int TSX_S16H_CELL = 14, TSX_S16H_BLOCK = TSX_PCS_C16 ? 20 : 16, TSX_S16H_BO = TSX_PCS_C16 ? 4 : 0;
 
 __device__ __forceinline__ uint4 tsx_pack_rows2(const double (&M)[4][4], int r0, double sub_diag) {
   auto v = [&](int a, int b) { return (float)(M[a][b] - (a == b ? sub_diag : 0.0)); };
@@ -737,20 +742,26 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcsh_pack_block(TsxGeo g, lon
     auto cf = [&](int dst, int src) { return (float)C[(size_t)(dst * D + src) * n + e]; };
     uint4 v = make_uint4(0, 0, 0, 0);
     if (!l1d[k]) {
-      if (grp < 4) {  // couplings into the top streams: word t = the four side sources of top dst t
+      if (TSX_PCS_C16 && grp < 8) {  // couplings into the top streams in fp16: record (t >> 1) [+ 4 for the x sources]
+        const int s0 = grp < 4 ? 12 : 8, t0 = 2 * (grp & 3);
+        v.x = tsx_to_h2(cf(t0, s0), cf(t0, s0 + 1));
+        v.y = tsx_to_h2(cf(t0, s0 + 2), cf(t0, s0 + 3));
+        v.z = tsx_to_h2(cf(t0 + 1, s0), cf(t0 + 1, s0 + 1));
+        v.w = tsx_to_h2(cf(t0 + 1, s0 + 2), cf(t0 + 1, s0 + 3));
+      } else if (!TSX_PCS_C16 && grp < 4) {  // couplings into the top streams: word t = the four side sources of top dst t
         const int s0 = grp < 2 ? 12 : 8, t0 = 4 * (grp & 1);
         v.x = tsx_to_fp8x4(cf(t0 + 0, s0), cf(t0 + 0, s0 + 1), cf(t0 + 0, s0 + 2), cf(t0 + 0, s0 + 3));
         v.y = tsx_to_fp8x4(cf(t0 + 1, s0), cf(t0 + 1, s0 + 1), cf(t0 + 1, s0 + 2), cf(t0 + 1, s0 + 3));
         v.z = tsx_to_fp8x4(cf(t0 + 2, s0), cf(t0 + 2, s0 + 1), cf(t0 + 2, s0 + 2), cf(t0 + 2, s0 + 3));
         v.w = tsx_to_fp8x4(cf(t0 + 3, s0), cf(t0 + 3, s0 + 1), cf(t0 + 3, s0 + 2), cf(t0 + 3, s0 + 3));
-      } else if (grp < 12) {  // side dst 8 + dd from the eight top sources
-        const int d = 8 + (grp - 4);
+      } else if (grp < 12 + TSX_S16H_BO) {  // side dst 8 + dd from the eight top sources
+        const int d = 8 + (grp - 4 - TSX_S16H_BO);
         v.x = tsx_to_h2(cf(d, 0), cf(d, 1));
         v.y = tsx_to_h2(cf(d, 2), cf(d, 3));
         v.z = tsx_to_h2(cf(d, 4), cf(d, 5));
         v.w = tsx_to_h2(cf(d, 6), cf(d, 7));
       } else {  // side dst from the side sources of the neighbouring columns
-        const int s0 = grp < 14 ? 12 : 8, d0 = 8 + 4 * (grp & 1);
+        const int s0 = grp < 14 + TSX_S16H_BO ? 12 : 8, d0 = 8 + 4 * (grp & 1);
         v.x = tsx_to_fp8x4(cf(d0 + 0, s0), cf(d0 + 0, s0 + 1), cf(d0 + 0, s0 + 2), cf(d0 + 0, s0 + 3));
         v.y = tsx_to_fp8x4(cf(d0 + 1, s0), cf(d0 + 1, s0 + 1), cf(d0 + 1, s0 + 2), cf(d0 + 1, s0 + 3));
         v.z = tsx_to_fp8x4(cf(d0 + 2, s0), cf(d0 + 2, s0 + 1), cf(d0 + 2, s0 + 2), cf(d0 + 2, s0 + 3));
@@ -948,6 +959,20 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
         nbr_load(c, nb[l]);
         float zx[4], zy[4];
         nbr_vals(nb[l], zx, zy);
+        if (TSX_PCS_C16) {  // fp16: two top dsts per record; the y sources first, then the x sources (four records live at a time)
+#pragma unroll
+          for (int ax = 0; ax < 2; ++ax) {
+            const float(&zz)[4] = ax == 0 ? zy : zx;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const tsx_h8 hh = __builtin_bit_cast(tsx_h8, brec(4 * ax + m, c, eid[l]));
+              const float e0 = (float)hh[0] * zz[0] + (float)hh[1] * zz[1] + (float)hh[2] * zz[2] + (float)hh[3] * zz[3];
+              const float e1 = (float)hh[4] * zz[0] + (float)hh[5] * zz[1] + (float)hh[6] * zz[2] + (float)hh[7] * zz[3];
+              ru[m] += e0;  // top dst t = 2 m (not inward: up), t = 2 m + 1 (down)
+              rd[m] += e1;
+            }
+          }
+        } else {
         const uint4 cy0 = brec(0, c, eid[l]), cy1 = brec(1, c, eid[l]), cx0 = brec(2, c, eid[l]), cx1 = brec(3, c, eid[l]);
         const unsigned wy[8] = {cy0.x, cy0.y, cy0.z, cy0.w, cy1.x, cy1.y, cy1.z, cy1.w};
         const unsigned wx[8] = {cx0.x, cx0.y, cx0.z, cx0.w, cx1.x, cx1.y, cx1.z, cx1.w};
@@ -960,6 +985,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
                            cp[2] * zx[2] + cp[3] * zx[3];
           if (t & 1) rd[t >> 1] += s8 * (1.0f / TSX_FP8_SCALE);
           else ru[t >> 1] += s8 * (1.0f / TSX_FP8_SCALE);
+        }
         }
       }
       float Fr[4];
@@ -1096,10 +1122,10 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     uint4 sy[2], sx[2];
     if (GS) {
       nbr_vals(nb[l], zx, zy);
-      sy[0] = brec(12, c, eid[l]);
-      sy[1] = brec(13, c, eid[l]);
-      sx[0] = brec(14, c, eid[l]);
-      sx[1] = brec(15, c, eid[l]);
+      sy[0] = brec(12 + TSX_S16H_BO, c, eid[l]);
+      sy[1] = brec(13 + TSX_S16H_BO, c, eid[l]);
+      sx[0] = brec(14 + TSX_S16H_BO, c, eid[l]);
+      sx[1] = brec(15 + TSX_S16H_BO, c, eid[l]);
     }
     const unsigned uy[8] = {sy[0].x, sy[0].y, sy[0].z, sy[0].w, sy[1].x, sy[1].y, sy[1].z, sy[1].w};
     const unsigned ux[8] = {sx[0].x, sx[0].y, sx[0].z, sx[0].w, sx[1].x, sx[1].y, sx[1].z, sx[1].w};
@@ -1122,7 +1148,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     float zo[8];
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd) {
-      const tsx_h8 row = __builtin_bit_cast(tsx_h8, brec(4 + dd, c, eid[l]));
+      const tsx_h8 row = __builtin_bit_cast(tsx_h8, brec(4 + TSX_S16H_BO + dd, c, eid[l]));
       float acc = 0.0f;
 #pragma unroll
       for (int a = 0; a < 4; ++a) acc += (float)row[2 * a] * Un[a] + (float)row[2 * a + 1] * V[a];

@@ -221,7 +221,7 @@ static int ensure_pc_buffers_t(tsx_solver *s) {
 int tsx_pc_ensure_half(tsx_solver *s) {
   const bool h1 = s->geo.ntop == 2;
   // 3_10: 8 groups, + 1 for the second half of record 1 in fp16 (tsx_k_pcs_pack_rec1h)
-  const long long n = (long long)(h1 ? TSX_P16_GROUPS + 1 : 30 /* max(TSX_P16H_GROUPS, 14 + 16 of the scan layout) */) * s->geo.Nc;
+  const long long n = (long long)(h1 ? TSX_P16_GROUPS + 1 : 34 /* max(TSX_P16H_GROUPS, 14 + 20 of the scan layout) */) * s->geo.Nc;
   if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
   const bool scan = s->pc_split && tsx_pcs_eligible(s);
   if (scan && (!s->coef_h_valid || !s->coef_h_scan || s->coef_h_dd != (s->dd_on && s->coef_bytes == 4))) {

@@ -67,8 +67,9 @@ bool tsx_pcs_eligible(const tsx_solver *s) {
   return on && pcs_config(s).lseg > 0;
 }
 
-static int pcsh_pack(tsx_solver *s) {  // 8_16: 14 matrix records per cell, then 16 block records per cell or per entry
+static int pcsh_pack(tsx_solver *s) {  // 8_16: 14 matrix records per cell, then 16 / 20 block records per cell or per entry
   const TsxGeo &g = s->geo;
+  s->coef_h_c16 = pcs_c16();
   uint4 *P = (uint4 *)s->coef_h, *PB = P + (size_t)TSX_S16H_CELL * g.Nc;
   s->coef_h_dd = false;
   const int nbc = (g.ncol + 63) / 64;
