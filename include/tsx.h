@@ -87,7 +87,13 @@ typedef struct {
   int32_t pc_sweeps;          /* ZEBRA / REDBLACK: pc_sweeps + 1 half-grid passes per application; COLUMN: Jacobi sweeps (1..32);
                                  0 (default) = automatic: 21 (22 passes) where the scan kernels run, else 9 */
   int32_t check_every;        /* host looks at the device convergence flag every n iterations (default 2) */
-  int32_t fp32_directions;    /* 1 (default): the directions p, p-hat, s-hat and the shadow residual are stored in fp32 --
+  int32_t fp32_directions;    /* 2 (default; with a preconditioner and rtol >= 1e-7, else like 1): as 1, and the recurrence vectors r, s, v, t are fp32
+                                 too.  The iterate x, b, every dot product and the stop rule stay fp64 on the exact blocks; the
+                                 recurrence residual is REPLACED by b - A x evaluated in fp64 whenever it has fallen four orders of
+                                 magnitude since the last replacement and before convergence is declared, so the reference's
+                                 criterion (MyKSPConverged) is decided on the true fp64 residual.  (The reference's ireals is
+                                 real32 or real64 by build option.)
+                                 1: the directions p, p-hat, s-hat and the shadow residual are stored in fp32 --
                                  flexible BiCGStab accepts any direction: x and r are updated consistently with A p-hat,
                                  A s-hat whatever they are; x, r, s, v, t, the dots and the stop rule stay fp64.  0: all fp64 */
   int32_t pc_coeff_fp16;      /* 1 (default): with fp32 directions the preconditioner reads a packed reduced-precision copy

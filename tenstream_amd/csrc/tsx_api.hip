@@ -146,7 +146,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->pc = TSX_PC_REDBLACK;  // this back-end's default preconditioner
   o->pc_sweeps = 0;  // automatic (prepare_ksp): 21 (22 passes) with the scan kernels, else 9
   o->check_every = 2;  // at most one iteration enqueued in vain; measured 1 / 2 / 3 / 4 / 6: 19.44 / 19.24 / 19.37 / 19.68 / 19.26 ms, warm start 3.40 / 3.47 / 3.58 / 3.69 / 3.82 ms
-  o->fp32_directions = 1;
+  o->fp32_directions = 2;
   o->pc_coeff_fp16 = 1;
   o->skip_complete_initial_run = 0;
   o->explicit_solver = 0;
@@ -855,8 +855,54 @@ static int enqueue_iteration_t(tsx_solver *s, bool first) {
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
+// The same iteration with the recurrence vectors in fp32 (tsx_kernels.hpp "fp32 Krylov vectors"): r in vr, v in vv, s in vs
+// (natural order; the preconditioner's colour-split copy in v32), t in vt -- the fp64 buffers reused as float arrays.
+template <int NTOP, int NSIDE>
+static int enqueue_iteration_k32(tsx_solver *s, bool first) {
+  const TsxGeo &g = s->geo;
+  const long long n2 = g.N / 2;
+  const int nbv = grid_for(n2);
+  int rc;
+  float *r32 = (float *)s->vr, *v32k = (float *)s->vv, *s32n = (float *)s->vs, *t32 = (float *)s->vt;
+  const float *rhat = (const float *)s->vrhat;
+  float *ph = (float *)s->vph, *sh = (float *)s->vsh;
+  if (!first)
+    hipLaunchKernelGGL(tsx_k_pupdate_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const float2 *)r32,
+                       (const float2 *)v32k, s->p32, g, (int)s->pc_split);
+  s->pc_rhs = s->p32;
+  if ((rc = tsx_pc_apply(s, s->vp, ph, true, true))) return rc;
+  if ((rc = launch_spmv_f32<NTOP, NSIDE, 1>(s, ph, v32k, rhat, true))) return rc;
+  if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
+  // the preconditioner reads s in its own order: natural (then one copy serves both) or colour-split (a second copy)
+  float *sdst = s->pc_split ? s32n : s->v32;
+  hipLaunchKernelGGL(tsx_k_supdate_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const float2 *)r32,
+                     (const float2 *)v32k, (float2 *)sdst, s->pc_split ? s->v32 : (float *)nullptr, g);
+  s->pc_rhs = s->v32;
+  if ((rc = tsx_pc_apply(s, s->vs, sh, true, true))) return rc;
+  if ((rc = launch_spmv_f32<NTOP, NSIDE, 5>(s, sh, t32, sdst, true))) return rc;
+  if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
+  hipLaunchKernelGGL(tsx_k_xrupdate_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (double2 *)s->vx, (const float2 *)ph,
+                     (const float2 *)sh, (const float2 *)sdst, (const float2 *)t32, (const float2 *)rhat, (float2 *)r32, s->partials);
+  if ((rc = scalar_stage(s, nbv, 2, TSX_STAGE_RHO))) return rc;
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+// replace the recurrence residual by b - A x evaluated in fp64 on the exact blocks; renews rho, the norm and the stop decision
+template <int NTOP, int NSIDE>
+static int k32_replace_residual(tsx_solver *s) {
+  const TsxGeo &g = s->geo;
+  int rc;
+  // t (fp32, in vt) is dead between iterations: its buffer takes A x in fp64
+  if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vx, s->vt, (const double *)nullptr, true))) return rc;
+  const int nbv = grid_for(g.N);
+  hipLaunchKernelGGL(tsx_k_residual_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, (float *)s->vr,
+                     (float *)s->vrhat, s->p32, s->partials, g, (int)s->pc_split, 0, 0, &s->scal->done);
+  if ((rc = scalar_stage(s, nbv, 2, TSX_STAGE_REPLACE))) return rc;
+  return TSX_OK;
+}
 template <int NTOP, int NSIDE>
 static int enqueue_iteration(tsx_solver *s, bool first) {
+  if (s->k32) return enqueue_iteration_k32<NTOP, NSIDE>(s, first);
   return s->mixed ? enqueue_iteration_t<NTOP, NSIDE, true>(s, first) : enqueue_iteration_t<NTOP, NSIDE, false>(s, first);
 }
 
@@ -884,7 +930,10 @@ static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o, bool restart = fal
   if (!yzero && (rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vx, s->vt, (const double *)nullptr, false))) return rc;
   s->x_is_zero = false;  // from here on x is the iterate
   const int nbv = grid_for(g.N);
-  if (s->mixed)
+  if (s->k32)
+    hipLaunchKernelGGL(tsx_k_residual_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, (float *)s->vr,
+                       (float *)s->vrhat, s->p32, s->partials, g, (int)s->pc_split, yzero, 1, (const int *)nullptr);
+  else if (s->mixed)
     hipLaunchKernelGGL(tsx_k_residual0<float>, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, g.N, s->vb, s->vt, s->vr,
                        (float *)s->vrhat, s->vp, s->pc != TSX_PC_NONE ? s->p32 : (float *)nullptr, s->partials, g, (int)s->pc_split,
                        yzero);
@@ -913,6 +962,24 @@ static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
     }
     HIPCHK(hipMemcpyAsync(s->scal_host, s->scal, sizeof(TsxScalars), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->k32) {
+      // fp32 recurrence: convergence is declared on the true residual only, and the recurrence is re-anchored to it whenever
+      // it has fallen four orders of magnitude since the last anchor (it cannot follow b - A x much further in fp32)
+      TsxScalars &h = *s->scal_host;
+      const bool conv = h.done && h.reason > 0;
+      const bool far = !h.done && h.rnorm <= 1e-4 * h.rnorm_true;
+      if ((conv || far) && h.rnorm_true != h.rnorm) {
+        if (conv) {  // un-declare: the kernels of the replacement must run
+          h.done = 0;
+          h.reason = 0;
+          HIPCHK(hipMemcpyAsync(s->scal, s->scal_host, sizeof(TsxScalars), hipMemcpyHostToDevice, s->stream));
+        }
+        if ((rc = k32_replace_residual<NTOP, NSIDE>(s))) return rc;
+        HIPCHK(hipMemcpyAsync(s->scal_host, s->scal, sizeof(TsxScalars), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if (conv && !h.done) enq = h.its;  // iterations enqueued after the premature stop did not run
+      }
+    }
     done = s->scal_host->done != 0 || enq >= o->maxit;
     if (s->scal_host->done && s->scal_host->reason == -5 && nrestart < 3 && s->scal_host->its < o->maxit) {
       // rho / (rhat,v) breakdown: restart from the current iterate with rhat = r (x keeps its progress).  The
@@ -1098,6 +1165,12 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   // Jacobi refinement and pc_coeff_fp16 = 0 work on fp64 directions and the exact blocks
   s->mixed = o->fp32_directions != 0 && !(o->pc == TSX_PC_COLUMN && o->pc_sweeps > 1) &&
              (o->pc == TSX_PC_NONE || o->pc_coeff_fp16 != 0);
+  // fp32 recurrence vectors too (fp32_directions = 2): with a preconditioner on the fp32 path; TSX_K32=0 falls back to 1
+  // ... and for tolerances an fp32 recurrence reaches between two replacements (rtol >= 1e-7: the reference's default is 1e-5);
+  // tighter solves keep the fp64 recurrence -- every replacement costs BiCGStab some of its super-linear convergence (a
+  // 130-level column at rtol 1e-10: 36 instead of 30 iterations)
+  s->k32 = s->mixed && o->fp32_directions >= 2 && o->pc != TSX_PC_NONE && !o->explicit_solver && o->rtol >= 1e-7 &&
+           !(getenv("TSX_K32") && atoi(getenv("TSX_K32")) == 0);
   // red-black ordering exists on the packed path; it needs an even number of columns per row, and an even
   // number of rows where the rank wraps onto itself in y (a periodic seam between equal colours) -- else zebra rows
   if (s->pc == TSX_PC_REDBLACK) {

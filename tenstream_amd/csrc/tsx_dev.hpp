@@ -67,6 +67,7 @@ template <> struct TsxVec<1> {
   static __device__ __forceinline__ void ld(const double *p, double *o) { o[0] = p[0]; }
   static __device__ __forceinline__ void ld(const float *p, double *o) { o[0] = (double)p[0]; }
   static __device__ __forceinline__ void st(double *p, const double *v) { p[0] = v[0]; }
+  static __device__ __forceinline__ void st(float *p, const double *v) { p[0] = (float)v[0]; }
 };
 template <> struct TsxVec<2> {
   static __device__ __forceinline__ void ld(const double *p, double *o) {
@@ -80,6 +81,9 @@ template <> struct TsxVec<2> {
   static __device__ __forceinline__ void st(double *p, const double *v) {
     double2 o; o.x = v[0]; o.y = v[1];
     *reinterpret_cast<double2 *>(p) = o;
+  }
+  static __device__ __forceinline__ void st(float *p, const double *v) {
+    *reinterpret_cast<float2 *>(p) = make_float2((float)v[0], (float)v[1]);
   }
 };
 template <> struct TsxVec<4> {
@@ -95,6 +99,9 @@ template <> struct TsxVec<4> {
     double2 a, b; a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
     reinterpret_cast<double2 *>(p)[0] = a;
     reinterpret_cast<double2 *>(p)[1] = b;
+  }
+  static __device__ __forceinline__ void st(float *p, const double *v) {
+    *reinterpret_cast<float4 *>(p) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
   }
 };
 

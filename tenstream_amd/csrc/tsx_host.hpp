@@ -84,9 +84,9 @@ int tsx_face_exchange_bufs(tsx_solver *s, hipStream_t st, double *const send[4],
 
 // operator apply: one translation unit per stream configuration (tsx_spmv_3_10.hip, tsx_spmv_8_16.hip).
 // combo = (fused dots, type of x, type of w): the variants the Krylov loop uses
-enum TsxSpmvCombo { TSX_SPMV_0DD = 0, TSX_SPMV_1FF, TSX_SPMV_5FD, TSX_SPMV_1DF, TSX_SPMV_1DD, TSX_SPMV_5DD };
-int tsx_spmv_launch_310(tsx_solver *s, int combo, const void *x, double *y, const void *w, bool in_solve);
-int tsx_spmv_launch_816(tsx_solver *s, int combo, const void *x, double *y, const void *w, bool in_solve);
+enum TsxSpmvCombo { TSX_SPMV_0DD = 0, TSX_SPMV_1FF, TSX_SPMV_5FD, TSX_SPMV_1DF, TSX_SPMV_1DD, TSX_SPMV_5DD, TSX_SPMV_1FF_YF, TSX_SPMV_5FF_YF };
+int tsx_spmv_launch_310(tsx_solver *s, int combo, const void *x, void *y, const void *w, bool in_solve);
+int tsx_spmv_launch_816(tsx_solver *s, int combo, const void *x, void *y, const void *w, bool in_solve);
 int tsx_halo_update_310(tsx_solver *s, const double *v, bool in_solve);
 int tsx_halo_update_816(tsx_solver *s, const double *v, bool in_solve);
 
@@ -100,6 +100,13 @@ constexpr int tsx_spmv_combo() {
 template <int NTOP, int NSIDE, int FUSE, typename XT = double, typename WT = double>
 static inline int launch_spmv(tsx_solver *s, const XT *x, double *y, const WT *w, bool in_solve) {
   constexpr int combo = tsx_spmv_combo<FUSE, XT, WT>();
+  return NTOP == 2 ? tsx_spmv_launch_310(s, combo, x, y, w, in_solve) : tsx_spmv_launch_816(s, combo, x, y, w, in_solve);
+}
+// v = A p-hat (fused (rhat, v)) / t = A s-hat (fused (s, t), (t, t)) with fp32 input, shadow vector and RESULT
+template <int NTOP, int NSIDE, int FUSE>
+static inline int launch_spmv_f32(tsx_solver *s, const float *x, float *y, const float *w, bool in_solve) {
+  static_assert(FUSE == 1 || FUSE == 5, "fp32-result variants: FUSE 1 and 5");
+  const int combo = FUSE == 1 ? TSX_SPMV_1FF_YF : TSX_SPMV_5FF_YF;
   return NTOP == 2 ? tsx_spmv_launch_310(s, combo, x, y, w, in_solve) : tsx_spmv_launch_816(s, combo, x, y, w, in_solve);
 }
 template <int NTOP, int NSIDE>

@@ -39,6 +39,7 @@ struct TsxGeo {
 struct TsxScalars {
   double rho, rho_old, alpha, omega, beta;
   double rnorm, rnorm0;
+  double rnorm_true;       // fp32 Krylov vectors: norm of the residual at its last replacement by b - A x (fp64)
   double red[TSX_NSLOTS];  // reduced (and, multi-rank, all-reduced) sums of the last stage
   double rtol, atol, dtol;
   int maxit;
@@ -123,6 +124,7 @@ struct tsx_solver {
   double *pc_tmp;      // column preconditioner: tsx_pc_ntmp planes of Nc doubles
   int pc, pc_sweeps;   // active preconditioner of the running solve
   bool mixed;          // fp32 storage of preconditioned directions and shadow residual
+  bool k32 = false;    // ... and of the recurrence vectors r, s, v, t (tsx_ksp_opts.fp32_directions = 2), residual replacement in fp64
   // staging in reference layout (for TSX_HOST callers and conversion)
   double *stage_a, *stage_b;
 

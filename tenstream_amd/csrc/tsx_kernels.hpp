@@ -126,6 +126,94 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xrupdate(long long n2, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32 Krylov vectors (tsx_ksp_opts.fp32_directions = 2, the default with a preconditioner).  The reference's `ireals` may be
+// real32 or real64 (CI builds both); here the iterate x, the right-hand side, every dot product and the stop rule stay fp64, the
+// operator works on the exact blocks, and the recurrence vectors r, s, v, t join p, p-hat, s-hat, r-hat in fp32: 96 instead of
+// 140 bytes per unknown and iteration.  A recurrence kept in fp32 drifts from b - A x by about 1e-7 |b|, so the residual is
+// REPLACED by the true one, b - A x evaluated in fp64 (van der Vorst & Ye's residual replacement: r, rho and the norm are
+// renewed, the search direction is kept), whenever the recurrence has fallen four orders of magnitude since the last
+// replacement and -- always -- before convergence is declared: the stop rule of MyKSPConverged (src/pprts.F90:4437-4486) is
+// decided on the fp64 norm of the true residual.
+// r = b - y (y = A x in fp64; yzero: x = 0, r = b) -> r32; init: also rhat32 = p32 = r.  slot0 = (rhat, r), slot1 = (r, r)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_residual_k32(long long n, const double *__restrict__ b, const double *__restrict__ y,
+                                                                float *__restrict__ r32, float *__restrict__ rhat32,
+                                                                float *__restrict__ p32, double *__restrict__ partials, TsxGeo g,
+                                                                int split, int yzero, int init, const int *__restrict__ done) {
+  if (done && *done) return;
+  double sum[2] = {0.0, 0.0};
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double vd = yzero ? b[q] : b[q] - y[q];  // the norm (what the stop rule sees) from the fp64 value
+    const float v = (float)vd;
+    r32[q] = v;
+    float rh;
+    if (init) {
+      rhat32[q] = v;
+      p32[split ? tsx_split_pos(q, g) : q] = v;
+      rh = v;
+    } else {
+      rh = rhat32[q];
+    }
+    sum[0] += (double)rh * (double)v;
+    sum[1] += vd * vd;
+  }
+  tsx_block_reduce_store<2>(sum, partials);
+}
+// p = r + beta (p - omega v), p in the preconditioner's order
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pupdate_k32(long long n2, const TsxScalars *__restrict__ sc,
+                                                               const float2 *__restrict__ r, const float2 *__restrict__ v,
+                                                               float *__restrict__ p32, TsxGeo g, int split) {
+  if (sc->done) return;
+  const double beta = sc->beta, omega = sc->omega;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
+    const float2 rr = r[q], vv = v[q];
+    const long long i0 = split ? tsx_split_pos(2 * q, g) : 2 * q, i1 = split ? tsx_split_pos(2 * q + 1, g) : 2 * q + 1;
+    const double p0 = (double)p32[i0], p1 = (double)p32[i1];
+    p32[i0] = (float)((double)rr.x + beta * (p0 - omega * (double)vv.x));
+    p32[i1] = (float)((double)rr.y + beta * (p1 - omega * (double)vv.y));
+  }
+}
+// s = r - alpha v: natural order (the operator's fused dots and the update read it) and, where the preconditioner works in
+// colour-split order, a second copy in that order
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_supdate_k32(long long n2, const TsxScalars *__restrict__ sc,
+                                                               const float2 *__restrict__ r, const float2 *__restrict__ v,
+                                                               float2 *__restrict__ s, float *__restrict__ ssplit, TsxGeo g) {
+  if (sc->done) return;
+  const double alpha = sc->alpha;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
+    const float2 rr = r[q], vv = v[q];
+    const float2 o = make_float2((float)((double)rr.x - alpha * (double)vv.x), (float)((double)rr.y - alpha * (double)vv.y));
+    s[q] = o;
+    if (ssplit) {
+      ssplit[tsx_split_pos(2 * q, g)] = o.x;
+      ssplit[tsx_split_pos(2 * q + 1, g)] = o.y;
+    }
+  }
+}
+// x += alpha ph + omega sh (fp64); r = s - omega t; slot0 = (rhat, r), slot1 = (r, r)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xrupdate_k32(long long n2, const TsxScalars *__restrict__ sc,
+                                                                double2 *__restrict__ x, const float2 *__restrict__ ph,
+                                                                const float2 *__restrict__ sh, const float2 *__restrict__ s,
+                                                                const float2 *__restrict__ t, const float2 *__restrict__ rhat,
+                                                                float2 *__restrict__ r, double *__restrict__ partials) {
+  if (sc->done) return;
+  const double alpha = sc->alpha, omega = sc->omega;
+  double sum[2] = {0.0, 0.0};
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
+    const double2 xx = x[q];
+    const float2 pp = ph[q], ss2 = sh[q], ss = s[q], tt = t[q], rh = rhat[q];
+    double2 xo;
+    xo.x = xx.x + alpha * (double)pp.x + omega * (double)ss2.x;
+    xo.y = xx.y + alpha * (double)pp.y + omega * (double)ss2.y;
+    const float2 ro = make_float2((float)((double)ss.x - omega * (double)tt.x), (float)((double)ss.y - omega * (double)tt.y));
+    x[q] = xo;
+    r[q] = ro;
+    sum[0] += (double)rh.x * (double)ro.x + (double)rh.y * (double)ro.y;
+    sum[1] += (double)ro.x * (double)ro.x + (double)ro.y * (double)ro.y;
+  }
+  tsx_block_reduce_store<2>(sum, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The explicit (stationary) solver, explicit_ediff of src/pprts_explicit.F90:461-713 on the device: sweeps until the change
 // of the iterate is small.  One outer iteration is a defect correction, x += M^-1 (b - A x), with M^-1 = the red-black passes
 // of the preconditioner -- for a stationary method, continuing the sweeps from x and sweeping on the defect from zero are the
@@ -155,7 +243,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xplus(long long n, const TsxS
 // Scalar stage: one block.  mode bit0: reduce the per-block partials into sc->red (fixed order);
 // mode bit1: run the stage's scalar algebra (after the all-reduce when ranks > 1).
 // Stop rule restates MyKSPConverged (src/pprts.F90:4437-4486).
-enum { TSX_STAGE_INIT = 0, TSX_STAGE_ALPHA = 1, TSX_STAGE_OMEGA = 2, TSX_STAGE_RHO = 3, TSX_STAGE_EXPLICIT = 4 };
+enum { TSX_STAGE_INIT = 0, TSX_STAGE_ALPHA = 1, TSX_STAGE_OMEGA = 2, TSX_STAGE_RHO = 3, TSX_STAGE_EXPLICIT = 4, TSX_STAGE_REPLACE = 5 };
 
 __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc, const double *__restrict__ partials,
                                                      int nblocks, int nslots, int stage, int mode) {
@@ -188,6 +276,7 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
     case TSX_STAGE_INIT: {
       const double rn = sqrt(sc->red[1]);
       sc->rnorm = rn;
+      sc->rnorm_true = rn;
       if (!sc->restart) {
         sc->rnorm0 = rn > tiny ? rn : tiny;  // n == 0: store initial norm, no test (:4455-4458)
         sc->hist[0] = rn;
@@ -231,6 +320,26 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
       sc->rnorm = rn;
       sc->its += 1;
       if (sc->nhist < 100) sc->hist[sc->nhist++] = rn;
+      int reason = 0;
+      if (rn / sc->rnorm0 <= sc->rtol) reason = 2;
+      else if (rn <= sc->atol) reason = 3;
+      else if (sc->its > sc->maxit) reason = -3;
+      else if (rn / sc->rnorm0 >= sc->dtol) reason = -4;
+      else if (rn != rn) reason = -9;
+      else if (sc->rho == 0.0 || sc->omega == 0.0) reason = -5;
+      if (reason) {
+        sc->reason = reason;
+        sc->done = 1;
+      } else {
+        sc->beta = (sc->rho / sc->rho_old) * (sc->alpha / sc->omega);
+      }
+    } break;
+    case TSX_STAGE_REPLACE: {  // the residual has been replaced by b - A x (fp64): renew rho and the norm, decide the stop rule on it
+      sc->rho = sc->red[0];
+      const double rn = sqrt(sc->red[1]);
+      sc->rnorm = rn;
+      sc->rnorm_true = rn;
+      if (sc->nhist > 0 && sc->nhist <= 100) sc->hist[sc->nhist - 1] = rn;  // the history holds true norms where they are known
       int reason = 0;
       if (rn / sc->rnorm0 <= sc->rtol) reason = 2;
       else if (rn <= sc->atol) reason = 3;

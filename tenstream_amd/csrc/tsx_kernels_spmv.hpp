@@ -48,12 +48,15 @@ template <> struct TsxIdx<2> {
   }
 };
 
-template <int NTOP, int NSIDE, typename CT, int FUSE, int CPT, typename XT, typename WT, bool HALO, bool HAS1D, bool IDX = false>
+// YT: storage of the result (float: the fp32 Krylov vectors v, t of tsx_ksp_opts.fp32_directions = 2; the fused dots then use
+// the value as stored)
+template <int NTOP, int NSIDE, typename CT, int FUSE, int CPT, typename XT, typename WT, bool HALO, bool HAS1D, bool IDX = false,
+          typename YT = double>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
     TsxGeo g, const CT *__restrict__ C, const int *__restrict__ cidx, long long nent, const uint8_t *__restrict__ l1d,
     const double *__restrict__ a11,
     const double *__restrict__ a12, const double *__restrict__ albedo, const XT *__restrict__ x,
-    double *__restrict__ y, const XT *__restrict__ hW, const XT *__restrict__ hE,
+    YT *__restrict__ y, const XT *__restrict__ hW, const XT *__restrict__ hE,
     const XT *__restrict__ hS, const XT *__restrict__ hN, const WT *__restrict__ w,
     double *__restrict__ partials, const int *__restrict__ done, int part) {
   constexpr int D = NTOP + 2 * NSIDE;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
   const long long ngroups = part == 2 ? (long long)Nz * nframe : Nc / CPT;
   const long long nchunks = (ngroups + TSX_BLOCK - 1) / TSX_BLOCK;
   const XT *__restrict__ xt = x + (size_t)D * Nc;
-  double *__restrict__ yt = y + (size_t)D * Nc;
+  YT *__restrict__ yt = y + (size_t)D * Nc;
   const WT *__restrict__ wt = (FUSE & 1) ? w + (size_t)D * Nc : nullptr;
 
   for (long long base = 0; base < nchunks; base += gridDim.x) {
@@ -237,6 +240,10 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
 #pragma unroll
           for (int m = 0; m < CPT; ++m) acc[m] = xo[m] - acc[m];
         }
+        if constexpr (std::is_same<YT, float>::value) {  // the dots see the value as stored
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) acc[m] = (double)(float)acc[m];
+        }
         V::st(y + (size_t)d * Nc + c, acc);
         if (d < NTOP && tsx_inward(d)) {
 #pragma unroll
@@ -280,6 +287,10 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_spmv_w(
 #pragma unroll
         for (int m = 0; m < CPT; ++m)
           yv[m] = (d < NTOP && !tsx_inward(d)) ? xv[m] - alb[m] / (double)(NTOP / 2) * down[m] : xv[m];
+        if constexpr (std::is_same<YT, float>::value) {
+#pragma unroll
+          for (int m = 0; m < CPT; ++m) yv[m] = (double)(float)yv[m];
+        }
         V::st(yt + (size_t)d * ncol + col, yv);
         if (FUSE & 1) {
           double wv[CPT];

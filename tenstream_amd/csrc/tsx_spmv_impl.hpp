@@ -16,49 +16,49 @@ static int halo_update_t(tsx_solver *s, const XT *v, bool in_solve) {
 }
 
 // part 0: whole grid; 1: interior (no halo reads); 2: frame, partial sums behind those of part 1
-template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT, bool HALO, bool HAS1D>
-static void launch_spmv_variant(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done, int part) {
+template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT, bool HALO, bool HAS1D, typename YT = double>
+static void launch_spmv_variant(tsx_solver *s, const XT *x, YT *y, const WT *w, const int *done, int part) {
   const TsxGeo &g = s->geo;
   const int nbmain = grid_for(g.Nc / CPT, TSX_MAX_PARTIAL_BLOCKS - TSX_FRAME_BLOCKS);
   const int nb = part == 2 ? grid_for(frame_groups(g, CPT), TSX_FRAME_BLOCKS) : nbmain;
   if constexpr (std::is_same<CT, float>::value) {
     if (s->dd_on) {  // shared storage of identical blocks (tsx_dedup.hip)
-      hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, float, FUSE, CPT, XT, WT, HALO, HAS1D, true>), dim3(nb), dim3(TSX_BLOCK), 0,
+      hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, float, FUSE, CPT, XT, WT, HALO, HAS1D, true, YT>), dim3(nb), dim3(TSX_BLOCK), 0,
                          s->stream, g, (const float *)s->dd_coef_e, (const int *)s->dd_cidx, (long long)s->dd_nent, s->l1d, s->a11,
                          s->a12, s->albedo, x, y, (const XT *)s->recvW, (const XT *)s->recvE, (const XT *)s->recvS,
                          (const XT *)s->recvN, w, s->partials + (part == 2 ? nbmain : 0), done, part);
       return;
     }
   }
-  hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT, XT, WT, HALO, HAS1D>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
+  hipLaunchKernelGGL((tsx_k_spmv_w<NTOP, NSIDE, CT, FUSE, CPT, XT, WT, HALO, HAS1D, false, YT>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g,
                      (const CT *)s->coef, (const int *)nullptr, 0ll, s->l1d, s->a11, s->a12, s->albedo, x, y, (const XT *)s->recvW,
                      (const XT *)s->recvE, (const XT *)s->recvS, (const XT *)s->recvN, w, s->partials + (part == 2 ? nbmain : 0),
                      done, part);
 }
 
-template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT>
-static void launch_spmv_flags(tsx_solver *s, const XT *x, double *y, const WT *w, const int *done, int part) {
+template <int NTOP, int NSIDE, int FUSE, typename CT, int CPT, typename XT, typename WT, typename YT = double>
+static void launch_spmv_flags(tsx_solver *s, const XT *x, YT *y, const WT *w, const int *done, int part) {
   const bool halo = !(s->geo.wrap_x && s->geo.wrap_y) && part != 1, has1d = s->any_l1d;
   if (halo) {
-    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, true>(s, x, y, w, done, part);
-    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, false>(s, x, y, w, done, part);
+    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, true, YT>(s, x, y, w, done, part);
+    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, true, false, YT>(s, x, y, w, done, part);
   } else {
-    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, true>(s, x, y, w, done, part);
-    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, false>(s, x, y, w, done, part);
+    if (has1d) launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, true, YT>(s, x, y, w, done, part);
+    else launch_spmv_variant<NTOP, NSIDE, FUSE, CT, CPT, XT, WT, false, false, YT>(s, x, y, w, done, part);
   }
 }
 
-template <int NTOP, int NSIDE, int FUSE, typename XT, typename WT>
-static int launch_spmv_t(tsx_solver *s, const XT *x, double *y, const WT *w, bool in_solve) {
+template <int NTOP, int NSIDE, int FUSE, typename XT, typename WT, typename YT = double>
+static int launch_spmv_t(tsx_solver *s, const XT *x, YT *y, const WT *w, bool in_solve) {
   const int *done = in_solve ? &s->scal->done : nullptr;
   const int cpt = spmv_cpt(s);
   auto launch = [&](int part) {
     if (s->coef_bytes == 4) {
-      if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, float, 2, XT, WT>(s, x, y, w, done, part);
-      else launch_spmv_flags<NTOP, NSIDE, FUSE, float, 1, XT, WT>(s, x, y, w, done, part);
+      if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, float, 2, XT, WT, YT>(s, x, y, w, done, part);
+      else launch_spmv_flags<NTOP, NSIDE, FUSE, float, 1, XT, WT, YT>(s, x, y, w, done, part);
     } else {
-      if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, double, 2, XT, WT>(s, x, y, w, done, part);
-      else launch_spmv_flags<NTOP, NSIDE, FUSE, double, 1, XT, WT>(s, x, y, w, done, part);
+      if (cpt == 2) launch_spmv_flags<NTOP, NSIDE, FUSE, double, 2, XT, WT, YT>(s, x, y, w, done, part);
+      else launch_spmv_flags<NTOP, NSIDE, FUSE, double, 1, XT, WT, YT>(s, x, y, w, done, part);
     }
   };
   if (!spmv_split(s)) {
@@ -89,9 +89,13 @@ static int launch_spmv_t(tsx_solver *s, const XT *x, double *y, const WT *w, boo
 #define TSX_CAT2(a, b) a##b
 #define TSX_CAT(a, b) TSX_CAT2(a, b)
 
-int TSX_CAT(tsx_spmv_launch_, TSX_SPMV_TAG)(tsx_solver *s, int combo, const void *x, double *y, const void *w, bool in_solve) {
+int TSX_CAT(tsx_spmv_launch_, TSX_SPMV_TAG)(tsx_solver *s, int combo, const void *x, void *yv, const void *w, bool in_solve) {
   constexpr int NT = TSX_SPMV_NTOP, NS = 4;
+  double *y = (double *)yv;
   switch (combo) {
+    // fp32 Krylov vectors (tsx_ksp_opts.fp32_directions = 2): v = A p-hat and t = A s-hat stored in fp32
+    case TSX_SPMV_1FF_YF: return launch_spmv_t<NT, NS, 1, float, float, float>(s, (const float *)x, (float *)yv, (const float *)w, in_solve);
+    case TSX_SPMV_5FF_YF: return launch_spmv_t<NT, NS, 5, float, float, float>(s, (const float *)x, (float *)yv, (const float *)w, in_solve);
     case TSX_SPMV_0DD: return launch_spmv_t<NT, NS, 0, double, double>(s, (const double *)x, y, (const double *)w, in_solve);
     case TSX_SPMV_1FF: return launch_spmv_t<NT, NS, 1, float, float>(s, (const float *)x, y, (const float *)w, in_solve);
     case TSX_SPMV_5FD: return launch_spmv_t<NT, NS, 5, float, double>(s, (const float *)x, y, (const double *)w, in_solve);
