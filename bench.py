@@ -310,7 +310,7 @@ def main():
     out = None
     if rank == 0:
         r_spmv = roof("tsx_k_spmv_w (y = (I - T) x, fp64 x and y)", spmv_ms, bytes_spmv,
-                      ["tsx_k_spmv", (",0,1,double,double", ",0,2,double,double"), ",true>" if dd_on else ",false>"],
+                      ["tsx_k_spmv", (",0,1,double,double", ",0,2,double,double"), ",true,double>" if dd_on else ",false,double>"],
                       bytes_survey_spmv)
         r_iter = roof("one BiCGStab iteration (2 M^-1, 2 SpMV, 3 vector updates)", iter_ms, bytes_iter, None)
         if not dd_on:   # the committed PMC profile is of the shared-block kernels
@@ -321,7 +321,7 @@ def main():
         if pass_ms is not None:
             kname = "tsx_k_pcs_rb" if solver == "3_10" else "tsx_k_pcsh_rb"
             r_pass = roof(f"{kname}<..., GS, MODE 0, RQ 2> (one intermediate red-black pass of M^-1)", pass_ms,
-                          bytes_pass, [kname, ",true,0,true,2>" if dd_on else ",true,0,false,2>"])
+                          bytes_pass, [kname, (",true,0,true,2,", ",true,0,true,2>") if dd_on else (",true,0,false,2,", ",true,0,false,2>")])
         r_pc = None
         if pc_ms is not None:
             r_pc = {"kernel": f"M^-1: {sweeps + 1} half-grid passes", "ms_per_application": pc_ms,
@@ -349,9 +349,11 @@ def main():
                 "process_grid": f"{npx}x{npy}",
                 "transport": "none (1 rank)" if world == 1 else {"rccl": "RCCL", "peer": "device-resident peer mailboxes (HIP IPC)",
                                                                     "host": "host-staged (gloo)"}[transport],
-                "coeff_storage": "fp32 blocks (lossless); x, r, s, v, t fp64; directions p, p-hat, s-hat and shadow residual fp32",
-                "preconditioner_storage": "inside M^-1 only: fp16 column blocks + fp8 couplings, fp32/bf16 iterates; operator, "
-                                          "Krylov vectors, dots and stop rule fp64 on the exact blocks",
+                "coeff_storage": "fp32 blocks (lossless); x, b, dots, stop rule fp64; recurrence vectors r, s, v, t, directions p, "
+                                 "p-hat, s-hat and shadow residual fp32, the residual replaced by b - A x in fp64 before "
+                                 "convergence is declared (fp32_directions = 2)",
+                "preconditioner_storage": "inside M^-1 only: fp16 column blocks and side-to-top couplings, fp8 side-to-side "
+                                          "couplings, fp32/bf16 iterates; the operator always uses the exact blocks",
                 "coeff_source": "device N-linear LUT interpolation (tsx_diff_set_optprop), synthetic table",
                 "coeff_dedup": dict(in_use=dd_on, distinct_blocks=dd_nent, cells_local=co.xm * co.ym * Nz,
                                     note="bit-identical blocks are stored once behind a per-cell index (lossless; TSX_DEDUP=0 "

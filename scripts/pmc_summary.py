@@ -63,7 +63,7 @@ def main():
         }
     # one default iteration: 2 applications of M^-1 (pass 0 without neighbours, P - 3 intermediate, the fp32 pass, the last
     # pass; P = argv[5], default 14), 2 operator applies with fused dots, 3 vector updates
-    P = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+    P = int(sys.argv[5]) if len(sys.argv) > 5 else 22
     rb = r"tsx_k_pcsh?_rb<\d+,\d+,\d+,"
     if any(re.match(rb + r"true,0,\w+,2", k) for k in kernels):
         # bf16 right-hand side words: per application pass 0 (no neighbours, leaves the words), pass 1 (leaves the words),
@@ -72,8 +72,13 @@ def main():
                   (rb + r"true,1", 2), (rb + r"true,2", 2)]
     else:
         passes = [(rb + r"false,0", 2), (rb + r"true,0", 2 * (P - 3)), (rb + r"true,1", 2), (rb + r"true,2", 2)]
-    per_iter = passes + [(r"tsx_k_spmv_w<\d+,\d+,\w+,1,\d,float,float", 1), (r"tsx_k_spmv_w<\d+,\d+,\w+,5,\d,float,double", 1),
-                         (r"tsx_k_pupdate32", 1), (r"tsx_k_supdate", 1), (r"tsx_k_xrupdate", 1)]
+    if any(k.startswith("tsx_k_xrupdate_k32") for k in kernels):   # fp32 Krylov vectors (round 3 default)
+        per_iter = passes + [(r"tsx_k_spmv_w<\d+,\d+,\w+,1,\d,float,float,.*float>$", 1),
+                             (r"tsx_k_spmv_w<\d+,\d+,\w+,5,\d,float,float,.*float>$", 1),
+                             (r"tsx_k_pupdate_k32", 1), (r"tsx_k_supdate_k32", 1), (r"tsx_k_xrupdate_k32", 1)]
+    else:
+        per_iter = passes + [(r"tsx_k_spmv_w<\d+,\d+,\w+,1,\d,float,float", 1), (r"tsx_k_spmv_w<\d+,\d+,\w+,5,\d,float,double", 1),
+                             (r"tsx_k_pupdate32", 1), (r"tsx_k_supdate", 1), (r"tsx_k_xrupdate", 1)]
     it_bytes, missing = 0.0, []
     for pat, mult in per_iter:
         hit = [v for name, v in kernels.items() if re.match(pat, name)]
