@@ -47,9 +47,9 @@ def parse():
     ap.add_argument("--global-nx", type=int, default=0, help="explicit global domain (implies fixed total work)")
     ap.add_argument("--global-ny", type=int, default=0)
     ap.add_argument("--transport", choices=("auto", "rccl", "peer", "host"), default="auto",
-                    help="auto: RCCL when every rank has a device of its own, else host-staged (gloo); peer: the "
-                         "device-resident transport (IPC-mapped mailboxes, tsx_peer.hip) -- works with one device per rank "
-                         "(xGMI) and with ranks sharing a device")
+                    help="auto: with a device per rank the device-resident peer transport (IPC-mapped mailboxes over xGMI, "
+                         "tsx_peer.hip) if its self test passes on every rank, else RCCL; with ranks sharing a device host-staged "
+                         "(gloo).  peer / rccl / host force one (peer also works with ranks sharing a device)")
     ap.add_argument("--nz", type=int, default=64)
     ap.add_argument("--solver", default="3_10")
     ap.add_argument("--pc", type=int, default=3,
@@ -131,8 +131,10 @@ def main():
     if ndev < 1:
         raise SystemExit("bench.py: no GPU visible (libtsx has no CPU fallback)")
     transport = args.transport
+    try_peer_first = False
     if transport == "auto":
         transport = "rccl" if ndev >= world else "host"
+        try_peer_first = transport == "rccl" and world > 1
     if transport == "rccl" and ndev < world:
         raise SystemExit(f"bench.py: RCCL needs one device per rank ({world} ranks, {ndev} devices); use --transport host")
     dev_index = local_rank % ndev
@@ -184,11 +186,16 @@ def main():
 
     s = DiffuseSolver(solver, Nz, co.xm, co.ym, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank, nranks=world,
                       neighbors=(co.west, co.east, co.south, co.north), device=dev_index)
+    if try_peer_first:
+        from tenstream_amd import hostcomm
+
+        if hostcomm.attach_peer_checked(s):   # agreed over the process group: every rank passed the self test
+            transport = "peer"
     if world > 1 and transport == "rccl":
         uid = [s.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         s.comm_init(uid[0])
-    elif world > 1 and transport == "peer":
+    elif world > 1 and transport == "peer" and not try_peer_first:
         from tenstream_amd import hostcomm
 
         hostcomm.attach_peer(s)
@@ -347,7 +354,8 @@ def main():
                 "workload": f"pprts {solver} diffuse solve, {Nx}x{Ny}x{Nz} cells global ({co.xm}x{co.ym}x{Nz} on rank 0), "
                             f"{scaling} scaling, single solar g-point, rtol 1e-5 / reference atol, zero initial guess",
                 "process_grid": f"{npx}x{npy}",
-                "transport": "none (1 rank)" if world == 1 else {"rccl": "RCCL", "peer": "device-resident peer mailboxes (HIP IPC)",
+                "transport": "none (1 rank)" if world == 1 else {"rccl": "RCCL" + (" (the peer transport's self test failed)" if try_peer_first else ""),
+                                                                    "peer": "device-resident peer mailboxes (HIP IPC)",
                                                                     "host": "host-staged (gloo)"}[transport],
                 "coeff_storage": "fp32 blocks (lossless); x, b, dots, stop rule fp64; recurrence vectors r, s, v, t, directions p, "
                                  "p-hat, s-hat and shadow residual fp32, the residual replaced by b - A x in fp64 before "

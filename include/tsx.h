@@ -161,6 +161,11 @@ int tsx_comm_init(tsx_solver *s, const void *id128);
 #define TSX_PEER_BLOB_BYTES 192
 int tsx_comm_peer_export(tsx_solver *s, void *blob);
 int tsx_comm_peer_attach(tsx_solver *s, const void *blobs);
+/* collective self test (patterned face exchanges of varying length, verified on the receiver, and all-reduces); *failed = 0 if this
+ * rank saw nothing wrong.  The caller reduces *failed over the ranks by other means and, if any rank failed, calls
+ * tsx_comm_peer_disable on every rank: the solver then uses RCCL / the callbacks. */
+int tsx_comm_peer_selftest(tsx_solver *s, int rounds, double *failed);
+int tsx_comm_peer_disable(tsx_solver *s);
 
 /* Alternative transport: host-staged callbacks, for hosts whose communicator is MPI (TenStream's own
  * solver%comm) without GPU-aware transport, and for multi-process tests on one GPU.  The library copies the

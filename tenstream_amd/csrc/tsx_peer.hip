@@ -223,6 +223,34 @@ __global__ __launch_bounds__(64) void tsx_k_peer_allreduce(PeerArArgs a, double 
   }
 }
 
+// ---- self test: patterns through the mailboxes (tsx_comm_peer_selftest)
+__device__ __forceinline__ double peer_pattern(int rank, int face, int round, long long i) {
+  return (double)rank * 1048576.0 + (double)face * 65536.0 + (double)(round & 255) * 256.0 + (double)(i % 251) + 0.5;
+}
+__global__ void tsx_k_peer_fill(double *__restrict__ b0, double *__restrict__ b1, double *__restrict__ b2, double *__restrict__ b3,
+                                long long nx, long long ny, int rank, int round) {
+  double *b[4] = {b0, b1, b2, b3};
+  for (int q = 0; q < 4; ++q) {
+    const long long n = q < 2 ? nx : ny;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      b[q][i] = peer_pattern(rank, q, round, i);
+  }
+}
+// recv[q] must hold what the neighbour behind face q sent through ITS face q ^ 1
+__global__ void tsx_k_peer_verify(const double *__restrict__ b0, const double *__restrict__ b1, const double *__restrict__ b2,
+                                  const double *__restrict__ b3, long long nx, long long ny, int nw, int ne, int ns, int nn, int round,
+                                  unsigned long long *__restrict__ bad) {
+  const double *b[4] = {b0, b1, b2, b3};
+  const int nb[4] = {nw, ne, ns, nn};
+  unsigned long long mine = 0;
+  for (int q = 0; q < 4; ++q) {
+    const long long n = q < 2 ? nx : ny;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+      mine += b[q][i] != peer_pattern(nb[q], q ^ 1, round, i);
+  }
+  if (mine) atomicAdd(bad, mine);
+}
+
 }  // namespace
 
 struct TsxPeer {
@@ -442,5 +470,76 @@ int tsx_peer_allreduce(tsx_solver *s, hipStream_t st, double *v, int nvals, cons
   (void)done;  // as for the exchange: the sequence stays in step on every rank
   hipLaunchKernelGGL(tsx_k_peer_allreduce, dim3(1), dim3(64), 0, st, a, v, (const int *)nullptr);
   HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+// Collective self test of the attached transport: `rounds` face exchanges of varying length with a pattern that names sender,
+// face, round and position, verified on the receiving side, and an all-reduce per round.  Meant to run right after attach
+// (TSX_PEER_TIMEOUT_S short): a node where the mailboxes cannot be reached -- or are reached with stale data -- is found out here,
+// and the caller falls back to RCCL (bench.py does).  *failed: 0 ok, else mismatching payload words + failed sums + 1e9 per
+// expired wait on this rank; the caller reduces it over the ranks (the transport cannot be trusted to) and disables it everywhere.
+extern "C" int tsx_comm_peer_selftest(tsx_solver *s, int rounds, double *failed) {
+  ARGCHK(s && failed && rounds >= 1, "tsx_comm_peer_selftest: bad argument");
+  if (!tsx_peer_ready(s)) {
+    tsx_set_error("tsx_comm_peer_selftest: no peer transport attached");
+    return TSX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  TsxPeer *p = s->peer;
+  const TsxGeo &g = s->geo;
+  const tsx_grid &gr = s->grid;
+  const size_t capd = p->cap / sizeof(double);
+  double *buf[8] = {nullptr};
+  TsxDevTmp guard[9];
+  for (int q = 0; q < 8; ++q) {
+    HIPCHK(guard[q].alloc(p->cap));
+    buf[q] = guard[q].as<double>();
+  }
+  HIPCHK(guard[8].alloc(sizeof(unsigned long long) + 4 * sizeof(double)));
+  unsigned long long *bad = guard[8].as<unsigned long long>();
+  double *red = reinterpret_cast<double *>(bad + 1);
+  HIPCHK(hipMemsetAsync(bad, 0, sizeof(unsigned long long), s->stream));
+  double wrong_sums = 0.0;
+  const unsigned long long keep_ticks = p->ticks;
+  if (p->ticks > 300000000ull) p->ticks = 300000000ull;  // 3 s per wait is plenty for a test message
+  struct Restore {
+    TsxPeer *p;
+    unsigned long long t;
+    ~Restore() { p->ticks = t; }
+  } restore{p, keep_ticks};
+  for (int n = 0; n < rounds; ++n) {
+    // lengths from a few doubles to the full slot; the same on every rank (the peers must agree on them like on any exchange)
+    const size_t cx = 1 + (capd - 1) * (size_t)((n * 37) % 101) / 100, cy = 1 + (capd - 1) * (size_t)((n * 53 + 11) % 101) / 100;
+    hipLaunchKernelGGL(tsx_k_peer_fill, dim3(64), dim3(256), 0, s->stream, buf[0], buf[1], buf[2], buf[3], (long long)cx, (long long)cy,
+                       gr.rank, n);
+    double *const send[4] = {buf[0], buf[1], buf[2], buf[3]};
+    double *const recv[4] = {buf[4], buf[5], buf[6], buf[7]};
+    int rc = tsx_peer_exchange(s, s->stream, send, recv, cx, cy, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tsx_k_peer_verify, dim3(64), dim3(256), 0, s->stream, buf[4], buf[5], buf[6], buf[7],
+                       g.wrap_x ? 0ll : (long long)cx, g.wrap_y ? 0ll : (long long)cy, gr.neigh_w, gr.neigh_e, gr.neigh_s, gr.neigh_n, n, bad);
+    const double mine[3] = {(double)(gr.rank + 1), 1.0, (double)n};
+    HIPCHK(hipMemcpyAsync(red, mine, sizeof(mine), hipMemcpyHostToDevice, s->stream));
+    if ((rc = tsx_peer_allreduce(s, s->stream, red, 3, nullptr))) return rc;
+    double got[3];
+    HIPCHK(hipMemcpyAsync(got, red, sizeof(got), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const double R = (double)gr.nranks;
+    if (gr.nranks > 1 && (got[0] != R * (R + 1.0) / 2.0 || got[1] != R || got[2] != R * (double)n)) wrong_sums += 1.0;
+    if (tsx_peer_check(s) != TSX_OK) {  // an expired wait: stop here, the counters of the peers are out of step now
+      *failed = 1e9;
+      return TSX_OK;
+    }
+  }
+  unsigned long long hbad = 0;
+  HIPCHK(hipMemcpy(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost));
+  *failed = (double)hbad + wrong_sums;
+  return TSX_OK;
+}
+
+// give the transport up (after a failed self test on any rank): the solver falls back to RCCL or the callbacks
+extern "C" int tsx_comm_peer_disable(tsx_solver *s) {
+  ARGCHK(s, "tsx_comm_peer_disable: null");
+  if (s->peer) s->peer->attached = false;
   return TSX_OK;
 }

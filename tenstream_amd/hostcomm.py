@@ -51,3 +51,28 @@ def attach_peer(solver):
         return out
 
     solver.comm_peer_init(allgather)
+
+
+def attach_peer_checked(solver, rounds=64):
+    """attach_peer + the transport's self test, agreed over the process group: True if every rank passed (the transport stays),
+    False if any rank failed (it is disabled on every rank; the caller attaches RCCL or the host-staged callbacks instead)"""
+    import torch
+    import torch.distributed as dist
+
+    ok = 1.0
+    try:
+        attach_peer(solver)
+        bad = solver.comm_peer_selftest(rounds)
+        ok = 1.0 if bad == 0.0 else 0.0
+    except Exception:   # attach refused (no IPC between these ranks ...): every rank still takes part in the agreement below
+        ok = 0.0
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([ok], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if float(t.item()) < 1.0:
+        try:
+            solver.comm_peer_disable()
+        except Exception:
+            pass
+        return False
+    return True

@@ -144,6 +144,15 @@ class DiffuseSolver:
         allb = C.create_string_buffer(b"".join(blobs), _lib.PEER_BLOB_BYTES * len(blobs))
         _lib.check(self.lib.tsx_comm_peer_attach(self.h, allb))
 
+    def comm_peer_selftest(self, rounds=64):
+        """collective; number of things this rank found wrong (0.0 = fine): tsx_comm_peer_selftest"""
+        bad = C.c_double(-1.0)
+        _lib.check(self.lib.tsx_comm_peer_selftest(self.h, int(rounds), C.byref(bad)))
+        return bad.value
+
+    def comm_peer_disable(self):
+        _lib.check(self.lib.tsx_comm_peer_disable(self.h))
+
     def comm_set_callbacks(self, exchange, allreduce):
         """Host-staged transport.  exchange(send: list of 4 numpy views W,E,S,N, recv: list of 4 writable views,
         peers: list of 4 ranks) and allreduce(buf: writable numpy view) operate on pinned host memory."""

@@ -205,6 +205,49 @@ def test_peer_transport_with_self_neighbours_in_one_process(gpu, monkeypatch):
     assert np.array_equal(i0.res_hist, i1.res_hist) and np.array_equal(x0, x1)
 
 
+def _selftest_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("TSX_PEER_TIMEOUT_S", "10")
+    import torch.distributed as dist
+
+    from tenstream_amd import DiffuseSolver, coord, hostcomm, synthetic
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Nx, Ny, Nz = 12, 8, 6
+        P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+        co = coord.coord(rank, world, Nx, Ny)
+        sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
+        s = DiffuseSolver("3_10", Nz, co.xm, co.ym, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank, nranks=world,
+                          neighbors=(co.west, co.east, co.south, co.north), device=0)
+        ok = hostcomm.attach_peer_checked(s, rounds=40)
+        loc = lambda k: np.ascontiguousarray(P[k][sl])
+        s.set_coeffs(loc("coeff"), P["l1d"], loc("a11"), loc("a12"), loc("albedo"))
+        x = np.zeros(s.vec_shape)
+        i1 = s.solve(np.ascontiguousarray(P["b"][sl]), x, rtol=1e-10, atol=1e-30)
+        # now give the transport up everywhere (what bench.py does when a rank's self test fails) and solve over the callbacks
+        s.comm_peer_disable()
+        hostcomm.attach(s, rank)
+        x2 = np.zeros(s.vec_shape)
+        i2 = s.solve(np.ascontiguousarray(P["b"][sl]), x2, rtol=1e-10, atol=1e-30)
+        ret[rank] = (ok, i1.reason, i1.niter, i2.reason, i2.niter, float(np.abs(x - x2).max() / np.abs(x).max()))
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_transport_self_test_and_fallback(gpu):
+    """tsx_comm_peer_selftest (patterned exchanges of varying length + all-reduces, verified on the receiver) passes with two rank
+    processes on one device, agreed over the process group (hostcomm.attach_peer_checked, what `bench.py --transport auto` runs
+    before it trusts the transport); after tsx_comm_peer_disable the same solver continues over the host-staged callbacks and
+    arrives at the same solution with the same iteration count."""
+    ret = _spawn(_selftest_worker, 2, ())
+    for ok, r1, n1, r2, n2, diff in ret.values():
+        assert ok is True and r1 == 2 and r2 == 2 and n1 == n2 and diff < 1e-9, (ok, r1, n1, r2, n2, diff)
+
+
 # ---- 8 ranks, 2 x 4: config 3's decomposition (src/pprts_base.F90:747-790: dims = [nyp, nxp] = [4, 2], ranks x-fastest) ----
 def _worker8(rank, world, port, Nx, Ny, Nz, ref_path, transport, ret):
     sys.path.insert(0, ROOT)
