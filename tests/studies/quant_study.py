@@ -156,6 +156,9 @@ variants = [
     ("fp8 only into top (side->side exact)", dict(noff_q=f8, only="top")),
     ("fp8 only side->side (into top exact)", dict(noff_q=f8, only="side")),
     ("fp8 side->side, column sums kept", dict(noff_q=f8, only="side_conserve")),
+    ("log4 3/4 only side->side (into top exact)", dict(noff_q=lambda v, g: log4(v, 0.75), only="side")),
+    ("log4 1/2 top -1 only side->side", dict(noff_q=lambda v, g: log4(v, 0.5, -1.0), only="side")),
+    ("log4 3/4 side->side + top->side fp8", dict(noff_q=lambda v, g: log4(v, 0.75), only="side", mtop_q=lambda v: e4m3(v))),
     ("off-column fp16", dict(noff_q=lambda v, g: v.astype(np.float16).astype(np.float64))),
     ("off-column e5m10-like 6 mantissa bits", dict(noff_q=lambda v, g: np.ldexp(np.round(np.ldexp(np.frexp(v)[0], 7)), np.frexp(v)[1] - 7))),
     ("off-column e2m1 + scale per cell", dict(noff_q=e2m1_block)),
