@@ -579,6 +579,7 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
   s->coef_h_valid = false;
   s->dd_valid = false;
   s->dd_on = false;
+  s->dd_pc = false;
   s->dd_hash_ready = false;  // imported blocks: tsx_dedup.hip hashes them itself
   return TSX_OK;
 }
@@ -737,6 +738,7 @@ extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const dou
   s->coef_h_valid = false;
   s->dd_valid = false;
   s->dd_on = false;
+  s->dd_pc = false;
   return TSX_OK;
 }
 
@@ -1282,12 +1284,13 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
   const TsxGeo &g = s->geo;
   const double sc = s->coef_bytes ? s->coef_bytes : 4, sv = 8;
   const double Nc = (double)g.Nc, N = (double)g.N, nent = (double)s->dd_nent;
-  const bool dd = s->dd_on;
+  const bool dd_op = s->dd_on;                    // the operator reads shared blocks only where they are bit-identical
+  const bool dd = s->dd_on || s->dd_pc;            // the preconditioner also where they are near-identical (tsx_dedup.hip)
   // B_spmv = Nc*D^2*sc + 2*N*sv ; B_iter = 2*B_spmv + 16*N*sv (every cell's block stored: kernels 10, 11).
   // With shared storage of identical blocks (tsx_dedup.hip) the operator's least traffic is every distinct block once, a
   // 4-byte index per cell and the two vectors: kernel 0 reports the bytes of the storage format in use.
   const double bspmv_full = Nc * g.D * g.D * sc + 2.0 * N * sv;
-  const double bspmv = dd ? nent * g.D * g.D * 4.0 + Nc * 4.0 + 2.0 * N * sv : bspmv_full;
+  const double bspmv = dd_op ? nent * g.D * g.D * 4.0 + Nc * 4.0 + 2.0 * N * sv : bspmv_full;
   if (kernel == 0) *bytes = bspmv;
   else if (kernel == 10) *bytes = bspmv_full;
   else if (kernel == 1 || kernel == 11) *bytes = 2.0 * bspmv_full + 16.0 * N * sv;
@@ -1415,7 +1418,7 @@ extern "C" int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent) {
   HIPCHK(hipSetDevice(s->device));
   int rc = tsx_dedup_ensure(s);
   if (rc) return rc;
-  *on = s->dd_on ? 1 : 0;
+  *on = s->dd_on ? 1 : (s->dd_pc ? 2 : 0);  // 2: near-identical blocks grouped for the preconditioner only
   *nent = s->dd_nent;
   return TSX_OK;
 }

@@ -273,15 +273,71 @@ static bool dedup_enabled() {
   return e ? atoi(e) != 0 : true;
 }
 
-// (re)build the shared-block storage for the current coefficients; leaves s->dd_on = false where it does not pay
-int tsx_dedup_ensure(tsx_solver *s) {
-  if (s->dd_valid) return TSX_OK;
-  s->dd_valid = true;
-  s->dd_on = false;
-  if (!dedup_enabled() || s->coef_bytes != 4 || !s->have_coeffs) return TSX_OK;
+// ---- NEAR-identical blocks, for the preconditioner only (round 3).  Where every cell has a block of its own (an LES humidity
+// field: tau and w0 differ from cell to cell) nothing is bit-identical, but the blocks still come from a smooth 4-parameter
+// family (tau, w0, aspect, g), and the preconditioner is an approximation anyway: its couplings are stored in fp8 (2^-4) and
+// fp16.  So cells whose blocks agree to about 1 % share one stored copy of the PRECONDITIONER's per-block records (the column
+// recurrences, record 0, stay exact and per cell; the operator keeps every cell's exact block): a pass then reads 68 B per cell
+// instead of 196 B.  Key: five characteristic coefficients (vertical transmission and reflection, top -> side, side straight
+// through, side x -> y) in logarithmic bins of 0.7 %; owner = the smallest cell of a bin; a cell joins its owner only if ALL
+// D*D coefficients agree to 1.2 % + 3e-4 (else it keeps an entry of its own) -- the 6 mantissa bits the side -> top couplings
+// need (tests/studies/quant_study.py) are kept.
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_hash_near(TsxGeo g, int D, const float *__restrict__ C,
+                                                                const uint8_t *__restrict__ l1d, unsigned long long *__restrict__ h) {
+  const long long Nc = g.Nc;
+  const int ns = g.ntop;  // first side dof
+  // (dst, src) of the five features
+  const int fd[5] = {0, 0, ns, ns + 1, ns + 5}, fs[5] = {0, 1, 0, ns + 1, ns + 1};
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int k = (int)(c / g.ncol);
+    unsigned long long v = TSX_DD_SEED;
+    if (l1d[k]) {
+      v = TSX_DD_H1D;
+    } else {
+      for (int q = 0; q < 5; ++q) {
+        const float x = C[(size_t)(fd[q] * D + fs[q]) * Nc + c];
+        const int bin = x > 1e-7f ? (int)floorf(__logf(x) * (1.0f / 0.00698f)) : -100000;  // ln(1.007)
+        v = tsx_dd_hash_step(v, q, __int_as_float(bin));
+      }
+      v = tsx_dd_hash_final(v);
+    }
+    h[c] = v;
+  }
+}
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_resolve_near(TsxGeo g, int DD, const float *__restrict__ C,
+                                                                   const uint8_t *__restrict__ l1d, unsigned long long mask,
+                                                                   const unsigned long long *__restrict__ h,
+                                                                   const unsigned long long *__restrict__ keys,
+                                                                   const int *__restrict__ owner, int *__restrict__ rep,
+                                                                   int *__restrict__ flag) {
+  const long long Nc = g.Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const unsigned long long hv = h[c];
+    unsigned long long slot = hv & mask;
+    while (keys[slot] != hv) slot = (slot + 1) & mask;
+    const int o = owner[slot];
+    bool same = true;
+    if (o != (int)c && !(l1d[(int)(c / g.ncol)] && l1d[o / g.ncol])) {
+      for (int q = 0; q < DD; ++q) {
+        const float a = C[(size_t)q * Nc + c], b = C[(size_t)q * Nc + o];
+        same &= fabsf(a - b) <= 0.012f * fmaxf(fabsf(a), fabsf(b)) + 3e-4f;
+      }
+    }
+    const int r = same ? o : (int)c;
+    rep[c] = r;
+    flag[c] = r == (int)c;
+  }
+}
+static bool dedup_near_enabled() {
+  const char *e = getenv("TSX_DEDUP_NEAR");  // TSX_DEDUP_NEAR=0: only bit-identical blocks are shared
+  return e ? atoi(e) != 0 : true;
+}
+
+// one build: near = the approximate grouping (preconditioner only), else bit-identical blocks.  *pays: at most half of the
+// cells need an entry of their own -- only then are the index and the compact copies made
+static int dd_build(tsx_solver *s, bool near, bool *pays) {
+  *pays = false;
   const TsxGeo &g = s->geo;
-  // cell indices are ints and the owner table's "no owner yet" value is 0x7f7f7f7f (byte-wise memset): stay below it
-  if (g.Nc >= 0x7f7f7f7fll || !tsx_dd_wave64(s)) return TSX_OK;
   const int DD = g.D * g.D;
   const long long Nc = g.Nc;
   TsxDdScratch w;
@@ -296,13 +352,19 @@ int tsx_dedup_ensure(tsx_solver *s) {
   HIPCHK(hipMemsetAsync(to.p, 0x7f, sizeof(int) * (size_t)tsz, s->stream));
   const float *C = (const float *)s->coef;
   const int nb = grid_for(Nc, 8192);
-  if (!s->dd_hash_ready)  // else tsx_k_lut_diff2diff has left the hashes of the blocks it produced (tsx_dedup_hash_buffer)
+  if (near)
+    hipLaunchKernelGGL(tsx_k_dd_hash_near, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, g.D, C, s->l1d, th.as<unsigned long long>());
+  else if (!s->dd_hash_ready)  // else tsx_k_lut_diff2diff has left the hashes of the blocks it produced (tsx_dedup_hash_buffer)
     hipLaunchKernelGGL(tsx_k_dd_hash, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, th.as<unsigned long long>());
   s->dd_hash_ready = false;
   hipLaunchKernelGGL(tsx_k_dd_insert, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, tsz - 1, th.as<unsigned long long>(),
                      tk.as<unsigned long long>(), to.as<int>());
-  hipLaunchKernelGGL(tsx_k_dd_resolve, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, tsz - 1,
-                     th.as<unsigned long long>(), tk.as<unsigned long long>(), to.as<int>(), trep.as<int>(), tflag.as<int>());
+  if (near)
+    hipLaunchKernelGGL(tsx_k_dd_resolve_near, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, tsz - 1,
+                       th.as<unsigned long long>(), tk.as<unsigned long long>(), to.as<int>(), trep.as<int>(), tflag.as<int>());
+  else
+    hipLaunchKernelGGL(tsx_k_dd_resolve, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, tsz - 1,
+                       th.as<unsigned long long>(), tk.as<unsigned long long>(), to.as<int>(), trep.as<int>(), tflag.as<int>());
   hipLaunchKernelGGL(tsx_k_scan_sums, dim3(nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, tflag.as<int>(), tsum.as<int>());
   hipLaunchKernelGGL(tsx_k_scan_top, dim3(1), dim3(1024), 0, s->stream, nsb, tsum.as<int>(), ttot.as<int>());
   hipLaunchKernelGGL(tsx_k_scan_write, dim3(nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, tflag.as<int>(), tsum.as<int>(), tpos.as<int>());
@@ -310,8 +372,10 @@ int tsx_dedup_ensure(tsx_solver *s) {
   int nent = 0;
   HIPCHK(hipMemcpyAsync(&nent, ttot.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
-  s->dd_nent = nent;
+  if (near) s->dd_nent_near = nent;
+  else s->dd_nent = nent;
   if ((long long)nent * 2 > Nc) return TSX_OK;  // mostly unique blocks: the dense planes are the better layout
+  s->dd_nent = nent;
   if (!s->dd_cidx) HIPCHK(hipMalloc((void **)&s->dd_cidx, sizeof(int) * (size_t)Nc));
   if (!s->dd_cidx_split) HIPCHK(hipMalloc((void **)&s->dd_cidx_split, sizeof(int) * (size_t)Nc));
   if (s->dd_cap < nent) {
@@ -339,7 +403,34 @@ int tsx_dedup_ensure(tsx_solver *s) {
   s->dd_coef_e = s->dd_coef + (size_t)DD * s->dd_cap;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
-  s->dd_on = true;
+  *pays = true;
+  return TSX_OK;
+}
+
+// (re)build the shared-block storage for the current coefficients; leaves s->dd_on = false where it does not pay, and then tries
+// the preconditioner-only grouping of near-identical blocks (s->dd_pc)
+int tsx_dedup_ensure(tsx_solver *s) {
+  if (s->dd_valid) return TSX_OK;
+  s->dd_valid = true;
+  s->dd_on = false;
+  s->dd_pc = false;
+  s->dd_nent_near = 0;
+  if (!dedup_enabled() || s->coef_bytes != 4 || !s->have_coeffs) return TSX_OK;
+  const TsxGeo &g = s->geo;
+  // cell indices are ints and the owner table's "no owner yet" value is 0x7f7f7f7f (byte-wise memset): stay below it
+  if (g.Nc >= 0x7f7f7f7fll || !tsx_dd_wave64(s)) return TSX_OK;
+  bool pays = false;
+  int rc = dd_build(s, false, &pays);
+  if (rc) return rc;
+  if (pays) {
+    s->dd_on = true;
+    return TSX_OK;
+  }
+  if (!dedup_near_enabled()) return TSX_OK;
+  const int nexact = s->dd_nent;
+  if ((rc = dd_build(s, true, &pays))) return rc;
+  if (pays) s->dd_pc = true;
+  else s->dd_nent = nexact;
   return TSX_OK;
 }
 

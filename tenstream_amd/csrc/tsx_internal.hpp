@@ -94,6 +94,9 @@ struct tsx_solver {
   bool any_l1d;
   // shared storage of bit-identical blocks (tsx_dedup.hip): planes over entries + per-cell entry index
   bool dd_valid, dd_on;
+  bool dd_pc = false;      // the index / entries group NEAR-identical blocks and serve the preconditioner only (tsx_dedup.hip);
+                           // the operator then works on every cell's exact block (dd_on stays false)
+  int dd_nent_near = 0;    // entries of that grouping (0: not attempted)
   int dd_nent, dd_cap;
   float *dd_coef;          // [D*D][dd_nent] plane-major (preconditioner packing)
   float *dd_coef_e = nullptr;  // [dd_nent][D*D] entry-major copy behind it (operator apply)

@@ -224,7 +224,7 @@ int tsx_pc_ensure_half(tsx_solver *s) {
   const long long n = (long long)(h1 ? TSX_P16_GROUPS + 1 : 34 /* max(TSX_P16H_GROUPS, 14 + 20 of the scan layout) */) * s->geo.Nc;
   if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
   const bool scan = s->pc_split && tsx_pcs_eligible(s);
-  if (scan && (!s->coef_h_valid || !s->coef_h_scan || s->coef_h_dd != (s->dd_on && s->coef_bytes == 4))) {
+  if (scan && (!s->coef_h_valid || !s->coef_h_scan || s->coef_h_dd != ((s->dd_on || s->dd_pc) && s->coef_bytes == 4))) {
     int rc = tsx_pcs_pack(s);
     if (rc) return rc;
     s->coef_h_valid = true;

@@ -38,7 +38,7 @@ static PcsCfg pcs_config(const tsx_solver *s) {
     // measured (scripts/pcsbench.py): 8 levels x 8 segments on large passes (>= 16 K columns: fewer, fatter threads),
     // 4 x 16 on small ones (more waves); deeper columns take the smallest pair that holds them
     if (g.Nz <= 64) {
-      const bool fat = nthr >= 16384 && !s->dd_on;  // with shared blocks a pass moves half the bytes: more waves win again
+      const bool fat = nthr >= 16384 && !(s->dd_on || s->dd_pc);  // with shared blocks a pass moves half the bytes: more waves win again
       c.lseg = fat ? 8 : 4;
       c.nseg = fat ? 8 : 16;
     } else if (g.Nz <= 128) {
@@ -76,7 +76,7 @@ static int pcsh_pack(tsx_solver *s) {  // 8_16: 14 matrix records per cell, then
   if (s->coef_bytes == 4) {
     hipLaunchKernelGGL((tsx_k_pcsh_pack_col<float>), dim3(nbc), dim3(64), 0, s->stream, g, (const float *)s->coef, s->l1d, s->a11,
                        s->a12, s->albedo, P);
-    if (s->dd_on) {
+    if (s->dd_on || s->dd_pc) {
       hipLaunchKernelGGL((tsx_k_pcsh_pack_block<float>), dim3(grid_for((long long)TSX_S16H_BLOCK * s->dd_nent)), dim3(TSX_BLOCK), 0,
                          s->stream, g, (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d, PB);
       s->coef_h_dd = true;
@@ -103,7 +103,7 @@ int tsx_pcs_pack(tsx_solver *s) {
   if (g.ntop == 8) return pcsh_pack(s);
   uint4 *P = (uint4 *)s->coef_h;
   s->coef_h_dd = false;
-  if (s->dd_on && s->coef_bytes == 4) {
+  if ((s->dd_on || s->dd_pc) && s->coef_bytes == 4) {
     // group 0 per cell, groups 1..7 per distinct block behind it (7 * nent <= 7 * Nc records: the same buffer holds them)
     hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->coef,
                        s->l1d, s->a11, s->a12, s->albedo, P);
