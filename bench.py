@@ -277,7 +277,7 @@ def main():
     # ---- second leg, reported under config.no_sharing and never part of `value`: the same solves with every cell's block
     # stored (TSX_DEDUP=0 / TSX_PC_RECSHARE=0: what any field whose cells all differ gets, e.g. --field heterogeneous)
     no_sharing = None
-    if (dd_on or getattr(s, "dedup_mode", 0) == 2) and not args.skip_no_sharing and not args.explicit:
+    if (dd_on or getattr(s, "dedup_mode", 0) & 2) and not args.skip_no_sharing and not args.explicit:
         keep = {k: os.environ.get(k) for k in ("TSX_DEDUP", "TSX_PC_RECSHARE")}
         os.environ["TSX_DEDUP"] = "0"
         os.environ["TSX_PC_RECSHARE"] = "0"
@@ -366,7 +366,7 @@ def main():
                                           "couplings, fp32/bf16 iterates; the operator always uses the exact blocks",
                 "coeff_source": "device N-linear LUT interpolation (tsx_diff_set_optprop), synthetic table",
                 "coeff_dedup": dict(in_use=dd_on, distinct_blocks=dd_nent, cells_local=co.xm * co.ym * Nz,
-                                    preconditioner_groups_near_identical_blocks=getattr(s, "dedup_mode", 0) == 2,
+                                    preconditioner_groups_near_identical_blocks=bool(getattr(s, "dedup_mode", 0) & 2),
                                     note="bit-identical blocks are stored once behind a per-cell index (lossless; TSX_DEDUP=0 "
                                          "disables); the rooflines count the bytes of this format"),
                 "preconditioner_records_shared": rec_shared,

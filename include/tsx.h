@@ -298,9 +298,10 @@ int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_ms);
 int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes);
 /* shared storage of bit-identical transport blocks (lossless; tsx_dedup.hip): how many distinct blocks the current
  * coefficients hold and whether the operator apply / preconditioner read them through the per-cell index (they do when
- * at most half of the cells need a block of their own; TSX_DEDUP=0 switches it off).  *on = 2: nothing is bit-identical, but
- * blocks that agree to about 1 % are grouped FOR THE PRECONDITIONER ONLY (its per-block records are approximate by design; the
- * operator keeps every cell's exact block); *nent = the groups.  TSX_DEDUP_NEAR=0 switches that off */
+ * at most half of the cells need a block of their own; TSX_DEDUP=0 switches it off).  *on bit 0: bit-identical blocks shared
+ * (*nent of them); bit 1: blocks that agree to about 1 % are grouped FOR THE PRECONDITIONER ONLY (its per-block records are
+ * approximate by design; the operator keeps exact blocks) -- alone where nothing is bit-identical (*nent = the groups), or on top
+ * of bit 0 where it halves the preconditioner's table.  TSX_DEDUP_NEAR=0 switches that off */
 int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent);
 /* the preconditioner the last solve / tsx_bench_kernel actually ran (after the automatic choices: red-black -> zebra rows
  * on odd grids, pc_sweeps 0 -> 19 or 9): TSX_PC_*, pc_sweeps, and scan: 0 = one-lane-per-column kernels, 1 = scan kernels,

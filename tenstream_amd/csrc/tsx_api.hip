@@ -266,7 +266,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->v32, s->p32, s->dsend[0], s->dsend[1], s->dsend[2], s->dsend[3], s->drecv[0], s->drecv[1], s->drecv[2], s->drecv[3],
-                  s->coef_h, s->coef, s->dd_coef, s->dd_cidx, s->dd_cidx_split, s->dd_ent_cell, s->dd_scratch, s->pcr_idx, s->pcr_ent, s->pcr_tab, s->pch_send[0], s->pch_send[1], s->pch_send[2], s->pch_send[3],
+                  s->coef_h, s->coef, s->dd_coef, s->dd_cidx, s->dd_cidx_split, s->dd_ent_cell, s->dd_scratch, s->pcn_coef, s->pcn_cidx_split, s->pcn_ent_cell, s->pcr_idx, s->pcr_ent, s->pcr_tab, s->pch_send[0], s->pch_send[1], s->pch_send[2], s->pch_send[3],
                   s->pch_recv[0], s->pch_recv[1], s->pch_recv[2], s->pch_recv[3], s->l1d,   s->a11,   s->a12,   s->albedo, s->vx,    s->vb,    s->vr,      s->vrhat, s->vp,
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
@@ -1283,14 +1283,16 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
   ARGCHK(s && bytes, "tsx_algorithmic_bytes: null");
   const TsxGeo &g = s->geo;
   const double sc = s->coef_bytes ? s->coef_bytes : 4, sv = 8;
-  const double Nc = (double)g.Nc, N = (double)g.N, nent = (double)s->dd_nent;
+  const double Nc = (double)g.Nc, N = (double)g.N;
+  // entries the operator reads (bit-identical blocks) and entries the preconditioner reads (the near grouping where it is on)
+  const double nent_op = (double)s->dd_nent, nent = (double)((s->dd_on || s->dd_pc) ? s->pc_nent : s->dd_nent);
   const bool dd_op = s->dd_on;                    // the operator reads shared blocks only where they are bit-identical
   const bool dd = s->dd_on || s->dd_pc;            // the preconditioner also where they are near-identical (tsx_dedup.hip)
   // B_spmv = Nc*D^2*sc + 2*N*sv ; B_iter = 2*B_spmv + 16*N*sv (every cell's block stored: kernels 10, 11).
   // With shared storage of identical blocks (tsx_dedup.hip) the operator's least traffic is every distinct block once, a
   // 4-byte index per cell and the two vectors: kernel 0 reports the bytes of the storage format in use.
   const double bspmv_full = Nc * g.D * g.D * sc + 2.0 * N * sv;
-  const double bspmv = dd_op ? nent * g.D * g.D * 4.0 + Nc * 4.0 + 2.0 * N * sv : bspmv_full;
+  const double bspmv = dd_op ? nent_op * g.D * g.D * 4.0 + Nc * 4.0 + 2.0 * N * sv : bspmv_full;
   if (kernel == 0) *bytes = bspmv;
   else if (kernel == 10) *bytes = bspmv_full;
   else if (kernel == 1 || kernel == 11) *bytes = 2.0 * bspmv_full + 16.0 * N * sv;
@@ -1418,8 +1420,10 @@ extern "C" int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent) {
   HIPCHK(hipSetDevice(s->device));
   int rc = tsx_dedup_ensure(s);
   if (rc) return rc;
-  *on = s->dd_on ? 1 : (s->dd_pc ? 2 : 0);  // 2: near-identical blocks grouped for the preconditioner only
-  *nent = s->dd_nent;
+  // bit 0: bit-identical blocks shared (operator and preconditioner); bit 1: near-identical blocks grouped for the
+  // preconditioner (on top of bit 0, or alone where nothing is bit-identical)
+  *on = (s->dd_on ? 1 : 0) | (s->dd_pc ? 2 : 0);
+  *nent = s->dd_on ? s->dd_nent : (s->dd_pc ? s->pc_nent : s->dd_nent);
   return TSX_OK;
 }
 

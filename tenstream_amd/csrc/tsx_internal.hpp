@@ -97,6 +97,14 @@ struct tsx_solver {
   bool dd_pc = false;      // the index / entries group NEAR-identical blocks and serve the preconditioner only (tsx_dedup.hip);
                            // the operator then works on every cell's exact block (dd_on stays false)
   int dd_nent_near = 0;    // entries of that grouping (0: not attempted)
+  // what the preconditioner packs from and indexes with: the near-identical grouping where it pays (own arrays: pc_own), else
+  // the bit-identical one (aliases of the dd_ arrays); valid when dd_on || dd_pc
+  float *pc_coef = nullptr;       // [D*D][pc_nent] plane-major
+  int *pc_cidx_split = nullptr;   // [Nc] colour-split order
+  int *pc_ent_cell = nullptr;     // [pc_nent]
+  int pc_nent = 0, pc_cap = 0;
+  float *pcn_coef = nullptr;      // the near grouping's own allocations (kept across coefficient sets)
+  int *pcn_cidx_split = nullptr, *pcn_ent_cell = nullptr;
   int dd_nent, dd_cap;
   float *dd_coef;          // [D*D][dd_nent] plane-major (preconditioner packing)
   float *dd_coef_e = nullptr;  // [dd_nent][D*D] entry-major copy behind it (operator apply)

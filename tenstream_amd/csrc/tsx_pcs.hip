@@ -77,8 +77,8 @@ static int pcsh_pack(tsx_solver *s) {  // 8_16: 14 matrix records per cell, then
     hipLaunchKernelGGL((tsx_k_pcsh_pack_col<float>), dim3(nbc), dim3(64), 0, s->stream, g, (const float *)s->coef, s->l1d, s->a11,
                        s->a12, s->albedo, P);
     if (s->dd_on || s->dd_pc) {
-      hipLaunchKernelGGL((tsx_k_pcsh_pack_block<float>), dim3(grid_for((long long)TSX_S16H_BLOCK * s->dd_nent)), dim3(TSX_BLOCK), 0,
-                         s->stream, g, (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d, PB);
+      hipLaunchKernelGGL((tsx_k_pcsh_pack_block<float>), dim3(grid_for((long long)TSX_S16H_BLOCK * s->pc_nent)), dim3(TSX_BLOCK), 0,
+                         s->stream, g, (long long)s->pc_nent, (const float *)s->pc_coef, (const int *)s->pc_ent_cell, s->l1d, PB);
       s->coef_h_dd = true;
       // where blocks repeat, so do the column recurrences below the lowest cloud of a column: share the 14 records too
       int rc = tsx_records_share(s, TSX_S16H_CELL, P);
@@ -109,16 +109,16 @@ int tsx_pcs_pack(tsx_solver *s) {
                        s->l1d, s->a11, s->a12, s->albedo, P);
     s->coef_h_c16 = pcs_c16();
     if (s->coef_h_c16)  // side -> top couplings in fp16: 8 records per distinct block
-      hipLaunchKernelGGL(tsx_k_pcs_pack_ent16, dim3(grid_for((long long)TSX_PCS_ENT16_SLOTS * s->dd_nent)), dim3(TSX_BLOCK), 0,
-                         s->stream, g.ncol, (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d,
+      hipLaunchKernelGGL(tsx_k_pcs_pack_ent16, dim3(grid_for((long long)TSX_PCS_ENT16_SLOTS * s->pc_nent)), dim3(TSX_BLOCK), 0,
+                         s->stream, g.ncol, (long long)s->pc_nent, (const float *)s->pc_coef, (const int *)s->pc_ent_cell, s->l1d,
                          P + g.Nc);
     else
-      hipLaunchKernelGGL(tsx_k_pcs_pack_ent, dim3(grid_for(7ll * s->dd_nent)), dim3(TSX_BLOCK), 0, s->stream, g.ncol,
-                         (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_ent_cell, s->l1d, P + g.Nc);
+      hipLaunchKernelGGL(tsx_k_pcs_pack_ent, dim3(grid_for(7ll * s->pc_nent)), dim3(TSX_BLOCK), 0, s->stream, g.ncol,
+                         (long long)s->pc_nent, (const float *)s->pc_coef, (const int *)s->pc_ent_cell, s->l1d, P + g.Nc);
     // the intermediate passes' copy of record 0 (block index in the word of A_k) in the last group's slot: the entries
     // fill at most 3.5 of the 7 groups behind record 0 (sharing is on only where 2 * nent <= Nc)
     hipLaunchKernelGGL(tsx_k_pcs_pack_r0g, dim3(grid_for(g.Nc)), dim3(TSX_BLOCK), 0, s->stream, (long long)g.Nc, (const uint4 *)P,
-                       (const int *)s->dd_cidx_split, P + (size_t)7 * g.Nc);
+                       (const int *)s->pc_cidx_split, P + (size_t)7 * g.Nc);
     HIPCHK(hipGetLastError());
     s->coef_h_dd = true;
     // below the lowest cloud of a column -- and in every clear column -- that record is the same for all columns of a level.
@@ -255,8 +255,8 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   const uint4 *P = (const uint4 *)s->coef_h;
   const float *r = (const float *)s->pc_rhs;
   const bool dd = s->coef_h_dd;
-  const int *cidx = (const int *)s->dd_cidx_split;
-  const long long nent = s->dd_nent;
+  const int *cidx = (const int *)s->pc_cidx_split;
+  const long long nent = s->pc_nent;
   const uint4 *PE = P + g.Nc;
   const TsxPcHalo hal = pcs_halo_arg(s);
   unsigned *rb = zb + (size_t)4 * g.Nc;  // behind the iterate's bf16 records in s->vw
@@ -306,8 +306,8 @@ static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, fl
   const long long pstride = s->pcr_on ? s->pcr_n : (long long)g.Nc;
   const float *r = (const float *)s->pc_rhs;
   const bool dd = s->coef_h_dd;
-  const long long bstride = dd ? (long long)s->dd_nent : g.Nc;
-  const int *cidx = (const int *)s->dd_cidx_split;
+  const long long bstride = dd ? (long long)s->pc_nent : g.Nc;
+  const int *cidx = (const int *)s->pc_cidx_split;
   const TsxPcHalo hal = pcs_halo_arg(s);
   unsigned *rb = zb + (size_t)4 * g.Nc;
 #define TSX_PCSH_GO(GSV, MODEV, RQV)                                                                                            \

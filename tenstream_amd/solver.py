@@ -324,8 +324,8 @@ class DiffuseSolver:
         """(in use?, number of distinct transport blocks) of the current coefficients"""
         on, n = C.c_int32(), C.c_int64()
         _lib.check(self.lib.tsx_dedup_info(self.h, C.byref(on), C.byref(n)))
-        self.dedup_mode = int(on.value)   # 0 off, 1 bit-identical blocks shared, 2 near-identical blocks grouped for M^-1 only
-        return on.value == 1, int(n.value)
+        self.dedup_mode = int(on.value)   # bit 0: bit-identical blocks shared; bit 1: near-identical blocks grouped for M^-1
+        return bool(on.value & 1), int(n.value)
 
     def pc_info(self):
         """(TSX_PC_* id, pc_sweeps, scan kernels?, identical recurrence records shared?) of the preconditioner the last

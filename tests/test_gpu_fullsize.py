@@ -15,19 +15,19 @@ import functools
 
 
 @functools.lru_cache(maxsize=2)
-def _fields(solver, Nx, Ny, Nz):
+def _fields(solver, Nx, Ny, Nz, heterogeneous=False):
     """host-side generation is the slow part on a busy box: do it once per configuration"""
-    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=20240611)
+    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=20240611, heterogeneous=heterogeneous)
     kabs, ksca, g = synthetic.delta_scale(kabs, ksca, g)
     b = synthetic.solar_source(solver, kabs, ksca, g, DZ, DX, np.full((Ny, Nx), ALB))
     return kabs, ksca, g, b
 
 
-def _solver(solver, Nx, Ny, Nz):
+def _solver(solver, Nx, Ny, Nz, heterogeneous=False):
     import torch
 
     dev = torch.device("cuda", 0)
-    kabs, ksca, g, b_host = _fields(solver, Nx, Ny, Nz)
+    kabs, ksca, g, b_host = _fields(solver, Nx, Ny, Nz, heterogeneous)
     s = DiffuseSolver(solver, Nz, Nx, Ny)
     s.set_lut_diffuse(lut.synthetic_diffuse_table(solver), lut.diffuse_axes(solver))
     t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
@@ -130,14 +130,17 @@ def test_solar_gpoint_energy_balance_full_size(gpu):
     P.close()
 
 
-@pytest.mark.parametrize("solver,Nx,Ny,Nz", [("3_10", 256, 256, 64), ("3_10", 128, 128, 64), ("8_16", 128, 128, 64)])
-def test_device_solution_equals_the_oracle_at_baseline_sizes(gpu, solver, Nx, Ny, Nz):
+@pytest.mark.parametrize("solver,Nx,Ny,Nz,het", [("3_10", 256, 256, 64, False), ("3_10", 128, 128, 64, False),
+                                                  ("8_16", 128, 128, 64, False), ("3_10", 128, 128, 64, True)])
+def test_device_solution_equals_the_oracle_at_baseline_sizes(gpu, solver, Nx, Ny, Nz, het):
     """The oracle's restatement of the reference's default CPU path (assembled AIJ + KSPFBCGS + PCBJACOBI/ILU(0),
     src/pprts.F90:4342-4371, 4415-4425; one subdomain per usable core, oracle/pprts_oracle_mt.c) solves the very system the
     device solved -- the device's own coefficient blocks read back through tsx_diff_get_coeffs, the same right-hand side --
     on BASELINE.json's metric domain (256x256x64), config 2 (128x128x64) and, for 8_16, the largest domain whose CSR and
     ILU factors fit comfortably (128x128x64: 0.29 G non-zeros; 256x256x64 would be 1.1 G = 27 GB for matrix + factors).
-    Bar: max |x_device - x_oracle| <= 1e-8 max |x| with both solves tightened to ~1e-10/1e-11."""
+    Bar: max |x_device - x_oracle| <= 1e-8 max |x| with both solves tightened to ~1e-10/1e-11.
+    het: every cell its own kabs / ksca (bench.py --field heterogeneous) -- nothing is bit-identical, the operator works on
+    every cell's own block, the preconditioner groups near-identical ones (tsx_dedup.hip): the solution is the same."""
     import sys
 
     sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
@@ -145,12 +148,17 @@ def test_device_solution_equals_the_oracle_at_baseline_sizes(gpu, solver, Nx, Ny
     from oracle import oracle as O
     from tenstream_amd.coord import decompose
 
-    s, b, dev = _solver(solver, Nx, Ny, Nz)
+    s, b, dev = _solver(solver, Nx, Ny, Nz, het)
     import torch
 
     x = torch.zeros_like(b)
     info = s.solve(b, x, rtol=1e-10, atol=1e-30)
     assert info.reason == 2
+    if het:
+        on, ngroups = s.dedup_info()
+        assert not on and s.dedup_mode == 2 and ngroups < 0.1 * Nx * Ny * Nz
+        xd5 = torch.zeros_like(b)
+        assert s.solve(b, xd5).niter <= 6   # reference default tolerances: the grouping costs no iteration (5 here)
     xd = x.cpu().numpy()
     coeff = s.get_coeffs()
     s.close()
