@@ -265,6 +265,7 @@ def main():
     bytes_iter = s.algorithmic_bytes(1)
     pc_ms = pass_ms = None
     dd_on, dd_nent = s.dedup_info()
+    pc_shared = dd_on or bool(getattr(s, "dedup_mode", 0) & 2)   # the preconditioner reads per-block records through an index
     pc_ran, sweeps, scan, rec_shared = s.pc_info()   # what the solves above actually ran (automatic pass count, zebra on odd grids)
     if scan and args.pc_sweeps == 0:
         pc_ms = s.bench_kernel(2, args.kernel_reps)
@@ -303,7 +304,7 @@ def main():
 
     def roof(kernel, ms, nbytes, patterns, full_storage_bytes=None):
         ach = nbytes / (ms * 1e-3) / 1e9
-        traffic, src = pmc_traffic(solver, f"{co.xm}x{co.ym}x{Nz}", patterns)
+        traffic, src = pmc_traffic(solver, f"{co.xm}x{co.ym}x{Nz}" + ("" if args.field == "clouds" else "_" + args.field), patterns)
         r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
              "traffic": traffic, "traffic_source": src, "bytes_per_launch": nbytes, "ms_per_launch": ms,
              "traffic_GBps": None if traffic is None else traffic / (ms * 1e-3) / 1e9}
@@ -328,7 +329,7 @@ def main():
         if pass_ms is not None:
             kname = "tsx_k_pcs_rb" if solver == "3_10" else "tsx_k_pcsh_rb"
             r_pass = roof(f"{kname}<..., GS, MODE 0, RQ 2> (one intermediate red-black pass of M^-1)", pass_ms,
-                          bytes_pass, [kname, (",true,0,true,2,", ",true,0,true,2>") if dd_on else (",true,0,false,2,", ",true,0,false,2>")])
+                          bytes_pass, [kname, (",true,0,true,2,", ",true,0,true,2>") if pc_shared else (",true,0,false,2,", ",true,0,false,2>")])
         r_pc = None
         if pc_ms is not None:
             r_pc = {"kernel": f"M^-1: {sweeps + 1} half-grid passes", "ms_per_application": pc_ms,
