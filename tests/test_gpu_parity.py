@@ -767,7 +767,9 @@ def test_shared_block_storage_is_lossless(gpu, monkeypatch, solver, Nx, Ny, Nz, 
     on, nent = s.dedup_info()
     # nothing bit-identical: the operator keeps the dense planes; the blocks agree to 0.1 % though, so the PRECONDITIONER groups
     # them (tsx_dedup.hip "near-identical blocks": its per-block records are approximate by design) ...
-    assert not on and s.dedup_mode == 2 and nent < 0.5 * Nx * Ny * Nz
+    # (3_10 only: the 8_16 pass gathers 20 records per level, scattered over the groups they cost more than streamed per cell)
+    near = solver == "3_10"
+    assert not on and s.dedup_mode == (2 if near else 0) and (nent < 0.5 * Nx * Ny * Nz) == near
     xs = np.zeros(s.vec_shape)
     i_near = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30)
     s.close()
