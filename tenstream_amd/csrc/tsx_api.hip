@@ -868,17 +868,42 @@ static int enqueue_iteration_k32(tsx_solver *s, bool first) {
   float *r32 = (float *)s->vr, *v32k = (float *)s->vv, *s32n = (float *)s->vs, *t32 = (float *)s->vt;
   const float *rhat = (const float *)s->vrhat;
   float *ph = (float *)s->vph, *sh = (float *)s->vsh;
-  if (!first)
-    hipLaunchKernelGGL(tsx_k_pupdate_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const float2 *)r32,
-                       (const float2 *)v32k, s->p32, g, (int)s->pc_split);
+  // with the scan passes the updates of p and s run cell by cell and leave the passes' bf16-pair words too
+  const bool words = s->pc_split && s->coef_h_scan && tsx_pcs_rhs16(s) && s->pc_sweeps + 1 >= 6 &&
+                     !(getenv("TSX_PC_WORDS") && atoi(getenv("TSX_PC_WORDS")) == 0);
+  const int nbc = grid_for(g.Nc);
+  if (!first) {
+    if (words) {
+      if (NTOP == 2)
+        hipLaunchKernelGGL((tsx_k_psupdate_k32c<10, 0>), dim3(nbc), dim3(TSX_BLOCK), 0, s->stream, g, s->scal, (const float *)r32,
+                           (const float *)v32k, s->p32, (float *)nullptr, tsx_pcs_words(s));
+      else
+        hipLaunchKernelGGL((tsx_k_psupdate_k32c<16, 0>), dim3(nbc), dim3(TSX_BLOCK), 0, s->stream, g, s->scal, (const float *)r32,
+                           (const float *)v32k, s->p32, (float *)nullptr, tsx_pcs_words(s));
+      s->pc_words_ready = true;
+    } else {
+      hipLaunchKernelGGL(tsx_k_pupdate_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const float2 *)r32,
+                         (const float2 *)v32k, s->p32, g, (int)s->pc_split);
+    }
+  }
   s->pc_rhs = s->p32;
   if ((rc = tsx_pc_apply(s, s->vp, ph, true, true))) return rc;
   if ((rc = launch_spmv_f32<NTOP, NSIDE, 1>(s, ph, v32k, rhat, true))) return rc;
   if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
   // the preconditioner reads s in its own order: natural (then one copy serves both) or colour-split (a second copy)
   float *sdst = s->pc_split ? s32n : s->v32;
-  hipLaunchKernelGGL(tsx_k_supdate_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const float2 *)r32,
-                     (const float2 *)v32k, (float2 *)sdst, s->pc_split ? s->v32 : (float *)nullptr, g);
+  if (words) {
+    if (NTOP == 2)
+      hipLaunchKernelGGL((tsx_k_psupdate_k32c<10, 1>), dim3(nbc), dim3(TSX_BLOCK), 0, s->stream, g, s->scal, (const float *)r32,
+                         (const float *)v32k, s->v32, sdst, tsx_pcs_words(s));
+    else
+      hipLaunchKernelGGL((tsx_k_psupdate_k32c<16, 1>), dim3(nbc), dim3(TSX_BLOCK), 0, s->stream, g, s->scal, (const float *)r32,
+                         (const float *)v32k, s->v32, sdst, tsx_pcs_words(s));
+    s->pc_words_ready = true;
+  } else {
+    hipLaunchKernelGGL(tsx_k_supdate_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const float2 *)r32,
+                       (const float2 *)v32k, (float2 *)sdst, s->pc_split ? s->v32 : (float *)nullptr, g);
+  }
   s->pc_rhs = s->v32;
   if ((rc = tsx_pc_apply(s, s->vs, sh, true, true))) return rc;
   if ((rc = launch_spmv_f32<NTOP, NSIDE, 5>(s, sh, t32, sdst, true))) return rc;

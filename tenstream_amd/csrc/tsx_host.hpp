@@ -132,5 +132,6 @@ int tsx_pcs_pack(tsx_solver *s);
 int tsx_pcs_apply(tsx_solver *s, float *z, const int *done);
 int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done, int rq, int part = 0);
 bool tsx_pcs_rhs16(const tsx_solver *s);
+unsigned *tsx_pcs_words(const tsx_solver *s);
 int tsx_records_share(tsx_solver *s, int R, const uint4 *P);
 int tsx_dedup_hash_buffer(tsx_solver *s, unsigned long long **h);

@@ -135,6 +135,8 @@ struct tsx_solver {
   double *pc_tmp;      // column preconditioner: tsx_pc_ntmp planes of Nc doubles
   int pc, pc_sweeps;   // active preconditioner of the running solve
   bool mixed;          // fp32 storage of preconditioned directions and shadow residual
+  bool pc_words_ready = false;  // the bf16-pair words of the right-hand side of the NEXT preconditioner application are already in
+                                // place (left by tsx_k_psupdate_k32c): every intermediate pass reads them, none writes them
   bool k32 = false;    // ... and of the recurrence vectors r, s, v, t (tsx_ksp_opts.fp32_directions = 2), residual replacement in fp64
   // staging in reference layout (for TSX_HOST callers and conversion)
   double *stage_a, *stage_b;

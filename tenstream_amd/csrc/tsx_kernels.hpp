@@ -189,6 +189,58 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_supdate_k32(long long n2, con
     }
   }
 }
+// The same two updates cell by cell, for the scan preconditioner: the thread of a cell has all D streams of it in hand and also
+// leaves the D / 2 bf16-pair words of the right-hand side that the red-black passes read (rb[w * Nc + split cell] = streams
+// 2 w, 2 w + 1; tsx_k_pcs_rb "RQ") -- the first two passes of an application then read 20 B per cell like every other
+// intermediate pass instead of 40 B of fp32 + writing the words themselves.  MODE 0: p = r + beta (p - omega v) (p in split
+// order); MODE 1: s = r - alpha v (natural copy s_nat and split copy s_split).  Tail rows (index >= D * Nc) element-wise.
+__device__ __forceinline__ unsigned tsx_bf16pair(float lo, float hi) {
+  auto b = [](float x) {  // round to nearest even, as tsx_to_bf16 (tsx_pack.hpp): the words equal the ones a pass would leave
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+  };
+  return b(lo) | (b(hi) << 16);
+}
+template <int D, int MODE>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_psupdate_k32c(TsxGeo g, const TsxScalars *__restrict__ sc, const float *__restrict__ r,
+                                                                 const float *__restrict__ v, float *__restrict__ p_or_ssplit,
+                                                                 float *__restrict__ s_nat, unsigned *__restrict__ rb) {
+  if (sc->done) return;
+  const double beta = sc->beta, omega = sc->omega, alpha = sc->alpha;
+  const long long Nc = g.Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int i = (int)(c % g.xm);
+    const long long t = c / g.xm;
+    const int j = (int)(t % g.ym);
+    const long long cs = (t / g.ym) * g.ncol + tsx_split_col(i, j, g.xm);
+    float o[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const size_t in = (size_t)d * Nc + c, sp = (size_t)d * Nc + cs;
+      if (MODE == 0) {
+        o[d] = (float)((double)r[in] + beta * ((double)p_or_ssplit[sp] - omega * (double)v[in]));
+      } else {
+        o[d] = (float)((double)r[in] - alpha * (double)v[in]);
+        s_nat[in] = o[d];
+      }
+      p_or_ssplit[sp] = o[d];
+    }
+#pragma unroll
+    for (int w = 0; w < D / 2; ++w) rb[(size_t)w * Nc + cs] = tsx_bf16pair(o[2 * w], o[2 * w + 1]);
+  }
+  const long long body = (long long)D * Nc;
+  for (long long q = body + (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < g.N; q += (long long)gridDim.x * TSX_BLOCK) {
+    const long long sp = tsx_split_pos(q, g);
+    if (MODE == 0) {
+      p_or_ssplit[sp] = (float)((double)r[q] + beta * ((double)p_or_ssplit[sp] - omega * (double)v[q]));
+    } else {
+      const float o = (float)((double)r[q] - alpha * (double)v[q]);
+      s_nat[q] = o;
+      p_or_ssplit[sp] = o;
+    }
+  }
+}
 // x += alpha ph + omega sh (fp64); r = s - omega t; slot0 = (rhat, r), slot1 = (r, r)
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xrupdate_k32(long long n2, const TsxScalars *__restrict__ sc,
                                                                 double2 *__restrict__ x, const float2 *__restrict__ ph,

@@ -275,13 +275,14 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   } while (0)
   if (!gs) {
     if (rq == 1) TSX_PCS_GO(false, 0, 1);
+    else if (rq == 2) TSX_PCS_GO(false, 0, 2);
     else TSX_PCS_GO(false, 0, 0);
   } else if (mode == 0) {
     if (rq == 2) TSX_PCS_GO(true, 0, 2);
     else if (rq == 1) TSX_PCS_GO(true, 0, 1);
     else TSX_PCS_GO(true, 0, 0);
   } else if (mode == 1) TSX_PCS_GO(true, 1, 0);
-  else TSX_PCS_GO(true, 2, 0);
+  else TSX_PCS_GO(true, 2, 0);  // (the two fp32 passes on the bf16 words too: measured, no gain -- 14.41 vs 14.48 ms)
 #undef TSX_PCS_GO
 }
 
@@ -321,6 +322,7 @@ static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, fl
   } while (0)
   if (!gs) {
     if (rq == 1) TSX_PCSH_GO(false, 0, 1);
+    else if (rq == 2) TSX_PCSH_GO(false, 0, 2);
     else TSX_PCSH_GO(false, 0, 0);
   } else if (mode == 0) {
     if (rq == 2) TSX_PCSH_GO(true, 0, 2);
@@ -335,6 +337,11 @@ static void pcsh_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, fl
 // intermediate passes read their right-hand side as bf16 pairs (TSX_PC_RHS16=0: fp32 throughout).  Measured: 3_10 pass
 // 43.6 -> 36.5 us; 8_16 pass 168 -> 162 us, which pays from about 14 passes on (the two passes that leave the words cost what
 // four reading passes save); same iteration counts
+// where the passes keep the bf16-pair words of their right-hand side (behind the iterate's records in s->vw)
+unsigned *tsx_pcs_words(const tsx_solver *s) {
+  float *zs = (float *)s->vw;
+  return (unsigned *)(zs + (size_t)s->geo.N) + (size_t)4 * s->geo.Nc;
+}
 bool tsx_pcs_rhs16(const tsx_solver *s) {
   static const bool on = !(getenv("TSX_PC_RHS16") && atoi(getenv("TSX_PC_RHS16")) == 0);
   (void)s;
@@ -380,6 +387,9 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
     if (rc) return rc;
   }
   const bool rhs16 = tsx_pcs_rhs16(s);
+  // the producer of the right-hand side has left the bf16-pair words already (fp32 Krylov vectors, tsx_k_psupdate_k32c)
+  const bool words_ready = rhs16 && s->pc_words_ready && P >= 6;
+  s->pc_words_ready = false;
   static const int every_env = getenv("TSX_PC_HALO_EVERY") ? atoi(getenv("TSX_PC_HALO_EVERY")) : 1;
   const int every = every_env > 0 ? every_env : 1;
   // Overlap (TSX_PC_OVERLAP != 0, several ranks): the exchange of pass p's boundary records runs on comm_stream while pass
@@ -392,7 +402,7 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
     const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
     // a colour's intermediate visits are passes c, c + 2, ... < P - 2: the first leaves the bf16 right-hand side if another
     // one follows, the later ones read it
-    const int rq = !rhs16 || mode != 0 ? 0 : (pass >= 2 ? 2 : (pass + 2 < P - 2 ? 1 : 0));
+    const int rq = !rhs16 || mode != 0 ? 0 : (words_ready ? 2 : (pass >= 2 ? 2 : (pass + 2 < P - 2 ? 1 : 0)));
     int rc;
     if (in_flight) {
       if ((rc = tsx_pcs_pass(s, pass, mode, z, done, rq, 1))) return rc;  // interior, under the exchange
