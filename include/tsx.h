@@ -129,6 +129,9 @@ typedef struct {
 const char *tsx_last_error(void);
 int tsx_version(void);
 int tsx_device_count(void);
+/* sizeof(tsx_grid), sizeof(tsx_ksp_opts), sizeof(tsx_ksp_result) as this library was built: what a binding in another language
+ * (the Fortran shim's bind(C) types, the ctypes mirror) checks its own declarations against */
+int tsx_abi_sizes(int32_t *sizes3);
 
 /* ---- lifetime: init_pprts/setup_grid allocate C_diff and the vectors (src/pprts.F90:213, 830-1097);
  *      destroy_pprts frees them (src/pprts_base.F90:877) */

@@ -25,6 +25,14 @@ void tsx_set_error(const std::string &msg) { g_err = msg; }
 extern "C" const char *tsx_last_error(void) { return g_err.c_str(); }
 extern "C" int tsx_version(void) { return TSX_VERSION; }
 
+extern "C" int tsx_abi_sizes(int32_t *sizes3) {
+  if (!sizes3) return TSX_ERR_ARG;
+  sizes3[0] = (int32_t)sizeof(tsx_grid);
+  sizes3[1] = (int32_t)sizeof(tsx_ksp_opts);
+  sizes3[2] = (int32_t)sizeof(tsx_ksp_result);
+  return TSX_OK;
+}
+
 extern "C" int tsx_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -16,6 +16,7 @@ module m_pprts_hip
   private
   public :: t_tsx_grid, t_tsx_ksp_opts, t_tsx_ksp_result, &
     & hip_diff_create, hip_diff_destroy, hip_diff_set_coeffs, hip_ediff, hip_diff_apply, hip_last_error, &
+    & tsx_abi_sizes, tsx_comm_peer_export, tsx_comm_peer_attach, &
     & TSX_HOST, TSX_DEVICE, TSX_PC_NONE, TSX_PC_COLUMN, TSX_PC_ZEBRA, TSX_PC_REDBLACK
 
   integer(c_int), parameter :: TSX_HOST = 0, TSX_DEVICE = 1
@@ -45,6 +46,7 @@ module m_pprts_hip
     integer(c_int32_t) :: pc_coeff_fp16
     integer(c_int32_t) :: skip_complete_initial_run   ! 0 (default): -ksp_complete_initial_run semantics, src/pprts.F90:4245-4256
     integer(c_int32_t) :: explicit_solver             ! 1: explicit_ediff's stationary iteration instead of the Krylov solve
+    integer(c_int32_t) :: accept_incomplete_solve     ! 1: -accept_incomplete_solve, no retry from zero (src/pprts.F90:4271-4273)
   end type
 
   type, bind(C) :: t_tsx_ksp_result
@@ -92,6 +94,22 @@ module m_pprts_hip
       integer(c_int), value :: where
       type(t_tsx_ksp_opts), intent(in) :: opts
       type(t_tsx_ksp_result), intent(out) :: res
+      integer(c_int) :: ierr
+    end function
+    ! device-resident peer transport (node-local): export this rank's 192-byte blob, MPI_Allgather them in rank order, attach
+    function tsx_comm_peer_export(handle, blob) bind(C, name='tsx_comm_peer_export') result(ierr)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle, blob
+      integer(c_int) :: ierr
+    end function
+    function tsx_comm_peer_attach(handle, blobs) bind(C, name='tsx_comm_peer_attach') result(ierr)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle, blobs
+      integer(c_int) :: ierr
+    end function
+    function tsx_abi_sizes(sizes3) bind(C, name='tsx_abi_sizes') result(ierr)
+      import :: c_int32_t, c_int
+      integer(c_int32_t), intent(out) :: sizes3(3)
       integer(c_int) :: ierr
     end function
     function tsx_last_error() bind(C, name='tsx_last_error') result(msg)

@@ -14,6 +14,16 @@ program test_shim
   real(c_double) :: hist(100), err
   integer :: src, dst
 
+  block   ! the bind(C) types of the shim must be the library's structs, field for field
+    integer(c_int32_t) :: sz(3)
+    type(t_tsx_ksp_opts) :: o
+    type(t_tsx_ksp_result) :: rr
+    ierr = tsx_abi_sizes(sz)
+    if (ierr .ne. 0 .or. sz(1) .ne. c_sizeof(grid) .or. sz(2) .ne. c_sizeof(o) .or. sz(3) .ne. c_sizeof(rr)) then
+      print *, 'ABI mismatch: library', sz, ' shim', c_sizeof(grid), c_sizeof(o), c_sizeof(rr)
+      stop 6
+    end if
+  end block
   grid = t_tsx_grid(310, Nz, Nx, Ny, 0, 0, Nx, Ny, 0, 1, 0, 0, 0, 0, -1, 0)
   call hip_diff_create(grid, h, ierr)
   if (ierr .ne. 0) then

@@ -103,3 +103,14 @@ def test_process_grid_like_mpi_dims_create(n, want):
 def test_uneven_split_matches_dmda_formula():
     cs = [coord.coord(r, 3, 10, 7, nxp=3, nyp=1) for r in range(3)]
     assert [(c.xs, c.xm) for c in cs] == [(0, 3), (3, 3), (6, 4)]
+
+
+def test_struct_mirrors_have_the_library_sizes():
+    """tsx_abi_sizes: the ctypes mirrors of tsx_grid / tsx_ksp_opts / tsx_ksp_result are the library's structs (a field added
+    to one side only -- round 3: accept_incomplete_solve was missing in the Fortran shim -- shows here and in test_shim.F90)"""
+    import ctypes as C
+
+    lib = _lib.load()
+    sz = (C.c_int32 * 3)()
+    assert lib.tsx_abi_sizes(sz) == 0
+    assert list(sz) == [C.sizeof(_lib.Grid), C.sizeof(_lib.KspOpts), C.sizeof(_lib.KspResult)]
