@@ -75,7 +75,13 @@ def main():
     if any(k.startswith("tsx_k_xrupdate_k32") for k in kernels):   # fp32 Krylov vectors (round 3 default)
         per_iter = passes + [(r"tsx_k_spmv_w<\d+,\d+,\w+,1,\d,float,float,.*float>$", 1),
                              (r"tsx_k_spmv_w<\d+,\d+,\w+,5,\d,float,float,.*float>$", 1),
-                             (r"tsx_k_pupdate_k32", 1), (r"tsx_k_supdate_k32", 1), (r"tsx_k_xrupdate_k32", 1)]
+                             (r"tsx_k_psupdate_k32c<\d+,0>|tsx_k_pupdate_k32", 1), (r"tsx_k_psupdate_k32c<\d+,1>|tsx_k_supdate_k32", 1),
+                             (r"tsx_k_xrupdate_k32", 1)]
+        if any(k.startswith("tsx_k_psupdate_k32c") for k in kernels):
+            # the vector updates leave the bf16 words: every intermediate pass of an application reads them (P - 2 of them, the
+            # first without neighbours), none writes them
+            passes = [(rb + r"false,0,\w+,2", 2), (rb + r"true,0,\w+,2", 2 * (P - 3)), (rb + r"true,1", 2), (rb + r"true,2", 2)]
+            per_iter = passes + per_iter[len(per_iter) - 5:]
     else:
         per_iter = passes + [(r"tsx_k_spmv_w<\d+,\d+,\w+,1,\d,float,float", 1), (r"tsx_k_spmv_w<\d+,\d+,\w+,5,\d,float,double", 1),
                              (r"tsx_k_pupdate32", 1), (r"tsx_k_supdate", 1), (r"tsx_k_xrupdate", 1)]
