@@ -267,8 +267,10 @@ struct TsxPeer {
 static size_t peer_capacity(const tsx_solver *s) {
   // the largest face message any exchange of this solver sends: the diffuse halo (nside / 2 streams x Nz x edge doubles), the
   // direct beam's (dirside streams x Nz x edge), the preconditioner's records (Nz x edge words)
+  // ... sized by the GLOBAL extents so that every rank of an uneven split (xs = (xi * Nx) / nxp) arrives at the same slot size
   const TsxGeo &g = s->geo;
-  const size_t edge = (size_t)(g.xm > g.ym ? g.xm : g.ym);
+  const int gx = s->grid.glob_xm > g.xm ? s->grid.glob_xm : g.xm, gy = s->grid.glob_ym > g.ym ? s->grid.glob_ym : g.ym;
+  const size_t edge = (size_t)(gx > gy ? gx : gy);
   const size_t streams = 4;  // >= nside / 2 (2) and dirside (1 / 2)
   size_t b = streams * (size_t)(g.Nz + 1) * edge * sizeof(double);
   return (b + 255) & ~(size_t)255;

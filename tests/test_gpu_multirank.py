@@ -165,7 +165,7 @@ def _worker(rank, world, port, solver, Nx, Ny, Nz, transport, ret):
 # on EVERY rank (tsx_pc_global_agree), not just on the odd ones (an even rank's messages would find no partner)
 @pytest.mark.parametrize("world,solver,Nx,Ny", [(2, "3_10", 10, 12), (4, "3_10", 12, 10), (2, "8_16", 6, 8), (2, "3_10", 10, 13),
                                                 (3, "3_10", 8, 8)])
-@pytest.mark.parametrize("transport", ["host", "peer"])
+@pytest.mark.parametrize("transport", ["host", "peer"])   # (uneven splits: the mailbox slots are sized by the global extents)
 def test_sharded_hip_solve_equals_global_oracle(gpu, world, solver, Nx, Ny, transport):
     """transport "host": the callbacks (gloo underneath); "peer": the device-resident transport -- halos stored by the sender's
     kernel into the receiver's IPC-mapped mailbox, all-reduces as all-to-all stores (tsx_peer.hip), the rank processes sharing
