@@ -990,7 +990,16 @@ static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
   int enq = 0, nrestart = 0;
   bool done = false, first_after_begin = true;
   while (!done) {
-    const int todo = (o->maxit - enq) < chunk ? (o->maxit - enq) : chunk;
+    int todo = (o->maxit - enq) < chunk ? (o->maxit - enq) : chunk;
+    {
+      // if the last iteration's reduction, applied once more, meets the stop rule, enqueue ONE iteration before the next look
+      // at the flag: the iterations enqueued beyond convergence return at once, but that is ~60 empty launches (0.1 ms)
+      const TsxScalars &h = *s->scal_host;
+      if (enq > 0 && todo > 1 && h.nhist >= 2 && h.nhist <= 100 && h.its == enq) {
+        const double last = h.hist[h.nhist - 1], prev = h.hist[h.nhist - 2];
+        if (prev > 0.0 && last < prev && last * (last / prev) <= fmax(o->rtol * h.rnorm0, o->atol)) todo = 1;
+      }
+    }
     for (int q = 0; q < todo; ++q, ++enq) {
       if ((rc = enqueue_iteration<NTOP, NSIDE>(s, first_after_begin))) return rc;
       first_after_begin = false;
