@@ -112,6 +112,10 @@ typedef struct {
                                  conservative solver (src/pprts.F90:4277-4302).  1: -accept_incomplete_solve (:4271-4273) -- the
                                  reference returns BEFORE that retry; the (warm-started) partial iterate and the negative
                                  reason are the result, e.g. with -<prefix>ksp_max_it N as a fixed work budget per call */
+  int32_t initial_guess_zero; /* tsx_diff_solve only.  0 (default): x holds the initial guess (KSPSetInitialGuessNonzero(TRUE),
+                                 src/pprts.F90:4343).  1: the caller states that the guess is zero -- x is not read at all (the
+                                 import of a zero guess otherwise costs a pass over x to find out), the solve starts from
+                                 r = b.  On several ranks every rank must pass the same value */
 } tsx_ksp_opts;
 
 /* what `solve` stores on the solution: Niter_diff, diff_ksp_residual_history(100)

@@ -34,7 +34,7 @@ class KspOpts(C.Structure):
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("dtol", C.c_double), ("maxit", C.c_int32),
                 ("pc", C.c_int32), ("pc_sweeps", C.c_int32), ("check_every", C.c_int32), ("fp32_directions", C.c_int32),
                 ("pc_coeff_fp16", C.c_int32), ("skip_complete_initial_run", C.c_int32), ("explicit_solver", C.c_int32),
-                ("accept_incomplete_solve", C.c_int32)]
+                ("accept_incomplete_solve", C.c_int32), ("initial_guess_zero", C.c_int32)]
 
 
 class KspResult(C.Structure):

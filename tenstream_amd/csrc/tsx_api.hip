@@ -159,6 +159,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->skip_complete_initial_run = 0;
   o->explicit_solver = 0;
   o->accept_incomplete_solve = 0;
+  o->initial_guess_zero = 0;
 }
 
 extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstrained_fraction, double *rtol,
@@ -1165,7 +1166,10 @@ static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, co
   }
   HIPCHK(hipEventRecord(e_imp0, s->stream));
   if ((rc = import_vec<NTOP, NSIDE>(s, bd, s->vb))) return rc;
-  {  // the import of the guess also tells whether it is zero
+  if (o->initial_guess_zero) {  // the caller says so: x is not read
+    HIPCHK(hipMemsetAsync(s->vx, 0, nb, s->stream));
+    s->x_is_zero = true;
+  } else {  // the import of the guess also tells whether it is zero
     int *nzflag = &s->scal->aux_flag;
     HIPCHK(hipMemsetAsync(nzflag, 0, sizeof(int), s->stream));
     if ((rc = import_vec<NTOP, NSIDE>(s, xd, s->vx, nzflag))) return rc;

@@ -47,6 +47,7 @@ module m_pprts_hip
     integer(c_int32_t) :: skip_complete_initial_run   ! 0 (default): -ksp_complete_initial_run semantics, src/pprts.F90:4245-4256
     integer(c_int32_t) :: explicit_solver             ! 1: explicit_ediff's stationary iteration instead of the Krylov solve
     integer(c_int32_t) :: accept_incomplete_solve     ! 1: -accept_incomplete_solve, no retry from zero (src/pprts.F90:4271-4273)
+    integer(c_int32_t) :: initial_guess_zero          ! 1: x is not read, the solve starts from r = b (tsx_diff_solve)
   end type
 
   type, bind(C) :: t_tsx_ksp_result

@@ -294,10 +294,11 @@ class DiffuseSolver:
 
     def solve(self, b, x, *, rtol=None, atol=None, maxit=None, dtol=None, pc=None, pc_sweeps=None,
               check_every=None, fp32_directions=None, pc_coeff_fp16=None, explicit_solver=None,
-              accept_incomplete_solve=None) -> KspInfo:
+              accept_incomplete_solve=None, initial_guess_zero=None) -> KspInfo:
         """Solve in place: x holds the initial guess on entry (src/pprts.F90:4343) and the solution on exit.
         explicit_solver=1: explicit_ediff's stationary iteration (-<prefix>explicit, src/pprts.F90:2799) instead of FBCGS.
-        accept_incomplete_solve=1: -accept_incomplete_solve (src/pprts.F90:4271-4273): no retry from zero after a failed solve."""
+        accept_incomplete_solve=1: -accept_incomplete_solve (src/pprts.F90:4271-4273): no retry from zero after a failed solve.
+        initial_guess_zero=1: x is not read (KSPSetInitialGuessNonzero(FALSE)); its content on entry is ignored."""
         if tuple(b.shape) != self.vec_shape or tuple(x.shape) != self.vec_shape:
             raise ValueError("b/x shape mismatch")
         o = _lib.KspOpts()
@@ -307,7 +308,7 @@ class DiffuseSolver:
         for name, val in (("rtol", rtol), ("atol", atol), ("maxit", maxit), ("dtol", dtol), ("pc", pc),
                           ("pc_sweeps", pc_sweeps), ("check_every", check_every), ("fp32_directions", fp32_directions),
                           ("pc_coeff_fp16", pc_coeff_fp16), ("explicit_solver", explicit_solver),
-                          ("accept_incomplete_solve", accept_incomplete_solve)):
+                          ("accept_incomplete_solve", accept_incomplete_solve), ("initial_guess_zero", initial_guess_zero)):
             if val is not None:
                 setattr(o, name, val)
         bp, where = _ptr(b, np.float64)

@@ -109,6 +109,20 @@ def test_solve_matches_oracle(gpu, solver, Nx, Ny, Nz, n1d, force_halo, pc):
     assert abs(info.res_hist[0] - np.linalg.norm(P["b"])) <= 1e-12 * np.linalg.norm(P["b"])
 
 
+def test_initial_guess_zero_ignores_what_x_holds(gpu):
+    """opts.initial_guess_zero = 1 (KSPSetInitialGuessNonzero(FALSE)): x is not read -- garbage on entry, the same iterates and
+    solution as a solve from an explicit zero guess."""
+    P = synthetic.make_problem("3_10", Nx=12, Ny=10, Nz=8, n1d=1)
+    s = DiffuseSolver("3_10", 8, 12, 10)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x0 = np.zeros(s.vec_shape)
+    i0 = s.solve(P["b"], x0, rtol=1e-10, atol=1e-30)
+    x1 = np.full(s.vec_shape, np.nan)
+    i1 = s.solve(P["b"], x1, rtol=1e-10, atol=1e-30, initial_guess_zero=1)
+    assert i1.reason == 2 and i1.niter == i0.niter and np.array_equal(i0.res_hist, i1.res_hist) and np.array_equal(x0, x1)
+    s.close()
+
+
 def test_solve_default_tolerances_and_warm_start(gpu):
     """Reference stop rule (rtol 1e-5 / atol formula, src/pprts_base.F90:1126-1131) and nonzero initial guess."""
     P = synthetic.make_problem("3_10", Nx=16, Ny=16, Nz=16)
