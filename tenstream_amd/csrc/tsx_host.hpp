@@ -41,7 +41,8 @@ static inline int spmv_cpt(const tsx_solver *s) {
   const int env = e ? atoi(e) : 0;
   // with shared block storage (tsx_dedup.hip) the coefficient loads are 4-byte gathers anyway: one cell per thread measured
   // 5-8 % faster there (more waves, fewer registers)
-  int want = env > 0 ? env : (s->dd_on ? 1 : TSX_DEFAULT_CPT);
+  // ... and with the fp32 recurrence vectors (round 3: every block stored, 256 x 256 x 64: 0.506 vs 0.520 ms per apply, 191 vs 186 M cells/s)
+  int want = env > 0 ? env : ((s->dd_on || s->k32) ? 1 : TSX_DEFAULT_CPT);
   if (want > 2) want = 2;
   while (want > 1 && (s->geo.xm % want) != 0) want >>= 1;
   return want;
