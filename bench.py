@@ -194,7 +194,18 @@ def main():
     if world > 1 and transport == "rccl":
         uid = [s.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        s.comm_init(uid[0])
+        ok = torch.ones(1, device=dev)
+        try:
+            s.comm_init(uid[0])
+        except Exception as e:   # no second communicator on this node: agreed below, then host-staged exchanges over gloo
+            print(f"bench.py: rank {rank}: RCCL communicator refused ({e})", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            from tenstream_amd import hostcomm
+
+            transport = "host"
+            hostcomm.attach(s, rank, group=dist.new_group(backend="gloo"))
     elif world > 1 and transport == "peer" and not try_peer_first:
         from tenstream_amd import hostcomm
 
@@ -240,7 +251,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev if transport == "rccl" else "cpu")
+            tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         return el, got

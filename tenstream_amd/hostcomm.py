@@ -8,8 +8,9 @@ from __future__ import annotations
 import numpy as np
 
 
-def attach(solver, rank: int):
-    """install exchange / allreduce callbacks on a DiffuseSolver / PprtsSolver; the default process group must exist"""
+def attach(solver, rank: int, group=None):
+    """install exchange / allreduce callbacks on a DiffuseSolver / PprtsSolver; the default process group must exist
+    (group: a gloo group to use instead, e.g. beside a default group on the nccl backend)"""
     import torch
     import torch.distributed as dist
 
@@ -21,13 +22,13 @@ def attach(solver, rank: int):
                 continue
             t = torch.from_numpy(recv[q])
             keep.append(t)
-            reqs.append(dist.irecv(t, src=peers[q], tag=want_tag[q]))
+            reqs.append(dist.irecv(t, src=peers[q], tag=want_tag[q], group=group))
         for q in range(4):
             if len(send[q]) == 0 or peers[q] == rank:
                 continue
             t = torch.from_numpy(np.array(send[q], copy=True))
             keep.append(t)
-            reqs.append(dist.isend(t, dst=peers[q], tag=q))
+            reqs.append(dist.isend(t, dst=peers[q], tag=q, group=group))
         for q in range(4):  # self neighbours
             if len(recv[q]) and peers[q] == rank:
                 recv[q][...] = send[q ^ 1]
@@ -35,7 +36,7 @@ def attach(solver, rank: int):
             r.wait()
 
     def allreduce(buf):
-        dist.all_reduce(torch.from_numpy(buf))
+        dist.all_reduce(torch.from_numpy(buf), group=group)
 
     solver.comm_set_callbacks(exchange, allreduce)
 

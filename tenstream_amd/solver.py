@@ -137,10 +137,19 @@ class DiffuseSolver:
         """Device-resident peer transport (tsx_comm_peer_export / _attach): `allgather(blob: bytes) -> list of every rank's
         blob in rank order` is the host's all-gather (torch.distributed.all_gather_object, MPI_Allgather ...)."""
         buf = C.create_string_buffer(_lib.PEER_BLOB_BYTES)
-        _lib.check(self.lib.tsx_comm_peer_export(self.h, buf))
-        blobs = allgather(buf.raw)
+        mine, err = bytes(_lib.PEER_BLOB_BYTES), None
+        try:
+            _lib.check(self.lib.tsx_comm_peer_export(self.h, buf))
+            mine = buf.raw
+        except Exception as e:   # this rank still takes part in the all-gather (an empty blob): the others must not wait for it
+            err = e
+        blobs = allgather(mine)
+        if err is not None:
+            raise err
         if len(blobs) != self.nranks or any(len(b) != _lib.PEER_BLOB_BYTES for b in blobs):
             raise ValueError("comm_peer_init: the all-gather must return one blob per rank")
+        if any(not any(b) for b in blobs):
+            raise RuntimeError("comm_peer_init: a rank could not export its mailbox")
         allb = C.create_string_buffer(b"".join(blobs), _lib.PEER_BLOB_BYTES * len(blobs))
         _lib.check(self.lib.tsx_comm_peer_attach(self.h, allb))
 

@@ -110,6 +110,6 @@ def fgmres(Minv, rtol=1e-5, maxit=200, m=30):
 
 if os.environ.get("OUTER"):
     print("outer iterations with red-black passes as M^-1 (preconditioner applications to rtol 1e-5):")
-    for P_ in (6, 10, 14):
+    for P_ in (10, 22):
         Minv = gs_passes(rb, [q % 2 for q in range(P_)])
         print(f"  {P_:2d} passes: BiCGStab {2 * fbcgs(Minv):3d} apps | FGMRES {fgmres(Minv):3d} apps | Richardson {richardson(Minv):3d} apps", flush=True)

@@ -109,3 +109,84 @@ def test_sharded_operator_equals_global(world, Nx, Ny):
         for p in procs:
             assert p.exitcode == 0
         assert len(ret) == world and max(ret.values()) < 1e-14, dict(ret)
+
+
+def _hostcomm_worker(rank, world, port, use_group, ret):
+    """the host-staged callbacks of tenstream_amd.hostcomm on a 2 x 1 periodic process grid (W and E neighbour are the same
+    rank, S and N the rank itself), and comm_peer_init's all-gather when one rank cannot export its mailbox"""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    from tenstream_amd import _lib, hostcomm
+    from tenstream_amd.solver import DiffuseSolver
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class Fake:
+            nranks = world
+            h = None
+
+            def comm_set_callbacks(self, exchange, allreduce):
+                self.exchange, self.allreduce = exchange, allreduce
+
+        f = Fake()
+        hostcomm.attach(f, rank, group=dist.new_group(backend="gloo") if use_group else None)
+        other = 1 - rank
+        peers = [other, other, rank, rank]
+        send = [np.full(5 + q, 100.0 * rank + q) for q in range(2)] + [np.full(3, 100.0 * rank + q) for q in (2, 3)]
+        recv = [np.zeros(6), np.zeros(5), np.zeros(3), np.zeros(3)]   # recv[W] <- peer's send[E] (6 long), recv[E] <- peer's send[W]
+        f.exchange(send, recv, peers)
+        ok = (np.all(recv[0] == 100.0 * other + 1) and np.all(recv[1] == 100.0 * other + 0) and np.all(recv[2] == 100.0 * rank + 3)
+              and np.all(recv[3] == 100.0 * rank + 2))
+        v = np.array([1.0 + rank, 10.0])
+        f.allreduce(v)
+        ok = ok and v[0] == 3.0 and v[1] == 20.0
+
+        # comm_peer_init: rank 1's export fails; both ranks must leave the all-gather, and both must refuse the transport
+        class FakeLib:
+            def tsx_comm_peer_export(self, h, buf):
+                if rank == 1:
+                    return 7
+                C.memset(buf, 0x5A, _lib.PEER_BLOB_BYTES)
+                return 0
+
+            def tsx_comm_peer_attach(self, h, blobs):
+                raise AssertionError("attach must not be reached")
+
+        f.lib = FakeLib()
+
+        def allgather(blob):
+            out = [None] * world
+            dist.all_gather_object(out, blob)
+            return out
+
+        try:
+            DiffuseSolver.comm_peer_init(f, allgather)
+            ok = False
+        except (_lib.TsxError, RuntimeError) as e:
+            ok = ok and isinstance(e, _lib.TsxError if rank == 1 else RuntimeError)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_group", [False, True])
+def test_hostcomm_callbacks_and_peer_bootstrap_failure(use_group):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        ret = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_hostcomm_worker, args=(r, 2, port, use_group, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=240)
+        for p in procs:
+            assert p.exitcode == 0
+        assert dict(ret) == {0: True, 1: True}, dict(ret)
