@@ -236,7 +236,7 @@ static int create_fill(tsx_solver *s, const tsx_grid *grid) {
   HIPCHK(hipEventCreateWithFlags(&s->ev_recv, hipEventDisableTiming));
   {
     const char *e = getenv("TSX_OVERLAP");
-    s->overlap = e ? atoi(e) != 0 : true;
+    s->overlap_env = e ? (atoi(e) != 0 ? 1 : 0) : -1;
   }
 
   const size_t nb = (size_t)g.N * sizeof(double);

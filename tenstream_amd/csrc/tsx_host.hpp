@@ -56,7 +56,19 @@ static inline long long frame_groups(const TsxGeo &g, int cpt) {
   const int ex = g.wrap_x ? 0 : (gx >= 2 ? 2 : 1);
   return (long long)g.Nz * (nfull * gx + (g.ym - nfull) * ex);
 }
-static inline bool spmv_split(const tsx_solver *s) { return s->overlap && !(s->geo.wrap_x && s->geo.wrap_y); }
+// Interior / frame split around an exchange (the operator's and the passes'), the exchange on comm_stream between two events.
+// TSX_OVERLAP=0|1 decides; unset: only where an exchange is a library call or a host round trip (RCCL, the callbacks).  With
+// the peer transport, and with self neighbours (device copies), an exchange is a few microseconds of kernels on the solver
+// stream, and the split -- a second launch with the pass's latency floor plus two cross-stream event waits -- costs more than
+// it hides at every size (scripts/shard_study.py, one rank with itself as its four neighbours: 128 x 64 columns 15.1 -> 7.1 ms
+// per solve, 128 x 256 24.5 -> 11.6, 256 x 256 30.6 -> 18.3, 512 x 512 82.2 -> 66.7 ms)
+bool tsx_peer_ready(const tsx_solver *s);  // tsx_peer.hip
+static inline bool tsx_overlap(const tsx_solver *s) {
+  if (s->overlap_env >= 0) return s->overlap_env != 0;
+  if (tsx_peer_ready(s)) return false;
+  return s->xchg_cb != nullptr || s->comm_ready;
+}
+static inline bool spmv_split(const tsx_solver *s) { return tsx_overlap(s) && !(s->geo.wrap_x && s->geo.wrap_y); }
 
 static inline int spmv_nblocks(const tsx_solver *s) {
   const int cpt = spmv_cpt(s);

@@ -193,7 +193,7 @@ struct tsx_solver {
   hipStream_t comm_stream;   // face exchange runs here while the interior SpMV runs on `stream`
   hipEvent_t ev_pack, ev_recv;
   int max_lds;               // hipDeviceAttributeMaxSharedMemoryPerBlock
-  bool overlap;              // split SpMV into interior + frame launches around the exchange (TSX_OVERLAP=0 disables)
+  int overlap_env;           // TSX_OVERLAP: -1 unset, else 0 / 1 (tsx_overlap, tsx_host.hpp: interior + frame launches around an exchange)
 };
 
 void tsx_set_error(const std::string &msg);

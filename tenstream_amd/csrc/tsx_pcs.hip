@@ -396,7 +396,7 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
   // p + 1 already works on the columns that touch no rank face (part 1, queued *before* the possibly host-synchronous
   // exchange so that it runs underneath it); the columns on a face follow once the records have arrived (part 2).
   static const bool overlap_env = !(getenv("TSX_PC_OVERLAP") && atoi(getenv("TSX_PC_OVERLAP")) == 0);
-  const bool overlap = halo && overlap_env && s->overlap && s->comm_stream != nullptr;  // s->overlap: TSX_OVERLAP, as for the operator
+  const bool overlap = halo && overlap_env && tsx_overlap(s) && s->comm_stream != nullptr;  // tsx_overlap: as for the operator
   bool in_flight = false;  // an exchange has been packed and handed to comm_stream (ev_pack) but not issued yet
   for (int pass = 0; pass < P; ++pass) {
     const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
