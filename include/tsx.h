@@ -173,6 +173,13 @@ int tsx_comm_peer_attach(tsx_solver *s, const void *blobs);
  * tsx_comm_peer_disable on every rank: the solver then uses RCCL / the callbacks. */
 int tsx_comm_peer_selftest(tsx_solver *s, int rounds, double *failed);
 int tsx_comm_peer_disable(tsx_solver *s);
+/* The mailboxes are uncached memory, so by default the kernels order payload and sequence word with s_waitcnt and relaxed
+ * system-scope accesses only; heavy = 1 (or TSX_PEER_FENCES=1) puts full system-scope release / acquire fences around every
+ * flag (each writes back / invalidates the L2: several microseconds per exchange) -- for a platform where the self test fails
+ * without them.  tsx_comm_peer_reset returns the transport to its state after attach (counters, flags, recorded error) for a
+ * second self test; the caller puts a barrier over all ranks before and after it. */
+int tsx_comm_peer_set_fences(tsx_solver *s, int heavy);
+int tsx_comm_peer_reset(tsx_solver *s);
 
 /* Alternative transport: host-staged callbacks, for hosts whose communicator is MPI (TenStream's own
  * solver%comm) without GPU-aware transport, and for multi-process tests on one GPU.  The library copies the

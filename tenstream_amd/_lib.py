@@ -50,7 +50,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 # every symbol include/tsx.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
     "tsx_last_error", "tsx_version", "tsx_device_count", "tsx_abi_sizes", "tsx_create", "tsx_destroy", "tsx_default_ksp_opts",
-    "tsx_determine_ksp_tolerances", "tsx_set_stream", "tsx_comm_unique_id", "tsx_comm_init", "tsx_comm_set_callbacks", "tsx_comm_peer_export", "tsx_comm_peer_attach", "tsx_comm_peer_selftest", "tsx_comm_peer_disable",
+    "tsx_determine_ksp_tolerances", "tsx_set_stream", "tsx_comm_unique_id", "tsx_comm_init", "tsx_comm_set_callbacks", "tsx_comm_peer_export", "tsx_comm_peer_attach", "tsx_comm_peer_selftest", "tsx_comm_peer_disable", "tsx_comm_peer_set_fences", "tsx_comm_peer_reset",
     "tsx_diff_set_coeffs", "tsx_lut_set_diffuse", "tsx_lut_load_diffuse_mmap4", "tsx_diff_set_optprop",
     "tsx_diff_get_coeffs", "tsx_pprts_set_angles", "tsx_lut_set_direct", "tsx_lut_load_direct_mmap4", "tsx_pprts_set_optprop", "tsx_pprts_set_optical_properties", "tsx_pprts_solve",
     "tsx_pprts_zero_guess", "tsx_pprts_get_result", "tsx_pprts_get_field", "tsx_diff_apply", "tsx_diff_solve", "tsx_diff_pc_apply", "tsx_bench_kernel", "tsx_algorithmic_bytes",
@@ -88,6 +88,8 @@ def load():
     lib.tsx_comm_peer_attach.argtypes = [vp, vp]
     lib.tsx_comm_peer_selftest.argtypes = [vp, ip, dp]
     lib.tsx_comm_peer_disable.argtypes = [vp]
+    lib.tsx_comm_peer_set_fences.argtypes = [vp, ip]
+    lib.tsx_comm_peer_reset.argtypes = [vp]
     lib.tsx_diff_set_coeffs.argtypes = [vp, vp, ip, vp, vp, vp, vp, ip]
     lib.tsx_lut_set_diffuse.argtypes = [vp, vp, C.c_int32, C.c_int64, C.c_int32, vp, vp, ip]
     lib.tsx_lut_load_diffuse_mmap4.argtypes = [vp, C.c_char_p]

@@ -70,6 +70,31 @@ struct TsxSolSlot {  // one stored solution (initial guess of the next solve wit
 
 struct TsxPeer;  // tsx_peer.hip
 
+// peer transport (tsx_peer_dev.hpp): what a kernel needs to consume a face message in place -- the sequence number that
+// announces it, per face W, E, S, N
+struct TsxPeerWait {
+  char *mine;                   // my mailbox; null: no peer transport, nothing to wait for
+  unsigned long long want[4];   // 0: face inactive
+  unsigned long long ticks;     // bound of the wait (100 MHz wall clock)
+  int heavy;                    // full system-scope fences (tsx_peer_dev.hpp)
+};
+
+// one exchange as its kernels see it (faces W, E, S, N)
+struct TsxPeerXArgs {
+  char *mine;                   // my mailbox
+  char *remote[4];              // mailbox of the neighbour behind face q
+  const char *src[4];           // send: the caller's send buffers;  recv: unused
+  char *dst[4];                 // recv: the caller's receive buffers
+  unsigned long long bytes[4];  // payload per face (0: face inactive)
+  unsigned long long n[4];      // sequence number of this message per face
+  unsigned long long ackn[4];   // send: messages received through face q by kernels that precede this one on the stream
+  unsigned long long rn[4];     // kernels that send AND receive (tsx_k_pcs_halo_xchg): number of the message to receive
+  unsigned long long cap, data_off, ticks;
+  unsigned int *blkctr;         // [4] workgroups that have finished their slice (local memory)
+  int heavy;                    // 1: system-scope release / acquire fences around the flags (TSX_PEER_FENCES=1), see below
+  const int *done;              // unused (the sequence numbers must stay in step whatever the convergence flag says)
+};
+
 struct tsx_solver {
   tsx_grid grid;
   TsxGeo geo;
@@ -112,6 +137,12 @@ struct tsx_solver {
   int *dd_cidx_split;      // [Nc] colour-split order (the preconditioner's)
   int *dd_ent_cell;        // [dd_nent] representative cell of every entry
   unsigned *pch_send[4], *pch_recv[4];  // preconditioner halo (bf16-pair records of the boundary columns), W E S N
+  // peer transport: the next pass reads the records in place, from these mailbox slots, after waiting for pch_wait (tsx_pcs.hip)
+  bool pch_inplace;
+  const void *pch_slot[4];
+  TsxPeerWait pch_wait;
+  bool pch_snd_on;           // ... and the pass about to be launched stores its boundary records into the neighbours' mailboxes itself
+  TsxPeerXArgs pch_snd;
   // several ranks: whether EVERY rank runs the scan red-black passes with the halo exchange (tsx_pc_global_agree); the
   // exchange is a matched send/recv with the neighbours, so it is on everywhere or nowhere.  pcg_key = the settings the
   // answer was agreed for (-1: not yet)

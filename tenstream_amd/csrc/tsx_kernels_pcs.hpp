@@ -33,6 +33,7 @@
 // direction instead of one per stream.
 #pragma once
 #include "tsx_pack.hpp"
+#include "tsx_peer_dev.hpp"
 
 // ---- matrix-only part: one lane per column, once per coefficient set
 template <typename CT>
@@ -240,9 +241,13 @@ __device__ __forceinline__ unsigned tsx_bf16x2(float lo, float hi) {
 // neighbour consumes are packed per face (tsx_k_pcs_halo_pack), exchanged like the operator's halo
 // (exchange_diffuse_boundary's pattern, src/pprts_explicit.F90:769-843) and read by the next pass at the rank faces --
 // without it the preconditioner would drop those couplings (block-Jacobi over ranks like the reference's PCBJACOBI) and need
-// 20-40 % more iterations.  Buffers: bf16-pair records [k][j] (W / E faces) and [k][i] (S / N faces); null = no exchange.
+// 20-40 % more iterations.  Buffers: bf16-pair records [j][k] (W / E faces) and [i][k] (S / N faces); null = no exchange.
+// message layout: one run of nzp = Nz rounded up to 4 words per boundary column, [j][k] (W / E faces) resp. [i][k] (S / N): a
+// thread's consecutive levels are consecutive words (16-byte stores / adjacent loads when the mailbox is accessed in place)
+__host__ __device__ __forceinline__ int tsx_pcs_halo_nzp(int Nz) { return (Nz + 3) & ~3; }
 struct TsxPcHalo {
   const unsigned *W, *E, *S, *N;
+  TsxPeerWait wait;  // peer transport (wait.mine != null): W .. N are mailbox slots, valid once the neighbour has published them
 };
 // my W face sends rec 0 (the -x streams of my columns i = 0: the west rank's E input), E face rec 1 of i = xm-1, S face rec 2
 // of j = 0, N face rec 3 of j = ym-1; zb: bf16 records, or zr (float2 records of the fp32 pass) when from_f32
@@ -254,7 +259,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_pack(TsxGeo g, const
   if (done && *done) return;
   const int xm = g.xm, ym = g.ym, Nz = g.Nz;
   const long long Nc = g.Nc;
-  const long long nx = g.wrap_x ? 0 : (long long)Nz * ym, ny = g.wrap_y ? 0 : (long long)Nz * xm;
+  const int nzp = tsx_pcs_halo_nzp(Nz);
+  const long long nx = g.wrap_x ? 0 : (long long)nzp * ym, ny = g.wrap_y ? 0 : (long long)nzp * xm;
   auto rec = [&](int m, int k, int i, int j) {
     const size_t idx = (size_t)m * Nc + (size_t)k * g.ncol + tsx_split_col(i, j, xm);
     if (!from_f32) return zb[idx];
@@ -263,16 +269,103 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_pack(TsxGeo g, const
   };
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < nx + ny; q += (long long)gridDim.x * TSX_BLOCK) {
     if (q < nx) {
-      const int j = (int)(q % ym), k = (int)(q / ym);
-      sW[q] = rec(0, k, 0, j);
-      sE[q] = rec(1, k, xm - 1, j);
+      const int k = (int)(q % nzp), j = (int)(q / nzp);
+      sW[q] = k < Nz ? rec(0, k, 0, j) : 0u;
+      sE[q] = k < Nz ? rec(1, k, xm - 1, j) : 0u;
     } else {
       const long long p = q - nx;
-      const int i = (int)(p % xm), k = (int)(p / xm);
-      sS[p] = rec(2, k, i, 0);
-      sN[p] = rec(3, k, i, ym - 1);
+      const int k = (int)(p % nzp), i = (int)(p / nzp);
+      sS[p] = k < Nz ? rec(2, k, i, 0) : 0u;
+      sN[p] = k < Nz ? rec(3, k, i, ym - 1) : 0u;
     }
   }
+}
+
+// The same records stored straight into the neighbours' mailboxes (peer transport, tsx_peer_dev.hpp): pack and send in one
+// kernel.  My W-face records are the west rank's E input: they land in its slot of face E (q ^ 1), and so on.
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_send(TsxGeo g, const unsigned *__restrict__ zb,
+                                                                 const float2 *__restrict__ zr, int from_f32, TsxPeerXArgs a) {
+  if (!tsx_peer_send_begin(a)) return;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  const long long Nc = g.Nc;
+  const int nzp = tsx_pcs_halo_nzp(Nz);
+  const long long nx = a.bytes[0] ? (long long)nzp * ym : 0, ny = a.bytes[2] ? (long long)nzp * xm : 0;
+  unsigned *sW = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[0], a.data_off, a.cap, 1, (int)(a.n[0] & 1)));
+  unsigned *sE = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[1], a.data_off, a.cap, 0, (int)(a.n[1] & 1)));
+  unsigned *sS = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[2], a.data_off, a.cap, 3, (int)(a.n[2] & 1)));
+  unsigned *sN = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[3], a.data_off, a.cap, 2, (int)(a.n[3] & 1)));
+  auto rec = [&](int m, int k, int i, int j) {
+    const size_t idx = (size_t)m * Nc + (size_t)k * g.ncol + tsx_split_col(i, j, xm);
+    if (!from_f32) return zb[idx];
+    const float2 v = zr[idx];
+    return (unsigned)tsx_to_bf16(v.x) | ((unsigned)tsx_to_bf16(v.y) << 16);
+  };
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < nx + ny; q += (long long)gridDim.x * TSX_BLOCK) {
+    if (q < nx) {
+      const int k = (int)(q % nzp), j = (int)(q / nzp);
+      sW[q] = k < Nz ? rec(0, k, 0, j) : 0u;
+      sE[q] = k < Nz ? rec(1, k, xm - 1, j) : 0u;
+    } else {
+      const long long p = q - nx;
+      const int k = (int)(p % nzp), i = (int)(p / nzp);
+      sS[p] = k < Nz ? rec(2, k, i, 0) : 0u;
+      sN[p] = k < Nz ? rec(3, k, i, ym - 1) : 0u;
+    }
+  }
+  tsx_peer_send_end(a, a.blkctr, gridDim.x);
+}
+// ... and the whole exchange in one kernel: workgroups [0, nsend) pack and send as above, the others receive -- wait for the
+// neighbour's sequence number, stream the message out of the (uncached) mailbox slot into the pass's cached receive buffer
+// a.dst[q], nrb workgroups per face.  All of them are resident together (a few dozen workgroups), so the receivers can spin
+// while the senders of this very kernel (one rank along a periodic axis) or of the neighbours' kernels deliver.  The
+// acknowledgement travels with the next send (ackn).
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_xchg(TsxGeo g, const unsigned *__restrict__ zb,
+                                                                 const float2 *__restrict__ zr, int from_f32, TsxPeerXArgs a,
+                                                                 int nsend, int nrb) {
+  if ((int)blockIdx.x >= nsend) {
+    const int rbk = (int)blockIdx.x - nsend, q = rbk / nrb, part = rbk - q * nrb;
+    if (!a.bytes[q]) return;
+    if (threadIdx.x == 0) {
+      unsigned long long have = 0;
+      if (!tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(a.mine)->seq[q], a.rn[q], a.ticks, &have, a.heavy))
+        tsx_peer_fail(a.mine, 2, q, a.rn[q], have);
+    }
+    __syncthreads();
+    const uint4 *src = reinterpret_cast<const uint4 *>(tsx_peer_data(a.mine, a.data_off, a.cap, q, (int)(a.rn[q] & 1)));
+    uint4 *dst = reinterpret_cast<uint4 *>(a.dst[q]);
+    const unsigned long long n16 = (a.bytes[q] + 15) >> 4;  // the slots and the receive buffers are padded to 256 / 8 bytes
+    for (unsigned long long i = (unsigned long long)part * TSX_BLOCK + threadIdx.x; i < n16; i += (unsigned long long)nrb * TSX_BLOCK)
+      dst[i] = src[i];
+    return;
+  }
+  if (!tsx_peer_send_begin(a)) return;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
+  const long long Nc = g.Nc;
+  const int nzp = tsx_pcs_halo_nzp(Nz);
+  const long long nx = a.bytes[0] ? (long long)nzp * ym : 0, ny = a.bytes[2] ? (long long)nzp * xm : 0;
+  unsigned *sW = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[0], a.data_off, a.cap, 1, (int)(a.n[0] & 1)));
+  unsigned *sE = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[1], a.data_off, a.cap, 0, (int)(a.n[1] & 1)));
+  unsigned *sS = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[2], a.data_off, a.cap, 3, (int)(a.n[2] & 1)));
+  unsigned *sN = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[3], a.data_off, a.cap, 2, (int)(a.n[3] & 1)));
+  auto rec = [&](int m, int k, int i, int j) {
+    const size_t idx = (size_t)m * Nc + (size_t)k * g.ncol + tsx_split_col(i, j, xm);
+    if (!from_f32) return zb[idx];
+    const float2 v = zr[idx];
+    return (unsigned)tsx_to_bf16(v.x) | ((unsigned)tsx_to_bf16(v.y) << 16);
+  };
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < nx + ny; q += (long long)nsend * TSX_BLOCK) {
+    if (q < nx) {
+      const int k = (int)(q % nzp), j = (int)(q / nzp);
+      sW[q] = k < Nz ? rec(0, k, 0, j) : 0u;
+      sE[q] = k < Nz ? rec(1, k, xm - 1, j) : 0u;
+    } else {
+      const long long p = q - nx;
+      const int k = (int)(p % nzp), i = (int)(p / nzp);
+      sS[p] = k < Nz ? rec(2, k, i, 0) : 0u;
+      sN[p] = k < Nz ? rec(3, k, i, ym - 1) : 0u;
+    }
+  }
+  tsx_peer_send_end(a, a.blkctr, (unsigned)nsend);
 }
 
 // ---- parts of a pass on several ranks (overlap of the boundary-record exchange with the pass, tsx_pcs_apply):
@@ -310,14 +403,18 @@ __device__ __forceinline__ bool tsx_pcs_on_frame(const TsxGeo &g, int jrow, int 
 // 40 B.  RQ 1: the colour's first visit reads fp32 and leaves those words; RQ 2: reads them; RQ 0: fp32 only.  (Measured:
 // rounding the intermediate passes' right-hand side to bf16 changes no iteration count, 8 / 13 at rtol 1e-5 / 1e-8.)
 // C16: the side -> top couplings (record 1) are two fp16 records (tsx_k_pcs_pack_rec1h / tsx_k_pcs_pack_ent16).
-template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false, int RQ = 0, bool C16 = false>
-__global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *__restrict__ P, const float *__restrict__ r,
+// PEER (MODE 0 / 1, peer transport): the columns on a rank face store the records their neighbour rank consumes straight into
+// that rank's mailbox slot (what tsx_k_pcs_halo_pack + tsx_k_peer_send would do after the pass), the workgroup that finishes
+// last publishes the sequence numbers -- an exchange without a kernel of its own (tsx_peer_dev.hpp; snd: this pass's messages).
+template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false, int RQ = 0, bool C16 = false, bool PEER = false>
+__global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) void tsx_k_pcs_rb(TsxGeo g, const uint4 *__restrict__ P, const float *__restrict__ r,
                                                          float *__restrict__ z, unsigned *__restrict__ zb,
                                                          float *__restrict__ zfin, const int *__restrict__ done, int rbc,
                                                          int nonbr, const int *__restrict__ cidx, long long nent,
                                                          const uint4 *__restrict__ PE, TsxPcHalo hal,
                                                          unsigned *__restrict__ rb, int part, const int *__restrict__ pidx,
-                                                         const uint4 *__restrict__ PT) {
+                                                         const uint4 *__restrict__ PT, TsxPeerXArgs snd) {
+  static_assert(!PEER || MODE != 2, "the last pass sends nothing");
   // pidx != null (intermediate passes with shared blocks): the cell's record 0 (with its block index) is entry pidx[cell] of
   // the table PT of distinct records (tsx_records_share)
   static_assert(RQ == 0 || MODE == 0, "bf16 right-hand side only in the intermediate passes");
@@ -373,6 +470,22 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
   // neighbour records of one level: [E (dofs 2,4), W (3,5), N (6,8), S (7,9)]
   // rank faces: the neighbour's records come from the exchanged buffers (bf16 pairs), [k][j] resp. [k][i]
   const bool face[4] = {hal.E && !nonbr && qe < 0, hal.W && !nonbr && qw < 0, hal.N && !nonbr && jn < 0, hal.S && !nonbr && js < 0};
+  if (!PEER && GS && hal.wait.mine) tsx_peer_wait_faces(hal.wait, face[1], face[0], face[3], face[2]);  // the records are read in place
+  // PEER: which faces this column sends through (bits W, E, S, N); the slots must be free before the first store.  Only the
+  // mask stays live (the kernel sits at the register count that allows four waves per SIMD)
+  int sendmask = 0;
+  if constexpr (PEER) {
+    if (live) sendmask = (snd.bytes[0] && icol == 0 ? 1 : 0) | (snd.bytes[1] && icol == g.xm - 1 ? 2 : 0) |
+                         (snd.bytes[2] && jrow == 0 ? 4 : 0) | (snd.bytes[3] && jrow == g.ym - 1 ? 8 : 0);
+    TsxPeerWait w = hal.wait;
+    if (!GS) w.mine = nullptr;
+    tsx_peer_begin_both(w, face[0] || face[1] || face[2] || face[3], true, snd, sendmask != 0);
+  }
+  // word of level k in the run of this column in the slot of face f (my W records land in the west rank's slot of face E ...)
+  auto send_word = [&](int f, int k, unsigned w) {
+    unsigned *base = reinterpret_cast<unsigned *>(tsx_peer_data(snd.remote[f], snd.data_off, snd.cap, f ^ 1, (int)(snd.n[f] & 1)));
+    base[(size_t)(f < 2 ? jrow : icol) * tsx_pcs_halo_nzp(Nz) + k] = w;
+  };
   auto nbr_load = [&](size_t c, uint2 (&o)[4]) {
     const long long off[4] = {offE, offW, offN, offS};
     const unsigned *hp[4] = {hal.E, hal.W, hal.N, hal.S};
@@ -380,7 +493,7 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const size_t idx = (size_t)m * Nc + c + off[m];
-      const size_t hidx = m < 2 ? (size_t)k * g.ym + jrow : (size_t)k * g.xm + icol;
+      const size_t hidx = (size_t)(m < 2 ? jrow : icol) * tsx_pcs_halo_nzp(Nz) + k;  // [j][k] resp. [i][k]
       if (MODE == 2) {
         o[m] = *reinterpret_cast<const uint2 *>(zr + idx);
         const unsigned hv = *(face[m] ? hp[m] + hidx : zb);  // unconditional load from a valid address, then select
@@ -632,6 +745,31 @@ __global__ __launch_bounds__(CW *NSEG) void tsx_k_pcs_rb(TsxGeo g, const uint4 *
     }
     V = Vn;
   }
+  if constexpr (PEER) {
+    // the columns on a rank face: the records just stored (rec 0 of i = 0 westwards, 1 of i = xm - 1, 2 of j = 0, 3 of j = ym - 1,
+    // like tsx_k_pcs_halo_pack) go into the neighbours' slots.  Re-read here, after the scan, where few registers are live: the
+    // stores inside the level loop cost 35 registers = a wave per SIMD (163 against 128 VGPRs)
+    if (sendmask) {
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) {
+        if (l >= nl) continue;
+        const size_t c = cell(l);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          if (!(sendmask & (1 << f))) continue;
+          unsigned w;
+          if (MODE == 0) {
+            w = zb[(size_t)f * Nc + c];
+          } else {
+            const float2 v = zr[(size_t)f * Nc + c];
+            w = tsx_bf16x2(v.x, v.y);
+          }
+          send_word(f, k0 + l, w);
+        }
+      }
+    }
+    tsx_peer_send_end(snd, snd.blkctr, gridDim.x);
+  }
 }
 
 // =====================================================================================================================
@@ -873,6 +1011,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   };
   // rank faces: the neighbour's records come from the exchanged buffers (bf16 pairs), [k][j] resp. [k][i]
   const bool face[4] = {hal.E && !nonbr && qe < 0, hal.W && !nonbr && qw < 0, hal.N && !nonbr && jn < 0, hal.S && !nonbr && js < 0};
+  if (GS && hal.wait.mine) tsx_peer_wait_faces(hal.wait, face[1], face[0], face[3], face[2]);  // the records are read in place
   auto nbr_load = [&](size_t c, uint2(&o)[4]) {
     const long long off[4] = {offE, offW, offN, offS};
     const unsigned *hp[4] = {hal.E, hal.W, hal.N, hal.S};
@@ -880,7 +1019,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const size_t idx = (size_t)m * Nc + c + off[m];
-      const size_t hidx = m < 2 ? (size_t)k * g.ym + jrow : (size_t)k * g.xm + icol;
+      const size_t hidx = (size_t)(m < 2 ? jrow : icol) * tsx_pcs_halo_nzp(Nz) + k;  // [j][k] resp. [i][k]
       if (MODE == 2) {
         o[m] = *reinterpret_cast<const uint2 *>(zr + idx);
         const unsigned hv = *(face[m] ? hp[m] + hidx : zb);  // unconditional load from a valid address, then select

@@ -1,7 +1,10 @@
 // tsx_pcs.hip -- host side of the segmented-scan red-black preconditioner (kernels: tsx_kernels_pcs.hpp)
 #include <stdio.h>
+#include <string.h>
 
 #include "tsx_host.hpp"
+#include "tsx_peer.hpp"
+#include "tsx_peer_dev.hpp"
 #include "tsx_kernels_pcs.hpp"
 
 struct PcsCfg {
@@ -149,6 +152,19 @@ int tsx_pcs_pack(tsx_solver *s) {
   return TSX_OK;
 }
 
+static int pcs_inplace_env() {
+  // TSX_PEER_INPLACE: 0 pack + tsx_k_peer_send + tsx_k_peer_recv like any exchange; 1 fused pack + send, the next pass reads in
+  // place; 2 only the fused pack + send; 3 only the in-place consumer; 4 one kernel packs, sends and receives; 5 (default) the
+  // pass stores its boundary records into the neighbours' mailboxes itself and the next pass reads them in place
+  static const int v = getenv("TSX_PEER_INPLACE") ? atoi(getenv("TSX_PEER_INPLACE")) : 5;
+  return v;
+}
+static bool pcs_peer_inkernel(const tsx_solver *s) {
+  if (pcs_inplace_env() != 5 || !tsx_peer_ready(s) || s->geo.ntop != 2) return false;
+  const PcsCfg c = pcs_config(s);
+  return c.lseg == 4 && c.nseg == 16 && (c.cw == 16 || c.cw == 32);
+}
+
 // ---- preconditioner halo on several ranks (tsx_k_pcs_halo_pack): on when some face of the rank is a real neighbour
 // (or force_halo), both local extents are even and TSX_PC_HALO != 0 -- on EVERY rank.  The exchange is a matched send / recv
 // with the four neighbours, so one rank deciding differently (an odd local extent from an uneven split such as
@@ -181,12 +197,12 @@ int tsx_pc_global_agree(tsx_solver *s) {
 }
 static size_t pcs_halo_doubles(const tsx_solver *s, int q) {  // message length in doubles (the exchange's unit), rounded up
   const TsxGeo &g = s->geo;
-  const size_t n = (size_t)g.Nz * (q < 2 ? g.ym : g.xm);
+  const size_t n = (size_t)tsx_pcs_halo_nzp(g.Nz) * (q < 2 ? g.ym : g.xm);
   return (n + 1) / 2;
 }
 static int pcs_halo_buffers(tsx_solver *s) {
   for (int q = 0; q < 4; ++q) {
-    const size_t bytes = pcs_halo_doubles(s, q) * sizeof(double);
+    const size_t bytes = (pcs_halo_doubles(s, q) * sizeof(double) + 15) & ~(size_t)15;  // tsx_k_pcs_halo_xchg copies 16-byte pieces
     if (!s->pch_send[q]) {
       HIPCHK(hipMalloc((void **)&s->pch_send[q], bytes));
       HIPCHK(hipMemsetAsync(s->pch_send[q], 0, bytes, s->stream));
@@ -199,9 +215,18 @@ static int pcs_halo_buffers(tsx_solver *s) {
   return TSX_OK;
 }
 static TsxPcHalo pcs_halo_arg(const tsx_solver *s) {
-  TsxPcHalo h = {nullptr, nullptr, nullptr, nullptr};
+  TsxPcHalo h;
+  memset((void *)&h, 0, sizeof(h));
   if (!pcs_halo_on(s) || !s->pch_recv[0]) return h;
   const TsxGeo &g = s->geo;
+  if (s->pch_inplace && tsx_peer_ready(s)) {  // the pass reads the neighbours' records where they land (pcs_halo_exchange)
+    h.W = (const unsigned *)s->pch_slot[0];
+    h.E = (const unsigned *)s->pch_slot[1];
+    h.S = (const unsigned *)s->pch_slot[2];
+    h.N = (const unsigned *)s->pch_slot[3];
+    h.wait = s->pch_wait;
+    return h;
+  }
   if (!g.wrap_x) {
     h.W = s->pch_recv[0];
     h.E = s->pch_recv[1];
@@ -224,7 +249,57 @@ static int pcs_halo_exchange(tsx_solver *s, bool from_f32, const int *done, bool
   float *zs = (float *)s->vw;
   const unsigned *zb = (const unsigned *)(zs + (size_t)g.N);
   const float2 *zr = reinterpret_cast<const float2 *>(zs + (size_t)g.ntop * g.Nc);
-  const long long n = (g.wrap_x ? 0 : (long long)g.Nz * g.ym) + (g.wrap_y ? 0 : (long long)g.Nz * g.xm);
+  const int nzp = tsx_pcs_halo_nzp(g.Nz);
+  const long long n = (g.wrap_x ? 0 : (long long)nzp * g.ym) + (g.wrap_y ? 0 : (long long)nzp * g.xm);
+  // Peer transport: ONE kernel packs the boundary records straight into the neighbours' mailboxes and publishes them; the next
+  // pass waits for its neighbours' sequence numbers itself and reads the records in place -- no send buffer, no receive kernel,
+  // no copy out (TSX_PEER_INPLACE=0: pack, tsx_k_peer_send, tsx_k_peer_recv as for any other exchange).  One rank with itself
+  // as its four neighbours, 128 x 64 columns (scripts/shard_study.py): 7.1 -> ... ms per solve
+  // TSX_PEER_INPLACE: 0 generic, 1 both, 2 only the fused pack + send, 3 only the in-place consumer
+  const int inplace_env = pcs_inplace_env() == 5 ? 1 : pcs_inplace_env();  // 5 where the pass cannot send itself (8_16 ...): 1
+  s->pch_inplace = false;
+  if (inplace_env && !overlap && tsx_peer_ready(s) && n > 0) {
+    const size_t bx = g.wrap_x ? 0 : (size_t)nzp * g.ym * sizeof(unsigned), by = g.wrap_y ? 0 : (size_t)nzp * g.xm * sizeof(unsigned);
+    const size_t bytes[4] = {bx, bx, by, by};
+    double *const send[4] = {(double *)s->pch_send[0], (double *)s->pch_send[1], (double *)s->pch_send[2], (double *)s->pch_send[3]};
+    double *const recv[4] = {(double *)s->pch_recv[0], (double *)s->pch_recv[1], (double *)s->pch_recv[2], (double *)s->pch_recv[3]};
+    int rc;
+    if (inplace_env == 4) {  // the whole exchange in one kernel; the pass reads the cached receive buffers as ever
+      TsxPeerXArgs a;
+      const void *slot[4];
+      TsxPeerWait w;
+      if ((rc = tsx_peer_prepare_send(s, bytes, &a))) return rc;
+      if ((rc = tsx_peer_expect(s, bytes, &w, slot))) return rc;
+      for (int q = 0; q < 4; ++q) {
+        a.rn[q] = w.want[q];
+        a.dst[q] = (char *)s->pch_recv[q];
+      }
+      int nsend = (int)((n + 4 * TSX_BLOCK - 1) / (4 * TSX_BLOCK));
+      nsend = nsend < 1 ? 1 : (nsend > 16 ? 16 : nsend);
+      const size_t maxb = bx > by ? bx : by;
+      const int nrb = maxb > 65536 ? 4 : (maxb > 16384 ? 2 : 1);
+      hipLaunchKernelGGL(tsx_k_pcs_halo_xchg, dim3(nsend + 4 * nrb), dim3(TSX_BLOCK), 0, s->stream, g, zb, zr, from_f32 ? 1 : 0, a,
+                         nsend, nrb);
+      HIPCHK(hipGetLastError());
+      return TSX_OK;
+    }
+    if (inplace_env != 3) {
+      TsxPeerXArgs a;
+      if ((rc = tsx_peer_prepare_send(s, bytes, &a))) return rc;
+      int nblk = (int)((n + 4 * TSX_BLOCK - 1) / (4 * TSX_BLOCK));
+      nblk = nblk < 1 ? 1 : (nblk > 16 ? 16 : nblk);
+      hipLaunchKernelGGL(tsx_k_pcs_halo_send, dim3(nblk), dim3(TSX_BLOCK), 0, s->stream, g, zb, zr, from_f32 ? 1 : 0, a);
+      HIPCHK(hipGetLastError());
+    } else {
+      hipLaunchKernelGGL(tsx_k_pcs_halo_pack, dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, zb, zr, from_f32 ? 1 : 0,
+                         s->pch_send[0], s->pch_send[1], s->pch_send[2], s->pch_send[3], done);
+      if ((rc = tsx_peer_exchange_part(s, s->stream, send, nullptr, pcs_halo_doubles(s, 0), pcs_halo_doubles(s, 2), nullptr, 1))) return rc;
+    }
+    if (inplace_env == 2) return tsx_peer_exchange_part(s, s->stream, nullptr, recv, pcs_halo_doubles(s, 0), pcs_halo_doubles(s, 2), nullptr, 2);
+    if ((rc = tsx_peer_expect(s, bytes, &s->pch_wait, s->pch_slot))) return rc;
+    s->pch_inplace = true;
+    return TSX_OK;
+  }
   hipLaunchKernelGGL(tsx_k_pcs_halo_pack, dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, zb, zr, from_f32 ? 1 : 0,
                      s->pch_send[0], s->pch_send[1], s->pch_send[2], s->pch_send[3], done);
   HIPCHK(hipGetLastError());
@@ -263,15 +338,29 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   const int *pidx = dd && s->pcr_on ? (const int *)s->pcr_idx : (const int *)nullptr;  // shared record 0 of the intermediate passes
   const uint4 *PT = (const uint4 *)s->pcr_tab;
   constexpr bool C16 = pcs_c16();
+  // the pass stores its boundary records into the neighbours' mailboxes itself (tsx_pcs_apply decided; kernels instantiated
+  // for the default configurations only, pcs_peer_kernel_ok)
+  constexpr bool PEEROK = L == 4 && S == 16 && (CW == 16 || CW == 32);
+  const bool peer = PEEROK && s->pch_snd_on && part == 0;
+  TsxPeerXArgs snd;
+  if (peer) snd = s->pch_snd;
+  else memset((void *)&snd, 0, sizeof(snd));
+#define TSX_PCS_GO1(GSV, MODEV, RQV, IDXV, PEERV)                                                                                \
+  hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, IDXV, RQV, C16, PEERV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r,  \
+                     zs, zb, zfin, done, rbc, nonbr, IDXV ? cidx : (const int *)nullptr, IDXV ? nent : 0ll,                      \
+                     IDXV ? PE : (const uint4 *)nullptr, hal, rb, part, IDXV ? pidx : (const int *)nullptr,                      \
+                     IDXV ? PT : (const uint4 *)nullptr, snd)
 #define TSX_PCS_GO(GSV, MODEV, RQV)                                                                                              \
   do {                                                                                                                           \
-    if (dd)                                                                                                                      \
-      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, true, RQV, C16>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs,  \
-                         zb, zfin, done, rbc, nonbr, cidx, nent, PE, hal, rb, part, pidx, PT);                                   \
-    else                                                                                                                         \
-      hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, false, RQV, C16>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r, zs, \
-                         zb, zfin, done, rbc, nonbr, (const int *)nullptr, 0ll, (const uint4 *)nullptr, hal, rb, part,           \
-                         (const int *)nullptr, (const uint4 *)nullptr);                                                          \
+    if constexpr (PEEROK && (MODEV) != 2) {                                                                                      \
+      if (peer) {                                                                                                                \
+        if (dd) TSX_PCS_GO1(GSV, MODEV, RQV, true, true);                                                                        \
+        else TSX_PCS_GO1(GSV, MODEV, RQV, false, true);                                                                          \
+        break;                                                                                                                   \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    if (dd) TSX_PCS_GO1(GSV, MODEV, RQV, true, false);                                                                           \
+    else TSX_PCS_GO1(GSV, MODEV, RQV, false, false);                                                                             \
   } while (0)
   if (!gs) {
     if (rq == 1) TSX_PCS_GO(false, 0, 1);
@@ -284,6 +373,7 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   } else if (mode == 1) TSX_PCS_GO(true, 1, 0);
   else TSX_PCS_GO(true, 2, 0);  // (the two fp32 passes on the bf16 words too: measured, no gain -- 14.41 vs 14.48 ms)
 #undef TSX_PCS_GO
+#undef TSX_PCS_GO1
 }
 
 template <int L, int S>
@@ -404,6 +494,22 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
     // one follows, the later ones read it
     const int rq = !rhs16 || mode != 0 ? 0 : (words_ready ? 2 : (pass >= 2 ? 2 : (pass + 2 < P - 2 ? 1 : 0)));
     int rc;
+    // peer transport, default configuration: the pass sends its boundary records itself (TSX_PEER_INPLACE=5, the default)
+    const bool xchg_after = halo && pass + 1 < P && pass % every == 0;
+    s->pch_snd_on = false;
+    if (xchg_after && !overlap && every == 1 && pcs_peer_inkernel(s)) {
+      const TsxGeo &g = s->geo;
+      const size_t nzp = (size_t)tsx_pcs_halo_nzp(g.Nz);
+      const size_t bx = g.wrap_x ? 0 : nzp * g.ym * sizeof(unsigned), by = g.wrap_y ? 0 : nzp * g.xm * sizeof(unsigned);
+      const size_t bytes[4] = {bx, bx, by, by};
+      if ((rc = tsx_peer_prepare_send(s, bytes, &s->pch_snd))) return rc;
+      s->pch_snd_on = true;
+      if ((rc = tsx_pcs_pass(s, pass, mode, z, done, rq, 0))) return rc;
+      s->pch_snd_on = false;
+      if ((rc = tsx_peer_expect(s, bytes, &s->pch_wait, s->pch_slot))) return rc;  // the next pass reads them in place
+      s->pch_inplace = true;
+      continue;
+    }
     if (in_flight) {
       if ((rc = tsx_pcs_pass(s, pass, mode, z, done, rq, 1))) return rc;  // interior, under the exchange
       if ((rc = pcs_halo_exchange_finish(s))) return rc;

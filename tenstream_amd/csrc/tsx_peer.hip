@@ -41,11 +41,12 @@
 
 #include "tsx_host.hpp"
 #include "tsx_peer.hpp"
+#include "tsx_peer_dev.hpp"
 
 namespace {
 
 constexpr int kMaxRanks = TSX_PEER_MAX_RANKS;
-constexpr size_t kHdrBytes = 4096;
+constexpr size_t kHdrBytes = TSX_PEER_HDR_BYTES;
 
 struct PeerArSlot {  // 64 bytes: one line per contribution
   double v[TSX_NSLOTS + 1];
@@ -54,13 +55,7 @@ struct PeerArSlot {  // 64 bytes: one line per contribution
 };
 static_assert(sizeof(PeerArSlot) == 64, "all-reduce slot is one 64-byte line");
 
-struct PeerHdr {
-  unsigned long long seq[4];
-  unsigned long long ack[4];
-  int error;  // 0 ok; 1 send timed out waiting for an acknowledgement, 2 recv timed out, 3 all-reduce timed out
-  int error_face;
-  unsigned long long error_want, error_have;
-};
+using PeerHdr = TsxPeerHdr;
 
 struct PeerBlob {  // what tsx_comm_peer_export hands to the host's all-gather (TSX_PEER_BLOB_BYTES)
   hipIpcMemHandle_t handle;
@@ -71,43 +66,12 @@ struct PeerBlob {  // what tsx_comm_peer_export hands to the host's all-gather (
 };
 static_assert(sizeof(PeerBlob) <= TSX_PEER_BLOB_BYTES, "blob size");
 
-__device__ __forceinline__ unsigned long long ld_acquire_sys(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ void st_release_sys(unsigned long long *p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// spin until *p >= want; false after `ticks` of the constant-rate wall clock
-__device__ __forceinline__ bool wait_ge(const unsigned long long *p, unsigned long long want, unsigned long long ticks,
-                                        unsigned long long *have) {
-  const unsigned long long t0 = wall_clock64();
-  for (;;) {
-    const unsigned long long v = ld_acquire_sys(p);
-    if (v >= want) return true;
-    if (wall_clock64() - t0 > ticks) {
-      *have = v;
-      return false;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-}
+using PeerXArgs = TsxPeerXArgs;
+#define ld_acquire_sys tsx_peer_ld_acquire
+#define st_release_sys tsx_peer_st_release
+#define wait_ge tsx_peer_wait_ge
+#define peer_data tsx_peer_data
 
-struct PeerXArgs {
-  char *mine;                 // my mailbox
-  char *remote[4];            // mailbox of the neighbour behind face q (W, E, S, N)
-  const char *src[4];         // send: the caller's send buffers;  recv: unused
-  char *dst[4];               // recv: the caller's receive buffers
-  unsigned long long bytes[4];  // payload per face (0: face inactive)
-  unsigned long long n[4];    // sequence number of this message per face
-  unsigned long long cap, data_off, ticks;
-  unsigned int *blkctr;       // [4] workgroups that have finished their slice (local memory)
-  const int *done;            // the solver's convergence flag (nullable): the exchange is skipped once it is set ... on
-                              // every rank alike (the flag follows all-reduced scalars)
-};
-
-__device__ __forceinline__ char *peer_data(char *box, unsigned long long data_off, unsigned long long cap, int face, int parity) {
-  return box + data_off + ((size_t)face * 2 + parity) * cap;
-}
 __device__ __forceinline__ void copy16(char *__restrict__ d, const char *__restrict__ s, unsigned long long bytes, int nblk) {
   // bytes is a multiple of 8 (doubles); 16-byte pieces, the odd double at the end by lane 0
   const unsigned long long n16 = bytes >> 4;
@@ -118,14 +82,7 @@ __device__ __forceinline__ void copy16(char *__restrict__ d, const char *__restr
   if ((bytes & 8) && blockIdx.x == 0 && threadIdx.x == 0)
     *reinterpret_cast<unsigned long long *>(d + (n16 << 4)) = *reinterpret_cast<const unsigned long long *>(s + (n16 << 4));
 }
-__device__ __forceinline__ void peer_fail(char *mine, int code, int face, unsigned long long want, unsigned long long have) {
-  PeerHdr *h = reinterpret_cast<PeerHdr *>(mine);
-  if (atomicCAS(&h->error, 0, code) == 0) {
-    h->error_face = face;
-    h->error_want = want;
-    h->error_have = have;
-  }
-}
+#define peer_fail tsx_peer_fail
 
 // grid (nblk, 4): blockIdx.y = face
 __global__ __launch_bounds__(256) void tsx_k_peer_send(PeerXArgs a) {
@@ -137,7 +94,10 @@ __global__ __launch_bounds__(256) void tsx_k_peer_send(PeerXArgs a) {
     const PeerHdr *h = reinterpret_cast<const PeerHdr *>(a.mine);
     unsigned long long have = 0;
     ok = 1;
-    if (a.n[q] > 2 && !wait_ge(&h->ack[q], a.n[q] - 2, a.ticks, &have)) {
+    // acknowledge what kernels before this one consumed in place (tsx_peer_expect): first, so that two ranks never wait for
+    // each other's acknowledgement
+    if (blockIdx.x == 0 && a.ackn[q]) tsx_peer_post(&reinterpret_cast<PeerHdr *>(a.remote[q])->ack[q ^ 1], a.ackn[q], a.heavy);
+    if (a.n[q] > 2 && !wait_ge(&h->ack[q], a.n[q] - 2, a.ticks, &have, a.heavy)) {
       ok = 0;
       peer_fail(a.mine, 1, q, a.n[q] - 2, have);
     }
@@ -145,14 +105,14 @@ __global__ __launch_bounds__(256) void tsx_k_peer_send(PeerXArgs a) {
   __syncthreads();
   if (!ok) return;
   copy16(peer_data(a.remote[q], a.data_off, a.cap, q ^ 1, (int)(a.n[q] & 1)), a.src[q], a.bytes[q], gridDim.x);
-  __threadfence_system();
+  tsx_peer_stores_done(a.heavy);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int prev = atomicAdd(&a.blkctr[q], 1u);
-    if (prev + 1 == gridDim.x) {  // every workgroup's stores are fenced: publish
+    if (prev + 1 == gridDim.x) {  // every workgroup's stores have reached memory: publish
       a.blkctr[q] = 0;
-      __threadfence_system();
-      st_release_sys(&reinterpret_cast<PeerHdr *>(a.remote[q])->seq[q ^ 1], a.n[q]);
+      if (a.heavy) __threadfence_system();
+      tsx_peer_post(&reinterpret_cast<PeerHdr *>(a.remote[q])->seq[q ^ 1], a.n[q], a.heavy);
     }
   }
 }
@@ -166,7 +126,7 @@ __global__ __launch_bounds__(256) void tsx_k_peer_recv(PeerXArgs a) {
     const PeerHdr *h = reinterpret_cast<const PeerHdr *>(a.mine);
     unsigned long long have = 0;
     ok = 1;
-    if (!wait_ge(&h->seq[q], a.n[q], a.ticks, &have)) {
+    if (!wait_ge(&h->seq[q], a.n[q], a.ticks, &have, a.heavy)) {
       ok = 0;
       peer_fail(a.mine, 2, q, a.n[q], have);
     }
@@ -175,12 +135,12 @@ __global__ __launch_bounds__(256) void tsx_k_peer_recv(PeerXArgs a) {
   if (!ok) return;
   copy16(a.dst[q], peer_data(a.mine, a.data_off, a.cap, q, (int)(a.n[q] & 1)), a.bytes[q], gridDim.x);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
+  if (threadIdx.x == 0) {  // every lane's loads from the slot have returned (their stores were issued before the barrier)
+    if (a.heavy) __threadfence();
     const unsigned int prev = atomicAdd(&a.blkctr[q], 1u);
     if (prev + 1 == gridDim.x) {
       a.blkctr[q] = 0;
-      st_release_sys(&reinterpret_cast<PeerHdr *>(a.remote[q])->ack[q ^ 1], a.n[q]);
+      tsx_peer_post(&reinterpret_cast<PeerHdr *>(a.remote[q])->ack[q ^ 1], a.n[q], a.heavy);
     }
   }
 }
@@ -188,7 +148,7 @@ __global__ __launch_bounds__(256) void tsx_k_peer_recv(PeerXArgs a) {
 struct PeerArArgs {
   char *mine;
   char *box[kMaxRanks];
-  int rank, nranks, nvals;
+  int rank, nranks, nvals, heavy;
   unsigned long long n, ar_off, ticks;
 };
 
@@ -203,11 +163,11 @@ __global__ __launch_bounds__(64) void tsx_k_peer_allreduce(PeerArArgs a, double 
   if (r < a.nranks) {
     PeerArSlot *slot = reinterpret_cast<PeerArSlot *>(a.box[r] + a.ar_off) + (size_t)par * kMaxRanks + a.rank;
     for (int k = 0; k < a.nvals; ++k) slot->v[k] = v[k];
-    __threadfence_system();
-    st_release_sys(&slot->seq, a.n);
+    tsx_peer_stores_done(a.heavy);
+    tsx_peer_post(&slot->seq, a.n, a.heavy);
     const PeerArSlot *in = reinterpret_cast<const PeerArSlot *>(a.mine + a.ar_off) + (size_t)par * kMaxRanks + r;
     unsigned long long have = 0;
-    if (!wait_ge(&in->seq, a.n, a.ticks, &have)) {
+    if (!wait_ge(&in->seq, a.n, a.ticks, &have, a.heavy)) {
       bad = 1;
       peer_fail(a.mine, 3, r, a.n, have);
     }
@@ -259,8 +219,9 @@ struct TsxPeer {
   char *box[kMaxRanks] = {nullptr};      // every rank's mailbox in this process's address space (box[rank] == mine)
   bool opened[kMaxRanks] = {false};      // mapped with hipIpcOpenMemHandle (to be closed)
   unsigned long long sent[4] = {0, 0, 0, 0}, rcvd[4] = {0, 0, 0, 0}, ar_n = 0;
-  unsigned int *blkctr = nullptr;        // [8]: send 0..3, recv 4..7
+  unsigned int *blkctr = nullptr;        // [16]: send 0..3, recv 4..7, producer kernels 8
   unsigned long long ticks = 0;
+  int heavy = 0;                         // TSX_PEER_FENCES / tsx_comm_peer_set_fences (tsx_peer_dev.hpp)
   bool attached = false;
 };
 
@@ -298,11 +259,12 @@ extern "C" int tsx_comm_peer_export(tsx_solver *s, void *blob) {
     }
     p->mine = (char *)m;
     HIPCHK(hipMemset(p->mine, 0, p->bytes));
-    HIPCHK(hipMalloc((void **)&p->blkctr, sizeof(unsigned int) * 8));
-    HIPCHK(hipMemset(p->blkctr, 0, sizeof(unsigned int) * 8));
+    HIPCHK(hipMalloc((void **)&p->blkctr, sizeof(unsigned int) * 16));
+    HIPCHK(hipMemset(p->blkctr, 0, sizeof(unsigned int) * 16));
     const char *to = getenv("TSX_PEER_TIMEOUT_S");
     const double sec = to ? atof(to) : 20.0;
     p->ticks = (unsigned long long)((sec > 0 ? sec : 20.0) * 1e8);  // wall_clock64: 100 MHz
+    p->heavy = getenv("TSX_PEER_FENCES") && atoi(getenv("TSX_PEER_FENCES")) != 0;
     HIPCHK(hipDeviceSynchronize());
     s->peer = p;
   }
@@ -406,6 +368,11 @@ int tsx_peer_check(tsx_solver *s) {
 
 int tsx_peer_exchange(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy,
                       const int *done) {
+  return tsx_peer_exchange_part(s, st, send, recv, cx, cy, done, 3);
+}
+// which: 1 = only the send kernel, 2 = only the receive kernel (the other half is a kernel that moves its messages itself)
+int tsx_peer_exchange_part(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy,
+                           const int *done, int which) {
   TsxPeer *p = s->peer;
   const TsxGeo &g = s->geo;
   const tsx_grid &gr = s->grid;
@@ -417,6 +384,7 @@ int tsx_peer_exchange(tsx_solver *s, hipStream_t st, double *const send[4], doub
   a.cap = p->cap;
   a.data_off = p->data_off;
   a.ticks = p->ticks;
+  a.heavy = p->heavy;
   a.done = done;
   size_t maxb = 0;
   for (int q = 0; q < 4; ++q) {
@@ -431,8 +399,8 @@ int tsx_peer_exchange(tsx_solver *s, hipStream_t st, double *const send[4], doub
       return TSX_ERR_ARG;
     }
     a.remote[q] = p->box[nb[q]];
-    a.src[q] = (const char *)send[q];
-    a.dst[q] = (char *)recv[q];
+    a.src[q] = send ? (const char *)send[q] : nullptr;
+    a.dst[q] = recv ? (char *)recv[q] : nullptr;
     maxb = a.bytes[q] > maxb ? a.bytes[q] : maxb;
   }
   if (maxb == 0) return TSX_OK;
@@ -440,18 +408,74 @@ int tsx_peer_exchange(tsx_solver *s, hipStream_t st, double *const send[4], doub
   // sides: an exchange skipped by `done` is skipped by both kernels of both ranks, and the host counts it nowhere -- but the
   // host cannot see `done`.  The counters therefore count ISSUED exchanges and the kernels of a skipped exchange still publish
   // their numbers: see below (done is honoured only for the payload copy).
-  for (int q = 0; q < 4; ++q)
-    if (a.bytes[q]) a.n[q] = ++p->sent[q];
   int nblk = (int)((maxb + 32767) / 32768);
   nblk = nblk < 1 ? 1 : (nblk > 8 ? 8 : nblk);
-  a.blkctr = p->blkctr;
   a.done = nullptr;  // see the comment above: sequence numbers must stay in step whatever `done` says
-  hipLaunchKernelGGL(tsx_k_peer_send, dim3(nblk, 4), dim3(256), 0, st, a);
-  for (int q = 0; q < 4; ++q)
-    if (a.bytes[q]) a.n[q] = ++p->rcvd[q];
-  a.blkctr = p->blkctr + 4;
-  hipLaunchKernelGGL(tsx_k_peer_recv, dim3(nblk, 4), dim3(256), 0, st, a);
+  if (which & 1) {
+    for (int q = 0; q < 4; ++q)
+      if (a.bytes[q]) {
+        a.ackn[q] = p->rcvd[q];
+        a.n[q] = ++p->sent[q];
+      }
+    a.blkctr = p->blkctr;
+    hipLaunchKernelGGL(tsx_k_peer_send, dim3(nblk, 4), dim3(256), 0, st, a);
+  }
+  if (which & 2) {
+    for (int q = 0; q < 4; ++q)
+      if (a.bytes[q]) a.n[q] = ++p->rcvd[q];
+    a.blkctr = p->blkctr + 4;
+    hipLaunchKernelGGL(tsx_k_peer_recv, dim3(nblk, 4), dim3(256), 0, st, a);
+  }
   HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+// ---- producers / consumers that move their messages themselves (tsx_peer_dev.hpp) -----------------------------------------
+// A producer kernel stores its face messages straight into the neighbours' mailboxes (tsx_peer_send_begin / _end in its body):
+// count them as sent and fill the kernel's view.  bytes[q]: payload through my face q (W, E, S, N; 0 = none).
+int tsx_peer_prepare_send(tsx_solver *s, const size_t bytes[4], TsxPeerXArgs *a) {
+  TsxPeer *p = s->peer;
+  const tsx_grid &gr = s->grid;
+  const int nb[4] = {gr.neigh_w, gr.neigh_e, gr.neigh_s, gr.neigh_n};
+  memset(a, 0, sizeof(*a));
+  a->mine = p->mine;
+  a->cap = p->cap;
+  a->data_off = p->data_off;
+  a->ticks = p->ticks;
+  a->heavy = p->heavy;
+  a->blkctr = p->blkctr + 8;
+  for (int q = 0; q < 4; ++q) {
+    if (!bytes[q]) continue;
+    if (bytes[q] > p->cap || nb[q] < 0 || nb[q] >= gr.nranks || !p->box[nb[q]]) {
+      tsx_set_error("peer send: message larger than the mailbox slots, or neighbour rank out of range");
+      return TSX_ERR_ARG;
+    }
+    a->bytes[q] = bytes[q];
+    a->remote[q] = p->box[nb[q]];
+    a->ackn[q] = p->rcvd[q];
+    a->n[q] = ++p->sent[q];
+  }
+  return TSX_OK;
+}
+// A consumer kernel reads its face messages in place (tsx_peer_wait_faces in its body): count them as received.  slot[q]: where
+// the message through my face q lands (null: none); w: what the kernel waits for.  The acknowledgement travels with this
+// rank's next send (ackn), which by stream order follows the consumer.
+int tsx_peer_expect(tsx_solver *s, const size_t bytes[4], TsxPeerWait *w, const void *slot[4]) {
+  TsxPeer *p = s->peer;
+  memset(w, 0, sizeof(*w));
+  w->mine = p->mine;
+  w->ticks = p->ticks;
+  w->heavy = p->heavy;
+  for (int q = 0; q < 4; ++q) {
+    slot[q] = nullptr;
+    if (!bytes[q]) continue;
+    if (bytes[q] > p->cap) {
+      tsx_set_error("peer receive: message larger than the mailbox slots");
+      return TSX_ERR_ARG;
+    }
+    w->want[q] = ++p->rcvd[q];
+    slot[q] = tsx_peer_data(p->mine, p->data_off, p->cap, q, (int)(w->want[q] & 1));
+  }
   return TSX_OK;
 }
 
@@ -469,6 +493,7 @@ int tsx_peer_allreduce(tsx_solver *s, hipStream_t st, double *v, int nvals, cons
   a.n = ++p->ar_n;
   a.ar_off = p->ar_off;
   a.ticks = p->ticks;
+  a.heavy = p->heavy;
   (void)done;  // as for the exchange: the sequence stays in step on every rank
   hipLaunchKernelGGL(tsx_k_peer_allreduce, dim3(1), dim3(64), 0, st, a, v, (const int *)nullptr);
   HIPCHK(hipGetLastError());
@@ -536,6 +561,31 @@ extern "C" int tsx_comm_peer_selftest(tsx_solver *s, int rounds, double *failed)
   unsigned long long hbad = 0;
   HIPCHK(hipMemcpy(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost));
   *failed = (double)hbad + wrong_sums;
+  return TSX_OK;
+}
+
+// Full system-scope fences around the flags (1) or the light ordering that uncached mailboxes allow (0, tsx_peer_dev.hpp).
+// Collective in effect: every rank must use the same setting only in so far as each wants correct data -- the two are
+// compatible on the wire.
+extern "C" int tsx_comm_peer_set_fences(tsx_solver *s, int heavy) {
+  ARGCHK(s && s->peer, "tsx_comm_peer_set_fences: no peer transport");
+  s->peer->heavy = heavy != 0;
+  return TSX_OK;
+}
+// Back to the state after attach: counters, flags and the recorded error cleared, on this rank's mailbox and host side.  For a
+// second self test after a failed one (whose expired waits leave the ranks' counters out of step).  The caller must put a host
+// barrier over all ranks BEFORE the call (nobody still sends) and AFTER it (nobody sends into a mailbox that is being cleared).
+extern "C" int tsx_comm_peer_reset(tsx_solver *s) {
+  ARGCHK(s && s->peer, "tsx_comm_peer_reset: no peer transport");
+  TsxPeer *p = s->peer;
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemset(p->mine, 0, p->data_off));
+  HIPCHK(hipMemset(p->blkctr, 0, sizeof(unsigned int) * 16));
+  HIPCHK(hipDeviceSynchronize());
+  for (int q = 0; q < 4; ++q) p->sent[q] = p->rcvd[q] = 0;
+  p->ar_n = 0;
+  s->pch_inplace = false;
   return TSX_OK;
 }
 

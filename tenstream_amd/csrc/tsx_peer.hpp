@@ -12,5 +12,13 @@ int tsx_peer_check(tsx_solver *s);  // after a synchronisation: did a bounded wa
 // the four face buffers W, E, S, N (cx / cy doubles per x / y face), entirely on stream st
 int tsx_peer_exchange(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy,
                       const int *done);
+int tsx_peer_exchange_part(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy,
+                           const int *done, int which);
 // nvals (<= TSX_NSLOTS + 1) doubles in device memory, summed over the ranks in place in rank order, on stream st
 int tsx_peer_allreduce(tsx_solver *s, hipStream_t st, double *v, int nvals, const int *done);
+
+// kernels that move their messages themselves (tsx_peer_dev.hpp): host-side bookkeeping of one message per face
+struct TsxPeerXArgs;
+struct TsxPeerWait;
+int tsx_peer_prepare_send(tsx_solver *s, const size_t bytes[4], TsxPeerXArgs *a);
+int tsx_peer_expect(tsx_solver *s, const size_t bytes[4], TsxPeerWait *w, const void *slot[4]);

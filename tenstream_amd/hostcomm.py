@@ -60,20 +60,38 @@ def attach_peer_checked(solver, rounds=64):
     import torch
     import torch.distributed as dist
 
-    ok = 1.0
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+    def agreed(ok):
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item()) >= 1.0
+
+    attached = True
     try:
         attach_peer(solver)
-        bad = solver.comm_peer_selftest(rounds)
-        ok = 1.0 if bad == 0.0 else 0.0
-    except Exception:   # attach refused (no IPC between these ranks ...): every rank still takes part in the agreement below
-        ok = 0.0
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([ok], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    if float(t.item()) < 1.0:
-        try:
+    except Exception:   # attach refused (no IPC between these ranks ...): every rank still takes part in the agreements below
+        attached = False
+    if not agreed(attached):
+        if attached:
             solver.comm_peer_disable()
-        except Exception:
-            pass
         return False
-    return True
+    # first with the light ordering that uncached mailboxes allow, then -- should a rank have seen stale or missing data -- once
+    # more with full system-scope fences (tsx_peer_dev.hpp) before the transport is given up
+    for heavy in (0, 1):
+        try:
+            if heavy:
+                dist.barrier()          # nobody still sends
+                solver.comm_peer_reset()
+                solver.comm_peer_set_fences(1)
+                dist.barrier()          # nobody sends into a mailbox that is being cleared
+            ok = solver.comm_peer_selftest(rounds) == 0.0
+        except Exception:
+            ok = False
+        if agreed(ok):
+            return True
+    try:
+        solver.comm_peer_disable()
+    except Exception:
+        pass
+    return False

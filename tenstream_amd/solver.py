@@ -162,6 +162,14 @@ class DiffuseSolver:
     def comm_peer_disable(self):
         _lib.check(self.lib.tsx_comm_peer_disable(self.h))
 
+    def comm_peer_set_fences(self, heavy):
+        """1: full system-scope fences around every flag of the peer transport (tsx_comm_peer_set_fences); 0: the light ordering"""
+        _lib.check(self.lib.tsx_comm_peer_set_fences(self.h, int(heavy)))
+
+    def comm_peer_reset(self):
+        """back to the state after attach; barrier over all ranks before and after (tsx_comm_peer_reset)"""
+        _lib.check(self.lib.tsx_comm_peer_reset(self.h))
+
     def comm_set_callbacks(self, exchange, allreduce):
         """Host-staged transport.  exchange(send: list of 4 numpy views W,E,S,N, recv: list of 4 writable views,
         peers: list of 4 ranks) and allreduce(buf: writable numpy view) operate on pinned host memory."""
