@@ -16,7 +16,8 @@ module m_pprts_hip
   private
   public :: t_tsx_grid, t_tsx_ksp_opts, t_tsx_ksp_result, &
     & hip_diff_create, hip_diff_destroy, hip_diff_set_coeffs, hip_ediff, hip_diff_apply, hip_last_error, &
-    & tsx_abi_sizes, tsx_comm_peer_export, tsx_comm_peer_attach, &
+    & tsx_abi_sizes, tsx_comm_peer_export, tsx_comm_peer_attach, tsx_comm_peer_selftest, tsx_comm_peer_disable, &
+    & tsx_comm_peer_set_fences, tsx_comm_peer_reset, &
     & TSX_HOST, TSX_DEVICE, TSX_PC_NONE, TSX_PC_COLUMN, TSX_PC_ZEBRA, TSX_PC_REDBLACK
 
   integer(c_int), parameter :: TSX_HOST = 0, TSX_DEVICE = 1
@@ -106,6 +107,31 @@ module m_pprts_hip
     function tsx_comm_peer_attach(handle, blobs) bind(C, name='tsx_comm_peer_attach') result(ierr)
       import :: c_ptr, c_int
       type(c_ptr), value :: handle, blobs
+      integer(c_int) :: ierr
+    end function
+    ! collective self test of the attached transport; failed = 0 if this rank saw nothing wrong (reduce it over the ranks)
+    function tsx_comm_peer_selftest(handle, rounds, failed) bind(C, name='tsx_comm_peer_selftest') result(ierr)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: handle
+      integer(c_int), value :: rounds
+      real(c_double), intent(out) :: failed
+      integer(c_int) :: ierr
+    end function
+    function tsx_comm_peer_disable(handle) bind(C, name='tsx_comm_peer_disable') result(ierr)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle
+      integer(c_int) :: ierr
+    end function
+    ! heavy = 1: full system-scope fences around every flag (after a failed self test); reset: back to the state after attach
+    function tsx_comm_peer_set_fences(handle, heavy) bind(C, name='tsx_comm_peer_set_fences') result(ierr)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle
+      integer(c_int), value :: heavy
+      integer(c_int) :: ierr
+    end function
+    function tsx_comm_peer_reset(handle) bind(C, name='tsx_comm_peer_reset') result(ierr)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle
       integer(c_int) :: ierr
     end function
     function tsx_abi_sizes(sizes3) bind(C, name='tsx_abi_sizes') result(ierr)
