@@ -88,7 +88,6 @@ struct TsxPeerXArgs {
   unsigned long long bytes[4];  // payload per face (0: face inactive)
   unsigned long long n[4];      // sequence number of this message per face
   unsigned long long ackn[4];   // send: messages received through face q by kernels that precede this one on the stream
-  unsigned long long rn[4];     // kernels that send AND receive (tsx_k_pcs_halo_xchg): number of the message to receive
   unsigned long long cap, data_off, ticks;
   unsigned int *blkctr;         // [4] workgroups that have finished their slice (local memory)
   int heavy;                    // 1: system-scope release / acquire fences around the flags (TSX_PEER_FENCES=1), see below

@@ -314,60 +314,6 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_send(TsxGeo g, const
   }
   tsx_peer_send_end(a, a.blkctr, gridDim.x);
 }
-// ... and the whole exchange in one kernel: workgroups [0, nsend) pack and send as above, the others receive -- wait for the
-// neighbour's sequence number, stream the message out of the (uncached) mailbox slot into the pass's cached receive buffer
-// a.dst[q], nrb workgroups per face.  All of them are resident together (a few dozen workgroups), so the receivers can spin
-// while the senders of this very kernel (one rank along a periodic axis) or of the neighbours' kernels deliver.  The
-// acknowledgement travels with the next send (ackn).
-__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_xchg(TsxGeo g, const unsigned *__restrict__ zb,
-                                                                 const float2 *__restrict__ zr, int from_f32, TsxPeerXArgs a,
-                                                                 int nsend, int nrb) {
-  if ((int)blockIdx.x >= nsend) {
-    const int rbk = (int)blockIdx.x - nsend, q = rbk / nrb, part = rbk - q * nrb;
-    if (!a.bytes[q]) return;
-    if (threadIdx.x == 0) {
-      unsigned long long have = 0;
-      if (!tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(a.mine)->seq[q], a.rn[q], a.ticks, &have, a.heavy))
-        tsx_peer_fail(a.mine, 2, q, a.rn[q], have);
-    }
-    __syncthreads();
-    const uint4 *src = reinterpret_cast<const uint4 *>(tsx_peer_data(a.mine, a.data_off, a.cap, q, (int)(a.rn[q] & 1)));
-    uint4 *dst = reinterpret_cast<uint4 *>(a.dst[q]);
-    const unsigned long long n16 = (a.bytes[q] + 15) >> 4;  // the slots and the receive buffers are padded to 256 / 8 bytes
-    for (unsigned long long i = (unsigned long long)part * TSX_BLOCK + threadIdx.x; i < n16; i += (unsigned long long)nrb * TSX_BLOCK)
-      dst[i] = src[i];
-    return;
-  }
-  if (!tsx_peer_send_begin(a)) return;
-  const int xm = g.xm, ym = g.ym, Nz = g.Nz;
-  const long long Nc = g.Nc;
-  const int nzp = tsx_pcs_halo_nzp(Nz);
-  const long long nx = a.bytes[0] ? (long long)nzp * ym : 0, ny = a.bytes[2] ? (long long)nzp * xm : 0;
-  unsigned *sW = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[0], a.data_off, a.cap, 1, (int)(a.n[0] & 1)));
-  unsigned *sE = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[1], a.data_off, a.cap, 0, (int)(a.n[1] & 1)));
-  unsigned *sS = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[2], a.data_off, a.cap, 3, (int)(a.n[2] & 1)));
-  unsigned *sN = reinterpret_cast<unsigned *>(tsx_peer_data(a.remote[3], a.data_off, a.cap, 2, (int)(a.n[3] & 1)));
-  auto rec = [&](int m, int k, int i, int j) {
-    const size_t idx = (size_t)m * Nc + (size_t)k * g.ncol + tsx_split_col(i, j, xm);
-    if (!from_f32) return zb[idx];
-    const float2 v = zr[idx];
-    return (unsigned)tsx_to_bf16(v.x) | ((unsigned)tsx_to_bf16(v.y) << 16);
-  };
-  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < nx + ny; q += (long long)nsend * TSX_BLOCK) {
-    if (q < nx) {
-      const int k = (int)(q % nzp), j = (int)(q / nzp);
-      sW[q] = k < Nz ? rec(0, k, 0, j) : 0u;
-      sE[q] = k < Nz ? rec(1, k, xm - 1, j) : 0u;
-    } else {
-      const long long p = q - nx;
-      const int k = (int)(p % nzp), i = (int)(p / nzp);
-      sS[p] = k < Nz ? rec(2, k, i, 0) : 0u;
-      sN[p] = k < Nz ? rec(3, k, i, ym - 1) : 0u;
-    }
-  }
-  tsx_peer_send_end(a, a.blkctr, (unsigned)nsend);
-}
-
 // ---- parts of a pass on several ranks (overlap of the boundary-record exchange with the pass, tsx_pcs_apply):
 // part 0 = every column of the colour; 1 = the same launch with the columns on a rank face idle (their neighbours' records
 // are still in flight); 2 = only the columns on a rank face.  Frame columns of colour rbc, enumerated: the rows j = 0 and

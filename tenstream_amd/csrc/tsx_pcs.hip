@@ -153,14 +153,16 @@ int tsx_pcs_pack(tsx_solver *s) {
 }
 
 static int pcs_inplace_env() {
-  // TSX_PEER_INPLACE: 0 pack + tsx_k_peer_send + tsx_k_peer_recv like any exchange; 1 fused pack + send, the next pass reads in
-  // place; 2 only the fused pack + send; 3 only the in-place consumer; 4 one kernel packs, sends and receives; 5 (default) the
-  // pass stores its boundary records into the neighbours' mailboxes itself and the next pass reads them in place
-  static const int v = getenv("TSX_PEER_INPLACE") ? atoi(getenv("TSX_PEER_INPLACE")) : 5;
+  // TSX_PEER_INPLACE (peer transport): 0 pack + tsx_k_peer_send + tsx_k_peer_recv like any exchange; 1 fused pack + send, the
+  // next pass reads in place; 2 (default) the pass stores its boundary records into the neighbours' mailboxes itself and the next
+  // pass reads them in place (tsx_k_pcs_rb<..., PEER>; 1 where no such kernel is instantiated).  Measured and dropped (one rank
+  // with itself as its neighbours, profiles/NEGATIVE_RESULTS.md): pack, send and receive in ONE kernel with the pass reading its
+  // cached receive buffers (no faster than three kernels).
+  static const int v = getenv("TSX_PEER_INPLACE") ? atoi(getenv("TSX_PEER_INPLACE")) : 2;
   return v;
 }
 static bool pcs_peer_inkernel(const tsx_solver *s) {
-  if (pcs_inplace_env() != 5 || !tsx_peer_ready(s) || s->geo.ntop != 2) return false;
+  if (pcs_inplace_env() != 2 || !tsx_peer_ready(s) || s->geo.ntop != 2) return false;
   const PcsCfg c = pcs_config(s);
   return c.lseg == 4 && c.nseg == 16 && (c.cw == 16 || c.cw == 32);
 }
@@ -251,51 +253,21 @@ static int pcs_halo_exchange(tsx_solver *s, bool from_f32, const int *done, bool
   const float2 *zr = reinterpret_cast<const float2 *>(zs + (size_t)g.ntop * g.Nc);
   const int nzp = tsx_pcs_halo_nzp(g.Nz);
   const long long n = (g.wrap_x ? 0 : (long long)nzp * g.ym) + (g.wrap_y ? 0 : (long long)nzp * g.xm);
-  // Peer transport: ONE kernel packs the boundary records straight into the neighbours' mailboxes and publishes them; the next
-  // pass waits for its neighbours' sequence numbers itself and reads the records in place -- no send buffer, no receive kernel,
-  // no copy out (TSX_PEER_INPLACE=0: pack, tsx_k_peer_send, tsx_k_peer_recv as for any other exchange).  One rank with itself
-  // as its four neighbours, 128 x 64 columns (scripts/shard_study.py): 7.1 -> ... ms per solve
-  // TSX_PEER_INPLACE: 0 generic, 1 both, 2 only the fused pack + send, 3 only the in-place consumer
-  const int inplace_env = pcs_inplace_env() == 5 ? 1 : pcs_inplace_env();  // 5 where the pass cannot send itself (8_16 ...): 1
+  // Peer transport, where the pass cannot send its records itself (8_16, non-default scan configurations; TSX_PEER_INPLACE=1): ONE
+  // kernel packs the boundary records straight into the neighbours' mailboxes and publishes them; the next pass waits for its
+  // neighbours' sequence numbers itself and reads the records in place -- no send buffer, no receive kernel, no copy out.
+  // TSX_PEER_INPLACE=0: pack, tsx_k_peer_send, tsx_k_peer_recv as for any other exchange.
   s->pch_inplace = false;
-  if (inplace_env && !overlap && tsx_peer_ready(s) && n > 0) {
+  if (pcs_inplace_env() != 0 && !overlap && tsx_peer_ready(s) && n > 0) {
     const size_t bx = g.wrap_x ? 0 : (size_t)nzp * g.ym * sizeof(unsigned), by = g.wrap_y ? 0 : (size_t)nzp * g.xm * sizeof(unsigned);
     const size_t bytes[4] = {bx, bx, by, by};
-    double *const send[4] = {(double *)s->pch_send[0], (double *)s->pch_send[1], (double *)s->pch_send[2], (double *)s->pch_send[3]};
-    double *const recv[4] = {(double *)s->pch_recv[0], (double *)s->pch_recv[1], (double *)s->pch_recv[2], (double *)s->pch_recv[3]};
     int rc;
-    if (inplace_env == 4) {  // the whole exchange in one kernel; the pass reads the cached receive buffers as ever
-      TsxPeerXArgs a;
-      const void *slot[4];
-      TsxPeerWait w;
-      if ((rc = tsx_peer_prepare_send(s, bytes, &a))) return rc;
-      if ((rc = tsx_peer_expect(s, bytes, &w, slot))) return rc;
-      for (int q = 0; q < 4; ++q) {
-        a.rn[q] = w.want[q];
-        a.dst[q] = (char *)s->pch_recv[q];
-      }
-      int nsend = (int)((n + 4 * TSX_BLOCK - 1) / (4 * TSX_BLOCK));
-      nsend = nsend < 1 ? 1 : (nsend > 16 ? 16 : nsend);
-      const size_t maxb = bx > by ? bx : by;
-      const int nrb = maxb > 65536 ? 4 : (maxb > 16384 ? 2 : 1);
-      hipLaunchKernelGGL(tsx_k_pcs_halo_xchg, dim3(nsend + 4 * nrb), dim3(TSX_BLOCK), 0, s->stream, g, zb, zr, from_f32 ? 1 : 0, a,
-                         nsend, nrb);
-      HIPCHK(hipGetLastError());
-      return TSX_OK;
-    }
-    if (inplace_env != 3) {
-      TsxPeerXArgs a;
-      if ((rc = tsx_peer_prepare_send(s, bytes, &a))) return rc;
-      int nblk = (int)((n + 4 * TSX_BLOCK - 1) / (4 * TSX_BLOCK));
-      nblk = nblk < 1 ? 1 : (nblk > 16 ? 16 : nblk);
-      hipLaunchKernelGGL(tsx_k_pcs_halo_send, dim3(nblk), dim3(TSX_BLOCK), 0, s->stream, g, zb, zr, from_f32 ? 1 : 0, a);
-      HIPCHK(hipGetLastError());
-    } else {
-      hipLaunchKernelGGL(tsx_k_pcs_halo_pack, dim3(grid_for(n)), dim3(TSX_BLOCK), 0, s->stream, g, zb, zr, from_f32 ? 1 : 0,
-                         s->pch_send[0], s->pch_send[1], s->pch_send[2], s->pch_send[3], done);
-      if ((rc = tsx_peer_exchange_part(s, s->stream, send, nullptr, pcs_halo_doubles(s, 0), pcs_halo_doubles(s, 2), nullptr, 1))) return rc;
-    }
-    if (inplace_env == 2) return tsx_peer_exchange_part(s, s->stream, nullptr, recv, pcs_halo_doubles(s, 0), pcs_halo_doubles(s, 2), nullptr, 2);
+    TsxPeerXArgs a;
+    if ((rc = tsx_peer_prepare_send(s, bytes, &a))) return rc;
+    int nblk = (int)((n + 4 * TSX_BLOCK - 1) / (4 * TSX_BLOCK));
+    nblk = nblk < 1 ? 1 : (nblk > 16 ? 16 : nblk);
+    hipLaunchKernelGGL(tsx_k_pcs_halo_send, dim3(nblk), dim3(TSX_BLOCK), 0, s->stream, g, zb, zr, from_f32 ? 1 : 0, a);
+    HIPCHK(hipGetLastError());
     if ((rc = tsx_peer_expect(s, bytes, &s->pch_wait, s->pch_slot))) return rc;
     s->pch_inplace = true;
     return TSX_OK;
@@ -494,7 +466,7 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
     // one follows, the later ones read it
     const int rq = !rhs16 || mode != 0 ? 0 : (words_ready ? 2 : (pass >= 2 ? 2 : (pass + 2 < P - 2 ? 1 : 0)));
     int rc;
-    // peer transport, default configuration: the pass sends its boundary records itself (TSX_PEER_INPLACE=5, the default)
+    // peer transport, default configuration: the pass sends its boundary records itself (TSX_PEER_INPLACE=2, the default)
     const bool xchg_after = halo && pass + 1 < P && pass % every == 0;
     s->pch_snd_on = false;
     if (xchg_after && !overlap && every == 1 && pcs_peer_inkernel(s)) {

@@ -368,11 +368,6 @@ int tsx_peer_check(tsx_solver *s) {
 
 int tsx_peer_exchange(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy,
                       const int *done) {
-  return tsx_peer_exchange_part(s, st, send, recv, cx, cy, done, 3);
-}
-// which: 1 = only the send kernel, 2 = only the receive kernel (the other half is a kernel that moves its messages itself)
-int tsx_peer_exchange_part(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy,
-                           const int *done, int which) {
   TsxPeer *p = s->peer;
   const TsxGeo &g = s->geo;
   const tsx_grid &gr = s->grid;
@@ -399,8 +394,8 @@ int tsx_peer_exchange_part(tsx_solver *s, hipStream_t st, double *const send[4],
       return TSX_ERR_ARG;
     }
     a.remote[q] = p->box[nb[q]];
-    a.src[q] = send ? (const char *)send[q] : nullptr;
-    a.dst[q] = recv ? (char *)recv[q] : nullptr;
+    a.src[q] = (const char *)send[q];
+    a.dst[q] = (char *)recv[q];
     maxb = a.bytes[q] > maxb ? a.bytes[q] : maxb;
   }
   if (maxb == 0) return TSX_OK;
@@ -411,21 +406,17 @@ int tsx_peer_exchange_part(tsx_solver *s, hipStream_t st, double *const send[4],
   int nblk = (int)((maxb + 32767) / 32768);
   nblk = nblk < 1 ? 1 : (nblk > 8 ? 8 : nblk);
   a.done = nullptr;  // see the comment above: sequence numbers must stay in step whatever `done` says
-  if (which & 1) {
-    for (int q = 0; q < 4; ++q)
-      if (a.bytes[q]) {
-        a.ackn[q] = p->rcvd[q];
-        a.n[q] = ++p->sent[q];
-      }
-    a.blkctr = p->blkctr;
-    hipLaunchKernelGGL(tsx_k_peer_send, dim3(nblk, 4), dim3(256), 0, st, a);
-  }
-  if (which & 2) {
-    for (int q = 0; q < 4; ++q)
-      if (a.bytes[q]) a.n[q] = ++p->rcvd[q];
-    a.blkctr = p->blkctr + 4;
-    hipLaunchKernelGGL(tsx_k_peer_recv, dim3(nblk, 4), dim3(256), 0, st, a);
-  }
+  for (int q = 0; q < 4; ++q)
+    if (a.bytes[q]) {
+      a.ackn[q] = p->rcvd[q];
+      a.n[q] = ++p->sent[q];
+    }
+  a.blkctr = p->blkctr;
+  hipLaunchKernelGGL(tsx_k_peer_send, dim3(nblk, 4), dim3(256), 0, st, a);
+  for (int q = 0; q < 4; ++q)
+    if (a.bytes[q]) a.n[q] = ++p->rcvd[q];
+  a.blkctr = p->blkctr + 4;
+  hipLaunchKernelGGL(tsx_k_peer_recv, dim3(nblk, 4), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }

@@ -12,8 +12,6 @@ int tsx_peer_check(tsx_solver *s);  // after a synchronisation: did a bounded wa
 // the four face buffers W, E, S, N (cx / cy doubles per x / y face), entirely on stream st
 int tsx_peer_exchange(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy,
                       const int *done);
-int tsx_peer_exchange_part(tsx_solver *s, hipStream_t st, double *const send[4], double *const recv[4], size_t cx, size_t cy,
-                           const int *done, int which);
 // nvals (<= TSX_NSLOTS + 1) doubles in device memory, summed over the ranks in place in rank order, on stream st
 int tsx_peer_allreduce(tsx_solver *s, hipStream_t st, double *v, int nvals, const int *done);
 

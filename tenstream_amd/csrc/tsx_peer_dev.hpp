@@ -21,8 +21,8 @@ struct TsxPeerHdr {
 // therefore only (i) a lane's payload stores have been acknowledged by memory before the sequence number is stored -- s_waitcnt
 // vmcnt(0) -- and (ii) the payload loads are issued after the sequence number has been seen -- program order behind the poll.
 // The language-level way to say this, a system-scope release fence + release store and an acquire load, also writes back and
-// invalidates the whole L2 (buffer_wbl2 / buffer_inv sc0 sc1) every time: measured, the passes' exchange kernel took 14 us with
-// them against ... us without.  heavy = 1 (TSX_PEER_FENCES=1, or hostcomm.attach_peer_checked after a failed self test) keeps
+// invalidates the whole L2 (buffer_wbl2 / buffer_inv sc0 sc1) every time: measured, a 128 x 64-column rank with itself as its
+// neighbours solved in 7.7 ms with them against 5.8 ms without (fused send kernel + in-place reader, scripts/shard_study.py).  heavy = 1 (TSX_PEER_FENCES=1, or hostcomm.attach_peer_checked after a failed self test) keeps
 // the full fences, for a platform where a peer's mapping of the mailbox turns out to be cached.
 __device__ __forceinline__ unsigned long long tsx_peer_ld_acquire(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -92,22 +92,6 @@ __device__ __forceinline__ bool tsx_peer_send_begin(const TsxPeerXArgs &a) {
   }
   __syncthreads();
   return ok_ != 0;
-}
-// ... for a kernel of which only some workgroups send (need: this lane will store into a slot): workgroup 0 acknowledges, the
-// workgroups with a sender wait for free slots.  Every lane must call (barriers inside); after a timeout the stores go ahead
-// (the host reports TSX_ERR_COMM at its next check).
-__device__ __forceinline__ void tsx_peer_send_begin_if(const TsxPeerXArgs &a, bool need) {
-  const int any = __syncthreads_or(need ? 1 : 0);
-  if (!any && blockIdx.x != 0) return;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if ((int)threadIdx.x != q || !a.bytes[q]) continue;
-    if (blockIdx.x == 0 && a.ackn[q]) tsx_peer_post(&reinterpret_cast<TsxPeerHdr *>(a.remote[q])->ack[q ^ 1], a.ackn[q], a.heavy);
-    unsigned long long have = 0;
-    if (any && a.n[q] > 2 && !tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(a.mine)->ack[q], a.n[q] - 2, a.ticks, &have, a.heavy))
-      tsx_peer_fail(a.mine, 1, q, a.n[q] - 2, have);
-  }
-  __syncthreads();
 }
 // ---- a kernel that consumes its neighbours' previous messages in place AND sends the next ones (a red-black pass): both waits
 // side by side -- lanes 0..3 poll the sequence numbers, lanes 4..7 the acknowledgements -- behind one barrier pair.
