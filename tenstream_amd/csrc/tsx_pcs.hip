@@ -158,8 +158,8 @@ static int pcs_inplace_env() {
   // pass reads them in place (tsx_k_pcs_rb<..., PEER>; 1 where no such kernel is instantiated).  Measured and dropped (one rank
   // with itself as its neighbours, profiles/NEGATIVE_RESULTS.md): pack, send and receive in ONE kernel with the pass reading its
   // cached receive buffers (no faster than three kernels).
-  static const int v = getenv("TSX_PEER_INPLACE") ? atoi(getenv("TSX_PEER_INPLACE")) : 2;
-  return v;
+  const char *e = getenv("TSX_PEER_INPLACE");  // read per call: tests switch it
+  return e ? atoi(e) : 2;
 }
 static bool pcs_peer_inkernel(const tsx_solver *s) {
   if (pcs_inplace_env() != 2 || !tsx_peer_ready(s) || s->geo.ntop != 2) return false;

@@ -189,23 +189,32 @@ def test_peer_transport_with_self_neighbours_in_one_process(gpu, monkeypatch):
     from tenstream_amd import DiffuseSolver, synthetic
 
     monkeypatch.setenv("TSX_PEER_TIMEOUT_S", "5")
-    P = synthetic.make_problem("3_10", Nx=12, Ny=10, Nz=8, n1d=1)
-    out = []
-    for peer in (False, True):
-        s = DiffuseSolver("3_10", 8, 12, 10, force_halo=True)
-        if peer:
-            s.comm_peer_init(lambda blob: [blob])
-        s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
-        x = np.random.default_rng(2).standard_normal(s.vec_shape)
-        y = s.apply(x)
-        sol = np.zeros(s.vec_shape)
-        info = s.solve(P["b"], sol, rtol=1e-10, atol=1e-30)
-        out.append((y, sol, info))
-        s.close()
-    (y0, x0, i0), (y1, x1, i1) = out
-    assert np.array_equal(y0, y1)
-    assert i0.reason == 2 and i1.reason == 2 and i0.niter == i1.niter
-    assert np.array_equal(i0.res_hist, i1.res_hist) and np.array_equal(x0, x1)
+    for solver, shape in (("3_10", (12, 10, 8)), ("8_16", (8, 6, 8))):
+        Nx, Ny, Nz = shape
+        P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=1)
+        out = []
+        # copies; then the three ways the passes' boundary records travel through the mailbox (TSX_PEER_INPLACE: 0 pack / send /
+        # receive kernels, 1 fused pack + send and the next pass reading in place, 2 the pass sends its records itself), the last
+        # one also with full system-scope fences around every flag
+        for peer, inplace, fences in ((False, "2", "0"), (True, "0", "0"), (True, "1", "0"), (True, "2", "0"), (True, "2", "1")):
+            monkeypatch.setenv("TSX_PEER_INPLACE", inplace)
+            monkeypatch.setenv("TSX_PEER_FENCES", fences)
+            s = DiffuseSolver(solver, Nz, Nx, Ny, force_halo=True)
+            if peer:
+                s.comm_peer_init(lambda blob: [blob])
+            s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+            x = np.random.default_rng(2).standard_normal(s.vec_shape)
+            y = s.apply(x)
+            sol = np.zeros(s.vec_shape)
+            info = s.solve(P["b"], sol, rtol=1e-10, atol=1e-30)
+            out.append((y, sol, info))
+            s.close()
+        y0, x0, i0 = out[0]
+        assert i0.reason == 2
+        for y1, x1, i1 in out[1:]:
+            assert np.array_equal(y0, y1)
+            assert i1.reason == 2 and i0.niter == i1.niter
+            assert np.array_equal(i0.res_hist, i1.res_hist) and np.array_equal(x0, x1)
 
 
 def _selftest_worker(rank, world, port, ret):
