@@ -124,6 +124,7 @@ extern "C" int tsx_comm_init(tsx_solver *s, const void *id128) {
   NCCLCHK(g_rccl.CommInitRank(&comm, s->grid.nranks, id, s->grid.rank));
   s->nccl_comm = comm;
   s->comm_ready = true;
+  s->pcg_key = -1;  // decisions agreed over the previous transport are agreed again (tsx_pc_global_agree)
   // The face exchanges run on comm_stream while the all-reduces run on the solver stream: give each stream a communicator
   // of its own (two streams driving one communicator concurrently is the classic RCCL hang).  TSX_RCCL_SPLIT=0 keeps one.
   const char *e = getenv("TSX_RCCL_SPLIT");
@@ -141,6 +142,7 @@ extern "C" int tsx_comm_set_callbacks(tsx_solver *s, tsx_exchange_fn exchange, t
   s->xchg_cb = exchange;
   s->allred_cb = allreduce;
   s->cb_ctx = ctx;
+  s->pcg_key = -1;  // decisions agreed over the previous transport are agreed again (tsx_pc_global_agree)
   return TSX_OK;
 }
 

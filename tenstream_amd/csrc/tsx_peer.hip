@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void tsx_k_peer_send(PeerXArgs a) {
     // acknowledge what kernels before this one consumed in place (tsx_peer_expect): first, so that two ranks never wait for
     // each other's acknowledgement
     if (blockIdx.x == 0 && a.ackn[q]) tsx_peer_post(&reinterpret_cast<PeerHdr *>(a.remote[q])->ack[q ^ 1], a.ackn[q], a.heavy);
-    if (a.n[q] > 2 && !wait_ge(&h->ack[q], a.n[q] - 2, a.ticks, &have, a.heavy)) {
+    if (a.n[q] > 2 && !wait_ge(&h->ack[q], a.n[q] - 2, a.ticks, &have, a.heavy, a.mine)) {
       ok = 0;
       peer_fail(a.mine, 1, q, a.n[q] - 2, have);
     }
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void tsx_k_peer_recv(PeerXArgs a) {
     const PeerHdr *h = reinterpret_cast<const PeerHdr *>(a.mine);
     unsigned long long have = 0;
     ok = 1;
-    if (!wait_ge(&h->seq[q], a.n[q], a.ticks, &have, a.heavy)) {
+    if (!wait_ge(&h->seq[q], a.n[q], a.ticks, &have, a.heavy, a.mine)) {
       ok = 0;
       peer_fail(a.mine, 2, q, a.n[q], have);
     }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64) void tsx_k_peer_allreduce(PeerArArgs a, double 
     tsx_peer_post(&slot->seq, a.n, a.heavy);
     const PeerArSlot *in = reinterpret_cast<const PeerArSlot *>(a.mine + a.ar_off) + (size_t)par * kMaxRanks + r;
     unsigned long long have = 0;
-    if (!wait_ge(&in->seq, a.n, a.ticks, &have, a.heavy)) {
+    if (!wait_ge(&in->seq, a.n, a.ticks, &have, a.heavy, a.mine)) {
       bad = 1;
       peer_fail(a.mine, 3, r, a.n, have);
     }
@@ -336,6 +336,7 @@ extern "C" int tsx_comm_peer_attach(tsx_solver *s, const void *blobs) {
     }
   }
   p->attached = true;
+  s->pcg_key = -1;  // decisions agreed over the previous transport are agreed again (tsx_pc_global_agree)
   return TSX_OK;
 }
 
@@ -577,6 +578,7 @@ extern "C" int tsx_comm_peer_reset(tsx_solver *s) {
   for (int q = 0; q < 4; ++q) p->sent[q] = p->rcvd[q] = 0;
   p->ar_n = 0;
   s->pch_inplace = false;
+  s->pcg_key = -1;
   return TSX_OK;
 }
 
@@ -584,5 +586,9 @@ extern "C" int tsx_comm_peer_reset(tsx_solver *s) {
 extern "C" int tsx_comm_peer_disable(tsx_solver *s) {
   ARGCHK(s, "tsx_comm_peer_disable: null");
   if (s->peer) s->peer->attached = false;
+  // a rank whose agreement (tsx_pc_global_agree) went through before the transport failed must not keep it while a rank whose
+  // all-reduce expired asks again over the next transport: everybody asks again
+  s->pcg_key = -1;
+  s->pch_inplace = false;
   return TSX_OK;
 }

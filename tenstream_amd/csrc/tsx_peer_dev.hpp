@@ -45,14 +45,18 @@ __device__ __forceinline__ void tsx_peer_stores_done(int heavy) {
   if (heavy) __threadfence_system();
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-// spin until *p >= want; false after `ticks` of the constant-rate wall clock
+// spin until *p >= want; false after `ticks` of the constant-rate wall clock -- or at once when a wait of this rank has expired
+// before (mine: my mailbox; its header records the first failure): after one expired wait the kernels still queued give up
+// immediately instead of `ticks` each, so a lost rank costs every rank one timeout, not one per exchange
 __device__ __forceinline__ bool tsx_peer_wait_ge(const unsigned long long *p, unsigned long long want, unsigned long long ticks,
-                                                 unsigned long long *have, int heavy = 1) {
+                                                 unsigned long long *have, int heavy = 1, const char *mine = nullptr) {
   const unsigned long long t0 = wall_clock64();
   for (;;) {
     const unsigned long long v = tsx_peer_peek(p, heavy);
     if (v >= want) return true;
-    if (wall_clock64() - t0 > ticks) {
+    const bool failed_before =
+        mine && __hip_atomic_load(&reinterpret_cast<const TsxPeerHdr *>(mine)->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+    if (failed_before || wall_clock64() - t0 > ticks) {
       *have = v;
       return false;
     }
@@ -85,7 +89,7 @@ __device__ __forceinline__ bool tsx_peer_send_begin(const TsxPeerXArgs &a) {
     if (blockIdx.x == 0 && a.ackn[q]) tsx_peer_post(&reinterpret_cast<TsxPeerHdr *>(a.remote[q])->ack[q ^ 1], a.ackn[q], a.heavy);
     const TsxPeerHdr *h = reinterpret_cast<const TsxPeerHdr *>(a.mine);
     unsigned long long have = 0;
-    if (a.n[q] > 2 && !tsx_peer_wait_ge(&h->ack[q], a.n[q] - 2, a.ticks, &have, a.heavy)) {
+    if (a.n[q] > 2 && !tsx_peer_wait_ge(&h->ack[q], a.n[q] - 2, a.ticks, &have, a.heavy, a.mine)) {
       ok_ = 0;
       tsx_peer_fail(a.mine, 1, q, a.n[q] - 2, have);
     }
@@ -105,14 +109,14 @@ __device__ __forceinline__ void tsx_peer_begin_both(const TsxPeerWait &w, bool n
   for (int q = 0; q < 4; ++q) {
     if (rcv && any && (int)threadIdx.x == q && w.want[q]) {
       unsigned long long have = 0;
-      if (!tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(w.mine)->seq[q], w.want[q], w.ticks, &have, w.heavy))
+      if (!tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(w.mine)->seq[q], w.want[q], w.ticks, &have, w.heavy, w.mine))
         tsx_peer_fail(w.mine, 2, q, w.want[q], have);
     }
     if (sending && (int)threadIdx.x == 4 + q && a.bytes[q]) {
       if (blockIdx.x == 0 && a.ackn[q]) tsx_peer_post(&reinterpret_cast<TsxPeerHdr *>(a.remote[q])->ack[q ^ 1], a.ackn[q], a.heavy);
       unsigned long long have = 0;
       if (any && a.n[q] > 2 &&
-          !tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(a.mine)->ack[q], a.n[q] - 2, a.ticks, &have, a.heavy))
+          !tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(a.mine)->ack[q], a.n[q] - 2, a.ticks, &have, a.heavy, a.mine))
         tsx_peer_fail(a.mine, 1, q, a.n[q] - 2, have);
     }
   }
@@ -144,7 +148,7 @@ __device__ __forceinline__ void tsx_peer_wait_faces(const TsxPeerWait &w, bool n
   for (int q = 0; q < 4; ++q) {
     if ((int)threadIdx.x != q || !w.want[q]) continue;
     unsigned long long have = 0;
-    if (!tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(w.mine)->seq[q], w.want[q], w.ticks, &have, w.heavy))
+    if (!tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(w.mine)->seq[q], w.want[q], w.ticks, &have, w.heavy, w.mine))
       tsx_peer_fail(w.mine, 2, q, w.want[q], have);
   }
   __syncthreads();

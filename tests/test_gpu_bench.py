@@ -80,3 +80,22 @@ def test_bench_eight_ranks_on_the_two_by_four_grid(gpu):
 def test_bench_refuses_a_rank_count_mismatch(gpu):
     p = _run(["--gpus", "2"] + SMALL, env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_bench_survives_a_peer_transport_that_fails_during_the_solves(gpu):
+    """Failure injection: the peer transport is attached (`--transport peer`: no self test) with a wait bound of a microsecond, so
+    the first message between the two rank processes 'is lost'.  Every rank must leave the timed loop (bounded waits, fail-fast
+    after the first expiry), agree on the failure, give the transport up -- including the preconditioner-halo agreement that one
+    rank may already have cached over it -- and measure over the host-staged exchanges instead: one valid line."""
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    clean["TSX_PEER_TIMEOUT_S"] = "0.000001"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "peer", "--nx", "64", "--ny", "48"]
+                       + SMALL, capture_output=True, text=True, timeout=600, env=clean, cwd=ROOT)
+    out = _line(p)
+    assert "falling back" in p.stderr
+    assert out["config"]["transport"].startswith("host-staged") and "after the peer transport failed" in out["config"]["transport"]
+    assert out["config"]["reason"] in (2, 3) and out["value"] > 0
+    # same iteration count as the run that never touched the peer transport
+    ref = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "host", "--nx", "64",
+                                "--ny", "48"] + SMALL, capture_output=True, text=True, timeout=600, env=clean, cwd=ROOT))
+    assert out["config"]["iterations"] == ref["config"]["iterations"]
