@@ -669,6 +669,17 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       zb[(size_t)2 * Nc + c] = tsx_bf16x2(zo[4], zo[6]);
       zb[(size_t)3 * Nc + c] = tsx_bf16x2(zo[5], zo[7]);
     }
+    if constexpr (PEER && CW < 32) {
+      // small passes (16-column workgroups: at most one workgroup per CU's worth of columns, latency-bound, registers to spare):
+      // the boundary columns send from the loop, so that the stores' acknowledgements arrive under the remaining levels;
+      // the 32-column kernel sends after the scan (below)
+      if (sendmask && st) {
+        if (sendmask & 1) send_word(0, k0 + l, tsx_bf16x2(zo[0], zo[2]));
+        if (sendmask & 2) send_word(1, k0 + l, tsx_bf16x2(zo[1], zo[3]));
+        if (sendmask & 4) send_word(2, k0 + l, tsx_bf16x2(zo[4], zo[6]));
+        if (sendmask & 8) send_word(3, k0 + l, tsx_bf16x2(zo[5], zo[7]));
+      }
+    }
     if (MODE == 1 && st) {
       zr[(size_t)0 * Nc + c] = make_float2(zo[0], zo[2]);
       zr[(size_t)1 * Nc + c] = make_float2(zo[1], zo[3]);
@@ -695,7 +706,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     // the columns on a rank face: the records just stored (rec 0 of i = 0 westwards, 1 of i = xm - 1, 2 of j = 0, 3 of j = ym - 1,
     // like tsx_k_pcs_halo_pack) go into the neighbours' slots.  Re-read here, after the scan, where few registers are live: the
     // stores inside the level loop cost 35 registers = a wave per SIMD (163 against 128 VGPRs)
-    if (sendmask) {
+    if (CW >= 32 && sendmask) {
 #pragma unroll
       for (int l = 0; l < LSEG; ++l) {
         if (l >= nl) continue;
