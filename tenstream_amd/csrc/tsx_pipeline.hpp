@@ -284,6 +284,144 @@ __global__ __launch_bounds__(64) void tsx_k_edir_sweep(TsxGeo g, TsxSun sun, con
   if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }
 
+// ---- K6, tiled (round 3): one wave = a tile of 8 x 8 columns marching down together.  Within a layer the side streams that
+//      leave a column enter its downwind neighbour IN THE SAME SWEEP when both are lanes of the tile: the layer's 64 cells are
+//      resolved in registers by 15 substeps (lane (ii, jj), counted in the sun's order of travel, is final after substep
+//      ii + jj), each a shuffle of the upwind lanes' side streams and the S x S product -- arithmetic that the memory-bound sweep
+//      has to spare.  The one-column-per-thread sweep above moves the beam ONE column sideways per sweep (35 sweeps per solve of
+//      the spectral loop's 256 x 256 x 64 domain); this one moves it a tile per sweep.  Across tile edges (and rank faces) the
+//      sources come from the previous sweep exactly as above: same fixed point, same residual definition, same stop rule.
+//      (A skewed variant -- lane (ii, jj) on layer t - ii - jj -- was measured first: every lane of a load on another layer,
+//      6.6 x the time per sweep.)
+template <int DTOP, int DSIDE>
+__global__ __launch_bounds__(64) void tsx_k_edir_sweep_tiled(TsxGeo g, TsxSun sun, const float *__restrict__ T,
+                                                             const uint8_t *__restrict__ l1d, const double *__restrict__ a33,
+                                                             double inc_solar, const double *__restrict__ xo,
+                                                             double *__restrict__ xn, double *__restrict__ partials,
+                                                             const int *__restrict__ done, TsxDirHalo hb, int tiles_x) {
+  constexpr int S = DTOP + 2 * DSIDE, TW = 8;
+  if (done && *done) return;
+  const bool offx = g.wrap_x == 0, offy = g.wrap_y == 0;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
+  const long long Nc = g.Nc, Ncl = (long long)(Nz + 1) * ncol;
+  const int ii = threadIdx.x % TW, jj = threadIdx.x / TW;  // position in the tile in the sun's order: upwind = ii - 1, jj - 1
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int i_ = tx * TW + (sun.xinc ? ii : TW - 1 - ii), j_ = ty * TW + (sun.yinc ? jj : TW - 1 - jj);
+  const bool inside = i_ < xm && j_ < ym;
+  const int i = inside ? i_ : 0, j = inside ? j_ : 0;  // lanes beyond the domain shadow column 0 (loads valid, nothing stored)
+  const int col = j * xm + i;
+  // the upwind neighbour is a lane of this wave and a column of this rank: its side streams arrive by shuffle
+  const bool shx = inside && ii > 0 && (sun.xinc || i + 1 < xm), shy = inside && jj > 0 && (sun.yinc || j + 1 < ym);
+  const int iu = sun.xinc ? i : (i + 1 == xm ? 0 : i + 1);
+  const int ju = sun.yinc ? j : (j + 1 == ym ? 0 : j + 1);
+  const int id = sun.xinc ? (i + 1 == xm ? 0 : i + 1) : i;
+  const int jd = sun.yinc ? (j + 1 == ym ? 0 : j + 1) : j;
+  double sum = 0.0;
+  double top[DTOP];
+#pragma unroll
+  for (int q = 0; q < DTOP; ++q) top[q] = inc_solar;  // setup_incSolar: level 0 top streams (src/pprts_base.F90:1164-1176)
+  if (inside) {
+#pragma unroll
+    for (int q = 0; q < DTOP; ++q) {
+      const double old = xo[(size_t)q * Ncl + col];
+      xn[(size_t)q * Ncl + col] = top[q];
+      sum += (top[q] - old) * (top[q] - old);
+    }
+  }
+  for (int k = 0; k < Nz; ++k) {
+    const size_t c = (size_t)k * ncol + col;
+    if (l1d[k]) {  // the same for every lane
+      const double t33 = a33[c];
+#pragma unroll
+      for (int q = 0; q < DTOP; ++q) top[q] *= t33;
+      // side streams of 1-D layers are never written by the reference: carry the old values
+      if (inside) {
+#pragma unroll
+        for (int q = 0; q < 2 * DSIDE; ++q) {
+          const size_t o = (size_t)(DTOP + q) * Ncl + c;
+          xn[o] = xo[o];
+        }
+      }
+    } else {
+      float Tm[S * S];
+#pragma unroll
+      for (int e = 0; e < S * S; ++e) Tm[e] = T[(size_t)e * Nc + c];
+      double mx[DSIDE], my[DSIDE];  // sources that do not come from a lane of the tile: the previous sweep / the received faces
+#pragma unroll
+      for (int q = 0; q < DSIDE; ++q) {
+        mx[q] = (offx && !sun.xinc && i + 1 == xm) ? hb.recvE[((size_t)q * Nz + k) * ym + j]
+                                                   : xo[(size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + iu];
+        my[q] = (offy && !sun.yinc && j + 1 == ym) ? hb.recvN[((size_t)q * Nz + k) * xm + i]
+                                                   : xo[(size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)ju * xm + i];
+      }
+      double out[S];
+#pragma unroll
+      for (int d = 0; d < S; ++d) out[d] = 0.0;
+      for (int sub = 0; sub <= 2 * (TW - 1); ++sub) {  // after substep ii + jj this lane's inputs are final
+        double src[S];
+#pragma unroll
+        for (int q = 0; q < DTOP; ++q) src[q] = top[q];
+#pragma unroll
+        for (int q = 0; q < DSIDE; ++q) {
+          const double sx = __shfl_up(out[DTOP + q], 1), sy = __shfl_up(out[DTOP + DSIDE + q], TW);
+          src[DTOP + q] = shx ? sx : mx[q];
+          src[DTOP + DSIDE + q] = shy ? sy : my[q];
+        }
+#pragma unroll
+        for (int d = 0; d < S; ++d) {
+          double a = 0.0;
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) a += src[s2] * (double)Tm[d * S + s2];
+          out[d] = a;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < DTOP; ++q) top[q] = out[q];
+      if (inside) {
+#pragma unroll
+        for (int q = 0; q < DSIDE; ++q) {
+          const size_t oxi = (size_t)(DTOP + q) * Ncl + (size_t)k * ncol + (size_t)j * xm + id;
+          const size_t oyi = (size_t)(DTOP + DSIDE + q) * Ncl + (size_t)k * ncol + (size_t)jd * xm + i;
+          if (offx && sun.xinc && i + 1 == xm) {
+            hb.sendE[((size_t)q * Nz + k) * ym + j] = out[DTOP + q];  // lands on the east rank's face 0
+          } else {
+            const double dx_ = out[DTOP + q] - xo[oxi];
+            xn[oxi] = out[DTOP + q];
+            sum += dx_ * dx_;
+            if (offx && !sun.xinc && i == 0) hb.sendW[((size_t)q * Nz + k) * ym + j] = out[DTOP + q];  // the west rank's face xm
+          }
+          if (offy && sun.yinc && j + 1 == ym) {
+            hb.sendN[((size_t)q * Nz + k) * xm + i] = out[DTOP + DSIDE + q];
+          } else {
+            const double dy_ = out[DTOP + DSIDE + q] - xo[oyi];
+            xn[oyi] = out[DTOP + DSIDE + q];
+            sum += dy_ * dy_;
+            if (offy && !sun.yinc && j == 0) hb.sendS[((size_t)q * Nz + k) * xm + i] = out[DTOP + DSIDE + q];
+          }
+        }
+      }
+    }
+    if (inside) {
+#pragma unroll
+      for (int q = 0; q < DTOP; ++q) {
+        const size_t o = (size_t)q * Ncl + (size_t)(k + 1) * ncol + col;
+        const double old = xo[o];
+        xn[o] = top[q];
+        sum += (top[q] - old) * (top[q] - old);
+      }
+    }
+  }
+  if (inside) {  // side entries at the bottom level are dummies: keep
+#pragma unroll
+    for (int q = 0; q < 2 * DSIDE; ++q) {
+      const size_t o = (size_t)(DTOP + q) * Ncl + (size_t)Nz * ncol + col;
+      xn[o] = xo[o];
+    }
+  }
+  const double r = tsx_wave_sum(sum);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
 // After the exchange: the faces received from the upwind rank become my face 0 (sun moving +x: recvW -> faces i = 0;
 // +y: recvS -> faces j = 0); their change enters my residual like any owned entry (the reference's norm runs over
 // owned entries after exchange_direct_boundary).  1-D layers carry no side streams.

@@ -336,3 +336,23 @@ def test_absorption_by_flux_divergence_equals_coeff_divergence(gpu, lsolar):
     fd = _abso_by_flux_divergence(P, P.get_field("edir") if lsolar else None, P.get_field("ediff"), lsolar)
     assert np.abs(abso).max() > 0
     assert np.abs(fd - abso).max() <= 1e-6 * np.abs(abso).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,phi0,theta0", [("3_10", 215.0, 65.0), ("3_10", 40.0, 50.0), ("8_16", 130.0, 60.0), ("3_10", 315.0, 30.0)])
+def test_tiled_direct_sweep_has_the_fixed_point_of_the_column_sweep(gpu, monkeypatch, solver, phi0, theta0):
+    """tsx_k_edir_sweep_tiled (a wave per 8 x 8 columns, the layer resolved inside the tile by shuffles) against tsx_k_edir_sweep (a
+    thread per column, neighbours from the previous sweep) on a domain whose extents are no multiples of the tile, a slant path of
+    many columns, 1-D layers on top, all four sun quadrants: the same direct field once both are converged hard."""
+    Nx, Ny, Nz = (43, 29, 14) if solver == "3_10" else (19, 13, 10)
+    fields = []
+    for tiled in ("0", "1"):
+        monkeypatch.setenv("TSX_EDIR_TILED", tiled)
+        P, I = _setup(Nx, Ny, Nz, phi0, theta0, 2, solver=solver)
+        P.set_optical_properties(0.2, I["kabs"], I["ksca"], I["g"], I["dz"])
+        for _ in range(4):   # every further solve warm-starts the sweep from the previous field: converged to rounding
+            info = P.solve(1000.0)
+        assert info.reason in (2, 3)
+        fields.append(P.get_field("edir"))
+    a, b = fields
+    assert np.abs(a - b).max() <= 1e-10 * np.abs(a).max()
