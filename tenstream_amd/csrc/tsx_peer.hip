@@ -8,9 +8,12 @@
 // Here every rank owns one *mailbox*: a fine-grained (uncached) device allocation that the other ranks of the node map into
 // their address space with hipIpcGetMemHandle / hipIpcOpenMemHandle (over xGMI on a node; two rank processes sharing one
 // device work the same way, which is how the 1-GPU test pool executes it).  A message is written by the SENDER's kernel
-// straight into the receiver's mailbox with plain stores, followed by a release store of a sequence number; the receiver's
-// kernel acquires that number, copies the payload out and releases an acknowledgement into the sender's mailbox.  Nothing
-// but kernels on the caller's stream: no host round trip, no library call, no second stream needed.
+// straight into the receiver's mailbox with plain stores, followed by the store of a sequence number once those stores have been
+// acknowledged; the receiver's kernel polls that number, copies the payload out and stores an acknowledgement into the sender's
+// mailbox (ordering for uncached memory without cache maintenance: tsx_peer_dev.hpp).  Nothing but kernels on the caller's
+// stream: no host round trip, no library call, no second stream needed.  Kernels that produce or consume halo data can take over
+// either half themselves (tsx_peer_prepare_send / tsx_peer_expect below): the red-black passes store their boundary records
+// into the neighbours' slots and read their neighbours' in place (tsx_kernels_pcs.hpp), acknowledging with their next send.
 //
 //   mailbox of rank r:
 //     seq[q]   q = W, E, S, N: number of messages delivered THROUGH MY FACE q (written by the neighbour behind that face)
@@ -32,7 +35,8 @@
 // axis the W and E neighbour are the same rank, with distinct faces and therefore distinct counters.
 //
 // Every wait is bounded (TSX_PEER_TIMEOUT_S, default 20 s of the 100 MHz wall clock): on expiry the kernel records an error in
-// the mailbox header and gives up, the host reports TSX_ERR_COMM at the next synchronisation -- a lost rank never hangs the GPU.
+// the mailbox header and gives up, the host reports TSX_ERR_COMM at the next synchronisation -- a lost rank never hangs the GPU;
+// once an error is recorded every further wait of this rank gives up at once.
 #include <string.h>
 #include <unistd.h>
 
