@@ -282,7 +282,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
-                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->edir_a, s->edir_b, s->dsc, s->abso};
+                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->edir_a, s->edir_b, s->dsc, s->abso, s->cell_samp};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->vph && s->vph != s->vp) (void)hipFree(s->vph);
@@ -683,6 +683,25 @@ extern "C" int tsx_lut_load_diffuse_mmap4(tsx_solver *s, const char *path) {
   return rc;
 }
 
+// the cells' LUT coordinates in cell order (tsx_k_cell_samples) -> s->cell_samp; TSX_CELL_SAMPLES=0: the coefficient kernels read
+// the level-fastest arrays themselves
+int tsx_cell_samples(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz, double dx) {
+  const TsxGeo &gm = s->geo;
+  const char *e = getenv("TSX_CELL_SAMPLES");
+  if (e && atoi(e) == 0) {
+    if (s->cell_samp) (void)hipFree(s->cell_samp);
+    s->cell_samp = nullptr;
+    return TSX_OK;
+  }
+  if (!s->cell_samp) HIPCHK(hipMalloc(&s->cell_samp, sizeof(float4) * (size_t)gm.Nc));
+  s->cell_samp_src[0] = kabs, s->cell_samp_src[1] = ksca, s->cell_samp_src[2] = g, s->cell_samp_src[3] = dz;
+  s->cell_samp_dx = dx;
+  hipLaunchKernelGGL(tsx_k_cell_samples, dim3((gm.ncol + 31) / 32, (gm.Nz + 31) / 32), dim3(TSX_BLOCK), 0, s->stream, gm, kabs, ksca, g, dz,
+                     dx, (float4 *)s->cell_samp);
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
 // alloc_coeff_diff2diff on the device: kabs/ksca/g/dz are device pointers in the reference layout
 static int lut_diffuse_launch(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz, double dx) {
   const TsxGeo &gm = s->geo;
@@ -708,12 +727,15 @@ static int lut_diffuse_launch(tsx_solver *s, const double *kabs, const double *k
   L.axes = H.d_axes;
   L.table = H.d_table;
   const int nbk = grid_for(gm.Nc, 8192);
+  int rcs = tsx_cell_samples(s, kabs, ksca, g, dz, dx);
+  if (rcs) return rcs;
+  const float4 *samp = (const float4 *)s->cell_samp;
   if (gm.D == 10)
     hipLaunchKernelGGL((tsx_k_lut_diff2diff<100>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, kabs, ksca, g, dz, dx,
-                       s->l1d, (float *)s->coef, hash);
+                       s->l1d, (float *)s->coef, hash, samp);
   else
     hipLaunchKernelGGL((tsx_k_lut_diff2diff<256>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, kabs, ksca, g, dz, dx,
-                       s->l1d, (float *)s->coef, hash);
+                       s->l1d, (float *)s->coef, hash, samp);
   s->dd_hash_ready = hash != nullptr;
   return TSX_OK;
 }

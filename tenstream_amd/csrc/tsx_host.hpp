@@ -135,6 +135,7 @@ int tsx_pc_ensure_buffers(tsx_solver *s);
 int tsx_pc_ensure_half(tsx_solver *s);
 int tsx_pc_narrow(tsx_solver *s, const double *a);
 int tsx_pc_widen(tsx_solver *s, const float *a, double *o);  // o = (double) a over the N unknowns
+int tsx_cell_samples(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz, double dx);  // tsx_api.hip
 // shared storage of bit-identical blocks (tsx_dedup.hip)
 int tsx_dedup_ensure(tsx_solver *s);
 // the red-black preconditioner of 3_10 as a segmented scan over the levels (tsx_pcs.hip); packed layout "S16" in s->coef_h

@@ -187,6 +187,9 @@ struct tsx_solver {
   TsxLutHost lut_T, lut_S;
   float *dirT, *dirS;            // direct coefficient planes (S*S, S*D)
   bool dir_coeffs_valid;
+  void *cell_samp;           // float4 per cell: the LUT coordinates in cell order (tsx_k_cell_samples) ...
+  const void *cell_samp_src[4];  // ... of these arrays (every writer of them is followed by the diffuse lookup, which renews it)
+  double cell_samp_dx;
   double *d_kabs, *d_ksca, *d_g, *d_dz;  // device copies, reference layout (k fastest)
   double opt_dx, opt_dy;
   bool have_optprop;

@@ -601,13 +601,44 @@ __device__ __forceinline__ void tsx_lut_weights(const TsxLutDev &L, const float 
   }
 }
 
-// diffuse coefficients for every 3-D cell -> planes C[q*Nc + cell] (float).  Inputs in reference layout (k fastest).
+// The LUT coordinates of every cell before clamping, (aspect, w0, tauz, g) as float32 exactly as src/pprts_base.F90:1517-1533
+// forms them, in CELL order: the optical properties arrive level-fastest, the coefficient kernels run column-fastest, and a lane
+// that fetches four doubles 512 bytes apart from its neighbour's moves 64 bytes for every 8 it uses (1 GB for 134 MB at
+// 256 x 256 x 64).  A tile of 32 columns x 32 levels goes through LDS: read along the levels, written along the columns.
+// Grid: (ceil(ncol / 32), ceil(Nz / 32)), 256 threads.
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_cell_samples(TsxGeo g, const double *__restrict__ kabs, const double *__restrict__ ksca,
+                                                                const double *__restrict__ gg, const double *__restrict__ dz, double dx,
+                                                                float4 *__restrict__ out) {
+  constexpr int TC = 32, TK = 32;
+  __shared__ float4 tile[TK][TC + 1];
+  const int Nz = g.Nz, ncol = g.ncol;
+  const int c0 = blockIdx.x * TC, k0 = blockIdx.y * TK;
+  for (int e = threadIdx.x; e < TC * TK; e += TSX_BLOCK) {
+    const int kk = e % TK, cc = e / TK;
+    const int col = c0 + cc, k = k0 + kk;
+    if (col >= ncol || k >= Nz) continue;
+    const size_t r = (size_t)k + (size_t)Nz * col;  // col = i + xm * j
+    const double ka = kabs[r], ks = ksca[r], dzz = dz[r];
+    tile[kk][cc] = make_float4((float)(dzz / dx), (float)(ks / fmax(ka + ks, 2.220446049250313e-16)), (float)((ka + ks) * dzz), (float)gg[r]);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < TC * TK; e += TSX_BLOCK) {
+    const int cc = e % TC, kk = e / TC;
+    const int col = c0 + cc, k = k0 + kk;
+    if (col >= ncol || k >= Nz) continue;
+    out[(size_t)k * ncol + col] = tile[kk][cc];
+  }
+}
+
+// diffuse coefficients for every 3-D cell -> planes C[q*Nc + cell] (float).  Inputs in reference layout (k fastest), or -- samp
+// != null -- the cells' LUT coordinates from tsx_k_cell_samples.
 template <int DD>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_diff2diff(TsxGeo g, TsxLutDev L, const double *__restrict__ kabs,
                                                                  const double *__restrict__ ksca, const double *__restrict__ gg,
                                                                  const double *__restrict__ dz, double dx,
                                                                  const uint8_t *__restrict__ l1d, float *__restrict__ C,
-                                                                 unsigned long long *__restrict__ hash) {
+                                                                 unsigned long long *__restrict__ hash,
+                                                                 const float4 *__restrict__ samp) {
   // hash (nullable): the block's 64-bit hash for the shared storage, taken while the block is in registers (tsx_dedup.hip
   // would otherwise read all planes again for it)
   const int xm = g.xm, ym = g.ym, Nz = g.Nz;
@@ -621,17 +652,24 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_diff2diff(TsxGeo g, TsxLu
       if (hash) hash[c] = TSX_DD_H1D;
       continue;
     }
-    const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
-    const double ka = kabs[r], ks = ksca[r], dzz = dz[r];
     // src/pprts_base.F90:1517-1533
-    float aspect = (float)(dzz / dx);
-    float w0 = (float)(ks / fmax(ka + ks, 2.220446049250313e-16));
-    float tauz = (float)((ka + ks) * dzz);
+    float aspect, w0, tauz, gcell;
+    if (samp) {
+      const float4 v = samp[c];
+      aspect = v.x, w0 = v.y, tauz = v.z, gcell = v.w;
+    } else {
+      const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
+      const double ka = kabs[r], ks = ksca[r], dzz = dz[r];
+      aspect = (float)(dzz / dx);
+      w0 = (float)(ks / fmax(ka + ks, 2.220446049250313e-16));
+      tauz = (float)((ka + ks) * dzz);
+      gcell = (float)gg[r];
+    }
     const float *ax = L.axes;
     aspect = fmaxf(ax[L.axis_off[2]], aspect);
     tauz = fmaxf(ax[L.axis_off[0]], fminf(ax[L.axis_off[0] + L.n[0] - 1], tauz));
     w0 = fmaxf(ax[L.axis_off[1]], fminf(ax[L.axis_off[1] + L.n[1] - 1], w0));
-    const float sample[4] = {tauz, w0, aspect, (float)gg[r]};
+    const float sample[4] = {tauz, w0, aspect, gcell};
     int ninterp;
     long long ofs_base, ioff_lo[4], ioff_hi[4];
     float wlo[4], whi[4];

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_dir(TsxGeo g, TsxLutDev L
                                                            const double *__restrict__ ksca, const double *__restrict__ gg,
                                                            const double *__restrict__ dz, double dx, float sym_phi, float theta,
                                                            int lswitch_east, int lswitch_north,
-                                                           const uint8_t *__restrict__ l1d, float *__restrict__ C) {
+                                                           const uint8_t *__restrict__ l1d, float *__restrict__ C,
+                                                           const float4 *__restrict__ samp) {
   const int xm = g.xm, ym = g.ym, Nz = g.Nz;
   const long long Nc = g.Nc;
   for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
@@ -80,16 +81,23 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_lut_dir(TsxGeo g, TsxLutDev L
     const int j = (int)(t % ym);
     const int k = (int)(t / ym);
     if (l1d[k]) continue;
-    const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
-    const double ka = kabs[r], ks = ksca[r], dzz = dz[r];
-    float aspect = (float)(dzz / dx);
-    float w0 = (float)(ks / fmax(ka + ks, 2.220446049250313e-16));
-    float tauz = (float)((ka + ks) * dzz);
+    float aspect, w0, tauz, gcell;
+    if (samp) {  // the cells' LUT coordinates in cell order (tsx_k_cell_samples)
+      const float4 v = samp[c];
+      aspect = v.x, w0 = v.y, tauz = v.z, gcell = v.w;
+    } else {
+      const size_t r = (size_t)k + (size_t)Nz * ((size_t)i + (size_t)xm * j);
+      const double ka = kabs[r], ks = ksca[r], dzz = dz[r];
+      aspect = (float)(dzz / dx);
+      w0 = (float)(ks / fmax(ka + ks, 2.220446049250313e-16));
+      tauz = (float)((ka + ks) * dzz);
+      gcell = (float)gg[r];
+    }
     const float *ax = L.axes;
     aspect = fmaxf(ax[L.axis_off[2]], aspect);
     tauz = fmaxf(ax[L.axis_off[0]], fminf(ax[L.axis_off[0] + L.n[0] - 1], tauz));
     w0 = fmaxf(ax[L.axis_off[1]], fminf(ax[L.axis_off[1] + L.n[1] - 1], w0));
-    const float sample[6] = {tauz, w0, aspect, (float)gg[r], sym_phi, theta};
+    const float sample[6] = {tauz, w0, aspect, gcell, sym_phi, theta};
     int ninterp;
     long long ofs_base, ioff_lo[6], ioff_hi[6];
     float wlo[6], whi[6];
