@@ -16,6 +16,7 @@
 
 #include "tsx_host.hpp"
 #include "tsx_peer.hpp"
+#include "tsx_peer_dev.hpp"
 #include "tsx_kernels.hpp"
 #include "tsx_pipeline.hpp"
 
@@ -408,16 +409,18 @@ int tsx_face_exchange_elems(tsx_solver *s, hipStream_t st, size_t elem_bytes) {
 
 // reduce partials -> (all-reduce) -> scalar algebra
 static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {
-  if (tsx_peer_ready(s) && s->grid.nranks > 1) {  // three small kernels on the solver stream, no library call, no host
-    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1);
-    int rc = tsx_peer_allreduce(s, s->stream, s->scal->red, TSX_NSLOTS, nullptr);
+  TsxPeerArArgs noar;
+  memset((void *)&noar, 0, sizeof(noar));
+  if (tsx_peer_ready(s) && s->grid.nranks > 1) {  // ONE kernel on the solver stream: partial sums, the sum over the ranks through
+    TsxPeerArArgs ar;                              // the mailboxes, the scalar algebra; no library call, no host
+    int rc = tsx_peer_ar_args(s, TSX_NSLOTS, &ar);
     if (rc) return rc;
-    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 2);
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 3, ar);
     HIPCHK(hipGetLastError());
     return TSX_OK;
   }
   if (s->allred_cb) {
-    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1);
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1, noar);
     HIPCHK(hipMemcpyAsync(s->scal_host->red, s->scal->red, sizeof(double) * TSX_NSLOTS, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (s->allred_cb(s->cb_ctx, s->scal_host->red, TSX_NSLOTS)) {
@@ -425,17 +428,17 @@ static int scalar_stage(tsx_solver *s, int nblocks, int nslots, int stage) {
       return TSX_ERR_COMM;
     }
     HIPCHK(hipMemcpyAsync(s->scal->red, s->scal_host->red, sizeof(double) * TSX_NSLOTS, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 2);
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 2, noar);
     HIPCHK(hipGetLastError());
     return TSX_OK;
   }
   if (s->comm_ready) {  // also with a 1-rank communicator (exercised by the single-GPU RCCL test)
-    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1);
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 1, noar);
     NCCLCHK(g_rccl.AllReduce(s->scal->red, s->scal->red, TSX_NSLOTS, TSX_NCCL_FLOAT64, TSX_NCCL_SUM, s->nccl_comm,
                              s->stream));
-    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 2);
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 2, noar);
   } else {
-    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 3);
+    hipLaunchKernelGGL(tsx_k_scalar, dim3(1), dim3(1024), 0, s->stream, s->scal, s->partials, nblocks, nslots, stage, 3, noar);
   }
   HIPCHK(hipGetLastError());
   return TSX_OK;

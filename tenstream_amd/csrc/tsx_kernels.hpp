@@ -2,6 +2,7 @@
 // (operator: tsx_kernels_spmv.hpp, preconditioner: tsx_kernels_pc.hpp, helpers: tsx_dev.hpp)
 #pragma once
 #include "tsx_dev.hpp"
+#include "tsx_peer_dev.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // BLAS-1 stages of the flexible BiCGStab (KSPFBCGS, selected at src/pprts.F90:4342), fused so that a
@@ -298,10 +299,15 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xplus(long long n, const TsxS
 enum { TSX_STAGE_INIT = 0, TSX_STAGE_ALPHA = 1, TSX_STAGE_OMEGA = 2, TSX_STAGE_RHO = 3, TSX_STAGE_EXPLICIT = 4, TSX_STAGE_REPLACE = 5 };
 
 __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc, const double *__restrict__ partials,
-                                                     int nblocks, int nslots, int stage, int mode) {
+                                                     int nblocks, int nslots, int stage, int mode, TsxPeerArArgs ar) {
+  // ar.nranks > 1 (peer transport, mode 3): the sum over the ranks happens here, between the reduction of the partial sums and
+  // the scalar algebra -- one kernel per reduction point instead of three.  Once the solve is done the ranks still exchange
+  // (whatever red holds): a rank writes all-reduce n only after n - 1 has completed everywhere, which is what lets the slots
+  // do without acknowledgements
   __shared__ double sm[TSX_NSLOTS][16];
-  if (sc->done) return;
-  if (mode & 1) {
+  const bool finished = sc->done != 0;
+  if (finished && ar.nranks <= 1) return;
+  if (!finished && (mode & 1)) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int s = 0; s < nslots; ++s) {
       double v = 0.0;
@@ -322,6 +328,8 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
     }
     __syncthreads();
   }
+  if (ar.nranks > 1) tsx_peer_allreduce_wg(ar, sc->red);  // red[] was written by lane 0 before the barrier above
+  if (finished) return;
   if (!(mode & 2) || threadIdx.x != 0) return;
   const double tiny = 2.2250738585072014e-308;
   switch (stage) {

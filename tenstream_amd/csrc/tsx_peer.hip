@@ -52,12 +52,8 @@ namespace {
 constexpr int kMaxRanks = TSX_PEER_MAX_RANKS;
 constexpr size_t kHdrBytes = TSX_PEER_HDR_BYTES;
 
-struct PeerArSlot {  // 64 bytes: one line per contribution
-  double v[TSX_NSLOTS + 1];
-  unsigned long long seq;
-  unsigned long long pad[8 - (TSX_NSLOTS + 1) - 1];
-};
-static_assert(sizeof(PeerArSlot) == 64, "all-reduce slot is one 64-byte line");
+using PeerArSlot = TsxPeerArSlot;
+static_assert(TSX_PEER_MAX_RANKS == TSX_PEER_MAX_RANKS_DEV, "rank limit");
 
 using PeerHdr = TsxPeerHdr;
 
@@ -149,43 +145,10 @@ __global__ __launch_bounds__(256) void tsx_k_peer_recv(PeerXArgs a) {
   }
 }
 
-struct PeerArArgs {
-  char *mine;
-  char *box[kMaxRanks];
-  int rank, nranks, nvals, heavy;
-  unsigned long long n, ar_off, ticks;
-};
+using PeerArArgs = TsxPeerArArgs;
 
 // one workgroup of 64 lanes; v: nvals (<= TSX_NSLOTS + 1) doubles in device memory, summed over the ranks in place
-__global__ __launch_bounds__(64) void tsx_k_peer_allreduce(PeerArArgs a, double *__restrict__ v, const int *__restrict__ done) {
-  if (done && *done) return;
-  const int r = threadIdx.x;
-  const int par = (int)(a.n & 1);
-  __shared__ int bad;
-  if (r == 0) bad = 0;
-  __syncthreads();
-  if (r < a.nranks) {
-    PeerArSlot *slot = reinterpret_cast<PeerArSlot *>(a.box[r] + a.ar_off) + (size_t)par * kMaxRanks + a.rank;
-    for (int k = 0; k < a.nvals; ++k) slot->v[k] = v[k];
-    tsx_peer_stores_done(a.heavy);
-    tsx_peer_post(&slot->seq, a.n, a.heavy);
-    const PeerArSlot *in = reinterpret_cast<const PeerArSlot *>(a.mine + a.ar_off) + (size_t)par * kMaxRanks + r;
-    unsigned long long have = 0;
-    if (!wait_ge(&in->seq, a.n, a.ticks, &have, a.heavy, a.mine)) {
-      bad = 1;
-      peer_fail(a.mine, 3, r, a.n, have);
-    }
-  }
-  __syncthreads();
-  if (r == 0 && !bad) {
-    const PeerArSlot *in = reinterpret_cast<const PeerArSlot *>(a.mine + a.ar_off) + (size_t)par * kMaxRanks;
-    for (int k = 0; k < a.nvals; ++k) {
-      double sum = 0.0;
-      for (int q = 0; q < a.nranks; ++q) sum += __hip_atomic_load(&in[q].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      v[k] = sum;
-    }
-  }
-}
+__global__ __launch_bounds__(64) void tsx_k_peer_allreduce(PeerArArgs a, double *__restrict__ v) { tsx_peer_allreduce_wg(a, v); }
 
 // ---- self test: patterns through the mailboxes (tsx_comm_peer_selftest)
 __device__ __forceinline__ double peer_pattern(int rank, int face, int round, long long i) {
@@ -476,22 +439,29 @@ int tsx_peer_expect(tsx_solver *s, const size_t bytes[4], TsxPeerWait *w, const 
 }
 
 // v: nvals doubles on the device, summed over the ranks in place, on stream st
-int tsx_peer_allreduce(tsx_solver *s, hipStream_t st, double *v, int nvals, const int *done) {
+// the next all-reduce of this rank as a kernel sees it (tsx_peer_allreduce_wg in its body: tsx_k_scalar does the Krylov dots' sum
+// between its reduction of the partial sums and the scalar algebra)
+int tsx_peer_ar_args(tsx_solver *s, int nvals, TsxPeerArArgs *a) {
   TsxPeer *p = s->peer;
   ARGCHK(nvals >= 1 && nvals <= TSX_NSLOTS + 1, "peer all-reduce: too many values");
+  memset(a, 0, sizeof(*a));
+  a->mine = p->mine;
+  for (int r = 0; r < s->grid.nranks; ++r) a->box[r] = p->box[r];
+  a->rank = s->grid.rank;
+  a->nranks = s->grid.nranks;
+  a->nvals = nvals;
+  a->n = ++p->ar_n;
+  a->ar_off = p->ar_off;
+  a->ticks = p->ticks;
+  a->heavy = p->heavy;
+  return TSX_OK;
+}
+int tsx_peer_allreduce(tsx_solver *s, hipStream_t st, double *v, int nvals, const int *done) {
   PeerArArgs a;
-  memset(&a, 0, sizeof(a));
-  a.mine = p->mine;
-  for (int r = 0; r < s->grid.nranks; ++r) a.box[r] = p->box[r];
-  a.rank = s->grid.rank;
-  a.nranks = s->grid.nranks;
-  a.nvals = nvals;
-  a.n = ++p->ar_n;
-  a.ar_off = p->ar_off;
-  a.ticks = p->ticks;
-  a.heavy = p->heavy;
+  int rc = tsx_peer_ar_args(s, nvals, &a);
+  if (rc) return rc;
   (void)done;  // as for the exchange: the sequence stays in step on every rank
-  hipLaunchKernelGGL(tsx_k_peer_allreduce, dim3(1), dim3(64), 0, st, a, v, (const int *)nullptr);
+  hipLaunchKernelGGL(tsx_k_peer_allreduce, dim3(1), dim3(64), 0, st, a, v);
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }

@@ -20,3 +20,5 @@ struct TsxPeerXArgs;
 struct TsxPeerWait;
 int tsx_peer_prepare_send(tsx_solver *s, const size_t bytes[4], TsxPeerXArgs *a);
 int tsx_peer_expect(tsx_solver *s, const size_t bytes[4], TsxPeerWait *w, const void *slot[4]);
+struct TsxPeerArArgs;
+int tsx_peer_ar_args(tsx_solver *s, int nvals, TsxPeerArArgs *a);

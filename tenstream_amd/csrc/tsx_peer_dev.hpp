@@ -153,3 +153,49 @@ __device__ __forceinline__ void tsx_peer_wait_faces(const TsxPeerWait &w, bool n
   }
   __syncthreads();
 }
+
+// ---- all-reduce through the mailboxes (see tsx_peer.hip): contribution slots of 64 bytes, [parity][rank]
+struct TsxPeerArSlot {  // one line per contribution
+  double v[TSX_NSLOTS + 1];
+  unsigned long long seq;
+  unsigned long long pad[8 - (TSX_NSLOTS + 1) - 1];
+};
+static_assert(sizeof(TsxPeerArSlot) == 64, "all-reduce slot is one 64-byte line");
+#define TSX_PEER_MAX_RANKS_DEV 16
+struct TsxPeerArArgs {
+  char *mine;
+  char *box[TSX_PEER_MAX_RANKS_DEV];
+  int rank, nranks, nvals, heavy;  // nranks <= 1: no all-reduce
+  unsigned long long n, ar_off, ticks;
+};
+// v: a.nvals doubles in device memory, summed over the ranks in place, in rank order.  Called by every thread of ONE workgroup of
+// at least 64 threads (barriers inside); lane r < nranks talks to rank r.
+__device__ __forceinline__ void tsx_peer_allreduce_wg(const TsxPeerArArgs &a, double *__restrict__ v) {
+  const int r = threadIdx.x;
+  const int par = (int)(a.n & 1);
+  __shared__ int bad_;
+  if (r == 0) bad_ = 0;
+  __syncthreads();
+  if (r < a.nranks) {
+    TsxPeerArSlot *slot = reinterpret_cast<TsxPeerArSlot *>(a.box[r] + a.ar_off) + (size_t)par * TSX_PEER_MAX_RANKS_DEV + a.rank;
+    for (int k = 0; k < a.nvals; ++k) slot->v[k] = v[k];
+    tsx_peer_stores_done(a.heavy);
+    tsx_peer_post(&slot->seq, a.n, a.heavy);
+    const TsxPeerArSlot *in = reinterpret_cast<const TsxPeerArSlot *>(a.mine + a.ar_off) + (size_t)par * TSX_PEER_MAX_RANKS_DEV + r;
+    unsigned long long have = 0;
+    if (!tsx_peer_wait_ge(&in->seq, a.n, a.ticks, &have, a.heavy, a.mine)) {
+      bad_ = 1;
+      tsx_peer_fail(a.mine, 3, r, a.n, have);
+    }
+  }
+  __syncthreads();
+  if (r == 0 && !bad_) {
+    const TsxPeerArSlot *in = reinterpret_cast<const TsxPeerArSlot *>(a.mine + a.ar_off) + (size_t)par * TSX_PEER_MAX_RANKS_DEV;
+    for (int k = 0; k < a.nvals; ++k) {
+      double sum = 0.0;
+      for (int q = 0; q < a.nranks; ++q) sum += __hip_atomic_load(&in[q].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v[k] = sum;
+    }
+  }
+  __syncthreads();
+}
