@@ -82,7 +82,10 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_resolve(TsxGeo g, int DD, 
                                                               const unsigned long long *__restrict__ h,
                                                               const unsigned long long *__restrict__ keys,
                                                               const int *__restrict__ owner, int *__restrict__ rep,
-                                                              int *__restrict__ flag) {
+                                                              int *__restrict__ flag, const float4 *__restrict__ samp) {
+  // samp (nullable): the LUT coordinates the blocks were interpolated from (tsx_k_cell_samples).  The interpolation is a
+  // deterministic function of them, so two cells with bit-identical coordinates have bit-identical blocks and the 2 x 400-byte
+  // comparison is spared (the whole clear-sky background); different coordinates are compared block by block as ever
   const long long Nc = g.Nc;
   for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
     const unsigned long long hv = h[c];
@@ -91,8 +94,15 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_resolve(TsxGeo g, int DD, 
     const int o = owner[slot];
     bool same = true;
     if (o != (int)c && !(l1d[(int)(c / g.ncol)] && l1d[o / g.ncol])) {
-      for (int q = 0; q < DD; ++q)
-        same &= __float_as_uint(C[(size_t)q * Nc + c]) == __float_as_uint(C[(size_t)q * Nc + o]);
+      bool coords = false;
+      if (samp) {
+        const float4 a = samp[c], b = samp[o];
+        coords = __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+                 __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
+      }
+      if (!coords)
+        for (int q = 0; q < DD; ++q)
+          same &= __float_as_uint(C[(size_t)q * Nc + c]) == __float_as_uint(C[(size_t)q * Nc + o]);
     }
     const int r = same ? o : (int)c;
     rep[c] = r;
@@ -356,6 +366,8 @@ static int dd_build(tsx_solver *s, bool near, bool *pays) {
     hipLaunchKernelGGL(tsx_k_dd_hash_near, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, g.D, C, s->l1d, th.as<unsigned long long>());
   else if (!s->dd_hash_ready)  // else tsx_k_lut_diff2diff has left the hashes of the blocks it produced (tsx_dedup_hash_buffer)
     hipLaunchKernelGGL(tsx_k_dd_hash, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, th.as<unsigned long long>());
+  // the blocks came from tsx_k_lut_diff2diff a moment ago: the cells' LUT coordinates are still there (tsx_cell_samples)
+  const float4 *samp = (!near && s->dd_hash_ready) ? (const float4 *)s->cell_samp : (const float4 *)nullptr;
   s->dd_hash_ready = false;
   hipLaunchKernelGGL(tsx_k_dd_insert, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, tsz - 1, th.as<unsigned long long>(),
                      tk.as<unsigned long long>(), to.as<int>());
@@ -364,7 +376,7 @@ static int dd_build(tsx_solver *s, bool near, bool *pays) {
                        th.as<unsigned long long>(), tk.as<unsigned long long>(), to.as<int>(), trep.as<int>(), tflag.as<int>());
   else
     hipLaunchKernelGGL(tsx_k_dd_resolve, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, DD, C, s->l1d, tsz - 1,
-                       th.as<unsigned long long>(), tk.as<unsigned long long>(), to.as<int>(), trep.as<int>(), tflag.as<int>());
+                       th.as<unsigned long long>(), tk.as<unsigned long long>(), to.as<int>(), trep.as<int>(), tflag.as<int>(), samp);
   hipLaunchKernelGGL(tsx_k_scan_sums, dim3(nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, tflag.as<int>(), tsum.as<int>());
   hipLaunchKernelGGL(tsx_k_scan_top, dim3(1), dim3(1024), 0, s->stream, nsb, tsum.as<int>(), ttot.as<int>());
   hipLaunchKernelGGL(tsx_k_scan_write, dim3(nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, tflag.as<int>(), tsum.as<int>(), tpos.as<int>());
