@@ -226,6 +226,18 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_compact(long long Nc, long
   }
 }
 
+// colsum[s][e] = sum over dst d of c(src s -> dst d) of distinct block e, accumulated in double in the order d = 0 .. D-1 exactly
+// like the per-cell loops of tsx_k_setup_b_thermal / tsx_k_flx_div it replaces (1 - colsum = what a stream loses to absorption)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_colsum(int D, long long nent, const float *__restrict__ Cd,
+                                                             double *__restrict__ out) {
+  for (long long e = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; e < nent; e += (long long)gridDim.x * TSX_BLOCK)
+    for (int sI = 0; sI < D; ++sI) {
+      double sum = 0.0;
+      for (int d = 0; d < D; ++d) sum += (double)Cd[(size_t)(d * D + sI) * nent + e];
+      out[(size_t)sI * nent + e] = sum;
+    }
+}
+
 struct TsxDdSlice {  // a piece of the solver's scratch allocation
   void *p;
   template <typename T> T *as() const { return static_cast<T *>(p); }
@@ -415,7 +427,16 @@ static int dd_build(tsx_solver *s, bool near, bool *pays) {
       hipLaunchKernelGGL(tsx_k_dd_compact<256>, dim3(nbt > 0 ? nbt : 1), dim3(TSX_BLOCK), 0, s->stream, Nc, (long long)nent, C,
                          *ent_cell, Cd, Ce);
   }
-  if (!near) s->dd_coef_e = s->dd_coef + (size_t)DD * s->dd_cap;
+  if (!near) {
+    s->dd_coef_e = s->dd_coef + (size_t)DD * s->dd_cap;
+    if (s->dd_colsum_cap < (long long)g.D * nent) {
+      if (s->dd_colsum) HIPCHK(hipFree(s->dd_colsum));
+      s->dd_colsum = nullptr;
+      HIPCHK(hipMalloc((void **)&s->dd_colsum, sizeof(double) * (size_t)g.D * nent));
+      s->dd_colsum_cap = (long long)g.D * nent;
+    }
+    hipLaunchKernelGGL(tsx_k_dd_colsum, dim3(grid_for(nent)), dim3(TSX_BLOCK), 0, s->stream, g.D, (long long)nent, s->dd_coef, s->dd_colsum);
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
   *pays = true;

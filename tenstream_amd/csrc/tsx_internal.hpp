@@ -187,6 +187,8 @@ struct tsx_solver {
   TsxLutHost lut_T, lut_S;
   float *dirT, *dirS;            // direct coefficient planes (S*S, S*D)
   bool dir_coeffs_valid;
+  double *dd_colsum;         // [D][dd_nent]: sum over dst of c(src, dst) per distinct block (absorptivity / emissivity terms of setup_b_thermal, flx_div)
+  long long dd_colsum_cap;
   void *cell_samp;           // float4 per cell: the LUT coordinates in cell order (tsx_k_cell_samples) ...
   const void *cell_samp_src[4];  // ... of these arrays (every writer of them is followed by the diffuse lookup, which renews it)
   double cell_samp_dx;

@@ -605,7 +605,9 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_setup_b_thermal(TsxGeo g, con
                                                                    const double *__restrict__ a12, const double *__restrict__ albedo,
                                                                    const double *__restrict__ planck, const double *__restrict__ kabs,
                                                                    const double *__restrict__ dz, double dx, double dy,
-                                                                   double *__restrict__ b) {
+                                                                   double *__restrict__ b, const double *__restrict__ colsum,
+                                                                   const int *__restrict__ cidx, long long nent) {
+  // colsum (nullable): sum over dst of c(src, :) per distinct block [D][nent] behind the per-cell index cidx (tsx_k_dd_colsum)
   constexpr int D = NTOP + 2 * NSIDE;
   const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol, L = Nz + 1;
   const long long Nc = g.Nc;
@@ -638,8 +640,12 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_setup_b_thermal(TsxGeo g, con
 #pragma unroll
       for (int s = 0; s < D; ++s) {
         double sum = 0.0;
+        if (colsum) {
+          sum = colsum[(size_t)s * nent + cidx[c]];
+        } else {
 #pragma unroll
-        for (int d = 0; d < D; ++d) sum += (double)C[(size_t)(d * D + s) * Nc + c];
+          for (int d = 0; d < D; ++d) sum += (double)C[(size_t)(d * D + s) * Nc + c];
+        }
         double emis = fmax(0.0, fmin(1.0, 1.0 - sum));
         double v;
         if (s < NTOP) {
@@ -672,7 +678,10 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_flx_div(TsxGeo g, TsxSun sun,
                                                            const double *__restrict__ x, const double *__restrict__ bsrc,
                                                            double *__restrict__ abso, TsxDirHalo hb,
                                                            const double *__restrict__ hW, const double *__restrict__ hE,
-                                                           const double *__restrict__ hS, const double *__restrict__ hN) {
+                                                           const double *__restrict__ hS, const double *__restrict__ hN,
+                                                           const double *__restrict__ colsum, const int *__restrict__ cidx,
+                                                           long long nent) {
+  // colsum (nullable): sum over dst of c(src, :) per distinct block [D][nent] behind the per-cell index cidx (tsx_k_dd_colsum)
   // hb: direct-beam faces from the upwind ranks; hW..hN: the diffuse halo of x (entering side streams, as the operator
   // reads them: [slot][k][j] / [slot][k][i]); only dereferenced where the rank does not wrap onto itself
   constexpr int D = NTOP + 2 * NSIDE, S = DTOP + 2 * DSIDE;
@@ -746,8 +755,12 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_flx_div(TsxGeo g, TsxSun sun,
 #pragma unroll
       for (int s = 0; s < D; ++s) {
         double sum = 0.0;
+        if (colsum) {
+          sum = colsum[(size_t)s * nent + cidx[c]];
+        } else {
 #pragma unroll
-        for (int d = 0; d < D; ++d) sum += (double)C[(size_t)(d * D + s) * Nc + c];
+          for (int d = 0; d < D; ++d) sum += (double)C[(size_t)(d * D + s) * Nc + c];
+        }
         a += xs[s] * (1.0 - sum);
       }
     } else {
