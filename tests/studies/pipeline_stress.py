@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import test_gpu_pipeline as T  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "2026")))
 worst = 0.0
 for case in range(n):
     solver = "3_10" if rng.random() < 0.7 else "8_16"
