@@ -65,6 +65,9 @@ def parse():
                          "cells share a transport block")
     ap.add_argument("--skip-no-sharing", action="store_true",
                     help="skip the second (reported, never `value`) leg that repeats the solves with every block stored per cell")
+    ap.add_argument("--skip-extra-legs", action="store_true",
+                    help="skip the reported-only legs config.all_fp64 (fp64 recurrence / no reduced precision anywhere) and "
+                         "config.heterogeneous (every cell its own block)")
     ap.add_argument("--check-every", type=int, default=None, help="host looks at the convergence flag every n iterations (library default 4)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,15 +173,17 @@ def main():
     # ---- synthetic optical properties for the owned block (same seed on all ranks -> one global field).  Only the cloud
     # mask is generated globally; delta scaling and the source term are evaluated on the owned block plus one periodic
     # halo column/row (the source of a side stream comes from the neighbouring column), so set-up cost does not grow with N
-    kabs, ksca, g = S.cloud_field(Nx, Ny, Nz, seed=args.seed, cover=args.cover, heterogeneous=args.field == "heterogeneous")
-    jj = np.arange(co.ys - 1, co.ys + co.ym + 1) % Ny
-    ii = np.arange(co.xs - 1, co.xs + co.xm + 1) % Nx
-    kabs, ksca, g = (np.ascontiguousarray(a[np.ix_(jj, ii)]) for a in (kabs, ksca, g))
-    kabs, ksca, g = S.delta_scale(kabs, ksca, g)
-    b_slab = S.solar_source(solver, kabs, ksca, g, dz, dx, np.full((co.ym + 2, co.xm + 2), albedo))
-    kabs_l, ksca_l, g_l = (np.ascontiguousarray(a[1:-1, 1:-1]) for a in (kabs, ksca, g))
-    b = torch.tensor(np.ascontiguousarray(b_slab[1:-1, 1:-1]), device=dev)
-    del b_slab, kabs, ksca, g
+    def make_field(field):
+        kabs, ksca, g = S.cloud_field(Nx, Ny, Nz, seed=args.seed, cover=args.cover, heterogeneous=field == "heterogeneous")
+        jj = np.arange(co.ys - 1, co.ys + co.ym + 1) % Ny
+        ii = np.arange(co.xs - 1, co.xs + co.xm + 1) % Nx
+        kabs, ksca, g = (np.ascontiguousarray(a[np.ix_(jj, ii)]) for a in (kabs, ksca, g))
+        kabs, ksca, g = S.delta_scale(kabs, ksca, g)
+        b_slab = S.solar_source(solver, kabs, ksca, g, dz, dx, np.full((co.ym + 2, co.xm + 2), albedo))
+        loc = tuple(np.ascontiguousarray(a[1:-1, 1:-1]) for a in (kabs, ksca, g))
+        return loc, torch.tensor(np.ascontiguousarray(b_slab[1:-1, 1:-1]), device=dev)
+
+    (kabs_l, ksca_l, g_l), b = make_field(args.field)
     l1d = torch.zeros(Nz, dtype=torch.uint8, device=dev)
     a11 = torch.zeros((co.ym, co.xm, Nz), dtype=torch.float64, device=dev)
     a12 = torch.zeros_like(a11)
@@ -239,16 +244,18 @@ def main():
     kw = dict(pc=args.pc, pc_sweeps=args.pc_sweeps, check_every=args.check_every, explicit_solver=int(args.explicit),
               maxit=10000 if args.explicit else None)
 
-    def timed_steps():
+    def timed_steps(rhs=None, **override):
         """W untimed + K timed solves from a zero guess, barrier + synchronize on both sides, max over ranks.  A solve that
         fails (a bounded wait of the peer transport expired ...) is recorded, not raised: every rank still reaches the barriers"""
         got, failed = [], None
+        rhs = b if rhs is None else rhs
+        kws = dict(kw, **override)
 
         def one():
             nonlocal failed
             if failed is None:
                 try:
-                    return s.solve(b, x, initial_guess_zero=1, **kw)
+                    return s.solve(rhs, x, initial_guess_zero=1, **kws)
                 except Exception as e:   # noqa: BLE001
                     failed = e
             return None
@@ -347,6 +354,62 @@ def main():
                 os.environ[k] = v
         s.set_optprop(*optprop)   # back to the default storage for what follows
 
+    # ---- third leg (reported under config.all_fp64, never `value`): the same solves without the fp32 recurrence --
+    # "recurrence_fp64": r, s, v, t in fp64, only the preconditioned directions in fp32 (fp32_directions = 1);
+    # "everything_fp64": no reduced precision anywhere, the preconditioner on the exact fp64 blocks (fp32_directions = 0,
+    # pc_coeff_fp16 = 0) -- the reference's default arithmetic (ireals = real64) end to end
+    all_fp64 = None
+    if not args.skip_extra_legs and not args.explicit:
+        all_fp64 = {}
+        for name, ov in (("recurrence_fp64", dict(fp32_directions=1)), ("everything_fp64", dict(fp32_directions=0, pc_coeff_fp16=0))):
+            dt_f, infos_f, failed_f = timed_steps(**ov)
+            if failed_f is not None:
+                raise failed_f
+            pcf = s.pc_info()
+            all_fp64[name] = {"cells_per_s": cells_total * args.steps / dt_f, "ms_per_step": dt_f / args.steps * 1e3,
+                              "iterations": infos_f[-1].niter, "reason": infos_f[-1].reason,
+                              "rel_residual": infos_f[-1].rnorm / infos_f[-1].rnorm0,
+                              "preconditioner": {0: "none", 1: "column-jacobi", 2: f"column-zebra({pcf[1] + 1} passes)",
+                                                 3: f"column-red-black({pcf[1] + 1} passes)"}.get(pcf[0], str(pcf[0])),
+                              "options": ov}
+
+    # ---- fourth leg (config.heterogeneous, never `value`): the general field -- log-normal noise on every cell's kabs / ksca,
+    # so no two cells share a transport block (what an LES humidity / aerosol field + gas optics delivers); same generator
+    # seed, same solves.  The operator reads every cell's own block, the preconditioner groups near-identical ones
+    heterogeneous = None
+    if world == 1 and args.field == "clouds" and not args.skip_extra_legs and not args.explicit:
+        (ka_h, ks_h, g_h), b_h = make_field("heterogeneous")
+        opt_h = (dev_f(ka_h), dev_f(ks_h), dev_f(g_h)) + optprop[3:]
+        s.set_optprop(*opt_h)
+        dt_h, infos_h, failed_h = timed_steps(rhs=b_h)
+        if failed_h is not None:
+            raise failed_h
+        on_h, nent_h = s.dedup_info()
+        _, sw_h, scan_h, _ = s.pc_info()
+        it_h = s.bench_kernel(1, max(4, args.kernel_reps // 4))
+        sp_h = s.bench_kernel(0, args.kernel_reps)
+        pass_h = s.bench_kernel(3, 4 * args.kernel_reps) if scan_h and args.pc_sweeps == 0 else None
+        pc_h = s.bench_kernel(2, args.kernel_reps) if scan_h and args.pc_sweeps == 0 else None
+        tag_h = f"{co.xm}x{co.ym}x{Nz}_heterogeneous"
+        kname_h = "tsx_k_pcs_rb" if solver == "3_10" else "tsx_k_pcsh_rb"
+        tr_sp, src_h = pmc_traffic(solver, tag_h, ["tsx_k_spmv", (",0,1,double,double", ",0,2,double,double"), ",false,double>"])
+        tr_pass, _ = pmc_traffic(solver, tag_h, [kname_h, (",true,0,true,2,", ",true,0,true,2>")])
+        tr_it, _ = pmc_traffic(solver, tag_h, None)
+        heterogeneous = {
+            "cells_per_s": cells_total * args.steps / dt_h, "ms_per_step": dt_h / args.steps * 1e3,
+            "iterations": infos_h[-1].niter, "reason": infos_h[-1].reason, "rel_residual": infos_h[-1].rnorm / infos_h[-1].rnorm0,
+            "distinct_blocks_or_groups": nent_h, "dedup_mode": int(getattr(s, "dedup_mode", 0)),
+            "iter_ms": it_h, "iter_frac_of_B_iter": s.algorithmic_bytes(1) / (it_h * 1e-3) / 1e9 / 8000.0,
+            "iter_traffic_bytes": tr_it,
+            "spmv_ms": sp_h, "spmv_bytes": s.algorithmic_bytes(0), "spmv_frac": s.algorithmic_bytes(0) / (sp_h * 1e-3) / 1e9 / 8000.0,
+            "spmv_traffic_bytes": tr_sp,
+            "pass_ms": pass_h, "pass_bytes": None if pass_h is None else s.algorithmic_bytes(3),
+            "pass_frac": None if pass_h is None else s.algorithmic_bytes(3) / (pass_h * 1e-3) / 1e9 / 8000.0,
+            "pass_traffic_bytes": tr_pass, "pc_ms": pc_h, "passes": sw_h + 1, "traffic_source": src_h,
+            "how": "--field heterogeneous of the same seed: log-normal noise on every cell's kabs / ksca"}
+        del opt_h, b_h
+        s.set_optprop(*optprop)
+
     def roof(kernel, ms, nbytes, patterns, full_storage_bytes=None):
         ach = nbytes / (ms * 1e-3) / 1e9
         traffic, src = pmc_traffic(solver, f"{co.xm}x{co.ym}x{Nz}" + ("" if args.field == "clouds" else "_" + args.field), patterns)
@@ -432,6 +495,8 @@ def main():
                 "copy_GBps_measured": copy_gbps,
                 "field": args.field,
                 "no_sharing": no_sharing,
+                "all_fp64": all_fp64,
+                "heterogeneous": heterogeneous,
                 "baseline_config": baseline_config(solver, Nx, Ny, Nz, world, npx, npy, scaling),
             },
             "roofline": dominant,

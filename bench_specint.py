@@ -92,6 +92,10 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
     # Planck surrogate: 288 K at the surface to 220 K at the top, band-integrated ~ sigma T^4 / pi / n_lw
     T = torch.linspace(220.0, 288.0, Nz + 1, dtype=torch.float64, device=dev)
     planck0 = (5.670374419e-8 * T**4 / np.pi).expand(Ny, Nx, Nz + 1).contiguous()
+    # the surface's own emission (atm%tskin -> Bsrfc, rrtmg/rrtmg/pprts_rrtmg.F90:609-642): a skin 0-3 K warmer than the air at
+    # the lowest level, varying over the ground; handed over as planck_srfc with every LW g-point like :681 does
+    tskin = 288.0 + 3.0 * torch.rand((Ny, Nx), dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
+    planck_srfc0 = (5.670374419e-8 * tskin**4 / np.pi).contiguous()
 
     # --streams K: K solver instances, each with its own HIP stream and host thread, work on different g-points at the same
     # time (the library is re-entrant per instance; ctypes calls release the GIL).  On 256 x 256 columns one g-point fills the
@@ -129,7 +133,8 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
         f = float(factors[q])
         lsolar = q < args.sw
         roll = lambda a: torch.roll(a, shifts=shift["n"], dims=1) if shift["n"] else a
-        P.set_optical_properties(alb, roll(kabs0) * f, roll(ksca0) * f, roll(g0), dz_d, planck=None if lsolar else planck0 * weights[q])
+        P.set_optical_properties(alb, roll(kabs0) * f, roll(ksca0) * f, roll(g0), dz_d, planck=None if lsolar else planck0 * weights[q],
+                                 planck_srfc=None if lsolar else planck_srfc0 * weights[q])
         kw = dict(pc_sweeps=args.pc_sweeps) if args.pc_sweeps > 0 else {}
         e0 = 1361.0 * weights[q] if lsolar else 0.0
         info = P.solve(e0, lsolar=lsolar, uid=q, **kw)

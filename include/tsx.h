@@ -255,19 +255,24 @@ int tsx_lut_set_direct(tsx_solver *s, const float *Tdir, const float *Sdir, int6
  * axes = the LUT_3_10 preset unless a `<tdir_path>.axes` text sidecar (ndim, then "n v1..vn" per axis) exists */
 int tsx_lut_load_direct_mmap4(tsx_solver *s, const char *tdir_path, const char *sdir_path);
 /* set_optical_properties (src/pprts.F90:1764): raw kabs/ksca/g/dz (zs:ze-1, xs:xe, ys:ye) real64, albedo (xs:xe, ys:ye),
- * planck (zs:ze, xs:xe, ys:ye) or NULL.  On the device: delta scaling with f = g**2 when ldelta_scaling (:1903-1917,
+ * planck (zs:ze, xs:xe, ys:ye) or NULL; planck_srfc (xs:xe, ys:ye) or NULL -- the optional argument of the same name
+ * (:1773, 1823-1829): the surface's own Planck emission atm%Bsrfc, which the thermal source then uses at the ground with
+ * the emissivity 1 - albedo clamped to [0, 1] (:4958-4970) instead of planck at the lowest level (:4971-4984); the rrtmg
+ * driver always passes it (rrtmg/rrtmg/pprts_rrtmg.F90:609-642, 681).  Like atm%Bsrfc it is dropped by a call without it.
+ * On the device: delta scaling with f = g**2 when ldelta_scaling (:1903-1917,
  * src/helper_functions.fypp:1622-1666), 1-D layer detection dz/dx > twostr_ratio = 2 (:669-677), eddington_coeff_ec of the
  * 1-D layers (:1962-1992, src/eddington.F90:173-241), diffuse coefficient lookup.  Needs tsx_pprts_set_angles and the
  * diffuse LUT first. */
 int tsx_pprts_set_optical_properties(tsx_solver *s, const double *albedo, const double *kabs, const double *ksca,
-                                     const double *g, const double *dz, const double *planck, double dx, double dy,
-                                     int ldelta_scaling, int where);
+                                     const double *g, const double *dz, const double *planck, const double *planck_srfc,
+                                     double dx, double dy, int ldelta_scaling, int where);
 /* optical properties of one g-point, (zs:ze-1, xs:xe, ys:ye) real64, already delta-scaled; a11..a33 only read for
- * 1-D layers (eddington coefficients, src/pprts.F90:1962-1992); planck (zs:ze, xs:xe, ys:ye) or NULL for solar */
+ * 1-D layers (eddington coefficients, src/pprts.F90:1962-1992); planck (zs:ze, xs:xe, ys:ye) or NULL for solar;
+ * planck_srfc (xs:xe, ys:ye) or NULL as above */
 int tsx_pprts_set_optprop(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz,
                           double dx, double dy, const double *albedo, const uint8_t *l1d, const double *a11,
                           const double *a12, const double *a13, const double *a23, const double *a33,
-                          const double *planck, int where);
+                          const double *planck, const double *planck_srfc, int where);
 /* solve_pprts/pprts() for one g-point: lsolar = edirTOA > 0 semantics are the caller's (pprts_f2c_solve,
  * c_wrapper/f2c_pprts.F90:340-341).  The previous solution of this handle is the initial guess
  * (src/pprts.F90:2542-2558) unless tsx_pprts_zero_guess was called. */

@@ -395,12 +395,15 @@ def setup_b_solar(lay, dlay, sun, dir2diff, l1d, a13, a23, albedo, edir):
     return b
 
 
-def setup_b_thermal(lay, diff2diff, l1d, a11, a12, albedo, planck, kabs, dz, dx, dy):
+def setup_b_thermal(lay, diff2diff, l1d, a11, a12, albedo, planck, kabs, dz, dx, dy, planck_srfc=None):
+    """planck_srfc (ym, xm) = atm%Bsrfc (set_optical_properties' optional argument, src/pprts.F90:1823-1829) or None"""
     diff2diff, a11, a12, albedo, planck, kabs, dz = (_c64(a) for a in (diff2diff, a11, a12, albedo, planck, kabs, dz))
+    srfc = None if planck_srfc is None else _c64(np.broadcast_to(planck_srfc, (lay.ym, lay.xm)))
     l1d = np.ascontiguousarray(l1d, dtype=np.uint8)
     b = np.zeros((lay.ym, lay.xm, lay.Nz + 1, lay.D))
     lib().orc_setup_b_thermal_1rank(C.byref(lay), _p(diff2diff), _p(l1d, C.c_uint8), _p(a11), _p(a12), _p(albedo),
-                                    _p(planck), _p(kabs), _p(dz), C.c_double(dx), C.c_double(dy), _p(b))
+                                    _p(planck), None if srfc is None else _p(srfc), _p(kabs), _p(dz), C.c_double(dx),
+                                    C.c_double(dy), _p(b))
     return b
 
 

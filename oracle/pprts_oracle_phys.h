@@ -105,7 +105,8 @@ void orc_setup_b_solar_1rank(const orc_layout *l, const orc_dir_layout *d, const
                              const uint8_t *l1d, const double *a13, const double *a23, const double *albedo,
                              const double *edir, double *b);
 void orc_setup_b_thermal_1rank(const orc_layout *l, const double *diff2diff, const uint8_t *l1d, const double *a11,
-                               const double *a12, const double *albedo, const double *planck, const double *kabs,
+                               const double *a12, const double *albedo, const double *planck,
+                               const double *planck_srfc /* (xm, ym) = atm%Bsrfc, or NULL */, const double *kabs,
                                const double *dz, double dx, double dy, double *b);
 
 /* gen_scale_*_flx_vec_arr: src/pprts.F90:3901-3987.  to_Wm2 = 1: W -> W/m2 */

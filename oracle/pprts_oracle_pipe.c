@@ -284,10 +284,13 @@ void orc_setup_b_solar_1rank(const orc_layout *l, const orc_dir_layout *d, const
   free(xe);
 }
 
-/* setup_b thermal: src/pprts.F90:4848-4987 (no collapse, planck at levels, surface emission from planck(ze)) */
+/* setup_b thermal: src/pprts.F90:4848-4987 (no collapse, planck at levels).  Surface emission (:4958-4985): from
+ * planck_srfc (xm, ym) = atm%Bsrfc when the caller of set_optical_properties gave it (src/pprts.F90:1823-1829; the rrtmg
+ * driver always does, rrtmg/rrtmg/pprts_rrtmg.F90:609-642, 681) with the emissivity 1 - albedo clamped to [0, 1] (:4965-4966),
+ * else (planck_srfc == NULL) from planck(ze) with the unclamped 1 - albedo (:4971-4984) */
 void orc_setup_b_thermal_1rank(const orc_layout *l, const double *diff2diff, const uint8_t *l1d, const double *a11,
-                               const double *a12, const double *albedo, const double *planck, const double *kabs,
-                               const double *dz, double dxm, double dym, double *b) {
+                               const double *a12, const double *albedo, const double *planck, const double *planck_srfc,
+                               const double *kabs, const double *dz, double dxm, double dym, double *b) {
   const int D = orc_D(l), Nz = l->Nz, L = Nz + 1, xm = l->xm, ym = l->ym, gxm = xm + 2;
   const int ntop = l->ntop, nside = l->nside;
   const double tstreams = (double)(ntop / 2), sstreams = (double)(nside / 2);
@@ -335,12 +338,18 @@ void orc_setup_b_thermal_1rank(const orc_layout *l, const double *diff2diff, con
           }
         }
       }
-  for (int j = 0; j < ym; ++j) /* surface emission, Bsrfc not allocated: planck(ze) :4971-4984 */
+  for (int j = 0; j < ym; ++j)
     for (int i = 0; i < xm; ++i)
       for (int q = 0; q < ntop; ++q)
-        if (!l->top_inward[q])
-          xs[GI(D, L, gxm, q, Nz, i, j)] += planck[(size_t)Nz + (size_t)L * (i + (size_t)xm * j)] * Az *
-                                            (1.0 - albedo[i + (size_t)xm * j]) * M_PI / tstreams;
+        if (!l->top_inward[q]) {
+          if (planck_srfc) { /* allocated(atm%Bsrfc) :4960-4970 */
+            double emis = 1.0 - albedo[i + (size_t)xm * j];
+            emis = fmax(0.0, fmin(1.0, emis));
+            xs[GI(D, L, gxm, q, Nz, i, j)] += planck_srfc[i + (size_t)xm * j] * Az * emis * M_PI / tstreams;
+          } else /* Bsrfc not allocated: planck(ze) :4971-4984 */
+            xs[GI(D, L, gxm, q, Nz, i, j)] += planck[(size_t)Nz + (size_t)L * (i + (size_t)xm * j)] * Az *
+                                              (1.0 - albedo[i + (size_t)xm * j]) * M_PI / tstreams;
+        }
   orc_halo_reduce_1rank(D, L, xm, ym, xs);
   orc_ghosted_to_owned(D, L, xm, ym, xs, b);
   free(xs);

@@ -98,8 +98,8 @@ def load():
     lib.tsx_pprts_set_angles.argtypes = [vp, C.c_double, C.c_double]
     lib.tsx_lut_set_direct.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, vp, vp, ip]
     lib.tsx_lut_load_direct_mmap4.argtypes = [vp, C.c_char_p, C.c_char_p]
-    lib.tsx_pprts_set_optprop.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, ip]
-    lib.tsx_pprts_set_optical_properties.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, ip, ip]
+    lib.tsx_pprts_set_optprop.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, ip]
+    lib.tsx_pprts_set_optical_properties.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, ip, ip]
     lib.tsx_pprts_solve.argtypes = [vp, C.c_double, ip, C.POINTER(KspOpts), C.POINTER(KspResult)]
     lib.tsx_pprts_zero_guess.argtypes = [vp]
     lib.tsx_pprts_select_solution.argtypes = [vp, C.c_int32]

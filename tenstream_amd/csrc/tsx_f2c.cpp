@@ -311,7 +311,8 @@ extern "C" void pprts_f2c_set_global_optical_properties(int Nz, int Nx, int Ny, 
     }
   // delta scaling (-pprts_delta_scale default true), 1-D layers, Eddington coefficients, lookups: on the device
   chk(tsx_pprts_set_optical_properties(st.h, alb.data(), ka.data(), ks.data(), gg.data(), dz.data(),
-                                       st.have_planck ? pl.data() : nullptr, st.dx, st.dy, 1, TSX_HOST),
+                                       st.have_planck ? pl.data() : nullptr, /* planck_srfc: set_global_optical_properties has none, src/pprts.F90:2341 */ nullptr,
+                                       st.dx, st.dy, 1, TSX_HOST),
       "tsx_pprts_set_optical_properties");
 }
 

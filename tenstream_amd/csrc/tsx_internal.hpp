@@ -197,6 +197,7 @@ struct tsx_solver {
   bool have_optprop;
   double *a13, *a23, *a33;       // cell-indexed, 1-D layers only
   double *planck;                // (L, xm, ym) reference layout
+  double *bsrfc = nullptr;       // (xm, ym): atm%Bsrfc, the surface's own Planck emission (planck_srfc of set_optical_properties); null = not given
   float *v32;                    // fp32 copy of the preconditioner's right-hand side s (mixed path)
   float *p32;                    // the search direction p, kept in fp32 only on the mixed + preconditioned path
   const float *pc_rhs;           // which of the two the next tsx_pc_apply (fp32 directions) reads

@@ -598,12 +598,13 @@ __device__ __forceinline__ double tsx_B_eff(double B_far, double B_near, double 
   return B * 2;
 }
 
-// Thermal: set_thermal_source (src/pprts.F90:4848-4987); planck at levels, reference layout (k over L fastest)
+// Thermal: set_thermal_source (src/pprts.F90:4848-4987); planck at levels, reference layout (k over L fastest); bsrfc (xm, ym) = atm%Bsrfc or null
 template <int NTOP, int NSIDE, typename CT>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_setup_b_thermal(TsxGeo g, const CT *__restrict__ C,
                                                                    const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
                                                                    const double *__restrict__ a12, const double *__restrict__ albedo,
-                                                                   const double *__restrict__ planck, const double *__restrict__ kabs,
+                                                                   const double *__restrict__ planck, const double *__restrict__ bsrfc,
+                                                                   const double *__restrict__ kabs,
                                                                    const double *__restrict__ dz, double dx, double dy,
                                                                    double *__restrict__ b, const double *__restrict__ colsum,
                                                                    const int *__restrict__ cidx, long long nent) {
@@ -659,7 +660,10 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_setup_b_thermal(TsxGeo g, con
       }
     }
     if (k == Nz - 1) {
-      const double srf = planck[(size_t)Nz + (size_t)L * ((size_t)i + (size_t)xm * j)] * Az * (1.0 - albedo[col]) * pi / tstreams;
+      // surface emission (src/pprts.F90:4958-4985): atm%Bsrfc with the emissivity 1 - albedo clamped to [0, 1] where the caller
+      // gave planck_srfc (:4960-4970), else planck at the lowest level with 1 - albedo as it is (:4971-4984)
+      const double srf = bsrfc ? bsrfc[col] * Az * fmax(0.0, fmin(1.0, 1.0 - albedo[col])) * pi / tstreams
+                               : planck[(size_t)Nz + (size_t)L * ((size_t)i + (size_t)xm * j)] * Az * (1.0 - albedo[col]) * pi / tstreams;
 #pragma unroll
       for (int d = 0; d < D; ++d) bt[(size_t)d * ncol + col] = (d < NTOP && !tsx_inward(d)) ? srf : 0.0;
     }

@@ -83,9 +83,10 @@ class PprtsSolver:
                                                int(Tdir.shape[0]), len(axes), n, C.c_void_p(ax.ctypes.data), 0))
 
     # -- set_optical_properties ------------------------------------------------------------------------
-    def set_optical_properties(self, albedo, kabs, ksca, g, dz, planck=None, ldelta_scaling=True):
+    def set_optical_properties(self, albedo, kabs, ksca, g, dz, planck=None, ldelta_scaling=True, planck_srfc=None):
         """Fields (Ny, Nx, Nz) float64 (numpy, or CUDA tensors to stay on the device), k = 0 at TOA; albedo scalar or
-        (Ny, Nx); planck (Ny, Nx, Nz+1) or None.  Delta scaling, 1-D layer detection, Eddington coefficients and the
+        (Ny, Nx); planck (Ny, Nx, Nz+1) or None; planck_srfc scalar or (Ny, Nx) or None: the surface's own Planck emission
+        (atm%Bsrfc, src/pprts.F90:1773, 1823-1829, used at :4958-4970).  Delta scaling, 1-D layer detection, Eddington coefficients and the
         coefficient lookups all run on the device (tsx_pprts_set_optical_properties)."""
         from .solver import _is_torch
 
@@ -100,12 +101,13 @@ class PprtsSolver:
             f = lambda a, shp: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), shp))
         raw = dict(kabs=f(kabs, shape), ksca=f(ksca, shape), g=f(g, shape), dz=f(dz, shape),
                    albedo=f(albedo, (self.Ny, self.Nx)),
-                   planck=None if planck is None else f(planck, (self.Ny, self.Nx, self.Nz + 1)))
+                   planck=None if planck is None else f(planck, (self.Ny, self.Nx, self.Nz + 1)),
+                   planck_srfc=None if planck_srfc is None else f(planck_srfc, (self.Ny, self.Nx)))
         self._raw, self._ldelta, self._fields = raw, bool(ldelta_scaling), None
         ptr = lambda a: None if a is None else _ptr(a, np.float64)[0]
         _lib.check(self.lib.tsx_pprts_set_optical_properties(
             self.h, ptr(raw["albedo"]), ptr(raw["kabs"]), ptr(raw["ksca"]), ptr(raw["g"]), ptr(raw["dz"]),
-            ptr(raw["planck"]), self.dx, self.dy, int(self._ldelta), 1 if on_dev else 0))
+            ptr(raw["planck"]), ptr(raw["planck_srfc"]), self.dx, self.dy, int(self._ldelta), 1 if on_dev else 0))
 
     @property
     def fields(self):
@@ -119,7 +121,7 @@ class PprtsSolver:
             ext = np.maximum(np.finfo(np.float64).tiny, kabs + ksca)
             a11, a12, a13, a23, a33 = eddington_coeff_ec(r["dz"] * ext, ksca / ext, g, self.mu0)
             self._fields = dict(kabs=kabs, ksca=ksca, g=g, dz=r["dz"], a11=a11, a12=a12, a13=a13, a23=a23, a33=a33,
-                                albedo=r["albedo"], planck=r["planck"])
+                                albedo=r["albedo"], planck=r["planck"], planck_srfc=r["planck_srfc"])
         return self._fields
 
     @property

@@ -50,7 +50,8 @@ def _oracle_pipeline(P, I, albedo, edirTOA, lsolar, planck=None, rtol=1e-10):
         out.update(dir2dir=t, dir2diff=sd, edir=edir, niter_dir=di["niter"])
     else:
         edir, t, sd = None, None, None
-        b = O.setup_b_thermal(lay, c, P.l1d, F["a11"], F["a12"], F["albedo"], planck, F["kabs"], F["dz"], I["dx"], I["dy"])
+        b = O.setup_b_thermal(lay, c, P.l1d, F["a11"], F["a12"], F["albedo"], planck, F["kabs"], F["dz"], I["dx"], I["dy"],
+                              planck_srfc=F["planck_srfc"])
     x, info = O.solve_ilu(lay, c, P.l1d, F["a11"], F["a12"], F["albedo"], b, rtol=rtol, atol=1e-30, maxit=3000)
     assert info["reason"] == 2
     abso = O.calc_flx_div(lay, dlay, sun, t, sd, c, P.l1d, F["a11"], F["a12"], F["kabs"], F["dz"], I["dx"], I["dy"], edir, x,
@@ -112,15 +113,40 @@ def test_solar_b_from_identical_edir_is_tight(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("srfc", [None, "skin"])   # "skin": planck_srfc given, as the rrtmg driver always does (pprts_rrtmg.F90:609-642, 681)
 @pytest.mark.parametrize("solver", ["3_10", "8_16"])
-def test_thermal_pipeline_matches_oracle(gpu, solver):
+def test_thermal_pipeline_matches_oracle(gpu, solver, srfc):
     Nx, Ny, Nz = 8, 6, 10
     P, I = _setup(Nx, Ny, Nz, 0.0, 0.0, tall_top=1, solver=solver)
-    planck = np.linspace(2.0, 6.0, Nz + 1)[None, None, :] * np.ones((Ny, Nx, 1)) * (1 + 0.05 * np.random.default_rng(0).random((Ny, Nx, 1)))
-    P.set_optical_properties(0.05, I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck)
+    rng = np.random.default_rng(0)
+    planck = np.linspace(2.0, 6.0, Nz + 1)[None, None, :] * np.ones((Ny, Nx, 1)) * (1 + 0.05 * rng.random((Ny, Nx, 1)))
+    # a skin temperature of its own: the surface emits more than the air at the lowest level would (atm%Bsrfc, src/pprts.F90:4958-4970)
+    planck_srfc = None if srfc is None else planck[:, :, -1] * (1.1 + 0.2 * rng.random((Ny, Nx)))
+    albedo = 0.05 + 0.1 * rng.random((Ny, Nx))
+    if srfc is not None:
+        albedo[2, 3] = -0.04   # unphysical on purpose: 1 - albedo > 1 is clamped to 1 on the Bsrfc branch only (src/pprts.F90:4965-4966)
+    P.set_optical_properties(albedo, I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck, planck_srfc=planck_srfc)
     info = P.solve(0.0, rtol=1e-10, atol=1e-30, maxit=3000)
     assert info.reason == 2
-    R = _oracle_pipeline(P, I, 0.05, 0.0, False, planck=planck)
+    R = _oracle_pipeline(P, I, albedo, 0.0, False, planck=planck)
+    if srfc is not None:   # the branch is taken: only the upward streams at the ground differ from the planck(ze) source
+        P2, _ = _setup(Nx, Ny, Nz, 0.0, 0.0, tall_top=1, solver=solver)
+        P2.set_optical_properties(albedo, I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck)
+        P2.solve(0.0, rtol=1e-10, atol=1e-30, maxit=3000)
+        d = P.get_field("b") - P2.get_field("b")
+        ntop = 2 if solver == "3_10" else 8
+        up = [q for q in range(ntop) if q % 2 == 0]   # is_inward = [F, T, ...]: even top dofs point upward (src/pprts.F90:339-343, 416-419)
+        want = (planck_srfc * np.clip(1 - albedo, 0, 1) - planck[:, :, -1] * (1 - albedo)) * 100.0 * 100.0 * np.pi / (ntop // 2)
+        assert np.abs(d[:, :, -1, up] - want[:, :, None]).max() <= 1e-12 * np.abs(want).max()
+        d[:, :, -1, up] = 0
+        assert np.abs(d).max() == 0.0
+        # a later call without planck_srfc drops atm%Bsrfc again (src/pprts.F90:1827-1829)
+        P.set_optical_properties(albedo, I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck)
+        P.solve(0.0, rtol=1e-10, atol=1e-30, maxit=3000)
+        assert np.array_equal(P.get_field("b"), P2.get_field("b"))
+        P.set_optical_properties(albedo, I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck, planck_srfc=planck_srfc)
+        P.solve(0.0, rtol=1e-10, atol=1e-30, maxit=3000, zero_guess=True)
+        P2.close()
     b = P.get_field("b")
     assert np.abs(b - R["b"]).max() <= 1e-13 * np.abs(R["b"]).max()
     edn, eup, abso, _ = P.get_result()

@@ -207,3 +207,32 @@ def test_flux_scaling_round_trip_like_the_reference_test():
     back_dir = O.scale_dir(lay, dlay, dz, dx, dx, True, w_dir)
     assert np.linalg.norm(back_diff) == pytest.approx(np.linalg.norm(ediff), rel=1e-14)
     assert np.linalg.norm(back_dir) == pytest.approx(np.linalg.norm(edir), rel=1e-14)
+
+
+def test_oracle_surface_emission_follows_planck_srfc():
+    """set_thermal_source's surface term (src/pprts.F90:4958-4985): with atm%Bsrfc the upward streams at the ground get
+    Bsrfc * Az * clamp(1 - albedo, 0, 1) * pi / streams, without it planck(ze) * Az * (1 - albedo) * pi / streams; nothing else
+    in b changes.  planck_srfc = planck(ze) with albedo in [0, 1] reproduces the other branch exactly."""
+    from tenstream_amd import synthetic
+
+    for solver, ntop in (("3_10", 2), ("8_16", 8)):
+        P = synthetic.make_problem(solver, Nx=5, Ny=4, Nz=6, n1d=1)
+        lay = O.layout(solver, 6, 5, 4)
+        rng = np.random.default_rng(3)
+        planck = 3.0 + rng.random((4, 5, 7))
+        kabs, dz = 1e-4 * (1 + rng.random((4, 5, 6))), np.full((4, 5, 6), 50.0)
+        albedo = np.array(P["albedo"], dtype=np.float64).reshape(4, 5)
+        albedo[1, 2], albedo[3, 0] = 1.3, -0.2   # both clamps
+        args = (lay, P["coeff"].astype(np.float64), P["l1d"], P["a11"], P["a12"], albedo, planck, kabs, dz, 100.0, 70.0)
+        b0 = O.setup_b_thermal(*args)
+        srfc = 5.0 + rng.random((4, 5))
+        b1 = O.setup_b_thermal(*args, planck_srfc=srfc)
+        d = b1 - b0
+        up = list(range(0, ntop, 2))
+        want = (srfc * np.clip(1 - albedo, 0, 1) - planck[:, :, -1] * (1 - albedo)) * 100.0 * 70.0 * np.pi / (ntop // 2)
+        assert np.abs(d[:, :, -1, up] - want[:, :, None]).max() <= 1e-12 * np.abs(want).max()
+        d[:, :, -1, up] = 0
+        assert np.abs(d).max() == 0.0
+        albedo2 = np.clip(albedo, 0, 1)
+        a2 = args[:5] + (albedo2,) + args[6:]
+        assert np.array_equal(O.setup_b_thermal(*a2), O.setup_b_thermal(*a2, planck_srfc=planck[:, :, -1]))
