@@ -229,6 +229,47 @@ int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int where);
 int tsx_diff_solve(tsx_solver *s, const double *b, double *x, int where, const tsx_ksp_opts *opts,
                    tsx_ksp_result *res);
 
+/* ---- the same two entries with the vectors in the caller's real kind: TenStream's ireals is real32 or real64 by build
+ *      (src/data_parameters.F90; the CI builds both).  vec_kind 8 = real64 (identical to the entries above), 4 = real32:
+ *      x, y, b are then float arrays, widened / narrowed on the device -- a real32 build hands its vectors over as they are. */
+int tsx_diff_apply_r(tsx_solver *s, const void *x, void *y, int vec_kind, int where);
+int tsx_diff_solve_r(tsx_solver *s, const void *b, void *x_inout, int vec_kind, int where, const tsx_ksp_opts *opts,
+                     tsx_ksp_result *res);
+
+/* ======================= the direct seam and setup_b on their own =========================================
+ * `pprts()` offers the same seam for the direct beam as for the diffuse system (src/pprts.F90:2698-2755):
+ *     if (lexplicit_dir) call explicit_edir(solver, prefix, edirTOA, solution%edir, lb, v0, solution, ierr)   else call edir(prefix)
+ * with set_dir_coeff (:4493-4630) filling the matrix from solver%dir2dir.  The entries below take what that branch has
+ * in hand -- coefficient blocks in the reference's layout, no optical properties, no LUT:
+ *   dir2dir  (1:S*S, zs:ze-1, xs:xe, ys:ye)  c(src, dst), src fastest: flat index dst*S + src   (:4523-4590; S = 3 | 8)
+ *   dir2diff (1:S*D, zs:ze-1, xs:xe, ys:ye)  c(src, dst), src fastest: flat index dst*S + src   (:4725-4821); NULL if only
+ *            the beam is wanted
+ *   coeff_kind 8 | 4 like tsx_diff_set_coeffs; the values must be exactly representable in real32 (they are: the tables
+ *   are irealLUT = real32 and the reference only widens them, :3121-3143) -- else TSX_ERR_UNSUPPORTED
+ *   l1d (zs:ze-1); a33 (beam transmission of the 1-D layers, :4513-4520), a13 / a23 (their sources, :4709-4721):
+ *   (zs:ze-1, xs:xe, ys:ye) real64, only read where a layer is 1-D (NULL if none is)
+ *   dx, dy: setup_incSolar's edirTOA * dx * dy / area_divider (src/pprts_base.F90:1146-1181)
+ * tsx_pprts_set_angles comes first (sweep order xinc / yinc, src/pprts.F90:1157-1167) and invalidates the coefficients
+ * when called again, exactly as set_angles does in the reference (:1100-1116). */
+int tsx_dir_set_coeffs(tsx_solver *s, const void *dir2dir, const void *dir2diff, int coeff_kind, const uint8_t *l1d,
+                       const double *a33, const double *a13, const double *a23, double dx, double dy, int where);
+/* explicit_edir (src/pprts_explicit.F90:60-459): edir (0:S-1, zs:ze, xs:xe, ys:ye) [W] of kind vec_kind is the initial
+ * iterate on entry (v0 = solution%edir, src/pprts.F90:2746) and the beam on exit.  Forward sweeps in sun order, repeated
+ * until the 2-norm of the change (mean over ranks) is < atol or < rtol times the first one's (:168-218); rtol / atol /
+ * maxit as explicit_edir has derived them from -solar_dir_ksp_* (:94-121), <= 0: determine_ksp_tolerances / 1000.
+ * *converged = 0 when maxit sweeps did not suffice (reported, not an error: -accept_incomplete_solve is the caller's). */
+int tsx_dir_solve(tsx_solver *s, double edirTOA, void *edir_inout, int vec_kind, int where, double rtol, double atol,
+                  int32_t maxit, int32_t *niter, double *residual, int32_t *converged);
+/* setup_b, solar (set_solar_source, src/pprts.F90:4684-4846): b (0:D-1, zs:ze, xs:xe, ys:ye) [W] from the beam: edir in the
+ * layout above, or NULL = the beam tsx_dir_solve left on the device (required on several ranks); albedo (xs:xe, ys:ye) or
+ * NULL = the one tsx_diff_set_coeffs received.  Needs tsx_dir_set_coeffs with dir2diff. */
+int tsx_setup_b_solar(tsx_solver *s, const void *edir, const double *albedo, void *b, int vec_kind, int where);
+/* setup_b, thermal (set_thermal_source, src/pprts.F90:4848-4987): planck (zs:ze, xs:xe, ys:ye), planck_srfc (xs:xe, ys:ye)
+ * or NULL (atm%Bsrfc, :4958-4970), kabs and dz (zs:ze-1, xs:xe, ys:ye), real64.  Emissivities come from the diffuse blocks,
+ * a11 / a12 and the albedo of tsx_diff_set_coeffs / tsx_diff_set_optprop, which comes first. */
+int tsx_setup_b_thermal(tsx_solver *s, const double *planck, const double *planck_srfc, const double *kabs, const double *dz,
+                        double dx, double dy, void *b, int vec_kind, int where);
+
 /* ======================= whole g-point on the device ===============================
  * The pieces of `pprts()` around the diffuse solve (src/pprts.F90:2668-2820) and of restore_solution /
  * pprts_get_result, so that only optical properties go in and four small flux arrays come out:

@@ -509,6 +509,7 @@ static int set_aux(tsx_solver *s, const uint8_t *l1d, const double *a11, const d
   HIPCHK(hipStreamSynchronize(s->stream));
   ARGCHK(!s->any_l1d || (a11 && a12), "a11/a12 required when any layer is 1-D");
   HIPCHK(hipMemcpyAsync(s->albedo, albedo, sizeof(double) * g.ncol, mk, s->stream));
+  s->have_albedo = true;
   if (s->any_l1d) {
     if (!s->a11) HIPCHK(hipMalloc((void **)&s->a11, sizeof(double) * g.Nc));
     if (!s->a12) HIPCHK(hipMalloc((void **)&s->a12, sizeof(double) * g.Nc));
@@ -1531,3 +1532,4 @@ extern "C" int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, d
 }
 
 #include "tsx_pipeline_api.inc"
+#include "tsx_seam_api.inc"

@@ -187,6 +187,8 @@ struct tsx_solver {
   TsxLutHost lut_T, lut_S;
   float *dirT, *dirS;            // direct coefficient planes (S*S, S*D)
   bool dir_coeffs_valid;
+  bool have_albedo = false;  // s->albedo holds the caller's surface albedo (set_coeffs / set_optprop / set_optical_properties / setup_b_solar)
+  bool dir_seam = false, dir_seam_S = false;  // dirT (and dirS) were handed over by tsx_dir_set_coeffs (the direct seam), not looked up
   double *dd_colsum;         // [D][dd_nent]: sum over dst of c(src, dst) per distinct block (absorptivity / emissivity terms of setup_b_thermal, flx_div)
   long long dd_colsum_cap;
   void *cell_samp;           // float4 per cell: the LUT coordinates in cell order (tsx_k_cell_samples) ...

@@ -39,6 +39,16 @@ def _is_torch(a):
     return type(a).__module__.startswith("torch")
 
 
+def _kind(a):
+    """real kind (bytes per element) of a vector handed to the seam: 8 = real64, 4 = real32 (ireals of a single-precision
+    TenStream build)"""
+    if _is_torch(a):
+        import torch
+
+        return {torch.float64: 8, torch.float32: 4}[a.dtype]
+    return {np.dtype(np.float64): 8, np.dtype(np.float32): 4}[a.dtype]
+
+
 def _ptr(a, dtype):
     """(void*, where) of a numpy array or torch CUDA tensor; checks dtype and contiguity."""
     if a is None:
@@ -279,11 +289,16 @@ class DiffuseSolver:
                 out = torch.empty_like(x)
             else:
                 out = np.empty_like(x)
-        xp, where = _ptr(x, np.float64)
-        yp, w2 = _ptr(out, np.float64)
+        kind = _kind(x)   # real32 vectors (a single-precision ireals build) go through tsx_diff_apply_r as they are
+        dt = np.float64 if kind == 8 else np.float32
+        xp, where = _ptr(x, dt)
+        yp, w2 = _ptr(out, dt)
         if where != w2:
             raise TypeError("x and out must live on the same side")
-        _lib.check(self.lib.tsx_diff_apply(self.h, xp, yp, where))
+        if kind == 8:
+            _lib.check(self.lib.tsx_diff_apply(self.h, xp, yp, where))
+        else:
+            _lib.check(self.lib.tsx_diff_apply_r(self.h, xp, yp, 4, where))
         return out
 
     def pc_apply(self, v, pc=1, sweeps=1, out=None, mixed=False):
@@ -328,14 +343,74 @@ class DiffuseSolver:
                           ("accept_incomplete_solve", accept_incomplete_solve), ("initial_guess_zero", initial_guess_zero)):
             if val is not None:
                 setattr(o, name, val)
-        bp, where = _ptr(b, np.float64)
-        xp, w2 = _ptr(x, np.float64)
+        kind = _kind(b)
+        if _kind(x) != kind:
+            raise TypeError("b and x must have the same real kind")
+        dt = np.float64 if kind == 8 else np.float32
+        bp, where = _ptr(b, dt)
+        xp, w2 = _ptr(x, dt)
         if where != w2:
             raise TypeError("b and x must live on the same side")
         r = _lib.KspResult()
-        _lib.check(self.lib.tsx_diff_solve(self.h, bp, xp, where, C.byref(o), C.byref(r)))
+        if kind == 8:
+            _lib.check(self.lib.tsx_diff_solve(self.h, bp, xp, where, C.byref(o), C.byref(r)))
+        else:   # ireals = real32: the vectors cross the seam as they are (tsx_diff_solve_r)
+            _lib.check(self.lib.tsx_diff_solve_r(self.h, bp, xp, 4, where, C.byref(o), C.byref(r)))
         return KspInfo(r.reason, r.niter, r.rnorm0, r.rnorm, np.array(r.res_hist[: r.nhist]), r.solve_ms,
                        r.import_ms, r.export_ms)
+
+    # -- the direct seam and setup_b on their own (src/pprts.F90:2698-2755, 4641-4987) ------------------------
+    @property
+    def S(self):
+        return 3 if self.D == 10 else 8   # dirtop%dof + 2 dirside%dof, src/pprts.F90:332-349, 413-425
+
+    def set_angles(self, phi0, theta0):
+        _lib.check(self.lib.tsx_pprts_set_angles(self.h, float(phi0), float(theta0)))
+
+    def dir_set_coeffs(self, dir2dir, dir2diff, l1d, dx, dy, a33=None, a13=None, a23=None):
+        """set_dir_coeff's input (src/pprts.F90:4493-4630): solver%dir2dir (ym, xm, Nz, S*S) and solver%dir2diff
+        (ym, xm, Nz, S*D) or None, float64 or float32, flat index dst*S + src; l1d (Nz); a33 / a13 / a23 (ym, xm, Nz) float64
+        where layers are 1-D.  set_angles comes first."""
+        kind = _kind(dir2dir)
+        dt = np.float64 if kind == 8 else np.float32
+        tp, where = _ptr(dir2dir, dt)
+        sp = _ptr(dir2diff, dt)[0] if dir2diff is not None else None
+        l1d = np.ascontiguousarray(l1d, dtype=np.uint8) if not _is_torch(l1d) else l1d
+        if _is_torch(l1d) != (where == TSX_DEVICE):
+            raise TypeError("all arrays of one call must live on the same side (host or device)")
+        p = lambda a: None if a is None else _ptr(a, np.float64)[0]
+        _lib.check(self.lib.tsx_dir_set_coeffs(self.h, tp, sp, kind, _ptr(l1d, np.uint8)[0], p(a33), p(a13), p(a23), float(dx),
+                                               float(dy), where))
+
+    def dir_solve(self, edirTOA, edir, rtol=0.0, atol=0.0, maxit=0):
+        """explicit_edir (src/pprts_explicit.F90:60-459) in place on edir (ym, xm, Nz+1, S) [W], float64 or float32;
+        returns (niter, residual, converged)"""
+        kind = _kind(edir)
+        ep, where = _ptr(edir, np.float64 if kind == 8 else np.float32)
+        it, cv, res = C.c_int32(), C.c_int32(), C.c_double()
+        _lib.check(self.lib.tsx_dir_solve(self.h, float(edirTOA), ep, kind, where, float(rtol), float(atol), int(maxit),
+                                          C.byref(it), C.byref(res), C.byref(cv)))
+        return it.value, res.value, bool(cv.value)
+
+    def setup_b_solar(self, b, edir=None, albedo=None):
+        """set_solar_source (src/pprts.F90:4684-4846) into b (vec_shape); edir None = the beam dir_solve left on the device"""
+        kind = _kind(b)
+        dt = np.float64 if kind == 8 else np.float32
+        bp, where = _ptr(b, dt)
+        ep = None if edir is None else _ptr(edir, dt)[0]
+        ap = None if albedo is None else _ptr(albedo, np.float64)[0]
+        _lib.check(self.lib.tsx_setup_b_solar(self.h, ep, ap, bp, kind, where))
+        return b
+
+    def setup_b_thermal(self, b, planck, kabs, dz, dx, dy, planck_srfc=None):
+        """set_thermal_source (src/pprts.F90:4848-4987) into b; planck (ym, xm, Nz+1), planck_srfc (ym, xm) or None, kabs, dz
+        (ym, xm, Nz) float64; the diffuse coefficients (set_coeffs / set_optprop) come first"""
+        kind = _kind(b)
+        bp, where = _ptr(b, np.float64 if kind == 8 else np.float32)
+        p = lambda a: None if a is None else _ptr(a, np.float64)[0]
+        _lib.check(self.lib.tsx_setup_b_thermal(self.h, p(planck), p(planck_srfc), p(kabs), p(dz), float(dx), float(dy), bp, kind,
+                                                where))
+        return b
 
     # -- measurement ---------------------------------------------------------------------------------
     def dedup_info(self):

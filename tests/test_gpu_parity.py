@@ -500,7 +500,11 @@ def test_fortran_shim_driver(gpu):
         pytest.skip("amdflang not available when the tree was built")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "shim ok" in r.stdout
+    # every group of bindings ran: the diffuse seam (real64, real32), the direct seam + setup_b, the communicator entries
+    # (Fortran callbacks, RCCL id / init), the LUT and whole-g-point entries
+    for line in ("shim ok", "shim real32 ok", "shim direct seam ok", "shim thermal source ok", "shim comm bindings ok",
+                 "shim pipeline ok (solar)", "shim pipeline ok (thermal)", "shim all ok"):
+        assert line in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("solver,Nx,Ny,Nz", [("3_10", 21, 9, 12), ("8_16", 8, 5, 6)])
