@@ -329,7 +329,10 @@ int tsx_pprts_select_solution(tsx_solver *s, int32_t uid);
  * W/m3, solar results multiplied by sun%mu (src/pprts.F90:5883-5888).  edir may be NULL. */
 int tsx_pprts_get_result(tsx_solver *s, double *edn, double *eup, double *abso, double *edir, int where);
 /* parity probes: which = 0 edir [W] (0:S-1, zs:ze, xs:xe, ys:ye); 1 b [W]; 2 ediff [W] (0:D-1, zs:ze, ...);
- * 3 dir2dir (S*S, zs:ze-1, ...); 4 dir2diff (S*D, ...) -- reference layouts, real64 */
+ * 3 dir2dir (S*S, zs:ze-1, ...); 4 dir2diff (S*D, ...) -- reference layouts, real64;
+ * what tsx_pprts_set_optical_properties derived on the device, (zs:ze-1, xs:xe, ys:ye): 5 kabs, 6 ksca, 7 g after delta scaling
+ * (src/pprts.F90:1903-1917); 8..12 the Eddington coefficients a11, a12, a13, a23, a33 of the 1-D layers (:1962-1992; NaN in
+ * layers that are not 1-D) */
 int tsx_pprts_get_field(tsx_solver *s, int which, double *out, int where);
 
 /* ---- coefficient probe: pprts_f2c_opp_get_coeff / _get_info (c_wrapper/f2c_pprts.h:54-83, f2c_pprts.F90:627-760).

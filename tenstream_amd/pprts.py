@@ -182,6 +182,8 @@ class PprtsSolver:
         shapes = {"edir": (0, (self.Ny, self.Nx, self.Nz + 1, S)), "b": (1, self.core.vec_shape),
                   "ediff": (2, self.core.vec_shape), "dir2dir": (3, (self.Ny, self.Nx, self.Nz, S * S)),
                   "dir2diff": (4, (self.Ny, self.Nx, self.Nz, S * D))}
+        cell = (self.Ny, self.Nx, self.Nz)   # what the device derived in set_optical_properties (delta scaling, Eddington)
+        shapes.update({n: (5 + q, cell) for q, n in enumerate(("kabs", "ksca", "g", "a11", "a12", "a13", "a23", "a33"))})
         idx, shp = shapes[which]
         out = np.empty(shp)
         _lib.check(self.lib.tsx_pprts_get_field(self.h, idx, _ptr(out, np.float64)[0], 0))

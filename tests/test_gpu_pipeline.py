@@ -382,3 +382,51 @@ def test_tiled_direct_sweep_has_the_fixed_point_of_the_column_sweep(gpu, monkeyp
         fields.append(P.get_field("edir"))
     a, b = fields
     assert np.abs(a - b).max() <= 1e-10 * np.abs(a).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("theta0", [0.0, 35.0, 70.0])
+def test_device_delta_scaling_and_eddington_equal_the_oracle(gpu, theta0):
+    """What tsx_pprts_set_optical_properties derives ON THE DEVICE (tsx_k_delta_scale, tsx_k_eddington; read back through
+    tsx_pprts_get_field 5..12) against the oracle's delta_scale (src/helper_functions.fypp:1622-1666, f = g**2) and
+    eddington_coeff_ec (src/eddington.F90:173-241) directly -- not through fluxes and not through the host mirror the other
+    pipeline tests feed the oracle with.  The inputs reach every branch: g = 1 (pure forward peak), ksca = kabs = 0 (no
+    extinction: untouched), optically very thin layers (the linearised Eddington branch, dtau / mu0 <= 1e-6), k mu0 = 1."""
+    Nx, Ny, Nz, tall = 8, 6, 12, 5
+    rng = np.random.default_rng(12)
+    kabs = 10.0 ** rng.uniform(-9, -2, (Ny, Nx, Nz))
+    ksca = 10.0 ** rng.uniform(-9, -1.5, (Ny, Nx, Nz))
+    g = rng.uniform(0.0, 0.95, (Ny, Nx, Nz))
+    g[0, 0, :] = 1.0
+    kabs[1, 1, :], ksca[1, 1, :] = 0.0, 0.0
+    kabs[2, 2, :], ksca[2, 2, :] = 1e-13, 1e-12           # slant path <= 1e-6: the thin branch
+    g[3, 3, :], kabs[3, 3, :] = 0.0, 0.0                  # conservative scattering, isotropic
+    dz = np.full((Ny, Nx, Nz), 50.0)
+    dz[:, :, :tall] = 300.0 + 100.0 * rng.random((Ny, Nx, tall))   # dz / dx > 2: 1-D layers on top
+    P = PprtsSolver(Nz, Nx, Ny, 100.0, 100.0, 140.0, theta0)
+    P.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
+    P.set_optical_properties(0.1, kabs, ksca, g, dz)
+    assert P.l1d.sum() == tall
+    ka, ks, gg = np.empty_like(kabs), np.empty_like(ksca), np.empty_like(g)
+    for idx in np.ndindex(kabs.shape):   # the oracle's delta_scale is the scalar routine of the reference
+        ka[idx], ks[idx], gg[idx] = O.delta_scale(float(kabs[idx]), float(ksca[idx]), float(g[idx]))
+    for name, want in (("kabs", ka), ("ksca", ks), ("g", gg)):
+        got = P.get_field(name)
+        assert np.abs(got - want).max() <= 4e-16 * np.abs(want).max(), name
+    mu0 = max(np.cos(np.deg2rad(theta0)), 0.0)
+    ext = np.maximum(np.finfo(np.float64).tiny, ka + ks)
+    got = {n: P.get_field(n) for n in ("a11", "a12", "a13", "a23", "a33")}
+    for n in got:
+        assert np.isnan(got[n][:, :, tall:]).all() and np.isfinite(got[n][:, :, :tall]).all()
+    worst = 0.0
+    for j in range(Ny):
+        for i in range(Nx):
+            for k in range(tall):
+                want = O.eddington_coeff_ec(dz[j, i, k] * ext[j, i, k], ks[j, i, k] / ext[j, i, k], gg[j, i, k], mu0)
+                for n, w in zip(("a11", "a12", "a13", "a23", "a33"), want):
+                    worst = max(worst, abs(got[n][j, i, k] - w) / max(abs(w), 1e-300) if abs(w) > 1e-12 else abs(got[n][j, i, k] - w))
+    assert worst <= 1e-11, worst   # exp() and sqrt() of two maths libraries, a few ulp amplified by (1 - (k mu0)^2)^-1
+    # no delta scaling on request: the properties stay as they came
+    P.set_optical_properties(0.1, kabs, ksca, g, dz, ldelta_scaling=False)
+    assert np.array_equal(P.get_field("ksca"), ksca) and np.array_equal(P.get_field("g"), g)
+    P.close()

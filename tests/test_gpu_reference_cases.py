@@ -540,3 +540,40 @@ def test_f2c_on_several_ranks_scatters_and_gathers_like_the_reference(gpu, tmp_p
     for r in range(1, world):   # "only zeroth node gets the results back"
         assert all((a == -7.0).all() for a in many[r])
     assert many[0][0].max() > 1.0
+
+
+def test_device_reads_the_byte_level_mmap4_fixture(gpu, tmp_path):
+    """a11: the `.mmap4` reader on a file that did NOT come from tenstream_amd.lut: tests/golden/make_mmap4_fixture.py builds
+    it from the description of the reference's writer (src/mmap.F90:63-127; committed header page + SHA-256).  At the nodes of
+    the preset lattice (tau31 x w020 x aspect_zx23 x g6, src/optprop_base.F90:228-240) the lookup returns table entries as they
+    are, so every coefficient must be the formula's value of entry e = i_tau + 31 (i_w0 + 20 (i_aspect + 23 i_g)), coefficient
+    index fastest (Fortran (Ncoeff, Nentries))."""
+    import ctypes as C
+
+    from test_lut_cpu import _mmap4_fixture
+    from tenstream_amd import DiffuseSolver, _lib, lut
+
+    gen, doc, _ = _mmap4_fixture()
+    path = tmp_path / doc["name"]
+    assert gen.write_file(str(path)) == doc["sha256"]
+    s = DiffuseSolver("3_10", 4, 4, 4)
+    s.load_lut_diffuse_mmap4(str(path))
+    tau, w0, asp, g = lut.diffuse_axes("3_10")
+    rng = np.random.default_rng(8)
+    out = np.empty(100, dtype=np.float32)
+    c = np.arange(100)
+    picks = [(0, 0, 0, 0), (30, 19, 22, 5), (1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1)]
+    picks += [tuple(int(rng.integers(0, n)) for n in (31, 20, 23, 6)) for _ in range(40)]
+    for it, iw, ia, ig in picks:
+        e = it + 31 * (iw + 20 * (ia + 23 * ig))
+        _lib.check(s.lib.tsx_opp_get_coeff(s.h, C.c_float(tau[it]), C.c_float(w0[iw]), C.c_float(g[ig]), C.c_float(asp[ia]),
+                                           C.c_float(0.0), C.c_float(0.0), 3, 0, 0, 100, C.c_void_p(out.ctypes.data)))
+        assert np.array_equal(out, (((7 * c + 13 * e) % 1009) / 131072.0).astype(np.float32)), (it, iw, ia, ig)
+    # a file whose header disagrees with itself is refused (n_bytes != dtype_size * n_elems)
+    bad = tmp_path / "bad.mmap4"
+    raw = bytearray(open(path, "rb").read(4096 + 400))
+    raw[16:24] = (12345).to_bytes(8, "little")
+    open(bad, "wb").write(raw)
+    with pytest.raises(_lib.TsxError):
+        s.load_lut_diffuse_mmap4(str(bad))
+    s.close()

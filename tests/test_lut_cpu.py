@@ -63,3 +63,46 @@ def test_mmap4_written_in_pieces_equals_the_single_write(tmp_path):
     lut.write_mmap4(tmp_path / "a.mmap4", full)
     lut.write_mmap4_generated(tmp_path / "b.mmap4", n, nc, lambda lo, hi: lut.hashed_table_values(lo, hi, nc, salt=1), chunk=300)
     assert (tmp_path / "a.mmap4").read_bytes() == (tmp_path / "b.mmap4").read_bytes()
+
+
+def _mmap4_fixture():
+    import importlib.util
+    import json
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_mmap4_fixture", os.path.join(here, "make_mmap4_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, json.load(open(os.path.join(here, "mmap4_fixture.json"))), here
+
+
+def test_mmap4_container_against_the_byte_fixture(tmp_path):
+    """The committed fixture (tests/golden/mmap4_*: header page, first payload bytes, SHA-256 of the whole file) was built from
+    the description of arr_to_binary_datafile_2d (src/mmap.F90:63-127) by a script that imports nothing from tenstream_amd.
+    The product's own writer must produce those bytes, and its reader must see the array of that file."""
+    import hashlib
+    import os
+
+    gen, doc, here = _mmap4_fixture()
+    header = open(os.path.join(here, "mmap4_diffuse_3_10_header.bin"), "rb").read()
+    assert len(header) == 4096 == lut.PAGESIZE
+    words = np.frombuffer(header, dtype="<u8")
+    assert list(words[:6]) == [4, 8556000, 34224000, 100, 85560, 0] and not words[6:].any()
+    assert gen.header_page(4, 100, 85560) == header   # the generator is the description, executable
+    path = tmp_path / doc["name"]
+    assert gen.write_file(str(path)) == doc["sha256"] and path.stat().st_size == doc["file_bytes"] == 4096 + 34224000
+    raw = open(path, "rb").read(4096 + 1024)
+    assert raw[4096:] == open(os.path.join(here, "mmap4_diffuse_3_10_first_payload.bin"), "rb").read()
+    # reader: (nentries, ncoeff) view of the Fortran (ncoeff, nentries) array, coefficient index fastest
+    t = lut.read_mmap4(path)
+    assert t.shape == (85560, 100)
+    e = np.array([0, 1, 30, 31, 85559, 4242])[:, None]
+    c = np.arange(100)[None, :]
+    assert np.array_equal(t[e[:, 0]], (((7 * c + 13 * e) % 1009) / 131072.0).astype(np.float32))
+    # writer: the same table through lut.write_mmap4 gives the fixture's bytes
+    E, Cc = np.meshgrid(np.arange(85560), np.arange(100), indexing="ij")
+    own = tmp_path / "own.mmap4"
+    lut.write_mmap4(own, (((7 * Cc + 13 * E) % 1009) / 131072.0).astype(np.float32))
+    assert hashlib.sha256(open(own, "rb").read()).hexdigest() == doc["sha256"]
+    assert lut.diffuse_lut_filename("LUT") == doc["name"]

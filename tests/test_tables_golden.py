@@ -197,3 +197,115 @@ def test_cell_kernels_relabel_like_the_reference_text(gpu, tmp_path, solver):
         assert np.array_equal(np.rint(d2f), np.broadcast_to(w2, d2f.shape))
         assert np.array_equal(np.rint(d2d), np.broadcast_to(w1, d2d.shape))
         ps.close()
+
+
+# ------------------------------------------------------------------------------------------------ 8_16 stream geometry
+# Known answers of the reference's Monte-Carlo box model for t_boxmc_8_16 (tests/test_boxmc_8_16/test_boxmc_8_16.F90:58-134,
+# committed as data in tests/golden/boxmc_8_16_streams.json): which of the 4 top direct sub-streams feeds which, for the sun in
+# the north / west / south / east, and which diffuse streams a downward top stream of each azimuth sector feeds.
+BMC = _golden("boxmc_8_16_streams.json")
+
+
+def _sun_switches(phi):
+    sun = O.suninfo(float(phi), 60.0)
+    return int(sun.xinc == 0), int(sun.yinc == 0), round(float(sun.symmetry_phi), 6)   # lswitch_east, lswitch_north (src/pprts_base.F90:1531-1539)
+
+
+def _close(a, b):
+    t = BMC["tolerance"]
+    return abs(a - b) <= t["atol"] + t["rtol"] * max(abs(a), abs(b))
+
+
+def _native_tables_from_boxmc():
+    """The LUT holds one orientation per (symmetric) azimuth; a solve relabels its vectors for the sun's quadrant
+    (dir2dir8_coeff_symmetry / dir8_to_diff16_coeff_symmetry, src/optprop.F90:1186-1302).  Undo that for every known-answer
+    vector: native[image[q]] = relabelled[q].  Two vectors that address the same native entry must agree within the Monte-Carlo
+    tolerance of the reference's own test -- that is what ties the relabelling tables to the reference's stream geometry."""
+    S = 8
+    native = {}   # (symmetry phi, family) -> {native flat index: value}
+    for c in BMC["direct_src_top_face"]["cases"]:
+        east, north, symphi = _sun_switches(c["phi"])
+        src = c["src"] - 1
+        for fam, vec in (("dir2dir8_coeff_symmetry", c["T_target"]), ("dir8_to_diff16_coeff_symmetry", c["S_target"])):
+            img = SYM[fam]["image"][f"e{east}n{north}"]
+            slot = native.setdefault((symphi, fam), {})
+            for dst, v in enumerate(vec):
+                q = img[dst * S + src]
+                if q in slot:
+                    assert _close(slot[q], v), (c["phi"], fam, dst, slot[q], v)
+                else:
+                    slot[q] = v
+    return native
+
+
+def test_relabelling_is_consistent_with_the_boxmc_8_16_known_answers():
+    native = _native_tables_from_boxmc()
+    assert sorted(k[0] for k in native) == [0.0, 0.0, 90.0, 90.0]
+    # the sun in the west (phi 270, no switch) and in the east (phi 90, both switches) read the SAME native dir2dir entries:
+    # (dst 0 <- src 1) and (dst 1 <- src 1), 0.063 and 0.301 in both vectors
+    t90 = {q: v for q, v in native[(90.0, "dir2dir8_coeff_symmetry")].items() if v > 0}
+    assert sorted(t90) == [0 * 8 + 1, 1 * 8 + 1] and _close(t90[1], 0.0630) and _close(t90[9], 0.3013)
+    # the sun in the north (phi 0) and in the south (phi 180) read the same native dir2diff entry (dst 5 <- src 2)
+    s0 = {q: v for q, v in native[(0.0, "dir8_to_diff16_coeff_symmetry")].items() if v > 0}
+    assert list(s0) == [5 * 8 + 2] and _close(s0[42], 0.625)
+    # the oracle's relabelling reproduces every known-answer vector from those native tables
+    for c in BMC["direct_src_top_face"]["cases"]:
+        east, north, symphi = _sun_switches(c["phi"])
+        for fam, is_t, n, vec in (("dir2dir8_coeff_symmetry", 1, 64, c["T_target"]), ("dir8_to_diff16_coeff_symmetry", 0, 128, c["S_target"])):
+            tab = np.zeros(n, dtype=np.float32)
+            for q, v in native[(symphi, fam)].items():
+                tab[q] = v
+            got = O.dir_coeff_symmetry(tab, is_t, 8, 16, east, north).reshape(-1, 8)[:, c["src"] - 1]
+            assert all(_close(float(g), w) for g, w in zip(got, vec)), (c["phi"], fam, got, vec)
+
+
+def test_side_stream_orientation_matches_the_boxmc_8_16_known_answers():
+    """A downward top stream of the north / west / south / east sector loses a few per cent to the side stream that moves the
+    same way: dof 14 (+y), 9 (-x), 13 (-y), 10 (+x), 1-based -- all in the first (downward-tilted) half of their side group, and
+    `is_inward` of t_solver_8_16 (src/pprts.F90:416-419, fixture solver_tables.json) says which of a pair moves towards +x / +y."""
+    tab = _golden("solver_tables.json")["solvers"]["t_solver_8_16"]
+    top_in, side_in = tab["difftop"]["is_inward"], tab["diffside"]["is_inward"]
+    want = {"north": (14, True), "west": (9, False), "south": (13, False), "east": (10, True)}
+    for c in BMC["diffuse_src_top_face"]["cases"]:
+        S = np.array(c["S_target"])
+        src = c["src"]
+        assert top_in[src - 1] and np.argmax(S) == src - 1 and S[src - 1] > 0.9            # a downward stream stays itself
+        side = S[8:]
+        dom = 9 + int(np.argmax(side))
+        dof, inward = want[c["quadrant"]]
+        assert dom == dof and side_in[(dof - 9) % 4] == inward, (c["quadrant"], dom)
+        # nothing reaches the upward-tilted halves (dofs 11, 12, 15, 16) or the upward top streams beyond Monte-Carlo noise
+        assert S[[10, 11, 14, 15]].max() < 1e-3 and S[[0, 2, 4, 6]].max() < 1e-3
+        assert abs(S.sum() - 1.0) < 5e-3 + 1e-3    # bg = (1e-6, 1e-3, .99): nearly nothing is absorbed in a 5 m layer
+
+
+@pytest.mark.gpu
+def test_device_relabelling_reproduces_the_boxmc_8_16_known_answers(gpu):
+    """The device's coefficient probe (tsx_opp_get_coeff: table lookup + quadrant relabelling, what pprts_f2c_opp_get_coeff serves)
+    on direct tables that hold the native vectors derived from the known answers: for the sun in the north, west, south and
+    east it returns the reference's T_target / S_target for the source stream of that case."""
+    from tenstream_amd import DiffuseSolver, _lib
+    from tenstream_amd.pprts import PprtsSolver
+
+    native = _native_tables_from_boxmc()
+    ax2 = lambda lo, hi: np.array([lo, hi], dtype=np.float32)
+    axes = [ax2(1e-10, 100.0), ax2(0.0, 0.99999), ax2(0.02, 7.451), ax2(0.0, 0.85), ax2(0.0, 90.0), ax2(0.0, 60.0)]
+    n_inner = 16
+    Tdir = np.zeros((64, 64), dtype=np.float32)    # (entries, S*S); entry = inner + 16 * (i_phi + 2 * i_theta)
+    Sdir = np.zeros((64, 128), dtype=np.float32)
+    for (symphi, fam), vals in native.items():
+        ip = 0 if symphi == 0.0 else 1
+        rows = slice(n_inner * (ip + 2 * 1), n_inner * (ip + 2 * 1) + n_inner)   # theta = 60: the upper node
+        for q, v in vals.items():
+            (Tdir if fam.startswith("dir2dir") else Sdir)[rows, q] = v
+    P = PprtsSolver(4, 4, 4, 100.0, 100.0, 0.0, 60.0, solver="8_16")
+    P.set_lut_direct(Tdir, Sdir, axes)
+    for c in BMC["direct_src_top_face"]["cases"]:
+        east, north, symphi = _sun_switches(c["phi"])
+        for imode, n, vec in ((1, 64, c["T_target"]), (2, 128, c["S_target"])):
+            out = np.full(n, -1, dtype=np.float32)
+            _lib.check(P.lib.tsx_opp_get_coeff(P.h, C.c_float(1.0), C.c_float(0.5), C.c_float(0.3), C.c_float(0.05), C.c_float(symphi),
+                                               C.c_float(60.0), imode, east, north, n, C.c_void_p(out.ctypes.data)))
+            got = out.reshape(-1, 8)[:, c["src"] - 1]
+            assert all(_close(float(g), w) for g, w in zip(got, vec)), (c["phi"], imode, got, vec)
+    P.close()
