@@ -418,14 +418,22 @@ def test_device_delta_scaling_and_eddington_equal_the_oracle(gpu, theta0):
     got = {n: P.get_field(n) for n in ("a11", "a12", "a13", "a23", "a33")}
     for n in got:
         assert np.isnan(got[n][:, :, tall:]).all() and np.isfinite(got[n][:, :, :tall]).all()
-    worst = 0.0
+    worst = (0.0, None)
     for j in range(Ny):
         for i in range(Nx):
             for k in range(tall):
                 want = O.eddington_coeff_ec(dz[j, i, k] * ext[j, i, k], ks[j, i, k] / ext[j, i, k], gg[j, i, k], mu0)
                 for n, w in zip(("a11", "a12", "a13", "a23", "a33"), want):
-                    worst = max(worst, abs(got[n][j, i, k] - w) / max(abs(w), 1e-300) if abs(w) > 1e-12 else abs(got[n][j, i, k] - w))
-    assert worst <= 1e-11, worst   # exp() and sqrt() of two maths libraries, a few ulp amplified by (1 - (k mu0)^2)^-1
+                    # the coefficients are O(1) fractions of the incoming energy; the closed forms cancel (sdir, rdir: differences
+                    # of products of exponentials), so an ulp in exp() shows as 1e-8 of a coefficient that is itself 1e-6
+                    err = abs(got[n][j, i, k] - w) / (1e-4 + abs(w))
+                    if (j, i) == (3, 3):
+                        # w0 = 1, g = 0: (g1 - g2)(g1 + g2) = 0 is clamped to 1e-12, A = 1e-6, and rdir / sdir divide differences of
+                        # exponentials by A: an ulp of exp() is amplified a million times (measured: 3e-8 .. 6e-8) in BOTH codes
+                        assert err <= 1e-6, (n, k, got[n][j, i, k], w)
+                    elif err > worst[0]:
+                        worst = (err, (n, j, i, k, got[n][j, i, k], w))
+    assert worst[0] <= 1e-10, worst   # the reference's own vectors are checked to 1e-4 (tests/eddington/test_delta_eddington.F90)
     # no delta scaling on request: the properties stay as they came
     P.set_optical_properties(0.1, kabs, ksca, g, dz, ldelta_scaling=False)
     assert np.array_equal(P.get_field("ksca"), ksca) and np.array_equal(P.get_field("g"), g)
