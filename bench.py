@@ -320,7 +320,8 @@ def main():
     if scan and args.pc_sweeps == 0:
         pc_ms = s.bench_kernel(2, args.kernel_reps)
         pass_ms = s.bench_kernel(3, 4 * args.kernel_reps)
-    copy_gbps = s.probe_copy_bandwidth(1 << 30, 10)
+    bw = s.probe_bandwidth(1 << 30, 5)   # what plain streaming kernels reach on this box: copy and read-only, best variant each
+    copy_gbps = bw["copy_GBps"]
     # the byte counts follow the storage format in use: take them while the solver is in the state that was timed
     bytes_survey_spmv = s.algorithmic_bytes(10)
     bytes_pass, bytes_pc = (s.algorithmic_bytes(3), s.algorithmic_bytes(2)) if pass_ms is not None else (None, None)
@@ -415,7 +416,12 @@ def main():
         traffic, src = pmc_traffic(solver, f"{co.xm}x{co.ym}x{Nz}" + ("" if args.field == "clouds" else "_" + args.field), patterns)
         r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
              "traffic": traffic, "traffic_source": src, "bytes_per_launch": nbytes, "ms_per_launch": ms,
-             "traffic_GBps": None if traffic is None else traffic / (ms * 1e-3) / 1e9}
+             "traffic_GBps": None if traffic is None else traffic / (ms * 1e-3) / 1e9,
+             # beside the nominal peak: the guide's achievable rate (MI355X_MICROARCH.md, HBM: about 6.3 TB/s) and this box's own
+             # best streaming copy (tsx_probe_bandwidth) -- algorithmic bytes, and the PMC traffic where a profile is committed
+             "frac_of_achievable": ach / 6300.0,
+             "frac_of_measured_copy": ach / copy_gbps,
+             "traffic_frac_of_achievable": None if traffic is None else traffic / (ms * 1e-3) / 1e9 / 6300.0}
         if full_storage_bytes is not None and full_storage_bytes != nbytes:
             # `achieved` counts the bytes of the storage format in use (distinct blocks once + a per-cell index); SURVEY
             # 8(d)'s figure for every cell's block stored is kept beside it (an equivalent rate, not a bandwidth)
@@ -493,6 +499,9 @@ def main():
                 "warm_start": {"iterations": warm.niter, "reason": warm.reason, "solve_ms": warm.solve_ms},
                 "iter_GBps": bytes_iter / (iter_ms * 1e-3) / 1e9,
                 "copy_GBps_measured": copy_gbps,
+                "read_GBps_measured": bw["read_GBps"],
+                "bandwidth_probe": dict(bw, note="best of 1 / 4 / 8 sixteen-byte accesses per lane in flight, plain and "
+                                                 "non-temporal, grids of 2048 / 4096 / 16384 workgroups, 1 GiB"),
                 "field": args.field,
                 "no_sharing": no_sharing,
                 "all_fp64": all_fp64,

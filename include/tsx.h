@@ -372,6 +372,10 @@ int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent);
 int tsx_pc_info(const tsx_solver *s, int32_t *pc, int32_t *pc_sweeps, int32_t *scan);
 /* device STREAM-like copy bandwidth probe (GB/s) for reporting against the measured peak */
 int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps);
+/* the same probe in full: out4 = [best copy GB/s (read + written bytes), best read-only GB/s, copy variant, read variant] over
+ * streaming kernels with 1 / 4 / 8 sixteen-byte accesses per lane in flight, plain and non-temporal, on capped grids -- the
+ * ceiling `roofline.frac_of_achievable` in bench.py is quoted against beside MI355X_MICROARCH.md's 6.3 TB/s */
+int tsx_probe_bandwidth(tsx_solver *s, size_t bytes, int reps, double *out4);
 
 #ifdef __cplusplus
 }

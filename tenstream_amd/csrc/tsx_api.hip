@@ -1509,26 +1509,111 @@ extern "C" int tsx_pc_info(const tsx_solver *s, int32_t *pc, int32_t *pc_sweeps,
   return TSX_OK;
 }
 
+// ---- bandwidth probes: what this device's memory system delivers to plain streaming kernels, as a ceiling to report the
+// rooflines against beside the nominal 8 TB/s (MI355X_MICROARCH.md: about 6.3 TB/s achievable).  U independent 16-byte
+// accesses per lane in flight, a capped grid with a grid-stride loop, optionally non-temporal; the best variant counts.
+typedef float tsx_f4v __attribute__((ext_vector_type(4)));  // a native vector: the non-temporal builtins take no HIP_vector_type
+template <int U, bool NT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_copy16u(long long n, const tsx_f4v *__restrict__ a, tsx_f4v *__restrict__ b) {
+  const long long stride = (long long)gridDim.x * TSX_BLOCK;
+  long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x;
+  for (; q + (U - 1) * stride < n; q += U * stride) {
+    tsx_f4v v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(&a[q + u * stride]) : a[q + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (NT) __builtin_nontemporal_store(v[u], &b[q + u * stride]);
+      else b[q + u * stride] = v[u];
+    }
+  }
+  for (; q < n; q += stride) b[q] = a[q];
+}
+template <int U, bool NT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_read16u(long long n, const tsx_f4v *__restrict__ a, float *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * TSX_BLOCK;
+  long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x;
+  float acc = 0.0f;
+  for (; q + (U - 1) * stride < n; q += U * stride) {
+    tsx_f4v v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(&a[q + u * stride]) : a[q + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+  }
+  for (; q < n; q += stride) acc += a[q][0];
+  if (acc == 123.456f) out[blockIdx.x] = acc;  // keeps the loads alive; the buffer holds a different constant
+}
+
+// best copy (read + write bytes) and best read rate over the variants, GB/s; variant ids for the record
+static int probe_bandwidth(tsx_solver *s, size_t bytes, int reps, double *copy_gbps, double *read_gbps, int *copy_variant,
+                           int *read_variant) {
+  HIPCHK(hipSetDevice(s->device));
+  TsxDevTmp A, B;
+  HIPCHK(A.alloc(bytes));
+  HIPCHK(B.alloc(bytes));
+  HIPCHK(hipMemsetAsync(A.p, 1, bytes, s->stream));
+  HIPCHK(hipMemsetAsync(B.p, 0, bytes, s->stream));
+  const long long n = (long long)(bytes / 16);
+  const tsx_f4v *a = A.as<tsx_f4v>();
+  tsx_f4v *b = B.as<tsx_f4v>();
+  const int grids[3] = {2048, 4096, 16384};
+  double best_c = 0, best_r = 0;
+  int vc = -1, vr = -1;
+  auto timed = [&](auto launch, double moved, double *best, int *bv, int id) -> int {
+    launch();  // warm
+    HIPCHK(hipEventRecord(s->ev0, s->stream));
+    for (int q = 0; q < reps; ++q) launch();
+    HIPCHK(hipEventRecord(s->ev1, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    const double g = moved * reps / (ms * 1e-3) / 1e9;
+    if (g > *best) {
+      *best = g;
+      *bv = id;
+    }
+    return TSX_OK;
+  };
+  int rc;
+  for (int gi = 0; gi < 3; ++gi) {
+    const int nb = (int)(n / TSX_BLOCK < grids[gi] ? (n / TSX_BLOCK > 0 ? n / TSX_BLOCK : 1) : grids[gi]);
+#define TSX_PROBE(U, NT, ID)                                                                                                        \
+  if ((rc = timed([&] { hipLaunchKernelGGL((tsx_k_copy16u<U, NT>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, n, a, b); },            \
+                  2.0 * (double)(n * 16), &best_c, &vc, gi * 10 + ID)))                                                             \
+    return rc;                                                                                                                      \
+  if ((rc = timed([&] { hipLaunchKernelGGL((tsx_k_read16u<U, NT>), dim3(nb), dim3(TSX_BLOCK), 0, s->stream, n, a, (float *)b); },   \
+                  (double)(n * 16), &best_r, &vr, gi * 10 + ID)))                                                                   \
+    return rc;
+    TSX_PROBE(1, false, 0)
+    TSX_PROBE(4, false, 1)
+    TSX_PROBE(8, false, 2)
+    TSX_PROBE(4, true, 3)
+    TSX_PROBE(8, true, 4)
+#undef TSX_PROBE
+  }
+  HIPCHK(hipGetLastError());
+  *copy_gbps = best_c;
+  *read_gbps = best_r;
+  if (copy_variant) *copy_variant = vc;
+  if (read_variant) *read_variant = vr;
+  return TSX_OK;
+}
+
 extern "C" int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps) {
   ARGCHK(s && gbps && reps >= 1 && bytes >= 16, "tsx_probe_copy_bandwidth: bad argument");
-  HIPCHK(hipSetDevice(s->device));
-  void *a = nullptr, *b = nullptr;
-  HIPCHK(hipMalloc(&a, bytes));
-  HIPCHK(hipMalloc(&b, bytes));
-  HIPCHK(hipMemsetAsync(a, 1, bytes, s->stream));
-  const long long n = (long long)(bytes / 16);
-  hipLaunchKernelGGL(tsx_k_copy16, dim3(grid_for(n, 8192)), dim3(TSX_BLOCK), 0, s->stream, n, (const float4 *)a, (float4 *)b);
-  HIPCHK(hipEventRecord(s->ev0, s->stream));
-  for (int q = 0; q < reps; ++q)
-    hipLaunchKernelGGL(tsx_k_copy16, dim3(grid_for(n, 8192)), dim3(TSX_BLOCK), 0, s->stream, n, (const float4 *)a, (float4 *)b);
-  HIPCHK(hipEventRecord(s->ev1, s->stream));
-  HIPCHK(hipStreamSynchronize(s->stream));
-  float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-  *gbps = 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9;
-  HIPCHK(hipFree(a));
-  HIPCHK(hipFree(b));
-  return TSX_OK;
+  double r = 0;
+  return probe_bandwidth(s, bytes, reps, gbps, &r, nullptr, nullptr);
+}
+// out4: best copy GB/s (bytes read + written), best read GB/s, and the variants that gave them (grid index * 10 + kernel id:
+// kernel 0 one access per lane, 1 / 2 four / eight in flight, 3 / 4 the same non-temporal; grids 2048, 4096, 16384 workgroups)
+extern "C" int tsx_probe_bandwidth(tsx_solver *s, size_t bytes, int reps, double *out4) {
+  ARGCHK(s && out4 && reps >= 1 && bytes >= 16, "tsx_probe_bandwidth: bad argument");
+  int vc = -1, vr = -1;
+  int rc = probe_bandwidth(s, bytes, reps, &out4[0], &out4[1], &vc, &vr);
+  out4[2] = vc;
+  out4[3] = vr;
+  return rc;
 }
 
 #include "tsx_pipeline_api.inc"

@@ -437,6 +437,12 @@ class DiffuseSolver:
         _lib.check(self.lib.tsx_algorithmic_bytes(self.h, kernel, C.byref(b)))
         return b.value
 
+    def probe_bandwidth(self, nbytes=1 << 30, reps=5):
+        """{copy_GBps, read_GBps, copy_variant, read_variant}: the best of the streaming probes (tsx_probe_bandwidth)"""
+        o = (C.c_double * 4)()
+        _lib.check(self.lib.tsx_probe_bandwidth(self.h, nbytes, reps, o))
+        return {"copy_GBps": o[0], "read_GBps": o[1], "copy_variant": int(o[2]), "read_variant": int(o[3])}
+
     def probe_copy_bandwidth(self, nbytes=1 << 30, reps=10) -> float:
         g = C.c_double()
         _lib.check(self.lib.tsx_probe_copy_bandwidth(self.h, nbytes, reps, C.byref(g)))
