@@ -25,6 +25,7 @@ dev = torch.device("cuda", 0)
 b = torch.tensor(P["b"], device=dev)
 coeff = torch.tensor(P["coeff"], device=dev)
 rest = [torch.tensor(P[k], device=dev) for k in ("l1d", "a11", "a12", "albedo")]
+KW = dict(pc_sweeps=int(os.environ["PC_SWEEPS"])) if os.environ.get("PC_SWEEPS") else {}   # half-grid passes - 1 (A/B)
 for mode in os.environ.get("SHARD_MODES", "wrap,copy,peer").split(","):
     s = DiffuseSolver("3_10", Nz, xm, ym, force_halo=mode != "wrap")
     if mode == "peer":
@@ -32,13 +33,13 @@ for mode in os.environ.get("SHARD_MODES", "wrap,copy,peer").split(","):
     s.set_coeffs(coeff, *rest)
     x = torch.zeros_like(b)
     for _ in range(3):
-        info = s.solve(b, x, initial_guess_zero=1)
+        info = s.solve(b, x, initial_guess_zero=1, **KW)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 10
     dev_ms = 0.0
     for _ in range(n):
-        info = s.solve(b, x, initial_guess_zero=1)
+        info = s.solve(b, x, initial_guess_zero=1, **KW)
         dev_ms += info.solve_ms
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / n * 1e3

@@ -845,16 +845,23 @@ extern "C" int tsx_diff_apply(tsx_solver *s, const double *x, double *y, int whe
   return s->geo.ntop == 2 ? diff_apply_t<2, 4>(s, x, y, where) : diff_apply_t<8, 4>(s, x, y, where);
 }
 
+// TSX_HALF_EXIT=0 switches the stop test at BiCGStab's half step off (A/B; read per call)
+static bool tsx_half_exit() {
+  const char *e = getenv("TSX_HALF_EXIT");
+  return !(e && atoi(e) == 0);
+}
+
 // One BiCGStab iteration on the stream (no host synchronisation).
 // One BiCGStab iteration on the stream (no host synchronisation).  MIX: preconditioned directions and the shadow
 // residual live in fp32 (s->mixed); x, r, p, s, v, t stay fp64.
 template <int NTOP, int NSIDE, bool MIX>
-static int enqueue_iteration_t(tsx_solver *s, bool first) {
+static int enqueue_iteration_t(tsx_solver *s, bool first, bool half_ok) {
   using PT = typename std::conditional<MIX, float, double>::type;  // directions
   using RT = PT;                                                    // shadow residual
   const TsxGeo &g = s->geo;
   const long long n2 = g.N / 2;
   const int nbv = grid_for(n2);
+  const bool half = half_ok && tsx_half_exit();
   int rc;
   if (!first) {
     if (MIX && s->pc != TSX_PC_NONE)  // p lives in fp32 only (s->v32), see tsx_k_pupdate32
@@ -872,7 +879,9 @@ static int enqueue_iteration_t(tsx_solver *s, bool first) {
     if ((rc = launch_spmv<NTOP, NSIDE, 1, PT, RT>(s, ph, s->vv, rhat, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
     hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
-                       (const double2 *)s->vv, (double2 *)s->vs, MIX ? (float2 *)s->v32 : (float2 *)nullptr, g, (int)s->pc_split);
+                       (const double2 *)s->vv, (double2 *)s->vs, MIX ? (float2 *)s->v32 : (float2 *)nullptr, g, (int)s->pc_split,
+                       half ? s->partials : (double *)nullptr);
+    if (half && (rc = scalar_stage(s, nbv, 1, TSX_STAGE_HALF))) return rc;
     s->pc_rhs = s->v32;
     if ((rc = tsx_pc_apply(s, s->vs, sh, std::is_same<PT, float>::value, true))) return rc;
     if ((rc = launch_spmv<NTOP, NSIDE, 5, PT, double>(s, sh, s->vt, s->vs, true))) return rc;
@@ -883,7 +892,8 @@ static int enqueue_iteration_t(tsx_solver *s, bool first) {
     if ((rc = launch_spmv<NTOP, NSIDE, 1, double, RT>(s, s->vp, s->vv, rhat, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 1, TSX_STAGE_ALPHA))) return rc;
     hipLaunchKernelGGL(tsx_k_supdate, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const double2 *)s->vr,
-                       (const double2 *)s->vv, (double2 *)s->vs, (float2 *)nullptr, g, 0);
+                       (const double2 *)s->vv, (double2 *)s->vs, (float2 *)nullptr, g, 0, half ? s->partials : (double *)nullptr);
+    if (half && (rc = scalar_stage(s, nbv, 1, TSX_STAGE_HALF))) return rc;
     if ((rc = launch_spmv<NTOP, NSIDE, 5, double, double>(s, s->vs, s->vt, s->vs, true))) return rc;
     if ((rc = scalar_stage(s, spmv_nblocks(s), 3, TSX_STAGE_OMEGA))) return rc;
     hipLaunchKernelGGL((tsx_k_xrupdate<double, RT>), dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (double2 *)s->vx,
@@ -897,7 +907,7 @@ static int enqueue_iteration_t(tsx_solver *s, bool first) {
 // The same iteration with the recurrence vectors in fp32 (tsx_kernels.hpp "fp32 Krylov vectors"): r in vr, v in vv, s in vs
 // (natural order; the preconditioner's colour-split copy in v32), t in vt -- the fp64 buffers reused as float arrays.
 template <int NTOP, int NSIDE>
-static int enqueue_iteration_k32(tsx_solver *s, bool first) {
+static int enqueue_iteration_k32(tsx_solver *s, bool first, bool half_ok) {
   const TsxGeo &g = s->geo;
   const long long n2 = g.N / 2;
   const int nbv = grid_for(n2);
@@ -909,14 +919,16 @@ static int enqueue_iteration_k32(tsx_solver *s, bool first) {
   const bool words = s->pc_split && s->coef_h_scan && tsx_pcs_rhs16(s) && s->pc_sweeps + 1 >= 6 &&
                      !(getenv("TSX_PC_WORDS") && atoi(getenv("TSX_PC_WORDS")) == 0);
   const int nbc = grid_for(g.Nc);
+  const bool half = half_ok && tsx_half_exit();
+  double *hp = half ? s->partials : (double *)nullptr;
   if (!first) {
     if (words) {
       if (NTOP == 2)
         hipLaunchKernelGGL((tsx_k_psupdate_k32c<10, 0>), dim3(nbc), dim3(TSX_BLOCK), 0, s->stream, g, s->scal, (const float *)r32,
-                           (const float *)v32k, s->p32, (float *)nullptr, tsx_pcs_words(s));
+                           (const float *)v32k, s->p32, (float *)nullptr, tsx_pcs_words(s), (double *)nullptr);
       else
         hipLaunchKernelGGL((tsx_k_psupdate_k32c<16, 0>), dim3(nbc), dim3(TSX_BLOCK), 0, s->stream, g, s->scal, (const float *)r32,
-                           (const float *)v32k, s->p32, (float *)nullptr, tsx_pcs_words(s));
+                           (const float *)v32k, s->p32, (float *)nullptr, tsx_pcs_words(s), (double *)nullptr);
       s->pc_words_ready = true;
     } else {
       hipLaunchKernelGGL(tsx_k_pupdate_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const float2 *)r32,
@@ -932,14 +944,16 @@ static int enqueue_iteration_k32(tsx_solver *s, bool first) {
   if (words) {
     if (NTOP == 2)
       hipLaunchKernelGGL((tsx_k_psupdate_k32c<10, 1>), dim3(nbc), dim3(TSX_BLOCK), 0, s->stream, g, s->scal, (const float *)r32,
-                         (const float *)v32k, s->v32, sdst, tsx_pcs_words(s));
+                         (const float *)v32k, s->v32, sdst, tsx_pcs_words(s), hp);
     else
       hipLaunchKernelGGL((tsx_k_psupdate_k32c<16, 1>), dim3(nbc), dim3(TSX_BLOCK), 0, s->stream, g, s->scal, (const float *)r32,
-                         (const float *)v32k, s->v32, sdst, tsx_pcs_words(s));
+                         (const float *)v32k, s->v32, sdst, tsx_pcs_words(s), hp);
     s->pc_words_ready = true;
+    if (half && (rc = scalar_stage(s, nbc, 1, TSX_STAGE_HALF))) return rc;
   } else {
     hipLaunchKernelGGL(tsx_k_supdate_k32, dim3(nbv), dim3(TSX_BLOCK), 0, s->stream, n2, s->scal, (const float2 *)r32,
-                       (const float2 *)v32k, (float2 *)sdst, s->pc_split ? s->v32 : (float *)nullptr, g);
+                       (const float2 *)v32k, (float2 *)sdst, s->pc_split ? s->v32 : (float *)nullptr, g, hp);
+    if (half && (rc = scalar_stage(s, nbv, 1, TSX_STAGE_HALF))) return rc;
   }
   s->pc_rhs = s->v32;
   if ((rc = tsx_pc_apply(s, s->vs, sh, true, true))) return rc;
@@ -965,9 +979,11 @@ static int k32_replace_residual(tsx_solver *s) {
   return TSX_OK;
 }
 template <int NTOP, int NSIDE>
-static int enqueue_iteration(tsx_solver *s, bool first) {
-  if (s->k32) return enqueue_iteration_k32<NTOP, NSIDE>(s, first);
-  return s->mixed ? enqueue_iteration_t<NTOP, NSIDE, true>(s, first) : enqueue_iteration_t<NTOP, NSIDE, false>(s, first);
+static int enqueue_iteration(tsx_solver *s, bool first, bool half_ok = true) {
+  // half_ok: run the stop test at the half step (TSX_STAGE_HALF: one more scalar stage, on several ranks one more all-reduce);
+  // the Krylov loop asks for it only in iterations in which it can plausibly fire
+  if (s->k32) return enqueue_iteration_k32<NTOP, NSIDE>(s, first, half_ok);
+  return s->mixed ? enqueue_iteration_t<NTOP, NSIDE, true>(s, first, half_ok) : enqueue_iteration_t<NTOP, NSIDE, false>(s, first, half_ok);
 }
 
 template <int NTOP, int NSIDE>
@@ -981,10 +997,13 @@ static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o, bool restart = fal
     init.atol = o->atol;
     init.dtol = o->dtol;
     init.maxit = o->maxit;
+    // half-step stop test: on the fp32 recurrence the decision is taken again on the true residual, so ask for a little more
+    init.half_margin = s->k32 ? 0.9 : 1.0;
     *s->scal_host = init;
   } else {  // breakdown restart: keep iteration count, history and the initial norm; new shadow residual
     s->scal_host->done = 0;
     s->scal_host->reason = 0;
+    s->scal_host->half = 0;
     s->scal_host->restart = 1;
   }
   HIPCHK(hipMemcpyAsync(s->scal, s->scal_host, sizeof(TsxScalars), hipMemcpyHostToDevice, s->stream));
@@ -1014,8 +1033,18 @@ template <int NTOP, int NSIDE>
 static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
   int rc;
   HIPCHK(hipEventRecord(s->ev0, s->stream));
+  const bool cold = s->x_is_zero;   // a zero guess: the first iterations are far from the stop rule
   if ((rc = krylov_begin<NTOP, NSIDE>(s, o))) return rc;
   const int chunk = o->check_every > 0 ? o->check_every : 2;
+  // the half-step test pays where the residual is about to meet the rule: predicted from the last two known norms (several
+  // ranks hold the same all-reduced history, so they agree); a warm start may be converged at once -- there from the start
+  auto half_plausible = [&](int ahead) {
+    const TsxScalars &h = *s->scal_host;
+    if (h.nhist < 1 || h.its == 0) return !cold;
+    const double last = h.hist[h.nhist - 1], prev = h.nhist >= 2 ? h.hist[h.nhist - 2] : last * 10.0;
+    const double ratio = prev > 0.0 && last < prev ? last / prev : 1.0;
+    return last * pow(ratio, (double)ahead) <= 30.0 * fmax(o->rtol * h.rnorm0, o->atol);
+  };
   int enq = 0, nrestart = 0;
   bool done = false, first_after_begin = true;
   while (!done) {
@@ -1030,11 +1059,29 @@ static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
       }
     }
     for (int q = 0; q < todo; ++q, ++enq) {
-      if ((rc = enqueue_iteration<NTOP, NSIDE>(s, first_after_begin))) return rc;
+      if ((rc = enqueue_iteration<NTOP, NSIDE>(s, first_after_begin, half_plausible(q + 1)))) return rc;
       first_after_begin = false;
     }
     HIPCHK(hipMemcpyAsync(s->scal_host, s->scal, sizeof(TsxScalars), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    const bool was_half = s->scal_host->done && s->scal_host->half;
+    if (was_half) {
+      // the stop rule was met by s = r - alpha v in the middle of an iteration (TSX_STAGE_HALF): the kernels of its second half
+      // returned at once; the iterate is x + alpha p-hat
+      const TsxGeo &gq = s->geo;
+      if (s->pc == TSX_PC_NONE)   // no preconditioner: p-hat is p itself (fp64 in every variant)
+        hipLaunchKernelGGL(tsx_k_xhalf<double>, dim3(grid_for(gq.N)), dim3(TSX_BLOCK), 0, s->stream, gq.N, s->scal, s->vx,
+                           (const double *)s->vp);
+      else if (s->k32 || s->mixed)
+        hipLaunchKernelGGL(tsx_k_xhalf<float>, dim3(grid_for(gq.N)), dim3(TSX_BLOCK), 0, s->stream, gq.N, s->scal, s->vx,
+                           (const float *)s->vph);
+      else
+        hipLaunchKernelGGL(tsx_k_xhalf<double>, dim3(grid_for(gq.N)), dim3(TSX_BLOCK), 0, s->stream, gq.N, s->scal, s->vx,
+                           (const double *)s->vph);
+      HIPCHK(hipGetLastError());
+      s->scal_host->half = 0;
+      enq = s->scal_host->its;
+    }
     if (s->k32) {
       // fp32 recurrence: convergence is declared on the true residual only, and the recurrence is re-anchored to it whenever
       // it has fallen four orders of magnitude since the last anchor (it cannot follow b - A x much further in fp32)
@@ -1051,6 +1098,12 @@ static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
         HIPCHK(hipMemcpyAsync(s->scal_host, s->scal, sizeof(TsxScalars), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         if (conv && !h.done) enq = h.its;  // iterations enqueued after the premature stop did not run
+        if (was_half && !h.done && enq < o->maxit) {
+          // the half step's recurrence residual met the rule, the true residual does not (yet): omega of this iteration was never
+          // formed, so the recurrence cannot go on -- start a new Krylov sequence from the current iterate (rhat = p = r = b - A x)
+          if ((rc = krylov_begin<NTOP, NSIDE>(s, o, true))) return rc;
+          first_after_begin = true;
+        }
       }
     }
     done = s->scal_host->done != 0 || enq >= o->maxit;

@@ -50,6 +50,8 @@ struct TsxScalars {
   int restart;   // set by the host before a breakdown restart: INIT keeps its / history / rnorm0
   int nranks;    // explicit solver: its residual is the mean over ranks of the local norms
   int aux_flag;  // scratch flag for kernels outside the loop (import: is the guess nonzero?)
+  int half;      // the stop rule was met by s = r - alpha v, in the middle of an iteration (TSX_STAGE_HALF): x still lacks alpha p-hat
+  double half_margin;  // factor on rtol / atol for that test (< 1 where the decision is re-taken on the true residual afterwards)
   double hist[100];
 };
 
@@ -118,6 +120,7 @@ struct tsx_solver {
   bool any_l1d;
   // shared storage of bit-identical blocks (tsx_dedup.hip): planes over entries + per-cell entry index
   bool dd_valid, dd_on;
+  bool pe_entry_major = false;  // the scan passes' per-block records are stored entry-major (tsx_k_pcs_pack_ent16)
   bool dd_pc = false;      // the index / entries group NEAR-identical blocks and serve the preconditioner only (tsx_dedup.hip);
                            // the operator then works on every cell's exact block (dd_on stays false)
   int dd_nent_near = 0;    // entries of that grouping (0: not attempted)

@@ -76,14 +76,16 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pupdate32(long long n2, const
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_supdate(long long n2, const TsxScalars *__restrict__ sc,
                                                            const double2 *__restrict__ r, const double2 *__restrict__ v,
                                                            double2 *__restrict__ s, float2 *__restrict__ s32, TsxGeo g,
-                                                           int split) {
+                                                           int split, double *__restrict__ partials) {
   if (sc->done) return;
   const double alpha = sc->alpha;
+  double sum[1] = {0.0};  // (s, s): the half-step stop test (TSX_STAGE_HALF)
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
     const double2 rr = r[q], vv = v[q];
     double2 o;
     o.x = rr.x - alpha * vv.x;
     o.y = rr.y - alpha * vv.y;
+    sum[0] += o.x * o.x + o.y * o.y;
     s[q] = o;
     if (s32) {
       if (split) {
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_supdate(long long n2, const T
       }
     }
   }
+  if (partials) tsx_block_reduce_store<1>(sum, partials);
 }
 
 // x += alpha ph + omega sh; r = s - omega t; slot0 = (rhat, r), slot1 = (r, r).  PT: storage of ph/sh, RT: of rhat
@@ -177,18 +180,22 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pupdate_k32(long long n2, con
 // colour-split order, a second copy in that order
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_supdate_k32(long long n2, const TsxScalars *__restrict__ sc,
                                                                const float2 *__restrict__ r, const float2 *__restrict__ v,
-                                                               float2 *__restrict__ s, float *__restrict__ ssplit, TsxGeo g) {
+                                                               float2 *__restrict__ s, float *__restrict__ ssplit, TsxGeo g,
+                                                               double *__restrict__ partials) {
   if (sc->done) return;
   const double alpha = sc->alpha;
+  double sum[1] = {0.0};  // (s, s) of the values as stored: the half-step stop test (TSX_STAGE_HALF)
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n2; q += (long long)gridDim.x * TSX_BLOCK) {
     const float2 rr = r[q], vv = v[q];
     const float2 o = make_float2((float)((double)rr.x - alpha * (double)vv.x), (float)((double)rr.y - alpha * (double)vv.y));
+    sum[0] += (double)o.x * (double)o.x + (double)o.y * (double)o.y;
     s[q] = o;
     if (ssplit) {
       ssplit[tsx_split_pos(2 * q, g)] = o.x;
       ssplit[tsx_split_pos(2 * q + 1, g)] = o.y;
     }
   }
+  if (partials) tsx_block_reduce_store<1>(sum, partials);
 }
 // The same two updates cell by cell, for the scan preconditioner: the thread of a cell has all D streams of it in hand and also
 // leaves the D / 2 bf16-pair words of the right-hand side that the red-black passes read (rb[w * Nc + split cell] = streams
@@ -206,10 +213,12 @@ __device__ __forceinline__ unsigned tsx_bf16pair(float lo, float hi) {
 template <int D, int MODE>
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_psupdate_k32c(TsxGeo g, const TsxScalars *__restrict__ sc, const float *__restrict__ r,
                                                                  const float *__restrict__ v, float *__restrict__ p_or_ssplit,
-                                                                 float *__restrict__ s_nat, unsigned *__restrict__ rb) {
+                                                                 float *__restrict__ s_nat, unsigned *__restrict__ rb,
+                                                                 double *__restrict__ partials) {
   if (sc->done) return;
   const double beta = sc->beta, omega = sc->omega, alpha = sc->alpha;
   const long long Nc = g.Nc;
+  double sum[1] = {0.0};  // MODE 1: (s, s) of the values as stored, the half-step stop test (TSX_STAGE_HALF)
   for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
     const int i = (int)(c % g.xm);
     const long long t = c / g.xm;
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_psupdate_k32c(TsxGeo g, const
       } else {
         o[d] = (float)((double)r[in] - alpha * (double)v[in]);
         s_nat[in] = o[d];
+        sum[0] += (double)o[d] * (double)o[d];
       }
       p_or_ssplit[sp] = o[d];
     }
@@ -239,8 +249,18 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_psupdate_k32c(TsxGeo g, const
       const float o = (float)((double)r[q] - alpha * (double)v[q]);
       s_nat[q] = o;
       p_or_ssplit[sp] = o;
+      sum[0] += (double)o * (double)o;
     }
   }
+  if (MODE == 1 && partials) tsx_block_reduce_store<1>(sum, partials);
+}
+// x += alpha p-hat: the iterate of a solve that stopped at the half step (TSX_STAGE_HALF; runs although `done` is set)
+template <typename PT>
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xhalf(long long n, const TsxScalars *__restrict__ sc, double *__restrict__ x,
+                                                         const PT *__restrict__ ph) {
+  const double alpha = sc->alpha;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK)
+    x[q] += alpha * (double)ph[q];
 }
 // x += alpha ph + omega sh (fp64); r = s - omega t; slot0 = (rhat, r), slot1 = (r, r)
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xrupdate_k32(long long n2, const TsxScalars *__restrict__ sc,
@@ -296,7 +316,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_xplus(long long n, const TsxS
 // Scalar stage: one block.  mode bit0: reduce the per-block partials into sc->red (fixed order);
 // mode bit1: run the stage's scalar algebra (after the all-reduce when ranks > 1).
 // Stop rule restates MyKSPConverged (src/pprts.F90:4437-4486).
-enum { TSX_STAGE_INIT = 0, TSX_STAGE_ALPHA = 1, TSX_STAGE_OMEGA = 2, TSX_STAGE_RHO = 3, TSX_STAGE_EXPLICIT = 4, TSX_STAGE_REPLACE = 5 };
+enum { TSX_STAGE_INIT = 0, TSX_STAGE_ALPHA = 1, TSX_STAGE_OMEGA = 2, TSX_STAGE_RHO = 3, TSX_STAGE_EXPLICIT = 4, TSX_STAGE_REPLACE = 5, TSX_STAGE_HALF = 6 };
 
 __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc, const double *__restrict__ partials,
                                                      int nblocks, int nslots, int stage, int mode, TsxPeerArArgs ar) {
@@ -367,6 +387,24 @@ __global__ __launch_bounds__(1024) void tsx_k_scalar(TsxScalars *__restrict__ sc
         sc->done = 1;
       } else {
         sc->alpha = sc->rho / d1;
+      }
+    } break;
+    case TSX_STAGE_HALF: {
+      // BiCGStab's first half step: x + alpha p-hat has the residual s = r - alpha v.  If s already meets the stop rule
+      // (MyKSPConverged's two tests, src/pprts.F90:4437-4486, on |s|), the second half -- M^-1 s, A s-hat, the omega update --
+      // is work on a converged system: stop here; the host adds alpha p-hat to x (tsx_k_xhalf).  red[0] = (s, s)
+      const double sn = sqrt(sc->red[0]);
+      const double m = sc->half_margin > 0.0 ? sc->half_margin : 1.0;
+      int reason = 0;
+      if (sn / sc->rnorm0 <= m * sc->rtol) reason = 2;
+      else if (sn <= m * sc->atol) reason = 3;
+      if (reason && sc->its + 1 <= sc->maxit) {
+        sc->rnorm = sn;
+        sc->its += 1;
+        if (sc->nhist < 100) sc->hist[sc->nhist++] = sn;
+        sc->reason = reason;
+        sc->half = 1;
+        sc->done = 1;
       }
     } break;
     case TSX_STAGE_OMEGA: {

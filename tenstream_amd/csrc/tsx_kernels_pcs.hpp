@@ -186,9 +186,14 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_rec1h(TsxGeo g, cons
   }
 }
 constexpr int TSX_PCS_ENT16_SLOTS = 8;
+// entry_major: PE[id * 8 + slot] -- an entry's eight records are one aligned 128-byte line.  For the groups of NEAR-identical
+// blocks the lanes of a wave hold unrelated ids (a group's members lie anywhere in the domain), so with PE[slot * nent + id]
+// every one of a level's eight gathers touches up to 64 different lines and uses 16 bytes of each; entry-major, the first
+// gather brings the lane's line and the other seven hit it.  Bit-identical sharing keeps the slot-major order: there a
+// wave's ids are equal (clear sky: a broadcast) or consecutive (cloud cells in cell order: coalesced).
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent16(int ncol, long long nent, const float *__restrict__ Cd,
                                                                   const int *__restrict__ ent_cell, const uint8_t *__restrict__ l1d,
-                                                                  uint4 *__restrict__ PE) {
+                                                                  uint4 *__restrict__ PE, int entry_major) {
   constexpr int D = 10;
   const long long n = nent * TSX_PCS_ENT16_SLOTS;
   for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < n; q += (long long)gridDim.x * TSX_BLOCK) {
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent16(int ncol, long
         v.w = tsx_to_fp8x4(cf(d0 + 3, s0), cf(d0 + 3, s0 + 1), cf(d0 + 3, s0 + 2), cf(d0 + 3, s0 + 3));
       }
     }
-    PE[q] = v;
+    PE[entry_major ? (size_t)id * TSX_PCS_ENT16_SLOTS + slot : (size_t)q] = v;
   }
 }
 
@@ -359,8 +364,11 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
                                                          int nonbr, const int *__restrict__ cidx, long long nent,
                                                          const uint4 *__restrict__ PE, TsxPcHalo hal,
                                                          unsigned *__restrict__ rb, int part, const int *__restrict__ pidx,
-                                                         const uint4 *__restrict__ PT, TsxPeerXArgs snd) {
+                                                         const uint4 *__restrict__ PT, TsxPeerXArgs snd, int pe_si) {
   static_assert(!PEER || MODE != 2, "the last pass sends nothing");
+  // per-block records: PE[slot * pe_ss + id * pe_si]; pe_si = 1: slot-major planes of nent entries, pe_si = 8 (C16 only):
+  // entry-major, an entry's eight records in one 128-byte line (tsx_k_pcs_pack_ent16)
+  const size_t pe_ss = pe_si == 1 ? (size_t)nent : (size_t)1;
   // pidx != null (intermediate passes with shared blocks): the cell's record 0 (with its block index) is entry pidx[cell] of
   // the table PT of distinct records (tsx_records_share)
   static_assert(RQ == 0 || MODE == 0, "bf16 right-hand side only in the intermediate passes");
@@ -472,7 +480,9 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   int eid[LSEG];
   // group g = 1..7 of the layout: per cell P[g * Nc + cell]; per block PE[(g - 1) * nent + id], or with C16 PE[g * nent + id]
   // (slots 0 and 1 hold record 1's two fp16 halves)
-  auto rec = [&](int grp, size_t c, int id) { return IDX ? PE[(size_t)(C16 ? grp : grp - 1) * nent + id] : P[(size_t)grp * Nc + c]; };
+  auto rec = [&](int grp, size_t c, int id) {
+    return IDX ? PE[(size_t)(C16 ? grp : grp - 1) * pe_ss + (size_t)id * (size_t)pe_si] : P[(size_t)grp * Nc + c];
+  };
   // four side -> top couplings as floats: fp8 word w, or the fp16 pair of words (a, b)
   auto dec4 = [&](unsigned w, unsigned a, unsigned b, float (&o)[4]) {
     if (C16) {
@@ -503,8 +513,8 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     }
     if (GS) {
       if (C16) {
-        r1[l] = IDX ? PE[eid[l]] : P[(size_t)1 * Nc + c];
-        r1x[l] = IDX ? PE[(size_t)nent + eid[l]] : P[(size_t)8 * Nc + c];
+        r1[l] = IDX ? PE[(size_t)eid[l] * (size_t)pe_si] : P[(size_t)1 * Nc + c];
+        r1x[l] = IDX ? PE[pe_ss + (size_t)eid[l] * (size_t)pe_si] : P[(size_t)8 * Nc + c];
       } else {
         r1[l] = rec(1, c, eid[l]);
       }

@@ -111,10 +111,15 @@ int tsx_pcs_pack(tsx_solver *s) {
     hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->coef,
                        s->l1d, s->a11, s->a12, s->albedo, P);
     s->coef_h_c16 = pcs_c16();
+    // near-identical grouping (dd_pc without dd_on): a wave's ids are unrelated -> an entry's records in one line (TSX_PC_ENTRY_MAJOR=0 / 1 overrides)
+    {
+      const char *e = getenv("TSX_PC_ENTRY_MAJOR");
+      s->pe_entry_major = pcs_c16() && (e ? atoi(e) != 0 : (s->dd_pc && !s->dd_on));
+    }
     if (s->coef_h_c16)  // side -> top couplings in fp16: 8 records per distinct block
       hipLaunchKernelGGL(tsx_k_pcs_pack_ent16, dim3(grid_for((long long)TSX_PCS_ENT16_SLOTS * s->pc_nent)), dim3(TSX_BLOCK), 0,
                          s->stream, g.ncol, (long long)s->pc_nent, (const float *)s->pc_coef, (const int *)s->pc_ent_cell, s->l1d,
-                         P + g.Nc);
+                         P + g.Nc, s->pe_entry_major ? 1 : 0);
     else
       hipLaunchKernelGGL(tsx_k_pcs_pack_ent, dim3(grid_for(7ll * s->pc_nent)), dim3(TSX_BLOCK), 0, s->stream, g.ncol,
                          (long long)s->pc_nent, (const float *)s->pc_coef, (const int *)s->pc_ent_cell, s->l1d, P + g.Nc);
@@ -321,7 +326,7 @@ static void pcs_launch(tsx_solver *s, bool gs, int mode, int rbc, int nonbr, flo
   hipLaunchKernelGGL((tsx_k_pcs_rb<L, S, CW, GSV, MODEV, IDXV, RQV, C16, PEERV>), dim3(nb), dim3(CW *S), 0, s->stream, g, P, r,  \
                      zs, zb, zfin, done, rbc, nonbr, IDXV ? cidx : (const int *)nullptr, IDXV ? nent : 0ll,                      \
                      IDXV ? PE : (const uint4 *)nullptr, hal, rb, part, IDXV ? pidx : (const int *)nullptr,                      \
-                     IDXV ? PT : (const uint4 *)nullptr, snd)
+                     IDXV ? PT : (const uint4 *)nullptr, snd, (IDXV && s->pe_entry_major) ? TSX_PCS_ENT16_SLOTS : 1)
 #define TSX_PCS_GO(GSV, MODEV, RQV)                                                                                              \
   do {                                                                                                                           \
     if constexpr (PEEROK && (MODEV) != 2) {                                                                                      \

@@ -803,3 +803,33 @@ def test_shared_block_storage_is_lossless(gpu, monkeypatch, solver, Nx, Ny, Nz, 
     # the same system either way (the operator is exact): same solution, iteration counts within one
     assert i_near.reason == 2 and i_own.reason == 2 and abs(i_near.niter - i_own.niter) <= 1
     assert np.abs(xs - xs2).max() <= 1e-8 * np.abs(xs2).max()
+
+
+def test_half_step_exit_meets_the_stop_rule_on_the_true_residual(gpu, monkeypatch):
+    """BiCGStab's first half step already has an iterate, x + alpha p-hat, with residual s = r - alpha v.  When s meets
+    MyKSPConverged's rule (src/pprts.F90:4437-4486) the solve stops there (TSX_STAGE_HALF) instead of finishing an iteration on
+    a converged system.  Same criterion, decided on the true residual where the recurrence is fp32: checked here with an
+    independent operator apply, against the same solves with the test switched off (TSX_HALF_EXIT=0)."""
+    taken = 0
+    for solver, shape, n1d in (("3_10", (16, 12, 10), 0), ("3_10", (12, 10, 8), 2), ("8_16", (8, 6, 8), 1), ("3_10", (24, 16, 12), 0)):
+        Nx, Ny, Nz = shape
+        P = synthetic.make_problem(solver, Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
+        s = DiffuseSolver(solver, Nz, Nx, Ny)
+        s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+        bn = np.linalg.norm(P["b"])
+        for kw in (dict(rtol=1e-5, atol=1e-30), dict(rtol=1e-7, atol=1e-30), dict(rtol=1e-10, atol=1e-30), dict(rtol=1e-4, atol=1e-30, pc=1, pc_sweeps=1),
+                   dict(rtol=1e-6, atol=1e-30, pc=0), dict(rtol=1e-6, atol=1e-30, fp32_directions=0, pc_coeff_fp16=0)):
+            out = {}
+            for env in ("1", "0"):
+                monkeypatch.setenv("TSX_HALF_EXIT", env)
+                x = np.zeros(s.vec_shape)
+                info = s.solve(P["b"], x, **kw)
+                rn = np.linalg.norm(P["b"] - s.apply(x))
+                assert info.reason == 2, (solver, kw, env, info)
+                assert rn <= kw["rtol"] * bn * (1 + 1e-6) + 1e-14 * bn, (solver, kw, env, rn / bn)
+                assert abs(info.rnorm - rn) <= 1e-6 * bn and abs(info.res_hist[-1] - info.rnorm) <= 1e-12 * bn
+                out[env] = (info.niter, x)
+            assert out["1"][0] <= out["0"][0], (solver, kw, out["1"][0], out["0"][0])
+            taken += not np.array_equal(out["1"][1], out["0"][1])
+        s.close()
+    assert taken >= 3, taken   # the exit is taken in a fair share of the solves (24 here)
