@@ -52,6 +52,8 @@ def parse(argv=None):
     ap.add_argument("--pc-sweeps", type=int, default=0, help="0 = library default")
     ap.add_argument("--phi0", type=float, default=180.0)
     ap.add_argument("--theta0", type=float, default=40.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline (the oracle's restatement of the reference's "
+                    "default CPU path on ONE g-point's diffuse system, extrapolated to the loop)")
     return ap.parse_args(argv)
 
 
@@ -191,9 +193,42 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
                           reasons=sorted({int(i.reason) for i in infos}), diffuse_solve_ms_total=float(sum(i.solve_ms for i in infos)),
                           energy_balance_max=float(max((o[1] for o in out), default=0.0)),
                           toa_net_down_Wm2=float((acc[0][:, :, 0] + acc[3][:, :, 0] - acc[1][:, :, 0]).mean())))
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and args.sw > 0:
+        # CPU baseline, one g-point (the solar one with the median optical-depth factor): the very diffuse system the device
+        # solved -- its blocks, 1-D layers, Eddington coefficients and right-hand side read back -- through the oracle's
+        # restatement of the reference's default CPU path (assembled AIJ + FBCGS + PCBJACOBI / ILU(0), one subdomain per usable
+        # core), zero guess, reference default tolerances; the loop is 252 such solves plus the rest of pprts()
+        import bench
+        from oracle import oracle as O
+        from tenstream_amd.coord import decompose
+
+        q = int(np.argsort(factors[:args.sw])[args.sw // 2])
+        shift["n"] = 0
+        info_d, _ = run(q)
+        P0 = Ps[0]
+        coeff = P0.core.get_coeffs()
+        nz0 = lambda a: np.nan_to_num(a, nan=0.0)
+        l1d = P0.l1d
+        threads = min(bench.usable_cores(), 128)
+        npx, npy = decompose(threads)
+        lay = O.layout("3_10", Nz, Nx, Ny)
+        frac = 1.0 - float(l1d.sum()) / Nz
+        rt, at, mx = O.default_tolerances(Nx, Ny, Nz + 1, frac)
+        _, oi = O.solve_bjacobi_ilu_mt(lay, coeff, l1d, nz0(P0.get_field("a11")), nz0(P0.get_field("a12")),
+                                       np.full((Ny, Nx), albedo), P0.get_field("b"), npx, npy, rtol=rt, atol=at, maxit=mx)
+        del coeff
+        cpu = {"value": 1.0 / oi["t_solve"], "unit": "g-points/s", "cores": threads, "kind": "port",
+               "sample": f"ONE of the {ng} g-points (solar, median factor {factors[q]:.3g}) on {Nx}x{Ny}x{Nz}: the device's own blocks and "
+                         f"right-hand side; assembled CSR + FBCGS + block-Jacobi / ILU(0) on {npx}x{npy} subdomains, zero guess, "
+                         f"{oi['niter']} its, reason {oi['reason']}, solve {oi['t_solve']:.2f}s (assembly {oi['t_assemble']:.2f}s and "
+                         f"factorisation {oi['t_factor']:.2f}s per g-point not counted; the device's solve of the same g-point: "
+                         f"{info_d.niter} its, {info_d.solve_ms:.1f} ms warm-started)",
+               "loop_extrapolated_s": ng * oi["t_solve"],
+               "loop_extrapolated_with_assembly_s": ng * (oi["t_solve"] + oi["t_assemble"] + oi["t_factor"])}
     for Pk in Ps:
         Pk.close()
-    return dict(ng=ng, rank_gpoints=len(mine), n1d_layers=n1d, calls=calls, mu0=mu0)
+    return dict(ng=ng, rank_gpoints=len(mine), n1d_layers=n1d, calls=calls, mu0=mu0, cpu_baseline=cpu)
 
 
 def main():
@@ -226,7 +261,8 @@ def main():
                                    f"g-points dealt in blocks to the GPUs" + (f" and to {args.streams} concurrent solver instances per GPU" if args.streams > 1 else "") + ", results all-reduced once; value = radiation call {last + 1} "
                                    f"of {len(secs)} (call 1 is cold: guess from the previous g-point)",
                        "cells_gpoints_per_s": ng * Nx * Ny * Nz / secs[last], "rank0_gpoints": R["rank_gpoints"],
-                       "calls": [dict(c, seconds=s_, gpoints_per_s=ng / s_) for c, s_ in zip(R["calls"], secs)]}}))
+                       "calls": [dict(c, seconds=s_, gpoints_per_s=ng / s_) for c, s_ in zip(R["calls"], secs)]},
+            "cpu_baseline": R["cpu_baseline"]}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -86,7 +86,8 @@ typedef struct {
   int32_t pc;                 /* TSX_PC_* */
   int32_t pc_sweeps;          /* ZEBRA / REDBLACK: pc_sweeps + 1 half-grid passes per application; COLUMN: Jacobi sweeps (1..32);
                                  0 (default) = automatic: 21 (22 passes) where the scan kernels run, else 9 */
-  int32_t check_every;        /* host looks at the device convergence flag every n iterations (default 2) */
+  int32_t check_every;        /* host looks at the device convergence flag every n iterations; 0 (default) = automatic: every 2, and
+                                 the first look where the previous solve of this handle from the same kind of guess ended, less one */
   int32_t fp32_directions;    /* 2 (default; with a preconditioner and rtol >= 1e-7, else like 1): as 1, and the recurrence vectors r, s, v, t are fp32
                                  too.  The iterate x, b, every dot product and the stop rule stay fp64 on the exact blocks; the
                                  recurrence residual is REPLACED by b - A x evaluated in fp64 whenever it has fallen four orders of

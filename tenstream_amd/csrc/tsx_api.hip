@@ -156,7 +156,7 @@ extern "C" void tsx_default_ksp_opts(tsx_ksp_opts *o) {
   o->maxit = 1000;  // src/pprts_base.F90:1118
   o->pc = TSX_PC_REDBLACK;  // this back-end's default preconditioner
   o->pc_sweeps = 0;  // automatic (prepare_ksp): 21 (22 passes) with the scan kernels, else 9
-  o->check_every = 2;  // at most one iteration enqueued in vain; measured 1 / 2 / 3 / 4 / 6: 19.44 / 19.24 / 19.37 / 19.68 / 19.26 ms, warm start 3.40 / 3.47 / 3.58 / 3.69 / 3.82 ms
+  o->check_every = 0;  // automatic: every 2 iterations (at most one enqueued in vain), the first look where the handle's previous solve ended (krylov_run); measured 1 / 2 / 3 / 4 / 6: 19.44 / 19.24 / 19.37 / 19.68 / 19.26 ms, warm start 3.40 / 3.47 / 3.58 / 3.69 / 3.82 ms
   o->fp32_directions = 2;
   o->pc_coeff_fp16 = 1;
   o->skip_complete_initial_run = 0;
@@ -1049,6 +1049,13 @@ static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
   bool done = false, first_after_begin = true;
   while (!done) {
     int todo = (o->maxit - enq) < chunk ? (o->maxit - enq) : chunk;
+    // the first look at the flag comes where the previous solve of this handle with the same kind of start (cold / warm) ended,
+    // less one: a repeated solve (a spectral loop, a time step) then synchronises with the host twice instead of every
+    // check_every iterations; overshooting costs the empty launches of the surplus iterations (about 0.1 ms each)
+    if (enq == 0 && o->check_every <= 0) {
+      const int hint = cold ? s->its_hint_cold : s->its_hint_warm;
+      if (hint - 1 > todo) todo = (hint - 1) < (o->maxit - enq) ? hint - 1 : (o->maxit - enq);
+    }
     {
       // if the last iteration's reduction, applied once more, meets the stop rule, enqueue ONE iteration before the next look
       // at the flag: the iterations enqueued beyond convergence return at once, but that is ~60 empty launches (0.1 ms)
@@ -1118,6 +1125,7 @@ static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
     }
   }
   HIPCHK(hipEventRecord(s->ev1, s->stream));
+  if (s->scal_host->reason > 0) (cold ? s->its_hint_cold : s->its_hint_warm) = s->scal_host->its;
   return TSX_OK;
 }
 

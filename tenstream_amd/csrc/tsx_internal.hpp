@@ -190,6 +190,7 @@ struct tsx_solver {
   TsxLutHost lut_T, lut_S;
   float *dirT, *dirS;            // direct coefficient planes (S*S, S*D)
   bool dir_coeffs_valid;
+  int its_hint_cold = 0, its_hint_warm = 0;  // iterations of the last converged Krylov solve from a zero / nonzero guess (krylov_run)
   bool have_albedo = false;  // s->albedo holds the caller's surface albedo (set_coeffs / set_optprop / set_optical_properties / setup_b_solar)
   bool dir_seam = false, dir_seam_S = false;  // dirT (and dirS) were handed over by tsx_dir_set_coeffs (the direct seam), not looked up
   double *dd_colsum;         // [D][dd_nent]: sum over dst of c(src, dst) per distinct block (absorptivity / emissivity terms of setup_b_thermal, flx_div)
