@@ -143,13 +143,12 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
         P.get_result(out=tmp)
         for a, t in zip(acc, tmp):
             a += t
-        # energy balance of this g-point: what the atmosphere absorbs is the convergence of the net flux (periodic domain)
+        # energy balance of this g-point: what the atmosphere absorbs is the convergence of the net flux (periodic domain).
+        # Left on the device (four sums in one small tensor): the host reads all of them after the loop, not per g-point
         edn, eup, abso, edir = tmp
-        net_toa = float((edn[:, :, 0] + edir[:, :, 0] - eup[:, :, 0]).sum())
-        net_srf = float((edn[:, :, -1] + edir[:, :, -1] - eup[:, :, -1]).sum())
-        atm = float((abso * dz_d).sum())
-        scale = max(abs(net_toa), abs(net_srf), float(eup[:, :, -1].sum()), 1e-30)
-        return info, abs(atm - (net_toa - net_srf)) / scale
+        bal = torch.stack(((edn[:, :, 0] + edir[:, :, 0] - eup[:, :, 0]).sum(), (edn[:, :, -1] + edir[:, :, -1] - eup[:, :, -1]).sum(),
+                           (abso * dz_d).sum(), eup[:, :, -1].sum()))
+        return info, bal
 
     def sync():
         torch.cuda.synchronize()
@@ -187,6 +186,11 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
                 all_reduce(a)
         sync()
         dt = time.perf_counter() - t0
+        def balance(t):   # |absorbed - (net TOA - net surface)| relative to the largest of the fluxes involved
+            net_toa, net_srf, atm, up_srf = (float(v) for v in t.tolist())
+            return abs(atm - (net_toa - net_srf)) / max(abs(net_toa), abs(net_srf), up_srf, 1e-30)
+
+        out = [(o[0], balance(o[1])) for o in out]
         infos = [o[0] for o in out]
         its = np.array([i.niter for i in infos]) if infos else np.zeros(1)
         calls.append(dict(seconds=dt, iterations_min_med_max=[int(its.min()), float(np.median(its)), int(its.max())],
