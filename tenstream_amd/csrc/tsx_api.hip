@@ -596,6 +596,7 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
   s->dd_on = false;
   s->dd_pc = false;
   s->dd_hash_ready = false;  // imported blocks: tsx_dedup.hip hashes them itself
+  s->coef_dense_valid = true;
   return TSX_OK;
 }
 
@@ -709,11 +710,12 @@ int tsx_cell_samples(tsx_solver *s, const double *kabs, const double *ksca, cons
 // alloc_coeff_diff2diff on the device: kabs/ksca/g/dz are device pointers in the reference layout
 static int lut_diffuse_launch(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz, double dx) {
   const TsxGeo &gm = s->geo;
-  unsigned long long *hash = nullptr;  // the kernel leaves the blocks' hashes for the shared storage (tsx_dedup.hip)
-  {
-    int rc = tsx_dedup_hash_buffer(s, &hash);
-    if (rc) return rc;
-  }
+  // a new coefficient set: whatever the shared storage held is gone (the callers used to reset these after the launch; the
+  // coordinate-keyed build below sets them itself)
+  s->dd_valid = false;
+  s->dd_on = false;
+  s->dd_pc = false;
+  s->coef_dense_valid = true;
   TsxLutDev L;
   memset(&L, 0, sizeof(L));
   const TsxLutHost &H = s->lut_diff;
@@ -730,9 +732,22 @@ static int lut_diffuse_launch(tsx_solver *s, const double *kabs, const double *k
   }
   L.axes = H.d_axes;
   L.table = H.d_table;
-  const int nbk = grid_for(gm.Nc, 8192);
   int rcs = tsx_cell_samples(s, kabs, ksca, g, dz, dx);
   if (rcs) return rcs;
+  // sharing keyed on the cells' LUT coordinates, before anything is interpolated (tsx_dedup.hip "coordinates first"): where
+  // it pays only the distinct tuples are interpolated, straight into the shared storage, and no dense planes are written
+  {
+    bool built = false;
+    int rc = tsx_dedup_from_coords(s, L, &built);
+    if (rc) return rc;
+    if (built) return TSX_OK;
+  }
+  unsigned long long *hash = nullptr;  // the kernel leaves the blocks' hashes for the shared storage (tsx_dedup.hip)
+  {
+    int rc = tsx_dedup_hash_buffer(s, &hash);
+    if (rc) return rc;
+  }
+  const int nbk = grid_for(gm.Nc, 8192);
   const float4 *samp = (const float4 *)s->cell_samp;
   if (gm.D == 10)
     hipLaunchKernelGGL((tsx_k_lut_diff2diff<100>), dim3(nbk), dim3(TSX_BLOCK), 0, s->stream, gm, L, kabs, ksca, g, dz, dx,
@@ -768,14 +783,11 @@ extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const dou
       p[q] = tmp[q].as<double>();
     }
   }
-  if ((rc = lut_diffuse_launch(s, p[0], p[1], p[2], p[3], dx))) return rc;
+  if ((rc = lut_diffuse_launch(s, p[0], p[1], p[2], p[3], dx))) return rc;  // (resets / sets the shared-storage state)
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
   s->have_coeffs = true;
   s->coef_h_valid = false;
-  s->dd_valid = false;
-  s->dd_on = false;
-  s->dd_pc = false;
   return TSX_OK;
 }
 
@@ -786,6 +798,10 @@ extern "C" int tsx_diff_get_coeffs(tsx_solver *s, double *diff2diff, int where) 
     return TSX_ERR_STATE;
   }
   HIPCHK(hipSetDevice(s->device));
+  {
+    int rc = tsx_coef_ensure_dense(s);  // the LUT path may have left the blocks in the shared storage only
+    if (rc) return rc;
+  }
   const TsxGeo &g = s->geo;
   const int DD = g.D * g.D;
   const size_t ncoef = (size_t)DD * g.Nc;
@@ -1320,6 +1336,11 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   {
     int rc = tsx_dedup_ensure(s);  // shared storage of identical blocks (operator apply and scan preconditioner)
     if (rc) return rc;
+    // dense per-cell planes: the operator and the scan passes on the packed path read the shared storage; everything else (exact
+    // fp64 preconditioner blocks, one-lane kernels, zebra rows on odd grids, 8_16) reads s->coef
+    const bool shared_only = s->dd_on && s->geo.ntop == 2 &&
+                             (s->pc == TSX_PC_NONE || (s->mixed && s->pc_split && tsx_pcs_eligible(s)));
+    if (!shared_only && (rc = tsx_coef_ensure_dense(s))) return rc;
     if ((rc = tsx_pc_global_agree(s))) return rc;  // several ranks: the preconditioner's halo exchange is on everywhere or nowhere
   }
   if (o->pc_sweeps == 0) {
@@ -1406,6 +1427,7 @@ extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int 
   s->mixed = mixed != 0;
   int rc = tsx_dedup_ensure(s);
   if (rc) return rc;
+  if ((rc = tsx_coef_ensure_dense(s))) return rc;  // a test hook: every variant may run, some read the dense planes
   if ((rc = tsx_pc_global_agree(s))) return rc;
   if ((rc = tsx_pc_ensure_buffers(s))) return rc;
   s->pc_half = false;

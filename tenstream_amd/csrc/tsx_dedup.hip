@@ -14,6 +14,7 @@
 // Cells of 1-D layers (their planes are never read: a11 / a12 are) all map to one entry.
 // Used only when it pays (Nent <= Nc / 2); the dense planes stay (setup_b thermal, flux divergence, export read them).
 #include "tsx_host.hpp"
+#include "tsx_lut_dev.hpp"
 
 
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_hash(TsxGeo g, int DD, const float *__restrict__ C,
@@ -440,6 +441,147 @@ static int dd_build(tsx_solver *s, bool near, bool *pays) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s->stream));
   *pays = true;
+  return TSX_OK;
+}
+
+// ---- coordinates first (round 4).  On the LUT path a block is a deterministic function of its cell's four clamped float32
+// coordinates, so cells can be grouped BEFORE anything is interpolated: hash the 16 bytes, same table / owner / compare (16
+// bytes instead of 400) / scan / index pipeline, then only the nent distinct tuples are interpolated, straight into the shared
+// storage (tsx_k_lut_diff2diff_ent).  The dense per-cell planes are not written at all (s->coef_dense_valid = false; whoever
+// needs them -- the exact fp64 preconditioner, the one-lane kernels, tsx_diff_get_coeffs -- has them expanded from the entries,
+// tsx_coef_ensure_dense).  Cells whose coordinates differ but whose blocks happen to coincide keep separate entries here
+// (lossless either way).  3_10 and fp32 blocks only; TSX_DEDUP_COORDS=0 switches it off.
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_hash_coords(TsxGeo g, TsxLutDev L, const float4 *__restrict__ samp,
+                                                                  const uint8_t *__restrict__ l1d, unsigned long long *__restrict__ h) {
+  const long long Nc = g.Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    unsigned long long v = TSX_DD_SEED;
+    if (l1d[(int)(c / g.ncol)]) {
+      v = TSX_DD_H1D;
+    } else {
+      const float4 a = tsx_lut_diff_clamp(L, samp[c]);
+      v = tsx_dd_hash_step(v, 0, a.x);
+      v = tsx_dd_hash_step(v, 1, a.y);
+      v = tsx_dd_hash_step(v, 2, a.z);
+      v = tsx_dd_hash_step(v, 3, a.w);
+      v = tsx_dd_hash_final(v);
+    }
+    h[c] = v;
+  }
+}
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_resolve_coords(TsxGeo g, TsxLutDev L, const float4 *__restrict__ samp,
+                                                                     const uint8_t *__restrict__ l1d, unsigned long long mask,
+                                                                     const unsigned long long *__restrict__ h,
+                                                                     const unsigned long long *__restrict__ keys,
+                                                                     const int *__restrict__ owner, int *__restrict__ rep,
+                                                                     int *__restrict__ flag) {
+  const long long Nc = g.Nc;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const unsigned long long hv = h[c];
+    unsigned long long slot = hv & mask;
+    while (keys[slot] != hv) slot = (slot + 1) & mask;
+    const int o = owner[slot];
+    bool same = true;
+    if (o != (int)c && !(l1d[(int)(c / g.ncol)] && l1d[o / g.ncol])) {
+      const float4 a = tsx_lut_diff_clamp(L, samp[c]), b = tsx_lut_diff_clamp(L, samp[o]);
+      same = __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+             __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w) &&
+             !l1d[(int)(c / g.ncol)] && !l1d[o / g.ncol];
+    }
+    const int r = same ? o : (int)c;
+    rep[c] = r;
+    flag[c] = r == (int)c;
+  }
+}
+// dense planes from the entries: C[q * Nc + c] = Cd[q * nent + cidx[c]]
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_expand(long long Nc, int DD, long long nent, const float *__restrict__ Cd,
+                                                             const int *__restrict__ cidx, float *__restrict__ C) {
+  const long long n = Nc * DD;
+  for (long long e = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; e < n; e += (long long)gridDim.x * TSX_BLOCK) {
+    const long long q = e / Nc, c = e - q * Nc;
+    C[e] = Cd[(size_t)q * nent + cidx[c]];
+  }
+}
+int tsx_coef_ensure_dense(tsx_solver *s) {
+  if (s->coef_dense_valid) return TSX_OK;
+  const TsxGeo &g = s->geo;
+  hipLaunchKernelGGL(tsx_k_dd_expand, dim3(grid_for(g.Nc * g.D * g.D, 8192)), dim3(TSX_BLOCK), 0, s->stream, g.Nc, g.D * g.D,
+                     (long long)s->dd_nent, (const float *)s->dd_coef, (const int *)s->dd_cidx, (float *)s->coef);
+  HIPCHK(hipGetLastError());
+  s->coef_dense_valid = true;
+  return TSX_OK;
+}
+
+// called by the LUT path right after tsx_cell_samples, BEFORE any interpolation.  *built = true: the shared storage holds the
+// coefficients (dd_on, Cd / Ce / cidx / colsum), nothing dense was written; false: sharing would not pay (or is off) -- the caller
+// interpolates every cell into the dense planes as before
+int tsx_dedup_from_coords(tsx_solver *s, const TsxLutDev &L, bool *built) {
+  *built = false;
+  const TsxGeo &g = s->geo;
+  const char *e = getenv("TSX_DEDUP_COORDS");
+  if ((e && atoi(e) == 0) || !dedup_enabled() || g.D != 10 || s->coef_bytes != 4 || !s->cell_samp) return TSX_OK;
+  if (g.Nc >= 0x7f7f7f7fll || !tsx_dd_wave64(s)) return TSX_OK;
+  const int DD = g.D * g.D;
+  const long long Nc = g.Nc;
+  TsxDdScratch w;
+  {
+    int rc = dd_scratch(s, Nc, &w);
+    if (rc) return rc;
+  }
+  const float4 *samp = (const float4 *)s->cell_samp;
+  HIPCHK(hipMemsetAsync(w.tk.p, 0, sizeof(unsigned long long) * (size_t)w.tsz, s->stream));
+  HIPCHK(hipMemsetAsync(w.to.p, 0x7f, sizeof(int) * (size_t)w.tsz, s->stream));
+  const int nb = grid_for(Nc, 8192);
+  hipLaunchKernelGGL(tsx_k_dd_hash_coords, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, L, samp, s->l1d, w.th.as<unsigned long long>());
+  hipLaunchKernelGGL(tsx_k_dd_insert, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, w.tsz - 1, w.th.as<unsigned long long>(),
+                     w.tk.as<unsigned long long>(), w.to.as<int>());
+  hipLaunchKernelGGL(tsx_k_dd_resolve_coords, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, L, samp, s->l1d, w.tsz - 1,
+                     w.th.as<unsigned long long>(), w.tk.as<unsigned long long>(), w.to.as<int>(), w.trep.as<int>(), w.tflag.as<int>());
+  hipLaunchKernelGGL(tsx_k_scan_sums, dim3(w.nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, w.tflag.as<int>(), w.tsum.as<int>());
+  hipLaunchKernelGGL(tsx_k_scan_top, dim3(1), dim3(1024), 0, s->stream, w.nsb, w.tsum.as<int>(), w.ttot.as<int>());
+  hipLaunchKernelGGL(tsx_k_scan_write, dim3(w.nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, w.tflag.as<int>(), w.tsum.as<int>(), w.tpos.as<int>());
+  HIPCHK(hipGetLastError());
+  int nent = 0;
+  HIPCHK(hipMemcpyAsync(&nent, w.ttot.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  if ((long long)nent * 2 > Nc) return TSX_OK;  // mostly distinct coordinates: dense planes, then the block-based build decides
+  s->dd_nent = nent;
+  if (!s->dd_cidx) HIPCHK(hipMalloc((void **)&s->dd_cidx, sizeof(int) * (size_t)Nc));
+  if (!s->dd_cidx_split) HIPCHK(hipMalloc((void **)&s->dd_cidx_split, sizeof(int) * (size_t)Nc));
+  if (s->dd_cap < nent) {
+    if (s->dd_coef) HIPCHK(hipFree(s->dd_coef));
+    if (s->dd_ent_cell) HIPCHK(hipFree(s->dd_ent_cell));
+    s->dd_coef = nullptr;
+    s->dd_ent_cell = nullptr;
+    HIPCHK(hipMalloc((void **)&s->dd_coef, sizeof(float) * (size_t)DD * nent * 2));  // plane-major, then entry-major
+    HIPCHK(hipMalloc((void **)&s->dd_ent_cell, sizeof(int) * (size_t)nent));
+    s->dd_cap = nent;
+  }
+  const bool split = g.xm % 2 == 0;
+  hipLaunchKernelGGL(tsx_k_dd_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, w.trep.as<int>(), w.tpos.as<int>(), s->dd_cidx,
+                     split ? s->dd_cidx_split : (int *)nullptr, s->dd_ent_cell);
+  s->dd_coef_e = s->dd_coef + (size_t)DD * s->dd_cap;
+  hipLaunchKernelGGL((tsx_k_lut_diff2diff_ent<100>), dim3(grid_for(nent, 8192)), dim3(TSX_BLOCK), 0, s->stream, g, L, s->l1d,
+                     (long long)nent, (const int *)s->dd_ent_cell, samp, s->dd_coef, s->dd_coef_e);
+  if (s->dd_colsum_cap < (long long)g.D * nent) {
+    if (s->dd_colsum) HIPCHK(hipFree(s->dd_colsum));
+    s->dd_colsum = nullptr;
+    HIPCHK(hipMalloc((void **)&s->dd_colsum, sizeof(double) * (size_t)g.D * nent));
+    s->dd_colsum_cap = (long long)g.D * nent;
+  }
+  hipLaunchKernelGGL(tsx_k_dd_colsum, dim3(grid_for(nent)), dim3(TSX_BLOCK), 0, s->stream, g.D, (long long)nent, s->dd_coef, s->dd_colsum);
+  HIPCHK(hipGetLastError());
+  s->dd_valid = true;
+  s->dd_on = true;
+  s->dd_pc = false;
+  s->dd_nent_near = 0;
+  s->dd_hash_ready = false;
+  s->pc_coef = s->dd_coef;
+  s->pc_cidx_split = s->dd_cidx_split;
+  s->pc_ent_cell = s->dd_ent_cell;
+  s->pc_nent = s->dd_nent;
+  s->coef_dense_valid = false;
+  *built = true;
   return TSX_OK;
 }
 

@@ -138,6 +138,9 @@ int tsx_pc_widen(tsx_solver *s, const float *a, double *o);  // o = (double) a o
 int tsx_cell_samples(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz, double dx);  // tsx_api.hip
 // shared storage of bit-identical blocks (tsx_dedup.hip)
 int tsx_dedup_ensure(tsx_solver *s);
+struct TsxLutDev;
+int tsx_dedup_from_coords(tsx_solver *s, const TsxLutDev &L, bool *built);  // LUT path: sharing keyed on the cells' LUT coordinates
+int tsx_coef_ensure_dense(tsx_solver *s);  // dense per-cell planes, expanded from the shared entries if the LUT path skipped them
 // the red-black preconditioner of 3_10 as a segmented scan over the levels (tsx_pcs.hip); packed layout "S16" in s->coef_h
 bool tsx_pcs_eligible(const tsx_solver *s);
 int tsx_pc_global_agree(tsx_solver *s);       // tsx_pcs.hip: collective, see there

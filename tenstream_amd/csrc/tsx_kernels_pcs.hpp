@@ -39,11 +39,14 @@
 template <typename CT>
 __global__ __launch_bounds__(64) void tsx_k_pcs_pack_col(TsxGeo g, const CT *__restrict__ C, const uint8_t *__restrict__ l1d,
                                                          const double *__restrict__ a11, const double *__restrict__ a12,
-                                                         const double *__restrict__ albedo, uint4 *__restrict__ P) {
+                                                         const double *__restrict__ albedo, uint4 *__restrict__ P,
+                                                         const int *__restrict__ cidx = nullptr, long long nent = 0) {
+  // cidx != null: C is the shared storage of bit-identical blocks, plane-major C[q * nent + cidx[cell]] (the LUT path may
+  // have skipped the dense planes altogether, tsx_dedup_from_coords); same values, so the same records
   constexpr int D = 10;
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col >= g.ncol) return;
-  const long long Nc = g.Nc;
+  const long long Nc = cidx ? nent : g.Nc;
   const long long sp = tsx_split_col(col % g.xm, col / g.xm, g.xm);
   double A = albedo[col];
   for (int k = g.Nz - 1; k >= 0; --k) {
@@ -53,10 +56,11 @@ __global__ __launch_bounds__(64) void tsx_k_pcs_pack_col(TsxGeo g, const CT *__r
       tuu = tdd = a11[c];
       rud = rdu = a12[c];
     } else {
-      tuu = (double)C[(size_t)(0 * D + 0) * Nc + c];
-      rud = (double)C[(size_t)(0 * D + 1) * Nc + c];
-      rdu = (double)C[(size_t)(1 * D + 0) * Nc + c];
-      tdd = (double)C[(size_t)(1 * D + 1) * Nc + c];
+      const size_t e = cidx ? (size_t)cidx[c] : c;
+      tuu = (double)C[(size_t)(0 * D + 0) * Nc + e];
+      rud = (double)C[(size_t)(0 * D + 1) * Nc + e];
+      rdu = (double)C[(size_t)(1 * D + 0) * Nc + e];
+      tdd = (double)C[(size_t)(1 * D + 1) * Nc + e];
     }
     const double G = 1.0 / (1.0 - rdu * A);
     const double GT = G * tdd;

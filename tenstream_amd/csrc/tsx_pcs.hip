@@ -108,8 +108,12 @@ int tsx_pcs_pack(tsx_solver *s) {
   s->coef_h_dd = false;
   if ((s->dd_on || s->dd_pc) && s->coef_bytes == 4) {
     // group 0 per cell, groups 1..7 per distinct block behind it (7 * nent <= 7 * Nc records: the same buffer holds them)
-    hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->coef,
-                       s->l1d, s->a11, s->a12, s->albedo, P);
+    if (s->dd_on && !s->coef_dense_valid)  // the LUT path left the blocks in the shared storage only: read them through the index
+      hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->dd_coef,
+                         s->l1d, s->a11, s->a12, s->albedo, P, (const int *)s->dd_cidx, (long long)s->dd_nent);
+    else
+      hipLaunchKernelGGL((tsx_k_pcs_pack_col<float>), dim3((g.ncol + 63) / 64), dim3(64), 0, s->stream, g, (const float *)s->coef,
+                         s->l1d, s->a11, s->a12, s->albedo, P, (const int *)nullptr, 0ll);
     s->coef_h_c16 = pcs_c16();
     // near-identical grouping (dd_pc without dd_on): a wave's ids are unrelated -> an entry's records in one line (TSX_PC_ENTRY_MAJOR=0 / 1 overrides)
     {
