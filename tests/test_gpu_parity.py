@@ -833,3 +833,53 @@ def test_half_step_exit_meets_the_stop_rule_on_the_true_residual(gpu, monkeypatc
             taken += not np.array_equal(out["1"][1], out["0"][1])
         s.close()
     assert taken >= 3, taken   # the exit is taken in a fair share of the solves (24 here)
+
+
+def test_sharing_keyed_on_lut_coordinates_is_lossless(gpu, monkeypatch):
+    """Round 4, tsx_dedup_from_coords: on the LUT path cells are grouped by their four clamped float32 LUT coordinates BEFORE
+    anything is interpolated; only the distinct tuples are interpolated, straight into the shared storage, and no dense per-cell
+    planes are written.  Against the same solver with TSX_DEDUP_COORDS=0 (every cell interpolated, blocks compared afterwards):
+    the blocks read back (expanded from the entries on demand) are bit-identical and equal the oracle's lookup, operator apply
+    and residual history are bit-identical; coordinates that differ may still give identical blocks, so the coordinate-keyed
+    storage has at least as many entries.  Every consumer of dense planes still works afterwards (exact fp64 preconditioner,
+    zebra rows)."""
+    from tenstream_amd import lut
+
+    Nx, Ny, Nz = 24, 16, 12
+    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=4, cover=0.2)
+    kabs, ksca, g = synthetic.delta_scale(kabs, ksca, g)
+    dz = np.full((Ny, Nx, Nz), 50.0)
+    dz[:, :, :2] = 300.0
+    l1d = np.zeros(Nz, dtype=np.uint8)
+    l1d[:2] = 1
+    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz, n1d=2, seed=4)
+    axes, table = lut.diffuse_axes("3_10"), lut.synthetic_diffuse_table("3_10")
+    x = np.random.default_rng(2).standard_normal(P["b"].shape)
+    res = {}
+    monkeypatch.setenv("TSX_SPMV_CPT", "1")
+    for dc in ("0", "1"):
+        monkeypatch.setenv("TSX_DEDUP_COORDS", dc)
+        s = DiffuseSolver("3_10", Nz, Nx, Ny)
+        s.set_lut_diffuse(table, axes)
+        s.set_optprop(kabs, ksca, g, dz, 100.0, l1d, P["a11"], P["a12"], P["albedo"])
+        on, nent = s.dedup_info()
+        y = s.apply(x)
+        xs = np.zeros(s.vec_shape)
+        info = s.solve(P["b"], xs, rtol=1e-10, atol=1e-30)
+        coeff = s.get_coeffs()     # dc = 1: expanded from the shared entries
+        # consumers of the dense planes after the fact: exact fp64 blocks in zebra order, and the bare operator again
+        x2 = np.zeros(s.vec_shape)
+        i2 = s.solve(P["b"], x2, rtol=1e-10, atol=1e-30, fp32_directions=0, pc_coeff_fp16=0)
+        assert i2.reason == 2 and np.abs(x2 - xs).max() <= 1e-8 * np.abs(xs).max()
+        assert np.array_equal(s.apply(x), y)
+        res[dc] = (on, nent, y, xs, info, coeff)
+        s.close()
+    assert res["0"][0] and res["1"][0] and res["1"][1] >= res["0"][1] and res["1"][1] < 0.5 * Nx * Ny * Nz
+    sl = slice(2, None)
+    assert np.array_equal(res["0"][5][:, :, sl], res["1"][5][:, :, sl])
+    Ld = O.make_lut(axes, table)
+    want = O.alloc_coeff_diff2diff(Ld, kabs, ksca, g, dz, 100.0, l1d)
+    assert np.array_equal(res["1"][5][:, :, sl], want[:, :, sl])
+    assert np.array_equal(res["0"][2], res["1"][2])
+    assert res["0"][4].niter == res["1"][4].niter and np.array_equal(res["0"][4].res_hist, res["1"][4].res_hist)
+    assert np.array_equal(res["0"][3], res["1"][3])
