@@ -360,7 +360,7 @@ def main():
     # "everything_fp64": no reduced precision anywhere, the preconditioner on the exact fp64 blocks (fp32_directions = 0,
     # pc_coeff_fp16 = 0) -- the reference's default arithmetic (ireals = real64) end to end
     all_fp64 = None
-    if not args.skip_extra_legs and not args.explicit:
+    if world == 1 and not args.skip_extra_legs and not args.explicit:   # (one rank: the driver's N = 1 line carries it)
         all_fp64 = {}
         for name, ov in (("recurrence_fp64", dict(fp32_directions=1)), ("everything_fp64", dict(fp32_directions=0, pc_coeff_fp16=0))):
             dt_f, infos_f, failed_f = timed_steps(**ov)
