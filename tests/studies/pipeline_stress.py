@@ -20,7 +20,8 @@ for case in range(n):
     tall = int(rng.integers(0, min(3, Nz)))
     lsolar = rng.random() < 0.6
     env = {"TSX_EDIR_TILED": str(int(rng.integers(0, 2))), "TSX_CELL_SAMPLES": str(int(rng.integers(0, 2))),
-           "TSX_DEDUP": str(int(rng.integers(0, 2)))}
+           "TSX_DEDUP": str(int(rng.integers(0, 2))), "TSX_DEDUP_COORDS": str(int(rng.integers(0, 2))),
+           "TSX_HALF_EXIT": str(int(rng.integers(0, 2)))}   # round 4: coordinates-first sharing, half-step stop test
     os.environ.update(env)
     P, I = T._setup(Nx, Ny, Nz, phi0, theta0, tall, solver=solver)
     if lsolar:
@@ -29,7 +30,8 @@ for case in range(n):
         R = T._oracle_pipeline(P, I, 0.15, 1000.0, True)
     else:
         planck = np.linspace(2.0, 6.0, Nz + 1)[None, None, :] * np.ones((Ny, Nx, 1)) * (1 + 0.05 * rng.random((Ny, Nx, 1)))
-        P.set_optical_properties(0.05, I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck)
+        srfc = planck[:, :, -1] * (1.0 + 0.3 * rng.random((Ny, Nx))) if rng.random() < 0.5 else None   # atm%Bsrfc (round 4)
+        P.set_optical_properties(0.05, I["kabs"], I["ksca"], I["g"], I["dz"], planck=planck, planck_srfc=srfc)
         info = P.solve(0.0, rtol=1e-10, atol=1e-30, maxit=3000)
         R = T._oracle_pipeline(P, I, 0.05, 0.0, False, planck=planck)
     edn, eup, abso, edir = P.get_result()
