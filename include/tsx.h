@@ -85,7 +85,7 @@ typedef struct {
   int32_t maxit;
   int32_t pc;                 /* TSX_PC_* */
   int32_t pc_sweeps;          /* ZEBRA / REDBLACK: pc_sweeps + 1 half-grid passes per application; COLUMN: Jacobi sweeps (1..32);
-                                 0 (default) = automatic: 21 (22 passes) where the scan kernels run, else 9 */
+                                 0 (default) = automatic: 27 (28 passes) where the scan kernels run, else 9 */
   int32_t check_every;        /* host looks at the device convergence flag every n iterations; 0 (default) = automatic: every 2, and
                                  the first look where the previous solve of this handle from the same kind of guess ended, less one */
   int32_t fp32_directions;    /* 2 (default; with a preconditioner and rtol >= 1e-7, else like 1): as 1, and the recurrence vectors r, s, v, t are fp32
@@ -368,7 +368,7 @@ int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes);
  * of bit 0 where it halves the preconditioner's table.  TSX_DEDUP_NEAR=0 switches that off */
 int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent);
 /* the preconditioner the last solve / tsx_bench_kernel actually ran (after the automatic choices: red-black -> zebra rows
- * on odd grids, pc_sweeps 0 -> 19 or 9): TSX_PC_*, pc_sweeps, and scan: 0 = one-lane-per-column kernels, 1 = scan kernels,
+ * on odd grids, pc_sweeps 0 -> 27 or 9): TSX_PC_*, pc_sweeps, and scan: 0 = one-lane-per-column kernels, 1 = scan kernels,
  * 3 = scan kernels reading identical recurrence records through a shared table */
 int tsx_pc_info(const tsx_solver *s, int32_t *pc, int32_t *pc_sweeps, int32_t *scan);
 /* device STREAM-like copy bandwidth probe (GB/s) for reporting against the measured peak */

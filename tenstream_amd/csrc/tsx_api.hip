@@ -1354,7 +1354,12 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
     // of 6 (256 x 256 x 64: 18.7 -> 16.4 ms; 128 x 128: 6.05 -> 5.29 ms; all blocks distinct: 35.7 -> 31.5 ms; 24 / 26 passes:
     // still 5 iterations, 17.2 / 17.8 ms)
     // 8_16 likewise: 20 passes 1.15e-5 after 5 iterations, 22 passes: 5 iterations, 47.0 -> 41.7 ms (24 passes: 44.6 ms)
-    const int auto_scan = 21;
+    // round 4: with the stop test at the half step the grid was measured again (scripts/sweeps_grid.py, 20 ... 32 passes x ten
+    // workloads): 28 passes reach the rule after FOUR iterations where 22 need five -- metric domain 14.2 -> 12.8 ms, 128 x 128
+    // 4.86 -> 4.46, 512 x 256 30.1 -> 27.5, every block distinct 20.8 -> 18.5, 8_16 39.1 -> 37.0 ms, config 4 123 -> 125 g-points/s,
+    // a 128 x 64 shard 3.55 -> 3.36 ms; slower on three of the ten (full cloud cover, cover 0.6 of another seed, 64 x 64 columns:
+    // BiCGStab's iteration counts are integers); 24 / 26 passes: still five iterations, 30 / 32: four, more expensive ones
+    const int auto_scan = 27;
     o->pc_sweeps = (s->pc == TSX_PC_REDBLACK || s->pc == TSX_PC_ZEBRA) ? (scan ? auto_scan : 9) : 1;
     s->pc_sweeps = o->pc_sweeps;
   }
