@@ -154,7 +154,9 @@ def test_f2c_reads_the_options_of_this_path(gpu, tmp_path, monkeypatch):
         "# as tests/test_pprts_symmetry/tenstream.options\n-solar_dir_ksp_rtol 1e-8\n-solar_diff_ksp_rtol 1e-8\n"
         "-solar_dir_ksp_atol 1e-30   ! comment\n-solar_diff_ksp_atol 1e-30\n-diff_ksp_monitor\n")
     e_tight = err(run())
-    assert e_tight <= 2e-6 and e_default > 3.0 * e_tight, (e_default, e_tight)
+    # (the file's tolerances took effect: visibly closer to the oracle than the default run -- a factor 2.4 with the 28-pass default
+    # of round 4, whose four iterations end nearer the solution than the five of 22 passes did)
+    assert e_tight <= 2e-6 and e_default > 1.5 * e_tight, (e_default, e_tight)
     monkeypatch.setenv("PETSC_OPTIONS", "-solar_diff_explicit -solar_diff_ksp_rtol 1e-9")   # overrides the file's 1e-8
     e_explicit = err(run())
     assert e_explicit <= 2e-6, e_explicit
