@@ -41,29 +41,10 @@ def collect(path, counter):
     return acc
 
 
-def main():
-    key, out, fcsv, wcsv = sys.argv[1:5]
-    assert out.endswith(".json") and fcsv.endswith(".csv") and wcsv.endswith(".csv"), "usage: key out.json fetch.csv write.csv [passes]"
-    F, W = collect(fcsv, "FETCH_SIZE"), collect(wcsv, "WRITE_SIZE")
-    kernels = {}
-    for k in sorted(set(F) | set(W)):
-        f = [v for v, _ in F.get(k, [])]
-        w = [v for v, _ in W.get(k, [])]
-        f = [v for v in f if v >= 0.5 * max(f)] if f and max(f) > 0 else f   # working launches only
-        w = [v for v in w if v >= 0.5 * max(w)] if w and max(w) > 0 else w
-        fm = sum(f) / len(f) if f else 0.0
-        wm = sum(w) / len(w) if w else 0.0
-        kernels[k] = {
-            "launches": max(len(f), len(w)),
-            "FETCH_SIZE_KiB_mean": fm,
-            "WRITE_SIZE_KiB_mean": wm,
-            "read_bytes_per_launch": 2.0 * fm * 1024.0,
-            "write_bytes_per_launch": wm * 1024.0,
-            "traffic_bytes_per_launch": 2.0 * fm * 1024.0 + wm * 1024.0,
-        }
+def compose(kernels, P):
+    """traffic of one default BiCGStab iteration from the per-kernel figures; P = half-grid passes per application of M^-1"""
     # one default iteration: 2 applications of M^-1 (pass 0 without neighbours, P - 3 intermediate, the fp32 pass, the last
     # pass; P = argv[5], default 14), 2 operator applies with fused dots, 3 vector updates
-    P = int(sys.argv[5]) if len(sys.argv) > 5 else 22
     rb = r"tsx_k_pcsh?_rb<\d+,\d+,\d+,"
     if any(re.match(rb + r"true,0,\w+,2", k) for k in kernels):
         # bf16 right-hand side words: per application pass 0 (no neighbours, leaves the words), pass 1 (leaves the words),
@@ -92,6 +73,40 @@ def main():
             it_bytes += mult * hit[0]["traffic_bytes_per_launch"]
         else:
             missing.append(pat)
+    return it_bytes, missing, per_iter
+
+
+def main():
+    if sys.argv[1] == "--recompose":   # pmc_summary.py --recompose traffic.json [passes]: renew the `iteration` entry of an existing file
+        doc = json.load(open(sys.argv[2]))
+        P = int(sys.argv[3]) if len(sys.argv) > 3 else 28
+        it_bytes, missing, per_iter = compose(doc["kernels"], P)
+        assert not missing, missing
+        doc["iteration"] = {"traffic_bytes": it_bytes, "passes_per_application": P, "composition": [f"{m} x {p}" for p, m in per_iter]}
+        json.dump(doc, open(sys.argv[2], "w"), indent=1)
+        print(sys.argv[2], it_bytes / 1e9, "GB per iteration,", P, "passes per application")
+        return
+    key, out, fcsv, wcsv = sys.argv[1:5]
+    assert out.endswith(".json") and fcsv.endswith(".csv") and wcsv.endswith(".csv"), "usage: key out.json fetch.csv write.csv [passes]"
+    F, W = collect(fcsv, "FETCH_SIZE"), collect(wcsv, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(F) | set(W)):
+        f = [v for v, _ in F.get(k, [])]
+        w = [v for v, _ in W.get(k, [])]
+        f = [v for v in f if v >= 0.5 * max(f)] if f and max(f) > 0 else f   # working launches only
+        w = [v for v in w if v >= 0.5 * max(w)] if w and max(w) > 0 else w
+        fm = sum(f) / len(f) if f else 0.0
+        wm = sum(w) / len(w) if w else 0.0
+        kernels[k] = {
+            "launches": max(len(f), len(w)),
+            "FETCH_SIZE_KiB_mean": fm,
+            "WRITE_SIZE_KiB_mean": wm,
+            "read_bytes_per_launch": 2.0 * fm * 1024.0,
+            "write_bytes_per_launch": wm * 1024.0,
+            "traffic_bytes_per_launch": 2.0 * fm * 1024.0 + wm * 1024.0,
+        }
+    P = int(sys.argv[5]) if len(sys.argv) > 5 else 28   # passes per application: the library's default where the scan kernels run
+    it_bytes, missing, per_iter = compose(kernels, P)
     doc = {"workload": key, "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950)", "kernels": kernels}
     if not missing:
         doc["iteration"] = {"traffic_bytes": it_bytes, "passes_per_application": P, "composition": [f"{m} x {p}" for p, m in per_iter]}
