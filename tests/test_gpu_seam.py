@@ -165,3 +165,64 @@ def test_real32_vectors_cross_the_diffuse_seam_as_they_are(gpu, solver, on_devic
     i2 = s.solve(b32, again)   # reference default tolerances: the rounded solution's residual is below atol at once
     assert i2.reason in (2, 3) and i2.niter <= 1
     s.close()
+
+
+def _seam_worker(rank, world, port, solver, Nx, Ny, Nz, phi0, theta0, transport, ret):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+
+    from tenstream_amd import coord, hostcomm
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("TSX_PEER_TIMEOUT_S", "10")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Q = _case(solver, Nx, Ny, Nz, phi0, theta0, 1)   # the global domain's blocks (same on every rank)
+        co = coord.coord(rank, world, Nx, Ny)
+        sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
+        loc = lambda a: np.ascontiguousarray(a[sl])
+        s = DiffuseSolver(solver, Nz, co.xm, co.ym, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank, nranks=world,
+                          neighbors=(co.west, co.east, co.south, co.north), device=0)
+        if transport == "peer":
+            hostcomm.attach_peer(s)
+        else:
+            hostcomm.attach(s, rank)
+        s.set_angles(phi0, theta0)
+        s.dir_set_coeffs(loc(Q["dir2dir"]), loc(Q["dir2diff"]), Q["l1d"], DX, DY, a33=loc(Q["a33"]), a13=loc(Q["a13"]), a23=loc(Q["a23"]))
+        edir = np.zeros((co.ym, co.xm, Nz + 1, Q["S"]))
+        niter, res, conv = s.dir_solve(700.0, edir, rtol=1e-12, atol=1e-6, maxit=60)   # (|edir| ~ 7e6 W: atol 1e-6 is 1e-13 of it)
+        b = s.setup_b_solar(np.zeros(s.vec_shape), albedo=loc(Q["albedo"]))   # the beam the sweep left on the device, its exchanged faces
+        refused = False
+        try:   # a beam handed in on several ranks would lack the faces the sweep exchanged
+            s.setup_b_solar(np.zeros(s.vec_shape), edir=edir)
+        except TsxError:
+            refused = True
+        want_e, _ = O.explicit_edir(Q["lay"], Q["dlay"], Q["sun"], Q["dir2dir"], Q["l1d"], Q["a33"], 700.0, DX, DY, rtol=1e-14, atol=1e-12,
+                                    maxit=500)
+        want_b = O.setup_b_solar(Q["lay"], Q["dlay"], Q["sun"], Q["dir2diff"], Q["l1d"], Q["a13"], Q["a23"], Q["albedo"], want_e)
+        ret[rank] = (conv, niter, float(np.abs(edir - want_e[sl]).max() / np.abs(want_e).max()),
+                     float(np.abs(b - want_b[sl]).max() / np.abs(want_b).max()), refused)
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,solver,Nx,Ny,phi0,theta0,transport", [(2, "3_10", 10, 8, 200.0, 50.0, "host"), (4, "3_10", 12, 10, 30.0, 35.0, "peer"),
+                                                                         (2, "8_16", 8, 6, 300.0, 40.0, "host")])
+def test_direct_seam_on_several_ranks_equals_the_global_oracle(gpu, world, solver, Nx, Ny, phi0, theta0, transport):
+    """tsx_dir_set_coeffs / tsx_dir_solve / tsx_setup_b_solar with the domain split over 2 / 4 rank processes (sharing cuda:0):
+    every sweep exchanges the downwind faces (exchange_direct_boundary, src/pprts_explicit.F90:1076-1140), the stop rule is on
+    the mean over ranks of the local norms -- against the oracle's explicit_edir and setup_b on the global domain."""
+    from test_gpu_multirank import _spawn
+
+    ret = _spawn(_seam_worker, world, (solver, Nx, Ny, 7, phi0, theta0, transport))
+    its = {v[1] for v in ret.values()}
+    assert len(its) == 1   # one (all-reduced) residual decides for every rank
+    for conv, niter, e_edir, e_b, refused in ret.values():
+        assert conv and niter <= 40 and e_edir <= 1e-9 and e_b <= 1e-9 and refused, (conv, niter, e_edir, e_b, refused)
