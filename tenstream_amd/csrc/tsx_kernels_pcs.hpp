@@ -242,8 +242,38 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_r0g(long long Nc, co
   }
 }
 
+typedef float tsx_f2 __attribute__((ext_vector_type(2)));
+// (lo, hi) -> two bf16 in one word, round to nearest even: gfx950's v_cvt_pk_bf16_f32 (one instruction; the integer spelling of
+// tsx_to_bf16 costs six per word, and an intermediate pass is bound by its vector instructions)
 __device__ __forceinline__ unsigned tsx_bf16x2(float lo, float hi) {
-  return (unsigned)tsx_to_bf16(lo) | ((unsigned)tsx_to_bf16(hi) << 16);
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const tsx_f2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+}
+// Element i of an array whose base is the same for the whole wave, i a 32-bit lane offset: a raw buffer access
+// (`buffer_load_dword v, v_off, s[rsrc:rsrc+3], 0 offen`).  The base lives in scalar registers and the byte offset is formed in
+// 32 bits, so an access costs no vector instruction of address arithmetic -- with plain pointers an intermediate pass of
+// tsx_k_pcs_rb spent one v_lshl_add_u64 per load and store (140 of its 1770 vector instructions), and the pass is bound by its
+// vector instructions (scripts/fold_probe.sh).  Needs i * sizeof(T) < 2^32, which pcs_config checks (Nc < 2^28).  The
+// descriptor: stride 0, no range limit, gfx9 dword 3 (data format 32).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tsx_rsrc(const void *base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ T tsx_ldu(const T *base, unsigned i) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "dword, dwordx2 or dwordx4");
+  const int off = (int)(i * (unsigned)sizeof(T));
+  if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(tsx_rsrc(base), off, 0, 0));
+  else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(tsx_rsrc(base), off, 0, 0));
+  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(tsx_rsrc(base), off, 0, 0));
+}
+template <typename T>
+__device__ __forceinline__ void tsx_stu(T *base, unsigned i, T v) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "dword or dwordx2");
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const int off = (int)(i * (unsigned)sizeof(T));
+  if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), tsx_rsrc(base), off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), tsx_rsrc(base), off, 0, 0);
 }
 
 // ---- several ranks: the other colour's boundary columns live on the neighbouring rank.  After every pass the records a
@@ -361,6 +391,20 @@ __device__ __forceinline__ bool tsx_pcs_on_frame(const TsxGeo &g, int jrow, int 
 // PEER (MODE 0 / 1, peer transport): the columns on a rank face store the records their neighbour rank consumes straight into
 // that rank's mailbox slot (what tsx_k_pcs_halo_pack + tsx_k_peer_send would do after the pass), the workgroup that finishes
 // last publishes the sequence numbers -- an exchange without a kernel of its own (tsx_peer_dev.hpp; snd: this pass's messages).
+// Analysis builds only (scripts/fold_probe.sh; never the shipped library): -DTSX_PCS_FOLD=2^n wraps the per-cell streams of an
+// intermediate pass (right-hand side words, neighbour records, stored records) onto the first 2^n cells of their planes, so that they
+// are served by L2 and what remains of the pass's time is its table gathers and arithmetic; -DTSX_PCS_FOLD_IDX wraps the record
+// index too (the gathers then hit L1).  The results are meaningless.
+#ifdef TSX_PCS_FOLD
+#define TSX_FOLDC(x) ((size_t)(x) & (size_t)(TSX_PCS_FOLD - 1))
+#else
+#define TSX_FOLDC(x) (x)
+#endif
+#ifdef TSX_PCS_FOLD_IDX
+#define TSX_FOLDI(x) TSX_FOLDC(x)
+#else
+#define TSX_FOLDI(x) (x)
+#endif
 template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false, int RQ = 0, bool C16 = false, bool PEER = false>
 __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) void tsx_k_pcs_rb(TsxGeo g, const uint4 *__restrict__ P, const float *__restrict__ r,
                                                          float *__restrict__ z, unsigned *__restrict__ zb,
@@ -381,6 +425,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   constexpr float CSC1 = C16 ? 1.0f : 1.0f / TSX_FP8_SCALE;  // the fp8 couplings are stored times TSX_FP8_SCALE
   __shared__ float2 sB[NSEG][CW], sV[NSEG][CW];
   if (done && *done) return;
+  // Lane offsets are 32-bit (tsx_ldu / tsx_stu), plane bases 64-bit and wave-uniform.
   const int h = g.xm >> 1;
   const int cl = threadIdx.x % CW, sg = threadIdx.x / CW;
   const int nthr = part == 2 ? tsx_pcs_nframe(g) : g.ym * h;
@@ -388,21 +433,22 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   bool live = t_ < nthr;  // dead lanes shadow the last column (loads stay valid, nothing is stored)
   if (!live) t_ = nthr - 1;
   if (part == 2) t_ = tsx_pcs_frame_thread(g, rbc, t_);
-  const long long Nc = g.Nc;
-  const int Nz = g.Nz, ncol = g.ncol;
+  const size_t Nc = (size_t)g.Nc;
+  const int Nz = g.Nz;
+  const unsigned ncol = (unsigned)g.ncol;
   const int jrow = t_ / h, qh = t_ - jrow * h;
   const int par = (jrow + rbc) & 1;
   const int icol = 2 * qh + par;
   if (part == 1 && tsx_pcs_on_frame(g, jrow, icol)) live = false;
-  const int col = jrow * g.xm + rbc * h + qh;  // colour-split column index (P, r, z, zb)
+  const unsigned col = (unsigned)(jrow * g.xm + rbc * h + qh);  // colour-split column index (P, r, z, zb)
   // neighbours (other colour) in split space; 0 = no neighbour (rank face / tile edge)
-  const long long oc = (long long)(1 - 2 * rbc) * h;
+  const int oc = (1 - 2 * rbc) * h;
   const int jn = jrow + 1 < g.ym ? jrow + 1 : (g.wrap_y ? 0 : -1), js = jrow > 0 ? jrow - 1 : (g.wrap_y ? g.ym - 1 : -1);
   const int qw = par ? qh : (qh > 0 ? qh - 1 : (g.wrap_x ? h - 1 : -1)), qe = par ? (qh + 1 < h ? qh + 1 : (g.wrap_x ? 0 : -1)) : qh;
-  long long offN = jn >= 0 ? (long long)(jn - jrow) * g.xm + oc : 0;
-  long long offS = js >= 0 ? (long long)(js - jrow) * g.xm + oc : 0;
-  long long offE = qe >= 0 ? oc + (qe - qh) : 0;
-  long long offW = qw >= 0 ? oc + (qw - qh) : 0;
+  int offN = jn >= 0 ? (jn - jrow) * g.xm + oc : 0;
+  int offS = js >= 0 ? (js - jrow) * g.xm + oc : 0;
+  int offE = qe >= 0 ? oc + (qe - qh) : 0;
+  int offW = qw >= 0 ? oc + (qw - qh) : 0;
   if (g.pc_tile_x > 0) {  // analysis knob: behave like a rank of pc_tile_x x pc_tile_y columns
     if ((icol + 1) % g.pc_tile_x == 0) offE = 0;
     if (icol % g.pc_tile_x == 0) offW = 0;
@@ -412,21 +458,23 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     if (jrow % g.pc_tile_y == 0) offS = 0;
   }
   if (nonbr) offN = offS = offE = offW = 0;
-  const int ncp = jrow * g.xm + 2 * qh;  // FINAL: natural index of the pair's first column
-  auto wpair = [&](float *dst, float mine, float partner) {
-    if (live) *reinterpret_cast<float2 *>(dst) = par ? make_float2(partner, mine) : make_float2(mine, partner);
+  const unsigned ncp = (unsigned)(jrow * g.xm + 2 * qh);  // FINAL: natural index of the pair's first column
+  auto wpair = [&](float *base, unsigned i, float mine, float partner) {
+    if (live) tsx_stu(reinterpret_cast<float2 *>(base), i >> 1, par ? make_float2(partner, mine) : make_float2(mine, partner));
   };
   const float *__restrict__ rt = r + (size_t)D * Nc;
   float *__restrict__ zt = z + (size_t)D * Nc;
   float2 *__restrict__ zr = reinterpret_cast<float2 *>(z + (size_t)2 * Nc);  // side-stream records of the fp32 iterate
-  const float rsurf = rt[col], V0 = rt[(size_t)ncol + col];
+  const float rsurf = tsx_ldu(rt, col), V0 = tsx_ldu(rt + ncol, col);
 
   const int k0 = sg * LSEG;
   const int nl = Nz - k0 < LSEG ? (Nz - k0 > 0 ? Nz - k0 : 0) : LSEG;  // levels of this segment that exist
-  auto cell = [&](int l) { return (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + col; };
+  auto level = [&](int l) { return k0 + l < Nz ? k0 + l : Nz - 1; };  // (clamped: the loads of absent levels stay valid)
+  auto cell = [&](int l) { return (unsigned)level(l) * ncol + col; };
 
   // neighbour records of one level: [E (dofs 2,4), W (3,5), N (6,8), S (7,9)]
   // rank faces: the neighbour's records come from the exchanged buffers (bf16 pairs), [k][j] resp. [k][i]
+  const bool anyface = (hal.E || hal.W || hal.N || hal.S) && !nonbr;  // wave-uniform
   const bool face[4] = {hal.E && !nonbr && qe < 0, hal.W && !nonbr && qw < 0, hal.N && !nonbr && jn < 0, hal.S && !nonbr && js < 0};
   if (!PEER && GS && hal.wait.mine) tsx_peer_wait_faces(hal.wait, face[1], face[0], face[3], face[2]);  // the records are read in place
   // PEER: which faces this column sends through (bits W, E, S, N); the slots must be free before the first store.  Only the
@@ -444,34 +492,44 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     unsigned *base = reinterpret_cast<unsigned *>(tsx_peer_data(snd.remote[f], snd.data_off, snd.cap, f ^ 1, (int)(snd.n[f] & 1)));
     base[(size_t)(f < 2 ? jrow : icol) * tsx_pcs_halo_nzp(Nz) + k] = w;
   };
-  auto nbr_load = [&](size_t c, uint2 (&o)[4]) {
-    const long long off[4] = {offE, offW, offN, offS};
-    const unsigned *hp[4] = {hal.E, hal.W, hal.N, hal.S};
-    const int k = (int)(c / (size_t)ncol);
+  // c = cell(l).  Lanes without a neighbour in a direction get zero words (the slot they would read may hold NaN); at a rank
+  // face the neighbour's record comes from the exchanged buffers (nbr_halo, a second stage: no branch between the loads of
+  // the levels, so that all of them are in flight together)
+  auto nbr_load = [&](unsigned c, uint2 (&o)[4]) {
+    const int off[4] = {offE, offW, offN, offS};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const size_t idx = (size_t)m * Nc + c + off[m];
+      const unsigned ci = (unsigned)((int)c + off[m]);
+      if (MODE == 2) o[m] = tsx_ldu(reinterpret_cast<const uint2 *>(zr) + (size_t)m * Nc, ci);
+      else o[m] = make_uint2(tsx_ldu(zb + (size_t)m * Nc, (unsigned)TSX_FOLDC(ci)), 0u);
+    }
+  };
+  auto nbr_halo = [&](int k, unsigned (&hv)[4]) {  // unconditional loads from valid addresses
+    const unsigned *hp[4] = {hal.E, hal.W, hal.N, hal.S};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
       const size_t hidx = (size_t)(m < 2 ? jrow : icol) * tsx_pcs_halo_nzp(Nz) + k;  // [j][k] resp. [i][k]
-      if (MODE == 2) {
-        o[m] = *reinterpret_cast<const uint2 *>(zr + idx);
-        const unsigned hv = *(face[m] ? hp[m] + hidx : zb);  // unconditional load from a valid address, then select
-        if (face[m]) o[m].x = hv;
-      } else {
-        o[m] = make_uint2(*(face[m] ? hp[m] + hidx : zb + idx), 0u);
-      }
+      hv[m] = *(face[m] ? hp[m] + hidx : zb);
+    }
+  };
+  auto nbr_select = [&](uint2 (&o)[4], const unsigned (&hv)[4], bool halo) {
+    const int off[4] = {offE, offW, offN, offS};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const bool has = off[m] != 0;
+      o[m].x = has ? o[m].x : 0u;
+      if (MODE == 2) o[m].y = has ? o[m].y : 0u;
+      if (halo && face[m]) o[m].x = hv[m];
     }
   };
   // -> values by stream: zx[q] = stream 2+q entering through an x face, zy[q] = stream 6+q through a y face
   auto nbr_vals = [&](const uint2 (&n)[4], float (&zx)[4], float (&zy)[4]) {
     float lo[4], hi[4];
-    const long long off[4] = {offE, offW, offN, offS};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const bool f32 = MODE == 2 && !face[m];
-      const float a = f32 ? __uint_as_float(n[m].x) : __uint_as_float(n[m].x << 16);
-      const float b = f32 ? __uint_as_float(n[m].y) : __uint_as_float(n[m].x & 0xffff0000u);
-      lo[m] = (off[m] || face[m]) ? a : 0.0f;  // select: the unused slot may hold NaN
-      hi[m] = (off[m] || face[m]) ? b : 0.0f;
+      lo[m] = f32 ? __uint_as_float(n[m].x) : __uint_as_float(n[m].x << 16);
+      hi[m] = f32 ? __uint_as_float(n[m].y) : __uint_as_float(n[m].x & 0xffff0000u);
     }
     zx[0] = lo[0]; zx[2] = hi[0]; zx[1] = lo[1]; zx[3] = hi[1];
     zy[0] = lo[2]; zy[2] = hi[2]; zy[1] = lo[3]; zy[3] = hi[3];
@@ -481,11 +539,11 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   uint4 r0[LSEG], r1[LSEG], r1x[C16 ? LSEG : 1];
   float ru[LSEG], rd[LSEG];
   uint2 nb[LSEG][4];
-  int eid[LSEG];
+  unsigned eid[LSEG];  // (times pe_si: the lane offset into a slot of the per-block records)
   // group g = 1..7 of the layout: per cell P[g * Nc + cell]; per block PE[(g - 1) * nent + id], or with C16 PE[g * nent + id]
   // (slots 0 and 1 hold record 1's two fp16 halves)
-  auto rec = [&](int grp, size_t c, int id) {
-    return IDX ? PE[(size_t)(C16 ? grp : grp - 1) * pe_ss + (size_t)id * (size_t)pe_si] : P[(size_t)grp * Nc + c];
+  auto rec = [&](int grp, unsigned c, unsigned ei) {
+    return IDX ? tsx_ldu(PE + (size_t)(C16 ? grp : grp - 1) * pe_ss, ei) : tsx_ldu(P + (size_t)grp * Nc, c);
   };
   // four side -> top couplings as floats: fp8 word w, or the fp16 pair of words (a, b)
   auto dec4 = [&](unsigned w, unsigned a, unsigned b, float (&o)[4]) {
@@ -496,34 +554,77 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       tsx_fp8x4(w, o);
     }
   };
+  // The loads are written stage by stage over the levels (indices -> independent words -> records behind the indices), with
+  // the wave-uniform decisions outside the loops: a branch per level fences the levels' loads off from each other, and a
+  // wave walks the chain index -> record -> block records four times in a row (it did: 33.4 us per pass against 30.1 us)
+  unsigned pi[LSEG];
+  if (IDX && MODE == 0) {
+    if (pidx) {
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) pi[l] = (unsigned)tsx_ldu(pidx, (unsigned)TSX_FOLDI(cell(l)));
+    }
+  } else if (IDX) {
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) pi[l] = (unsigned)tsx_ldu(cidx, cell(l));
+  }
 #pragma unroll
   for (int l = 0; l < LSEG; ++l) {
-    const size_t c = cell(l);
-    if (IDX && MODE == 0) {  // record 0 with the block index in place of A_k (tsx_k_pcs_pack_r0g)
-      r0[l] = pidx ? PT[pidx[c]] : P[(size_t)7 * Nc + c];
-      eid[l] = (int)r0[l].w;
-    } else {
-      eid[l] = IDX ? cidx[c] : 0;
-      r0[l] = P[c];
-    }
+    const unsigned c = cell(l);
     if (RQ == 2) {
-      const unsigned w = rb[c];
+      const unsigned w = tsx_ldu(rb, (unsigned)TSX_FOLDC(c));
       ru[l] = __uint_as_float(w << 16);
       rd[l] = __uint_as_float(w & 0xffff0000u);
     } else {
-      ru[l] = r[c];
-      rd[l] = r[(size_t)Nc + c];
-      if (RQ == 1 && live && l < nl) rb[c] = tsx_bf16x2(ru[l], rd[l]);
+      ru[l] = tsx_ldu(r, c);
+      rd[l] = tsx_ldu(r + Nc, c);
     }
-    if (GS) {
+    if (GS) nbr_load(c, nb[l]);
+  }
+  if (IDX && MODE == 0) {  // record 0 with the block index in place of A_k (tsx_k_pcs_pack_r0g)
+    if (pidx) {
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) r0[l] = tsx_ldu(PT, pi[l]);
+    } else {
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) r0[l] = tsx_ldu(P + (size_t)7 * Nc, cell(l));
+    }
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) eid[l] = r0[l].w * (unsigned)pe_si;
+  } else {
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) {
+      eid[l] = IDX ? pi[l] * (unsigned)pe_si : 0u;
+      r0[l] = tsx_ldu(P, cell(l));
+    }
+  }
+  if (GS) {
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) {
+      const unsigned c = cell(l);
       if (C16) {
-        r1[l] = IDX ? PE[(size_t)eid[l] * (size_t)pe_si] : P[(size_t)1 * Nc + c];
-        r1x[l] = IDX ? PE[pe_ss + (size_t)eid[l] * (size_t)pe_si] : P[(size_t)8 * Nc + c];
+        r1[l] = IDX ? tsx_ldu(PE, eid[l]) : tsx_ldu(P + (size_t)1 * Nc, c);
+        r1x[l] = IDX ? tsx_ldu(PE + pe_ss, eid[l]) : tsx_ldu(P + (size_t)8 * Nc, c);
       } else {
         r1[l] = rec(1, c, eid[l]);
       }
-      nbr_load(c, nb[l]);
     }
+    if (anyface) {
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) {
+        unsigned hv[4];
+        nbr_halo(level(l), hv);
+        nbr_select(nb[l], hv, true);
+      }
+    } else {
+      const unsigned none[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) nbr_select(nb[l], none, false);
+    }
+  }
+  if (RQ == 1) {
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l)
+      if (live && l < nl) tsx_stu(rb, cell(l), tsx_bf16x2(ru[l], rd[l]));
   }
   float Bloc[LSEG], Pcum[LSEG], rdg[LSEG];
   {
@@ -594,24 +695,29 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   // ---- phase 3: true V, U; side streams; stores
   if (sg == 0) {  // tail rows: TOA Edn (identity row) and the side dummies at level Nz
     if (MODE == 1 && live) zt[(size_t)ncol + col] = V0;
-    if (FINAL) wpair(zfin + (size_t)D * Nc + (size_t)ncol + ncp, V0, zt[(size_t)ncol + col + oc]);
+    if (FINAL) wpair(zfin + (size_t)D * Nc + (size_t)ncol, ncp, V0, zt[(size_t)ncol + col + oc]);
 #pragma unroll
     for (int d = NTOP; d < D; ++d) {
       const float v = rt[(size_t)d * ncol + col];
       if (MODE == 1 && live) zt[(size_t)d * ncol + col] = v;
-      if (FINAL) wpair(zfin + (size_t)D * Nc + (size_t)d * ncol + ncp, v, zt[(size_t)d * ncol + col + oc]);
+      if (FINAL) wpair(zfin + (size_t)D * Nc + (size_t)d * ncol, ncp, v, zt[(size_t)d * ncol + col + oc]);
     }
   }
-  // (loads are unconditional -- a load under a branch costs a full wait -- and only the stores are predicated)
+  // (only the stores are predicated.  Measured and dropped, scripts/ab_lib.sh on one box: a second copy of this loop with
+  // unconditional stores behind a wave-uniform "every lane stores every level" test, so that the scheduler may start a level's
+  // loads under the arithmetic of the one before: pass 30.1 -> 30.8 us; the four right-hand side words per level fetched at the
+  // top of the kernel straight into LDS (`buffer_load_dword ... lds`): 30.1 -> 32.7 us -- the pass is bound by the texture
+  // addresser's cycles (TA busy 65-74 %, scripts/pass_pmc.sh), not by the latency of this chain, and each DMA is one more
+  // vector-memory instruction)
   float V = Vin;
 #pragma unroll
   for (int l = 0; l < LSEG; ++l) {
     const bool st = live && l < nl;
-    auto wpair2 = [&](float *dst, float mine, float partner) {
-      if (st) *reinterpret_cast<float2 *>(dst) = par ? make_float2(partner, mine) : make_float2(mine, partner);
+    const unsigned c = cell(l);
+    const unsigned cn = (unsigned)level(l) * ncol + ncp;
+    auto wpair2 = [&](float *base, float mine, float partner) {
+      if (st) tsx_stu(reinterpret_cast<float2 *>(base), cn >> 1, par ? make_float2(partner, mine) : make_float2(mine, partner));
     };
-    const size_t c = cell(l);
-    const size_t cn = (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + ncp;
     const tsx_h8 m = __builtin_bit_cast(tsx_h8, r0[l]);
     const uint4 wcu = rec(2, c, eid[l]), wcv = rec(3, c, eid[l]);
     uint4 wy[2], wx[2];
@@ -625,40 +731,42 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     if (RQ == 2) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const unsigned w = rb[(size_t)(1 + q) * Nc + c];
+        const unsigned w = tsx_ldu(rb + (size_t)(1 + q) * Nc, (unsigned)TSX_FOLDC(c));
         rs[2 * q] = __uint_as_float(w << 16);
         rs[2 * q + 1] = __uint_as_float(w & 0xffff0000u);
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+      for (int q = 0; q < 8; ++q) rs[q] = tsx_ldu(r + (size_t)(NTOP + q) * Nc, c);
       if (RQ == 1 && st) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rb[(size_t)(1 + q) * Nc + c] = tsx_bf16x2(rs[2 * q], rs[2 * q + 1]);
+        for (int q = 0; q < 4; ++q) tsx_stu(rb + (size_t)(1 + q) * Nc, c, tsx_bf16x2(rs[2 * q], rs[2 * q + 1]));
       }
     }
     float pt[2];
     float2 ps[4];
     if (FINAL) {
-      pt[0] = z[c + oc];
-      pt[1] = z[(size_t)Nc + c + oc];
+      const unsigned co = (unsigned)((int)c + oc);
+      pt[0] = tsx_ldu(z, co);
+      pt[1] = tsx_ldu(z + Nc, co);
 #pragma unroll
-      for (int m2 = 0; m2 < 4; ++m2) ps[m2] = zr[(size_t)m2 * Nc + c + oc];
+      for (int m2 = 0; m2 < 4; ++m2) ps[m2] = tsx_ldu(zr + (size_t)m2 * Nc, co);
     }
     const float Bn = l + 1 < LSEG ? Bk[l + 1] : Bin;
     const float Vn = Vloc[l] + Qcum[l] * Vin;
     const float Un = (float)m[5] * Vn + Bn;
     const float U = (float)m[6] * V + Bk[l];
     if (MODE == 1 && st) {
-      z[c] = U;
-      z[(size_t)Nc + c] = Vn;
+      tsx_stu(z, c, U);
+      tsx_stu(z + Nc, c, Vn);
     }
     if (FINAL) {
-      wpair2(zfin + cn, U, pt[0]);
-      wpair2(zfin + (size_t)Nc + cn, Vn, pt[1]);
+      wpair2(zfin, U, pt[0]);
+      wpair2(zfin + Nc, Vn, pt[1]);
     }
     float zx[4], zy[4];
     if (GS) nbr_vals(nb[l], zx, zy);
+    const tsx_f2 zy01 = {zy[0], zy[1]}, zy23 = {zy[2], zy[3]}, zx01 = {zx[0], zx[1]}, zx23 = {zx[2], zx[3]};
     const tsx_h8 hcu = __builtin_bit_cast(tsx_h8, wcu), hcv = __builtin_bit_cast(tsx_h8, wcv);
     const unsigned uy[8] = {wy[0].x, wy[0].y, wy[0].z, wy[0].w, wy[1].x, wy[1].y, wy[1].z, wy[1].w};
     const unsigned ux[8] = {wx[0].x, wx[0].y, wx[0].z, wx[0].w, wx[1].x, wx[1].y, wx[1].z, wx[1].w};
@@ -667,21 +775,22 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     for (int dd = 0; dd < 8; ++dd) {
       float acc = (float)hcu[dd] * Un + (float)hcv[dd] * V;
       if (GS) {
-        float cq[4], cp[4];
-        tsx_fp8x4(uy[dd], cq);
-        tsx_fp8x4(ux[dd], cp);
-        float a8 = cq[0] * zy[0] + cq[1] * zy[1] + cq[2] * zy[2] + cq[3] * zy[3];
-        a8 += cp[0] * zx[0] + cp[1] * zx[1] + cp[2] * zx[2] + cp[3] * zx[3];
-        acc += a8 * (1.0f / TSX_FP8_SCALE);
+        // eight fp8 couplings against the eight entering streams as four packed fp32 FMAs (v_pk_fma_f32: the pairs that
+        // v_cvt_pk_f32_fp8 delivers times the pairs of neighbour values), then one horizontal add
+        tsx_f2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)uy[dd], false) * zy01;
+        a = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)uy[dd], true), zy23, a);
+        a = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)ux[dd], false), zx01, a);
+        a = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)ux[dd], true), zx23, a);
+        acc += (a.x + a.y) * (1.0f / TSX_FP8_SCALE);
       }
       zo[dd] = rs[dd] + acc;
     }
     // records: (2,4) (3,5) (6,8) (7,9)  = zo[0,2] zo[1,3] zo[4,6] zo[5,7]
     if (MODE == 0 && st) {
-      zb[(size_t)0 * Nc + c] = tsx_bf16x2(zo[0], zo[2]);
-      zb[(size_t)1 * Nc + c] = tsx_bf16x2(zo[1], zo[3]);
-      zb[(size_t)2 * Nc + c] = tsx_bf16x2(zo[4], zo[6]);
-      zb[(size_t)3 * Nc + c] = tsx_bf16x2(zo[5], zo[7]);
+      tsx_stu(zb + (size_t)0 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[0], zo[2]));
+      tsx_stu(zb + (size_t)1 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[1], zo[3]));
+      tsx_stu(zb + (size_t)2 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[4], zo[6]));
+      tsx_stu(zb + (size_t)3 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[5], zo[7]));
     }
     if constexpr (PEER && CW < 32) {
       // small passes (16-column workgroups: at most one workgroup per CU's worth of columns, latency-bound, registers to spare):
@@ -695,24 +804,24 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       }
     }
     if (MODE == 1 && st) {
-      zr[(size_t)0 * Nc + c] = make_float2(zo[0], zo[2]);
-      zr[(size_t)1 * Nc + c] = make_float2(zo[1], zo[3]);
-      zr[(size_t)2 * Nc + c] = make_float2(zo[4], zo[6]);
-      zr[(size_t)3 * Nc + c] = make_float2(zo[5], zo[7]);
+      tsx_stu(zr + (size_t)0 * Nc, c, make_float2(zo[0], zo[2]));
+      tsx_stu(zr + (size_t)1 * Nc, c, make_float2(zo[1], zo[3]));
+      tsx_stu(zr + (size_t)2 * Nc, c, make_float2(zo[4], zo[6]));
+      tsx_stu(zr + (size_t)3 * Nc, c, make_float2(zo[5], zo[7]));
     }
     if (FINAL) {
-      wpair2(zfin + (size_t)2 * Nc + cn, zo[0], ps[0].x);
-      wpair2(zfin + (size_t)4 * Nc + cn, zo[2], ps[0].y);
-      wpair2(zfin + (size_t)3 * Nc + cn, zo[1], ps[1].x);
-      wpair2(zfin + (size_t)5 * Nc + cn, zo[3], ps[1].y);
-      wpair2(zfin + (size_t)6 * Nc + cn, zo[4], ps[2].x);
-      wpair2(zfin + (size_t)8 * Nc + cn, zo[6], ps[2].y);
-      wpair2(zfin + (size_t)7 * Nc + cn, zo[5], ps[3].x);
-      wpair2(zfin + (size_t)9 * Nc + cn, zo[7], ps[3].y);
+      wpair2(zfin + (size_t)2 * Nc, zo[0], ps[0].x);
+      wpair2(zfin + (size_t)4 * Nc, zo[2], ps[0].y);
+      wpair2(zfin + (size_t)3 * Nc, zo[1], ps[1].x);
+      wpair2(zfin + (size_t)5 * Nc, zo[3], ps[1].y);
+      wpair2(zfin + (size_t)6 * Nc, zo[4], ps[2].x);
+      wpair2(zfin + (size_t)8 * Nc, zo[6], ps[2].y);
+      wpair2(zfin + (size_t)7 * Nc, zo[5], ps[3].x);
+      wpair2(zfin + (size_t)9 * Nc, zo[7], ps[3].y);
     }
     if (k0 + l == Nz - 1) {  // U_Nz = alb V_Nz + ru_Nz: the surface row
       if (MODE == 1 && live) zt[col] = Un;
-      if (FINAL) wpair(zfin + (size_t)D * Nc + ncp, Un, zt[col + oc]);
+      if (FINAL) wpair(zfin + (size_t)D * Nc, ncp, Un, zt[(size_t)((int)col + oc)]);
     }
     V = Vn;
   }
@@ -724,7 +833,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
 #pragma unroll
       for (int l = 0; l < LSEG; ++l) {
         if (l >= nl) continue;
-        const size_t c = cell(l);
+        const unsigned c = cell(l);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
           if (!(sendmask & (1 << f))) continue;
