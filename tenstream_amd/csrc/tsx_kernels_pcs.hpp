@@ -267,6 +267,24 @@ __device__ __forceinline__ T tsx_ldu(const T *base, unsigned i) {
   else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(tsx_rsrc(base), off, 0, 0));
   else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(tsx_rsrc(base), off, 0, 0));
 }
+// the same with a wave-uniform plane offset of `plane` elements carried in the instruction's scalar offset: planes of one array
+// share one descriptor (four scalar registers each -- tsx_k_pcsh_rb walks 50 planes).  Needs plane * sizeof(T) < 2^32.
+template <typename T>
+__device__ __forceinline__ T tsx_ldo(const T *base, size_t plane, unsigned i) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "dword, dwordx2 or dwordx4");
+  const int off = (int)(i * (unsigned)sizeof(T)), so = (int)(unsigned)(plane * sizeof(T));
+  if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(tsx_rsrc(base), off, so, 0));
+  else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(tsx_rsrc(base), off, so, 0));
+  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(tsx_rsrc(base), off, so, 0));
+}
+template <typename T>
+__device__ __forceinline__ void tsx_sto(T *base, size_t plane, unsigned i, T v) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "dword or dwordx2");
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const int off = (int)(i * (unsigned)sizeof(T)), so = (int)(unsigned)(plane * sizeof(T));
+  if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), tsx_rsrc(base), off, so, 0);
+  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), tsx_rsrc(base), off, so, 0);
+}
 template <typename T>
 __device__ __forceinline__ void tsx_stu(T *base, unsigned i, T v) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8, "dword or dwordx2");
@@ -1000,28 +1018,40 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcsh_pack_block(TsxGeo g, lon
 struct TsxM4 {  // a 4 x 4 block in registers
   float m[4][4];
 };
-__device__ __forceinline__ TsxM4 tsx_m4(const uint4 &lo, const uint4 &hi, float add_diag) {
-  TsxM4 M;
-  const tsx_h8 a = __builtin_bit_cast(tsx_h8, lo), b = __builtin_bit_cast(tsx_h8, hi);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    M.m[0][q] = (float)a[q] + (q == 0 ? add_diag : 0.0f);
-    M.m[1][q] = (float)a[4 + q] + (q == 1 ? add_diag : 0.0f);
-    M.m[2][q] = (float)b[q] + (q == 2 ? add_diag : 0.0f);
-    M.m[3][q] = (float)b[4 + q] + (q == 3 ? add_diag : 0.0f);
-  }
+// A block as loaded: fp16, rows 0 and 1 in lo, rows 2 and 3 in hi (tsx_pack_rows2).  The products read the halves in place
+// (v_fma_mix_f32): converting the 16 elements first cost 750 of the pass's 4500 vector instructions and 8 registers per block
+struct TsxH4 {
+  tsx_h8 lo, hi;
+  __device__ __forceinline__ float e(int a, int b) const { return a < 2 ? (float)lo[4 * a + b] : (float)hi[4 * (a - 2) + b]; }
+};
+__device__ __forceinline__ TsxH4 tsx_h4m(const uint4 &lo, const uint4 &hi) {
+  TsxH4 M;
+  M.lo = __builtin_bit_cast(tsx_h8, lo);
+  M.hi = __builtin_bit_cast(tsx_h8, hi);
   return M;
 }
-__device__ __forceinline__ void tsx_mv4(const TsxM4 &M, const float (&v)[4], float (&o)[4]) {
+// o = M v, or (M + I) v -- the layout stores G - I
+template <bool PLUS_I = false>
+__device__ __forceinline__ void tsx_mv4(const TsxH4 &M, const float (&v)[4], float (&o)[4]) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a) o[a] = M.m[a][0] * v[0] + M.m[a][1] * v[1] + M.m[a][2] * v[2] + M.m[a][3] * v[3];
+  for (int a = 0; a < 4; ++a) {
+    float acc = PLUS_I ? __builtin_fmaf(M.e(a, 0), v[0], v[a]) : M.e(a, 0) * v[0];
+    acc = __builtin_fmaf(M.e(a, 1), v[1], acc);
+    acc = __builtin_fmaf(M.e(a, 2), v[2], acc);
+    o[a] = __builtin_fmaf(M.e(a, 3), v[3], acc);
+  }
 }
-__device__ __forceinline__ TsxM4 tsx_mm4(const TsxM4 &X, const TsxM4 &Y) {
+__device__ __forceinline__ TsxM4 tsx_mm4(const TsxH4 &X, const TsxM4 &Y) {
   TsxM4 O;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) O.m[a][b] = X.m[a][0] * Y.m[0][b] + X.m[a][1] * Y.m[1][b] + X.m[a][2] * Y.m[2][b] + X.m[a][3] * Y.m[3][b];
+    for (int b = 0; b < 4; ++b) {
+      float acc = X.e(a, 0) * Y.m[0][b];
+      acc = __builtin_fmaf(X.e(a, 1), Y.m[1][b], acc);
+      acc = __builtin_fmaf(X.e(a, 2), Y.m[2][b], acc);
+      O.m[a][b] = __builtin_fmaf(X.e(a, 3), Y.m[3][b], acc);
+    }
   return O;
 }
 
@@ -1051,20 +1081,22 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   bool live = t_ < nthr;
   if (!live) t_ = nthr - 1;
   if (part == 2) t_ = tsx_pcs_frame_thread(g, rbc, t_);
-  const long long Nc = g.Nc;
-  const int Nz = g.Nz, ncol = g.ncol;
+  // lane offsets are 32-bit (tsx_ldu / tsx_stu), plane bases 64-bit and wave-uniform, as in tsx_k_pcs_rb
+  const size_t Nc = (size_t)g.Nc;
+  const int Nz = g.Nz;
+  const unsigned ncol = (unsigned)g.ncol;
   const int jrow = t_ / h, qh = t_ - jrow * h;
   const int par = (jrow + rbc) & 1;
   const int icol = 2 * qh + par;
   if (part == 1 && tsx_pcs_on_frame(g, jrow, icol)) live = false;
-  const int col = jrow * g.xm + rbc * h + qh;
-  const long long oc = (long long)(1 - 2 * rbc) * h;
+  const unsigned col = (unsigned)(jrow * g.xm + rbc * h + qh);
+  const int oc = (1 - 2 * rbc) * h;
   const int jn = jrow + 1 < g.ym ? jrow + 1 : (g.wrap_y ? 0 : -1), js = jrow > 0 ? jrow - 1 : (g.wrap_y ? g.ym - 1 : -1);
   const int qw = par ? qh : (qh > 0 ? qh - 1 : (g.wrap_x ? h - 1 : -1)), qe = par ? (qh + 1 < h ? qh + 1 : (g.wrap_x ? 0 : -1)) : qh;
-  long long offN = jn >= 0 ? (long long)(jn - jrow) * g.xm + oc : 0;
-  long long offS = js >= 0 ? (long long)(js - jrow) * g.xm + oc : 0;
-  long long offE = qe >= 0 ? oc + (qe - qh) : 0;
-  long long offW = qw >= 0 ? oc + (qw - qh) : 0;
+  int offN = jn >= 0 ? (jn - jrow) * g.xm + oc : 0;
+  int offS = js >= 0 ? (js - jrow) * g.xm + oc : 0;
+  int offE = qe >= 0 ? oc + (qe - qh) : 0;
+  int offW = qw >= 0 ? oc + (qw - qh) : 0;
   if (g.pc_tile_x > 0) {
     if ((icol + 1) % g.pc_tile_x == 0) offE = 0;
     if (icol % g.pc_tile_x == 0) offW = 0;
@@ -1074,51 +1106,53 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     if (jrow % g.pc_tile_y == 0) offS = 0;
   }
   if (nonbr) offN = offS = offE = offW = 0;
-  const int ncp = jrow * g.xm + 2 * qh;
-  auto wpair_if = [&](bool on, float *dst, float mine, float partner) {
-    if (on) *reinterpret_cast<float2 *>(dst) = par ? make_float2(partner, mine) : make_float2(mine, partner);
+  const unsigned ncp = (unsigned)(jrow * g.xm + 2 * qh);
+  auto wpair_if = [&](bool on, float *base, unsigned i, float mine, float partner) {
+    if (on) tsx_stu(reinterpret_cast<float2 *>(base), i >> 1, par ? make_float2(partner, mine) : make_float2(mine, partner));
   };
   const float *__restrict__ rt = r + (size_t)D * Nc;
   float *__restrict__ zt = z + (size_t)D * Nc;
   float2 *__restrict__ zr = reinterpret_cast<float2 *>(z + (size_t)NTOP * Nc);
   const int k0 = sg * LSEG;
   const int nl = Nz - k0 < LSEG ? (Nz - k0 > 0 ? Nz - k0 : 0) : LSEG;
-  auto cell = [&](int l) { return (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + col; };
-  auto brec = [&](int grp, size_t c, int id) { return PB[(size_t)grp * bstride + (IDX ? (size_t)id : c)]; };
-  auto prow = [&](size_t c) { return pidx ? (size_t)pidx[c] : c; };
-  auto mat = [&](int grp, size_t pr, float add_diag) {
-    return tsx_m4(P[(size_t)grp * pstride + pr], P[(size_t)(grp + 1) * pstride + pr], add_diag);
+  auto level = [&](int l) { return k0 + l < Nz ? k0 + l : Nz - 1; };
+  auto cell = [&](int l) { return (unsigned)level(l) * ncol + col; };
+  // record planes in fours per descriptor (the plane within the four as scalar offset: 3 * stride * 16 B < 2^32, pcs_config)
+  auto brec = [&](int grp, unsigned c, unsigned id) {
+    return tsx_ldo(PB + (size_t)(grp & ~3) * (size_t)bstride, (size_t)(grp & 3) * (size_t)bstride, IDX ? id : c);
   };
+  auto prec = [&](int grp, unsigned pr) { return tsx_ldo(P + (size_t)(grp & ~3) * (size_t)pstride, (size_t)(grp & 3) * (size_t)pstride, pr); };
+  auto mat = [&](int grp, unsigned pr) { return tsx_h4m(prec(grp, pr), prec(grp + 1, pr)); };
   // rank faces: the neighbour's records come from the exchanged buffers (bf16 pairs), [k][j] resp. [k][i]
   const bool face[4] = {hal.E && !nonbr && qe < 0, hal.W && !nonbr && qw < 0, hal.N && !nonbr && jn < 0, hal.S && !nonbr && js < 0};
   if (GS && hal.wait.mine) tsx_peer_wait_faces(hal.wait, face[1], face[0], face[3], face[2]);  // the records are read in place
-  auto nbr_load = [&](size_t c, uint2(&o)[4]) {
-    const long long off[4] = {offE, offW, offN, offS};
+  const bool anyface = (hal.E || hal.W || hal.N || hal.S) && !nonbr;  // wave-uniform
+  // k = level(l), c = cell(l).  Lanes without a neighbour in a direction get zero words (the slot they would read may hold NaN)
+  auto nbr_load = [&](int k, unsigned c, uint2(&o)[4]) {
+    const int off[4] = {offE, offW, offN, offS};
     const unsigned *hp[4] = {hal.E, hal.W, hal.N, hal.S};
-    const int k = (int)(c / (size_t)ncol);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const size_t idx = (size_t)m * Nc + c + off[m];
-      const size_t hidx = (size_t)(m < 2 ? jrow : icol) * tsx_pcs_halo_nzp(Nz) + k;  // [j][k] resp. [i][k]
-      if (MODE == 2) {
-        o[m] = *reinterpret_cast<const uint2 *>(zr + idx);
-        const unsigned hv = *(face[m] ? hp[m] + hidx : zb);  // unconditional load from a valid address, then select
+      const unsigned ci = (unsigned)((int)c + off[m]);
+      const bool has = off[m] != 0 || face[m];
+      if (MODE == 2) o[m] = tsx_ldo(reinterpret_cast<const uint2 *>(zr), (size_t)m * Nc, ci);
+      else o[m] = make_uint2(tsx_ldo(zb, (size_t)m * Nc, ci), 0u);
+      if (anyface) {  // unconditional load from a valid address, then select
+        const size_t hidx = (size_t)(m < 2 ? jrow : icol) * tsx_pcs_halo_nzp(Nz) + k;  // [j][k] resp. [i][k]
+        const unsigned hv = *(face[m] ? hp[m] + hidx : zb);
         if (face[m]) o[m].x = hv;
-      } else {
-        o[m] = make_uint2(*(face[m] ? hp[m] + hidx : zb + idx), 0u);
       }
+      o[m].x = has ? o[m].x : 0u;
+      if (MODE == 2) o[m].y = has ? o[m].y : 0u;
     }
   };
   auto nbr_vals = [&](const uint2(&n)[4], float(&zx)[4], float(&zy)[4]) {
     float lo[4], hi[4];
-    const long long off[4] = {offE, offW, offN, offS};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const bool f32 = MODE == 2 && !face[m];
-      const float a = f32 ? __uint_as_float(n[m].x) : __uint_as_float(n[m].x << 16);
-      const float b = f32 ? __uint_as_float(n[m].y) : __uint_as_float(n[m].x & 0xffff0000u);
-      lo[m] = (off[m] || face[m]) ? a : 0.0f;  // select: the unused slot may hold NaN
-      hi[m] = (off[m] || face[m]) ? b : 0.0f;
+      lo[m] = f32 ? __uint_as_float(n[m].x) : __uint_as_float(n[m].x << 16);
+      hi[m] = f32 ? __uint_as_float(n[m].y) : __uint_as_float(n[m].x & 0xffff0000u);
     }
     zx[0] = lo[0]; zx[2] = hi[0]; zx[1] = lo[1]; zx[3] = hi[1];
     zy[0] = lo[2]; zy[2] = hi[2]; zy[1] = lo[3]; zy[3] = hi[3];
@@ -1134,7 +1168,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const float4 m = sS[s2][1 + a][cl];
-      o[a] += m.x * x[0] + m.y * x[1] + m.z * x[2] + m.w * x[3];
+      o[a] = __builtin_fmaf(m.w, x[3], __builtin_fmaf(m.z, x[2], __builtin_fmaf(m.y, x[1], __builtin_fmaf(m.x, x[0], o[a]))));
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) x[a] = o[a];
@@ -1145,7 +1179,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   // per level would halve the occupancy)
   float beta[LSEG][4], rdg[LSEG][4];
   uint2 nb[LSEG][4];
-  int eid[LSEG];
+  unsigned eid[LSEG];
   unsigned pr[LSEG];  // row of the level's recurrence records (the cell, or its entry of the shared table)
   {
     float Bl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1156,26 +1190,26 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       for (int b = 0; b < 4; ++b) Pc.m[a][b] = a == b ? 1.0f : 0.0f;
 #pragma unroll
     for (int l = LSEG - 1; l >= 0; --l) {
-      const size_t c = cell(l);
+      const unsigned c = cell(l);
       const bool act = l < nl;
-      eid[l] = IDX ? cidx[c] : 0;
-      pr[l] = (unsigned)prow(c);
-      const TsxM4 F = mat(2, pr[l], 0.0f);
+      eid[l] = IDX ? (unsigned)tsx_ldu(cidx, c) : 0u;
+      pr[l] = pidx ? (unsigned)tsx_ldu(pidx, c) : c;
+      const TsxH4 F = mat(2, pr[l]);
       float ru[4], rd[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         if (RQ == 2) {
-          const unsigned w = rb[(size_t)a * Nc + c];
+          const unsigned w = tsx_ldo(rb, (size_t)a * Nc, c);
           ru[a] = __uint_as_float(w << 16);
           rd[a] = __uint_as_float(w & 0xffff0000u);
         } else {
-          ru[a] = r[(size_t)(2 * a) * Nc + c];
-          rd[a] = r[(size_t)(2 * a + 1) * Nc + c];
-          if (RQ == 1 && live && act) rb[(size_t)a * Nc + c] = tsx_bf16x2(ru[a], rd[a]);
+          ru[a] = tsx_ldo(r, (size_t)(2 * a) * Nc, c);
+          rd[a] = tsx_ldo(r, (size_t)(2 * a + 1) * Nc, c);
+          if (RQ == 1 && live && act) tsx_sto(rb, (size_t)a * Nc, c, tsx_bf16x2(ru[a], rd[a]));
         }
       }
       if (GS) {
-        nbr_load(c, nb[l]);
+        nbr_load(level(l), c, nb[l]);
         float zx[4], zy[4];
         nbr_vals(nb[l], zx, zy);
         if (TSX_PCS_C16) {  // fp16: two top dsts per record; the y sources first, then the x sources (four records live at a time)
@@ -1185,10 +1219,11 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
               const tsx_h8 hh = __builtin_bit_cast(tsx_h8, brec(4 * ax + m, c, eid[l]));
-              const float e0 = (float)hh[0] * zz[0] + (float)hh[1] * zz[1] + (float)hh[2] * zz[2] + (float)hh[3] * zz[3];
-              const float e1 = (float)hh[4] * zz[0] + (float)hh[5] * zz[1] + (float)hh[6] * zz[2] + (float)hh[7] * zz[3];
-              ru[m] += e0;  // top dst t = 2 m (not inward: up), t = 2 m + 1 (down)
-              rd[m] += e1;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {  // top dst t = 2 m (not inward: up), t = 2 m + 1 (down)
+                ru[m] = __builtin_fmaf((float)hh[q], zz[q], ru[m]);
+                rd[m] = __builtin_fmaf((float)hh[4 + q], zz[q], rd[m]);
+              }
             }
           }
         } else {
@@ -1209,7 +1244,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       }
       float Fr[4];
       tsx_mv4(F, rd, Fr);
-      const TsxM4 E = mat(0, pr[l], 0.0f);
+      const TsxH4 E = mat(0, pr[l]);
       float EB[4];
       tsx_mv4(E, Bl, EB);
       const TsxM4 EP = tsx_mm4(E, Pc);
@@ -1227,7 +1262,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   __syncthreads();
   float Bin[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) Bin[a] = rt[(size_t)(2 * a) * ncol + col];  // B_Nz = ru_Nz
+  for (int a = 0; a < 4; ++a) Bin[a] = tsx_ldu(rt + (size_t)(2 * a) * ncol, col);  // B_Nz = ru_Nz
   for (int s2 = NSEG - 1; s2 > sg; --s2) chain(s2, Bin);
   // ---- phase 2: the true B of every level (re-run with the true inflow)
   float Bk[LSEG][4];
@@ -1235,7 +1270,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     float Bc[4] = {Bin[0], Bin[1], Bin[2], Bin[3]};
 #pragma unroll
     for (int l = LSEG - 1; l >= 0; --l) {
-      const TsxM4 E = mat(0, pr[l], 0.0f);
+      const TsxH4 E = mat(0, pr[l]);
       float EB[4];
       tsx_mv4(E, Bc, EB);
 #pragma unroll
@@ -1258,12 +1293,12 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
 #pragma unroll
     for (int l = 0; l < LSEG; ++l) {
       const bool act = l < nl;
-      const TsxM4 G = mat(4, pr[l], 1.0f), Hm = mat(6, pr[l], 0.0f);
-      const TsxM4 GT = mat(8, pr[l], 0.0f);
+      const TsxH4 G = mat(4, pr[l]), Hm = mat(6, pr[l]);  // (G stored minus the identity)
+      const TsxH4 GT = mat(8, pr[l]);
       float Bn[4], Gr[4], HB[4], GV[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) Bn[a] = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l][a] : Bin[a];
-      tsx_mv4(G, rdg[l], Gr);
+      tsx_mv4<true>(G, rdg[l], Gr);
       tsx_mv4(Hm, Bn, HB);
       tsx_mv4(GT, Vl, GV);
       const TsxM4 GQ = tsx_mm4(GT, Qc);
@@ -1280,18 +1315,18 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   __syncthreads();
   float V[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) V[a] = rt[(size_t)(2 * a + 1) * ncol + col];  // V_0 = rd_TOA
+  for (int a = 0; a < 4; ++a) V[a] = tsx_ldu(rt + (size_t)(2 * a + 1) * ncol, col);  // V_0 = rd_TOA
   if (sg == 0) {  // tail rows: the TOA identity rows and the side dummies at level Nz
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       if (MODE == 1 && live) zt[(size_t)(2 * a + 1) * ncol + col] = V[a];
-      if (FINAL) wpair_if(live, zfin + (size_t)D * Nc + (size_t)(2 * a + 1) * ncol + ncp, V[a], zt[(size_t)(2 * a + 1) * ncol + col + oc]);
+      if (FINAL) wpair_if(live, zfin + (size_t)D * Nc + (size_t)(2 * a + 1) * ncol, ncp, V[a], zt[(size_t)(2 * a + 1) * ncol + (size_t)((int)col + oc)]);
     }
 #pragma unroll
     for (int d = NTOP; d < D; ++d) {
       const float v = rt[(size_t)d * ncol + col];
       if (MODE == 1 && live) zt[(size_t)d * ncol + col] = v;
-      if (FINAL) wpair_if(live, zfin + (size_t)D * Nc + (size_t)d * ncol + ncp, v, zt[(size_t)d * ncol + col + oc]);
+      if (FINAL) wpair_if(live, zfin + (size_t)D * Nc + (size_t)d * ncol, ncp, v, zt[(size_t)d * ncol + (size_t)((int)col + oc)]);
     }
   }
   for (int s2 = 0; s2 < sg; ++s2) chain(s2, V);
@@ -1299,9 +1334,9 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
 #pragma unroll
   for (int l = 0; l < LSEG; ++l) {
     const bool st = live && l < nl;
-    const size_t c = cell(l);
-    const size_t cn = (size_t)(k0 + l < Nz ? k0 + l : Nz - 1) * ncol + ncp;
-    const TsxM4 GT = mat(8, pr[l], 0.0f), An = mat(10, pr[l], 0.0f);
+    const unsigned c = cell(l);
+    const unsigned cn = (unsigned)level(l) * ncol + ncp;
+    const TsxH4 GT = mat(8, pr[l]), An = mat(10, pr[l]);
     float Bn[4], GV[4], Vn[4], AV[4], Un[4], U[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) Bn[a] = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l][a] : Bin[a];
@@ -1312,7 +1347,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
 #pragma unroll
     for (int a = 0; a < 4; ++a) Un[a] = AV[a] + Bn[a];
     if (MODE != 0) {
-      const TsxM4 Ao = mat(12, pr[l], 0.0f);
+      const TsxH4 Ao = mat(12, pr[l]);
       float AoV[4];
       tsx_mv4(Ao, V, AoV);
 #pragma unroll
@@ -1322,19 +1357,19 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     float2 ps[4];
     if (FINAL) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) pt[q] = z[(size_t)q * Nc + c + oc];
+      for (int q = 0; q < 8; ++q) pt[q] = tsx_ldo(z, (size_t)q * Nc, (unsigned)((int)c + oc));
 #pragma unroll
-      for (int m2 = 0; m2 < 4; ++m2) ps[m2] = zr[(size_t)m2 * Nc + c + oc];
+      for (int m2 = 0; m2 < 4; ++m2) ps[m2] = tsx_ldo(zr, (size_t)m2 * Nc, (unsigned)((int)c + oc));
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       if (MODE == 1 && st) {
-        z[(size_t)(2 * a) * Nc + c] = U[a];
-        z[(size_t)(2 * a + 1) * Nc + c] = Vn[a];
+        tsx_sto(z, (size_t)(2 * a) * Nc, c, U[a]);
+        tsx_sto(z, (size_t)(2 * a + 1) * Nc, c, Vn[a]);
       }
       if (FINAL) {
-        wpair_if(st, zfin + (size_t)(2 * a) * Nc + cn, U[a], pt[2 * a]);
-        wpair_if(st, zfin + (size_t)(2 * a + 1) * Nc + cn, Vn[a], pt[2 * a + 1]);
+        wpair_if(st, zfin + (size_t)(2 * a) * Nc, cn, U[a], pt[2 * a]);
+        wpair_if(st, zfin + (size_t)(2 * a + 1) * Nc, cn, Vn[a], pt[2 * a + 1]);
       }
     }
     float zx[4], zy[4];
@@ -1352,60 +1387,60 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     if (RQ == 2) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const unsigned w = rb[(size_t)(4 + q) * Nc + c];
+        const unsigned w = tsx_ldo(rb, (size_t)(4 + q) * Nc, c);
         rs[2 * q] = __uint_as_float(w << 16);
         rs[2 * q + 1] = __uint_as_float(w & 0xffff0000u);
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) rs[q] = r[(size_t)(NTOP + q) * Nc + c];
+      for (int q = 0; q < 8; ++q) rs[q] = tsx_ldo(r, (size_t)(NTOP + q) * Nc, c);
       if (RQ == 1 && st) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rb[(size_t)(4 + q) * Nc + c] = tsx_bf16x2(rs[2 * q], rs[2 * q + 1]);
+        for (int q = 0; q < 4; ++q) tsx_sto(rb, (size_t)(4 + q) * Nc, c, tsx_bf16x2(rs[2 * q], rs[2 * q + 1]));
       }
     }
+    const tsx_f2 zy01 = {zy[0], zy[1]}, zy23 = {zy[2], zy[3]}, zx01 = {zx[0], zx[1]}, zx23 = {zx[2], zx[3]};
     float zo[8];
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd) {
       const tsx_h8 row = __builtin_bit_cast(tsx_h8, brec(4 + TSX_S16H_BO + dd, c, eid[l]));
-      float acc = 0.0f;
+      float acc = rs[dd];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) acc += (float)row[2 * a] * Un[a] + (float)row[2 * a + 1] * V[a];
-      if (GS) {
-        float cq[4], cp[4];
-        tsx_fp8x4(uy[dd], cq);
-        tsx_fp8x4(ux[dd], cp);
-        const float a8 = cq[0] * zy[0] + cq[1] * zy[1] + cq[2] * zy[2] + cq[3] * zy[3] + cp[0] * zx[0] + cp[1] * zx[1] +
-                         cp[2] * zx[2] + cp[3] * zx[3];
-        acc += a8 * (1.0f / TSX_FP8_SCALE);
+      for (int a = 0; a < 4; ++a) acc = __builtin_fmaf((float)row[2 * a + 1], V[a], __builtin_fmaf((float)row[2 * a], Un[a], acc));
+      if (GS) {  // packed fp32 FMAs on the pairs that v_cvt_pk_f32_fp8 delivers, as in tsx_k_pcs_rb
+        tsx_f2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)uy[dd], false) * zy01;
+        a2 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)uy[dd], true), zy23, a2);
+        a2 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)ux[dd], false), zx01, a2);
+        a2 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)ux[dd], true), zx23, a2);
+        acc = __builtin_fmaf(a2.x + a2.y, 1.0f / TSX_FP8_SCALE, acc);
       }
-      zo[dd] = rs[dd] + acc;
+      zo[dd] = acc;
     }
     // records by consumer: side dofs (8,10) (9,11) (12,14) (13,15) = zo[0,2] zo[1,3] zo[4,6] zo[5,7]
     if (MODE == 0 && st) {
-      zb[(size_t)0 * Nc + c] = tsx_bf16x2(zo[0], zo[2]);
-      zb[(size_t)1 * Nc + c] = tsx_bf16x2(zo[1], zo[3]);
-      zb[(size_t)2 * Nc + c] = tsx_bf16x2(zo[4], zo[6]);
-      zb[(size_t)3 * Nc + c] = tsx_bf16x2(zo[5], zo[7]);
+      tsx_sto(zb, (size_t)0 * Nc, c, tsx_bf16x2(zo[0], zo[2]));
+      tsx_sto(zb, (size_t)1 * Nc, c, tsx_bf16x2(zo[1], zo[3]));
+      tsx_sto(zb, (size_t)2 * Nc, c, tsx_bf16x2(zo[4], zo[6]));
+      tsx_sto(zb, (size_t)3 * Nc, c, tsx_bf16x2(zo[5], zo[7]));
     }
     if (MODE == 1 && st) {
-      zr[(size_t)0 * Nc + c] = make_float2(zo[0], zo[2]);
-      zr[(size_t)1 * Nc + c] = make_float2(zo[1], zo[3]);
-      zr[(size_t)2 * Nc + c] = make_float2(zo[4], zo[6]);
-      zr[(size_t)3 * Nc + c] = make_float2(zo[5], zo[7]);
+      tsx_sto(zr, (size_t)0 * Nc, c, make_float2(zo[0], zo[2]));
+      tsx_sto(zr, (size_t)1 * Nc, c, make_float2(zo[1], zo[3]));
+      tsx_sto(zr, (size_t)2 * Nc, c, make_float2(zo[4], zo[6]));
+      tsx_sto(zr, (size_t)3 * Nc, c, make_float2(zo[5], zo[7]));
     }
     if (FINAL) {
       const int dofs[8] = {8, 10, 9, 11, 12, 14, 13, 15};
       const float mine[8] = {zo[0], zo[2], zo[1], zo[3], zo[4], zo[6], zo[5], zo[7]};
       const float part[8] = {ps[0].x, ps[0].y, ps[1].x, ps[1].y, ps[2].x, ps[2].y, ps[3].x, ps[3].y};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) wpair_if(st, zfin + (size_t)dofs[q] * Nc + cn, mine[q], part[q]);
+      for (int q = 0; q < 8; ++q) wpair_if(st, zfin + (size_t)dofs[q] * Nc, cn, mine[q], part[q]);
     }
     if (k0 + l == Nz - 1) {  // U_Nz = (albedo / streams) sum V_Nz + ru_Nz: the surface rows
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         if (MODE == 1 && live) zt[(size_t)(2 * a) * ncol + col] = Un[a];
-        if (FINAL) wpair_if(live, zfin + (size_t)D * Nc + (size_t)(2 * a) * ncol + ncp, Un[a], zt[(size_t)(2 * a) * ncol + col + oc]);
+        if (FINAL) wpair_if(live, zfin + (size_t)D * Nc + (size_t)(2 * a) * ncol, ncp, Un[a], zt[(size_t)(2 * a) * ncol + (size_t)((int)col + oc)]);
       }
     }
 #pragma unroll
