@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtsx.so")
+# TSX_LIB: another build of the library (A/B scripts: scripts/ab_lib.sh); the default is the in-tree one
+LIB_PATH = os.environ.get("TSX_LIB") or os.path.join(_HERE, "lib", "libtsx.so")
 
 TSX_HOST, TSX_DEVICE = 0, 1
 TSX_SOLVER_3_10, TSX_SOLVER_8_16 = 310, 816

@@ -1055,6 +1055,12 @@ __device__ __forceinline__ TsxM4 tsx_mm4(const TsxH4 &X, const TsxM4 &Y) {
   return O;
 }
 
+#ifndef TSX_PCSH_KEEP_E
+#define TSX_PCSH_KEEP_E 1  // E of a thread's levels stays in registers between the two upward phases (0: loaded again)
+#endif
+#ifndef TSX_PCSH_KEEP_GT
+#define TSX_PCSH_KEEP_GT 1  // likewise GT between the two downward phases
+#endif
 #ifndef TSX_PCSH_WAVES
 #define TSX_PCSH_WAVES 2
 #endif
@@ -1181,6 +1187,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   uint2 nb[LSEG][4];
   unsigned eid[LSEG];
   unsigned pr[LSEG];  // row of the level's recurrence records (the cell, or its entry of the shared table)
+  TsxH4 Ekeep[TSX_PCSH_KEEP_E ? LSEG : 1];  // E of the levels, held for the re-run of phase 2 (8 registers per level as fp16)
   {
     float Bl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     TsxM4 Pc;
@@ -1245,6 +1252,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       float Fr[4];
       tsx_mv4(F, rd, Fr);
       const TsxH4 E = mat(0, pr[l]);
+      if (TSX_PCSH_KEEP_E) Ekeep[l] = E;
       float EB[4];
       tsx_mv4(E, Bl, EB);
       const TsxM4 EP = tsx_mm4(E, Pc);
@@ -1270,7 +1278,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     float Bc[4] = {Bin[0], Bin[1], Bin[2], Bin[3]};
 #pragma unroll
     for (int l = LSEG - 1; l >= 0; --l) {
-      const TsxH4 E = mat(0, pr[l]);
+      const TsxH4 E = TSX_PCSH_KEEP_E ? Ekeep[l] : mat(0, pr[l]);
       float EB[4];
       tsx_mv4(E, Bc, EB);
 #pragma unroll
@@ -1283,6 +1291,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   __syncthreads();  // everybody has read the upward summaries: the buffer is free for the downward ones
   // ---- phase 3: local downward scan with zero inflow; keeps gamma and GT of its levels
   float gam[LSEG][4];
+  TsxH4 GTkeep[TSX_PCSH_KEEP_GT ? LSEG : 1];
   {
     float Vl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     TsxM4 Qc;
@@ -1295,6 +1304,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       const bool act = l < nl;
       const TsxH4 G = mat(4, pr[l]), Hm = mat(6, pr[l]);  // (G stored minus the identity)
       const TsxH4 GT = mat(8, pr[l]);
+      if (TSX_PCSH_KEEP_GT) GTkeep[l] = GT;
       float Bn[4], Gr[4], HB[4], GV[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) Bn[a] = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l][a] : Bin[a];
@@ -1336,7 +1346,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     const bool st = live && l < nl;
     const unsigned c = cell(l);
     const unsigned cn = (unsigned)level(l) * ncol + ncp;
-    const TsxH4 GT = mat(8, pr[l]), An = mat(10, pr[l]);
+    const TsxH4 GT = TSX_PCSH_KEEP_GT ? GTkeep[l] : mat(8, pr[l]), An = mat(10, pr[l]);
     float Bn[4], GV[4], Vn[4], AV[4], Un[4], U[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) Bn[a] = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l][a] : Bin[a];
