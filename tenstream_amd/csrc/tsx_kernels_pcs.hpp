@@ -413,6 +413,9 @@ __device__ __forceinline__ bool tsx_pcs_on_frame(const TsxGeo &g, int jrow, int 
 // intermediate pass (right-hand side words, neighbour records, stored records) onto the first 2^n cells of their planes, so that they
 // are served by L2 and what remains of the pass's time is its table gathers and arithmetic; -DTSX_PCS_FOLD_IDX wraps the record
 // index too (the gathers then hit L1).  The results are meaningless.
+#ifndef TSX_PCS_STAGED
+#define TSX_PCS_STAGED 0  // 1: the staged order of phase 1's loads for every layout (A/B builds)
+#endif
 #ifdef TSX_PCS_FOLD
 #define TSX_FOLDC(x) ((size_t)(x) & (size_t)(TSX_PCS_FOLD - 1))
 #else
@@ -518,8 +521,8 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const unsigned ci = (unsigned)((int)c + off[m]);
-      if (MODE == 2) o[m] = tsx_ldu(reinterpret_cast<const uint2 *>(zr) + (size_t)m * Nc, ci);
-      else o[m] = make_uint2(tsx_ldu(zb + (size_t)m * Nc, (unsigned)TSX_FOLDC(ci)), 0u);
+      if (MODE == 2) o[m] = tsx_ldo(reinterpret_cast<const uint2 *>(zr), (size_t)m * Nc, ci);
+      else o[m] = make_uint2(tsx_ldo(zb, (size_t)m * Nc, (unsigned)TSX_FOLDC(ci)), 0u);
     }
   };
   auto nbr_halo = [&](int k, unsigned (&hv)[4]) {  // unconditional loads from valid addresses
@@ -561,7 +564,8 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   // group g = 1..7 of the layout: per cell P[g * Nc + cell]; per block PE[(g - 1) * nent + id], or with C16 PE[g * nent + id]
   // (slots 0 and 1 hold record 1's two fp16 halves)
   auto rec = [&](int grp, unsigned c, unsigned ei) {
-    return IDX ? tsx_ldu(PE + (size_t)(C16 ? grp : grp - 1) * pe_ss, ei) : tsx_ldu(P + (size_t)grp * Nc, c);
+    const int slot = C16 ? grp : grp - 1;  // planes in fours per descriptor, the plane within the four as scalar offset
+    return IDX ? tsx_ldo(PE + (size_t)(slot & ~3) * pe_ss, (size_t)(slot & 3) * pe_ss, ei) : tsx_ldo(P + (size_t)(grp & ~3) * Nc, (size_t)(grp & 3) * Nc, c);
   };
   // four side -> top couplings as floats: fp8 word w, or the fp16 pair of words (a, b)
   auto dec4 = [&](unsigned w, unsigned a, unsigned b, float (&o)[4]) {
@@ -575,6 +579,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   // The loads are written stage by stage over the levels (indices -> independent words -> records behind the indices), with
   // the wave-uniform decisions outside the loops: a branch per level fences the levels' loads off from each other, and a
   // wave walks the chain index -> record -> block records four times in a row (it did: 33.4 us per pass against 30.1 us)
+  if (TSX_PCS_STAGED || pe_si == 1) {
   unsigned pi[LSEG];
   if (IDX && MODE == 0) {
     if (pidx) {
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       rd[l] = __uint_as_float(w & 0xffff0000u);
     } else {
       ru[l] = tsx_ldu(r, c);
-      rd[l] = tsx_ldu(r + Nc, c);
+      rd[l] = tsx_ldo(r, Nc, c);
     }
     if (GS) nbr_load(c, nb[l]);
   }
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       for (int l = 0; l < LSEG; ++l) r0[l] = tsx_ldu(PT, pi[l]);
     } else {
 #pragma unroll
-      for (int l = 0; l < LSEG; ++l) r0[l] = tsx_ldu(P + (size_t)7 * Nc, cell(l));
+      for (int l = 0; l < LSEG; ++l) r0[l] = tsx_ldo(P + (size_t)4 * Nc, (size_t)3 * Nc, cell(l));
     }
 #pragma unroll
     for (int l = 0; l < LSEG; ++l) eid[l] = r0[l].w * (unsigned)pe_si;
@@ -620,8 +625,8 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     for (int l = 0; l < LSEG; ++l) {
       const unsigned c = cell(l);
       if (C16) {
-        r1[l] = IDX ? tsx_ldu(PE, eid[l]) : tsx_ldu(P + (size_t)1 * Nc, c);
-        r1x[l] = IDX ? tsx_ldu(PE + pe_ss, eid[l]) : tsx_ldu(P + (size_t)8 * Nc, c);
+        r1[l] = IDX ? tsx_ldu(PE, eid[l]) : tsx_ldo(P, Nc, c);
+        r1x[l] = IDX ? tsx_ldo(PE, pe_ss, eid[l]) : tsx_ldu(P + (size_t)8 * Nc, c);
       } else {
         r1[l] = rec(1, c, eid[l]);
       }
@@ -637,6 +642,40 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       const unsigned none[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int l = 0; l < LSEG; ++l) nbr_select(nb[l], none, false);
+    }
+  }
+  } else {
+    // entry-major per-block records (every lane another entry: the gathers of one level already occupy the L1): level by level
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) {
+      const unsigned c = cell(l);
+      if (IDX && MODE == 0) {
+        r0[l] = pidx ? tsx_ldu(PT, (unsigned)tsx_ldu(pidx, (unsigned)TSX_FOLDI(c))) : tsx_ldo(P + (size_t)4 * Nc, (size_t)3 * Nc, c);
+        eid[l] = r0[l].w * (unsigned)pe_si;
+      } else {
+        eid[l] = IDX ? (unsigned)tsx_ldu(cidx, c) * (unsigned)pe_si : 0u;
+        r0[l] = tsx_ldu(P, c);
+      }
+      if (RQ == 2) {
+        const unsigned w = tsx_ldu(rb, (unsigned)TSX_FOLDC(c));
+        ru[l] = __uint_as_float(w << 16);
+        rd[l] = __uint_as_float(w & 0xffff0000u);
+      } else {
+        ru[l] = tsx_ldu(r, c);
+        rd[l] = tsx_ldo(r, Nc, c);
+      }
+      if (GS) {
+        if (C16) {
+          r1[l] = IDX ? tsx_ldu(PE, eid[l]) : tsx_ldo(P, Nc, c);
+          r1x[l] = IDX ? tsx_ldo(PE, pe_ss, eid[l]) : tsx_ldu(P + (size_t)8 * Nc, c);
+        } else {
+          r1[l] = rec(1, c, eid[l]);
+        }
+        nbr_load(c, nb[l]);
+        unsigned hv[4] = {0u, 0u, 0u, 0u};
+        if (anyface) nbr_halo(level(l), hv);
+        nbr_select(nb[l], hv, anyface);
+      }
     }
   }
   if (RQ == 1) {
@@ -749,16 +788,16 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     if (RQ == 2) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const unsigned w = tsx_ldu(rb + (size_t)(1 + q) * Nc, (unsigned)TSX_FOLDC(c));
+        const unsigned w = tsx_ldo(rb, (size_t)(1 + q) * Nc, (unsigned)TSX_FOLDC(c));
         rs[2 * q] = __uint_as_float(w << 16);
         rs[2 * q + 1] = __uint_as_float(w & 0xffff0000u);
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) rs[q] = tsx_ldu(r + (size_t)(NTOP + q) * Nc, c);
+      for (int q = 0; q < 8; ++q) rs[q] = tsx_ldo(r, (size_t)(NTOP + q) * Nc, c);
       if (RQ == 1 && st) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tsx_stu(rb + (size_t)(1 + q) * Nc, c, tsx_bf16x2(rs[2 * q], rs[2 * q + 1]));
+        for (int q = 0; q < 4; ++q) tsx_sto(rb, (size_t)(1 + q) * Nc, c, tsx_bf16x2(rs[2 * q], rs[2 * q + 1]));
       }
     }
     float pt[2];
@@ -766,9 +805,9 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     if (FINAL) {
       const unsigned co = (unsigned)((int)c + oc);
       pt[0] = tsx_ldu(z, co);
-      pt[1] = tsx_ldu(z + Nc, co);
+      pt[1] = tsx_ldo(z, Nc, co);
 #pragma unroll
-      for (int m2 = 0; m2 < 4; ++m2) ps[m2] = tsx_ldu(zr + (size_t)m2 * Nc, co);
+      for (int m2 = 0; m2 < 4; ++m2) ps[m2] = tsx_ldo(zr, (size_t)m2 * Nc, co);
     }
     const float Bn = l + 1 < LSEG ? Bk[l + 1] : Bin;
     const float Vn = Vloc[l] + Qcum[l] * Vin;
@@ -776,7 +815,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     const float U = (float)m[6] * V + Bk[l];
     if (MODE == 1 && st) {
       tsx_stu(z, c, U);
-      tsx_stu(z + Nc, c, Vn);
+      tsx_sto(z, Nc, c, Vn);
     }
     if (FINAL) {
       wpair2(zfin, U, pt[0]);
@@ -805,10 +844,10 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     }
     // records: (2,4) (3,5) (6,8) (7,9)  = zo[0,2] zo[1,3] zo[4,6] zo[5,7]
     if (MODE == 0 && st) {
-      tsx_stu(zb + (size_t)0 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[0], zo[2]));
-      tsx_stu(zb + (size_t)1 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[1], zo[3]));
-      tsx_stu(zb + (size_t)2 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[4], zo[6]));
-      tsx_stu(zb + (size_t)3 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[5], zo[7]));
+      tsx_sto(zb, (size_t)0 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[0], zo[2]));
+      tsx_sto(zb, (size_t)1 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[1], zo[3]));
+      tsx_sto(zb, (size_t)2 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[4], zo[6]));
+      tsx_sto(zb, (size_t)3 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[5], zo[7]));
     }
     if constexpr (PEER && CW < 32) {
       // small passes (16-column workgroups: at most one workgroup per CU's worth of columns, latency-bound, registers to spare):
@@ -822,10 +861,10 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       }
     }
     if (MODE == 1 && st) {
-      tsx_stu(zr + (size_t)0 * Nc, c, make_float2(zo[0], zo[2]));
-      tsx_stu(zr + (size_t)1 * Nc, c, make_float2(zo[1], zo[3]));
-      tsx_stu(zr + (size_t)2 * Nc, c, make_float2(zo[4], zo[6]));
-      tsx_stu(zr + (size_t)3 * Nc, c, make_float2(zo[5], zo[7]));
+      tsx_sto(zr, (size_t)0 * Nc, c, make_float2(zo[0], zo[2]));
+      tsx_sto(zr, (size_t)1 * Nc, c, make_float2(zo[1], zo[3]));
+      tsx_sto(zr, (size_t)2 * Nc, c, make_float2(zo[4], zo[6]));
+      tsx_sto(zr, (size_t)3 * Nc, c, make_float2(zo[5], zo[7]));
     }
     if (FINAL) {
       wpair2(zfin + (size_t)2 * Nc, zo[0], ps[0].x);
