@@ -11,6 +11,7 @@ T = {t: json.load(open(P(f"{t}_traffic.json"))) for t in L}
 b = L["bench"]; c = b["config"]
 ns, fp, het, cb = c["no_sharing"], c["all_fp64"], c["heterogeneous"], b["cpu_baseline"]
 s4, s1 = json.load(open(P("config4_specint_252gpoints.json"))), json.load(open(P("config4_specint_252gpoints_one_instance.json")))
+cb4 = s4.get('cpu_baseline') or s1.get('cpu_baseline')
 c3p, c3h = json.load(open(P("config3_8ranks_one_device_peer_line.json"))), json.load(open(P("config3_8ranks_one_device_host_line.json")))
 
 
@@ -27,6 +28,13 @@ def row(t):
             f"{T[t]['iteration']['traffic_bytes'] / 1e9:.2f} GB of traffic")
 
 
+import re
+sh = {}
+for line in open(P("shard_study.txt")):
+    m = re.match(r"(\d+x\d+)x\d+ (\w+)\s+wall\s+([\d.]+) ms", line)
+    if m:
+        sh[(m.group(1), m.group(2))] = float(m.group(3))
+shard = "; ".join(f"{k.replace('x', ' × ')} columns wrap {sh[(k, 'wrap')]:.2f} ms, peer {sh[(k, 'peer')]:.2f} ms" for k in ("128x64", "128x128", "256x256") if (k, "wrap") in sh)
 txt = f"""# profiles/{rnd} — round-4 rocprofv3 summaries (one MI355X, gfx950)
 
 Collected by `ROUND={rnd} bash scripts/profile_round.sh <tag> [bench.py arguments]` on the GPU box (`cd /tmp && export TMPDIR=/tmp`, the program
@@ -45,13 +53,16 @@ csv -- python3 bench.py --no-cpu-baseline --skip-no-sharing --skip-extra-legs --
 | `heterogeneous` | `--field heterogeneous` | {row('heterogeneous')} (per-block records entry-major for the near-identical grouping) |
 | `config2` | `--nx 128 --ny 128` | {row('config2')} |
 | `config5` | `--solver 8_16` | {row('config5')} |
-| `config4_specint_252gpoints.json`, `…_one_instance.json` | `python3 bench_specint.py`, `--streams 1` | 252 g-points warm: **{s4['value']:.1f} g-points/s** with four instances in flight, **{s1['value']:.1f}** with one (cold call {s4['config']['calls'][0]['gpoints_per_s']:.1f} / {s1['config']['calls'][0]['gpoints_per_s']:.1f}; box to box 118–125 / 135–136); LW half with `planck_srfc`; `cpu_baseline`: the oracle's port of the reference's CPU path on ONE g-point's diffuse system, {s1['cpu_baseline']['value']:.2f} g-points/s on {s1['cpu_baseline']['cores']} threads (solve only) |
+| `config4_specint_252gpoints.json`, `…_one_instance.json` | `python3 bench_specint.py`, `--streams 1` | 252 g-points warm: **{s4['value']:.1f} g-points/s** with four instances in flight, **{s1['value']:.1f}** with one (cold call {s4['config']['calls'][0]['gpoints_per_s']:.1f} / {s1['config']['calls'][0]['gpoints_per_s']:.1f}; box to box 124–126 / 135–142); LW half with `planck_srfc`; `cpu_baseline`: the oracle's port of the reference's CPU path on ONE g-point's diffuse system, {cb4['value']:.2f} g-points/s on {cb4['cores']} threads (solve only) |
 | `config3_8ranks_one_device_{{peer,host}}_line.json` | `python3 bench.py --gpus 8 --global-nx 512 --global-ny 512 --transport peer \\| host` | configs[2] at its own size with the 8 rank processes sharing the box's one GPU (first half of the round, 22 passes): {c3p['ms_per_step'] / 1e3:.1f} s / {c3h['ms_per_step'] / 1e3:.1f} s per step, {c3p['config']['iterations']} iterations on both (8 processes time-slice the device; the peer kernels spin on mailboxes of ranks that are not scheduled): functional evidence for `tests/test_gpu_config3.py`, not a rate |
 
-`sweeps_grid.txt` (`python scripts/sweeps_grid.py`): iterations, final residual and time per solve for 20 … 32 passes per `M⁻¹` on ten workloads — why 28
-is the default. `shard_study.txt` (`python scripts/shard_study.py xm ym`, modes in `profiles/r03/README.md`): 128 × 64 columns wrap 3.37 ms, peer 4.84 ms
-(round 3: 3.53 / 5.30); 128 × 128: 4.54 / 6.69; 256 × 256: 13.1 / 16.9 ms. `shard_128x64_wrap_kernel_stats.csv`: kernel trace of the periodic
-128 × 64 × 64 shard at 22 passes (intermediate pass 10.9 µs, 59 % of the solve).
+`sweeps_grid.txt` (`python scripts/sweeps_grid.py`, first half of the round): iterations, final residual and time per solve for 20 … 32 passes per `M⁻¹`
+on ten workloads — why 28 is the default. `shard_study.txt` (`python scripts/shard_study.py xm ym`, modes in `profiles/r03/README.md`): {shard}
+(round 3: 3.53 / 5.30 ms at 128 × 64). `shard_128x64_wrap_kernel_stats.csv`: kernel trace of the periodic 128 × 64 × 64 shard at 22 passes, before the
+pass kernels were rewritten (intermediate pass 10.9 µs, 59 % of the solve). `pass_pmc_3_10.txt` (`bash scripts/pass_pmc.sh`): SQ / TA / TCP / TCC counters
+of the intermediate 3_10 pass on the metric domain, one `--pmc` run per set, whole-device sums per launch: 944 vector instructions per wave, `VALUBusy`
+31 %, the texture addresser busy 60–68 % of the kernel (`TA_BUSY_avr` / `SQ_BUSY_CYCLES` per unit), waves waiting on memory 55 % of their cycles — what
+DESIGN §4 "what bounds a pass" quotes.
 """
 open(P("README.md"), "w").write(txt)
 print(txt)
