@@ -254,7 +254,7 @@ __device__ __forceinline__ unsigned tsx_bf16x2(float lo, float hi) {
 // (`buffer_load_dword v, v_off, s[rsrc:rsrc+3], 0 offen`).  The base lives in scalar registers and the byte offset is formed in
 // 32 bits, so an access costs no vector instruction of address arithmetic -- with plain pointers an intermediate pass of
 // tsx_k_pcs_rb spent one v_lshl_add_u64 per load and store (140 of its 1770 vector instructions), and the pass is bound by its
-// vector instructions (scripts/fold_probe.sh).  Needs i * sizeof(T) < 2^32, which pcs_config checks (Nc < 2^28).  The
+// vector instructions (scripts/fold_probe.sh).  Needs i * sizeof(T) < 2^32, which pcs_config checks (Nc < 2^26).  The
 // descriptor: stride 0, no range limit, gfx9 dword 3 (data format 32).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tsx_rsrc(const void *base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
@@ -268,7 +268,7 @@ __device__ __forceinline__ T tsx_ldu(const T *base, unsigned i) {
   else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(tsx_rsrc(base), off, 0, 0));
 }
 // the same with a wave-uniform plane offset of `plane` elements carried in the instruction's scalar offset: planes of one array
-// share one descriptor (four scalar registers each -- tsx_k_pcsh_rb walks 50 planes).  Needs plane * sizeof(T) < 2^32.
+// share one descriptor (four scalar registers each -- tsx_k_pcsh_rb walks 50 planes).  Needs plane * sizeof(T) < 2^32 (pcs_config).
 template <typename T>
 __device__ __forceinline__ T tsx_ldo(const T *base, size_t plane, unsigned i) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "dword, dwordx2 or dwordx4");

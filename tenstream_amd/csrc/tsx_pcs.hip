@@ -17,7 +17,9 @@ static const int k_pairs[][2] = {{4, 16}, {8, 8}, {8, 16}, {16, 16}};
 static PcsCfg pcs_config(const tsx_solver *s) {
   const TsxGeo &g = s->geo;
   PcsCfg c = {0, 0, 0};
-  if (g.Nc >= (1ll << 28)) return c;  // the scan kernels address their planes with 32-bit lane offsets of 16-byte records (tsx_ldu)
+  // the scan kernels address their planes through buffer descriptors: 32-bit lane offsets of 16-byte records (tsx_ldu) and
+  // 32-bit scalar offsets of up to fifteen 4-byte planes / three 16-byte planes (tsx_ldo)
+  if (g.Nc >= (1ll << 26)) return c;
   int e_l = 0, e_s = 0, e_cw = 0;  // TSX_PCS_CFG=lseg,nseg,cw (A/B knob; read per call so that tests can switch it)
   if (const char *e = getenv("TSX_PCS_CFG")) sscanf(e, "%d,%d,%d", &e_l, &e_s, &e_cw);
   if (e_l > 0 && e_l * e_s >= g.Nz) {
