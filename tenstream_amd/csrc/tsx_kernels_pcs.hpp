@@ -413,6 +413,9 @@ __device__ __forceinline__ bool tsx_pcs_on_frame(const TsxGeo &g, int jrow, int 
 // intermediate pass (right-hand side words, neighbour records, stored records) onto the first 2^n cells of their planes, so that they
 // are served by L2 and what remains of the pass's time is its table gathers and arithmetic; -DTSX_PCS_FOLD_IDX wraps the record
 // index too (the gathers then hit L1).  The results are meaningless.
+#ifndef TSX_PCS_PROBE
+#define TSX_PCS_PROBE 0  // analysis builds (scripts/pass_parts.sh): bit 0 no side-stream right-hand side loads in phase 3, 1 no stores of
+#endif                   // the intermediate passes, 2 no neighbour loads, 3 every lane the block entry 0, 4 every lane record 0 of PT, 5 one store per thread
 #ifndef TSX_PCS_STAGED
 #define TSX_PCS_STAGED 0  // 1: the staged order of phase 1's loads for every layout (A/B builds)
 #endif
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     for (int m = 0; m < 4; ++m) {
       const unsigned ci = (unsigned)((int)c + off[m]);
       if (MODE == 2) o[m] = tsx_ldo(reinterpret_cast<const uint2 *>(zr), (size_t)m * Nc, ci);
-      else o[m] = make_uint2(tsx_ldo(zb, (size_t)m * Nc, (unsigned)TSX_FOLDC(ci)), 0u);
+      else o[m] = make_uint2((TSX_PCS_PROBE & 4) ? 0x3f803f80u : tsx_ldo(zb, (size_t)m * Nc, (unsigned)TSX_FOLDC(ci)), 0u);
     }
   };
   auto nbr_halo = [&](int k, unsigned (&hv)[4]) {  // unconditional loads from valid addresses
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   if (IDX && MODE == 0) {
     if (pidx) {
 #pragma unroll
-      for (int l = 0; l < LSEG; ++l) pi[l] = (unsigned)tsx_ldu(pidx, (unsigned)TSX_FOLDI(cell(l)));
+      for (int l = 0; l < LSEG; ++l) pi[l] = (TSX_PCS_PROBE & 16) ? 0u : (unsigned)tsx_ldu(pidx, (unsigned)TSX_FOLDI(cell(l)));
     }
   } else if (IDX) {
 #pragma unroll
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       for (int l = 0; l < LSEG; ++l) r0[l] = tsx_ldo(P + (size_t)4 * Nc, (size_t)3 * Nc, cell(l));
     }
 #pragma unroll
-    for (int l = 0; l < LSEG; ++l) eid[l] = r0[l].w * (unsigned)pe_si;
+    for (int l = 0; l < LSEG; ++l) eid[l] = (TSX_PCS_PROBE & 8) ? 0u : r0[l].w * (unsigned)pe_si;
   } else {
 #pragma unroll
     for (int l = 0; l < LSEG; ++l) {
@@ -766,6 +769,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   // top of the kernel straight into LDS (`buffer_load_dword ... lds`): 30.1 -> 32.7 us -- the pass is bound by the texture
   // addresser's cycles (TA busy 65-74 %, scripts/pass_pmc.sh), not by the latency of this chain, and each DMA is one more
   // vector-memory instruction)
+  float probe_acc = 0.0f;
   float V = Vin;
 #pragma unroll
   for (int l = 0; l < LSEG; ++l) {
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     if (RQ == 2) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const unsigned w = tsx_ldo(rb, (size_t)(1 + q) * Nc, (unsigned)TSX_FOLDC(c));
+        const unsigned w = (TSX_PCS_PROBE & 1) ? 0x3f803f80u : tsx_ldo(rb, (size_t)(1 + q) * Nc, (unsigned)TSX_FOLDC(c));
         rs[2 * q] = __uint_as_float(w << 16);
         rs[2 * q + 1] = __uint_as_float(w & 0xffff0000u);
       }
@@ -843,7 +847,11 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       zo[dd] = rs[dd] + acc;
     }
     // records: (2,4) (3,5) (6,8) (7,9)  = zo[0,2] zo[1,3] zo[4,6] zo[5,7]
-    if (MODE == 0 && st) {
+    if (MODE == 0 && (TSX_PCS_PROBE & 32)) {  // one store per thread instead of four per level: what the stores cost
+      probe_acc += zo[0] + zo[1] + zo[2] + zo[3] + zo[4] + zo[5] + zo[6] + zo[7];
+      if (l == LSEG - 1 && st) tsx_sto(zb, (size_t)0, (unsigned)TSX_FOLDC(c), __float_as_uint(probe_acc));
+    } else
+    if (MODE == 0 && st && !(TSX_PCS_PROBE & 2)) {
       tsx_sto(zb, (size_t)0 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[0], zo[2]));
       tsx_sto(zb, (size_t)1 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[1], zo[3]));
       tsx_sto(zb, (size_t)2 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[4], zo[6]));
