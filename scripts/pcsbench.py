@@ -6,7 +6,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from tenstream_amd import DiffuseSolver, synthetic as S, lut as LUT
 Nx = Ny = int(os.environ.get("NX", 256)); Nz = int(os.environ.get("NZ", 64))
 dev = torch.device("cuda", 0)
-kabs, ksca, g = S.cloud_field(Nx, Ny, Nz); kabs, ksca, g = S.delta_scale(kabs, ksca, g)
+kabs, ksca, g = S.cloud_field(Nx, Ny, Nz, heterogeneous=os.environ.get("FIELD", "clouds") == "heterogeneous"); kabs, ksca, g = S.delta_scale(kabs, ksca, g)
 alb = np.full((Ny, Nx), 0.1)
 b = torch.tensor(S.solar_source("3_10", kabs, ksca, g, 50.0, 100.0, alb), device=dev)
 t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)

@@ -416,6 +416,9 @@ __device__ __forceinline__ bool tsx_pcs_on_frame(const TsxGeo &g, int jrow, int 
 #ifndef TSX_PCS_PROBE
 #define TSX_PCS_PROBE 0  // analysis builds (scripts/pass_parts.sh): bit 0 no side-stream right-hand side loads in phase 3, 1 no stores of
 #endif                   // the intermediate passes, 2 no neighbour loads, 3 every lane the block entry 0, 4 every lane record 0 of PT, 5 one store per thread
+#ifndef TSX_PCS_COOP
+#define TSX_PCS_COOP 1  // 0: entry-major per-block records gathered lane by lane also in phase 3 (A/B builds)
+#endif
 #ifndef TSX_PCS_STAGED
 #define TSX_PCS_STAGED 0  // 1: the staged order of phase 1's loads for every layout (A/B builds)
 #endif
@@ -448,6 +451,13 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   constexpr bool FINAL = MODE == 2;
   constexpr float CSC1 = C16 ? 1.0f : 1.0f / TSX_FP8_SCALE;  // the fp8 couplings are stored times TSX_FP8_SCALE
   __shared__ float2 sB[NSEG][CW], sV[NSEG][CW];
+  // COOP (entry-major per-block records, pe_si = 8: every lane another 128-byte entry -- the near-identical grouping of a field
+  // without identical blocks): the six records of phase 3 are fetched by groups of eight lanes, lane j of a group the record 2 + j
+  // of the entry of the group's t-th lane, t = 0..7 -- an instruction touches 8 lines instead of 64 (the texture addresser is
+  // 80 % busy there, one tag look-up per lane and gather) -- and handed to their lanes through LDS (rows of 7 records: no bank
+  // conflicts on the way out).  One wave's rows are private to it: LDS executes a wave's instructions in order, no barrier.
+  constexpr bool COOP = TSX_PCS_COOP && IDX && C16 && GS && MODE == 0 && !PEER && (CW == 32 || CW == 16) && (CW * NSEG) % 64 == 0;
+  __shared__ uint4 sE[COOP ? CW * NSEG / 64 : 1][COOP ? 64 * 7 : 1];
   if (done && *done) return;
   // Lane offsets are 32-bit (tsx_ldu / tsx_stu), plane bases 64-bit and wave-uniform.
   const int h = g.xm >> 1;
@@ -780,13 +790,37 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       if (st) tsx_stu(reinterpret_cast<float2 *>(base), cn >> 1, par ? make_float2(partner, mine) : make_float2(mine, partner));
     };
     const tsx_h8 m = __builtin_bit_cast(tsx_h8, r0[l]);
-    const uint4 wcu = rec(2, c, eid[l]), wcv = rec(3, c, eid[l]);
-    uint4 wy[2], wx[2];
-    if (GS) {
-      wy[0] = rec(4, c, eid[l]);
-      wy[1] = rec(5, c, eid[l]);
-      wx[0] = rec(6, c, eid[l]);
-      wx[1] = rec(7, c, eid[l]);
+    uint4 wcu, wcv, wy[2], wx[2];
+    if (COOP && pe_si == TSX_PCS_ENT16_SLOTS) {
+      const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6), g8 = lane & 56, j = lane & 7;
+      const unsigned jj = (unsigned)(j < 6 ? j : 5);  // (lanes 6 and 7 of a group repeat record 7: no branch around the loads)
+      uint4 got[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const unsigned et = (unsigned)__builtin_amdgcn_ds_bpermute((g8 + t) << 2, (int)eid[l]);
+        got[t] = tsx_ldu(PE + 2, et + jj);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (j < 6) sE[wv][(g8 + t) * 7 + j] = got[t];
+      __builtin_amdgcn_wave_barrier();
+      wcu = sE[wv][lane * 7 + 0];
+      wcv = sE[wv][lane * 7 + 1];
+      wy[0] = sE[wv][lane * 7 + 2];
+      wy[1] = sE[wv][lane * 7 + 3];
+      wx[0] = sE[wv][lane * 7 + 4];
+      wx[1] = sE[wv][lane * 7 + 5];
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      wcu = rec(2, c, eid[l]);
+      wcv = rec(3, c, eid[l]);
+      if (GS) {
+        wy[0] = rec(4, c, eid[l]);
+        wy[1] = rec(5, c, eid[l]);
+        wx[0] = rec(6, c, eid[l]);
+        wx[1] = rec(7, c, eid[l]);
+      }
     }
     float rs[8];
     if (RQ == 2) {
