@@ -456,7 +456,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   // of the entry of the group's t-th lane, t = 0..7 -- an instruction touches 8 lines instead of 64 (the texture addresser is
   // 80 % busy there, one tag look-up per lane and gather) -- and handed to their lanes through LDS (rows of 7 records: no bank
   // conflicts on the way out).  One wave's rows are private to it: LDS executes a wave's instructions in order, no barrier.
-  constexpr bool COOP = TSX_PCS_COOP && IDX && C16 && GS && MODE == 0 && !PEER && (CW == 32 || CW == 16) && (CW * NSEG) % 64 == 0;
+  constexpr bool COOP = TSX_PCS_COOP && IDX && C16 && GS && !PEER && (CW == 32 || CW == 16) && (CW * NSEG) % 64 == 0;
   __shared__ uint4 sE[COOP ? CW * NSEG / 64 : 1][COOP ? 64 * 7 : 1];
   if (done && *done) return;
   // Lane offsets are 32-bit (tsx_ldu / tsx_stu), plane bases 64-bit and wave-uniform.
