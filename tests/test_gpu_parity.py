@@ -812,6 +812,33 @@ def test_shared_block_storage_is_lossless(gpu, monkeypatch, solver, Nx, Ny, Nz, 
     assert np.abs(xs - xs2).max() <= 1e-8 * np.abs(xs2).max()
 
 
+@pytest.mark.parametrize("Nx,Ny,Nz", [(64, 32, 20), (128, 128, 12)])
+def test_entry_major_records_fetched_by_lane_groups_equal_the_lane_by_lane_fetch(gpu, monkeypatch, Nx, Ny, Nz):
+    """Near-identical grouping stores the preconditioner's per-block records entry-major (an entry's eight records in one
+    128-byte line); the passes fetch phase 3's six records of such entries by groups of eight lanes and hand them over through
+    LDS (tsx_k_pcs_rb COOP; 16-column workgroups on the first domain, 32-column ones on the second).  Slot-major storage of the
+    same records (TSX_PC_ENTRY_MAJOR=0) is fetched lane by lane: M^-1 v must be bit-identical, for the default number of passes
+    and for a short sequence."""
+    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+    coeff = (P["coeff"] * (1 + 1e-3 * np.random.default_rng(11).random(P["coeff"].shape))).astype(np.float32)
+    v = np.random.default_rng(12).standard_normal(P["b"].shape)
+    out = {}
+    for env in ("1", "0"):
+        monkeypatch.setenv("TSX_PC_ENTRY_MAJOR", env)
+        s = DiffuseSolver("3_10", Nz, Nx, Ny)
+        s.set_coeffs(coeff, P["l1d"], P["a11"], P["a12"], P["albedo"])
+        on, nent = s.dedup_info()
+        assert not on and s.dedup_mode == 2 and nent < 0.5 * Nx * Ny * Nz   # grouped for the preconditioner only
+        out[env] = [s.pc_apply(v, pc=3, sweeps=sw, mixed=True) for sw in (27, 3)]
+        x = np.zeros(s.vec_shape)
+        info = s.solve(P["b"], x, rtol=1e-8, atol=1e-30)
+        assert info.reason == 2
+        out[env].append(x)
+        s.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
 def test_half_step_exit_meets_the_stop_rule_on_the_true_residual(gpu, monkeypatch):
     """BiCGStab's first half step already has an iterate, x + alpha p-hat, with residual s = r - alpha v.  When s meets
     MyKSPConverged's rule (src/pprts.F90:4437-4486) the solve stops there (TSX_STAGE_HALF) instead of finishing an iteration on
