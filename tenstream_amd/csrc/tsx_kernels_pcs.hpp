@@ -32,6 +32,8 @@
 // bf16 pairs (4 B) in zb for the intermediate passes, float2 in z for the last two: a neighbour value costs one load per
 // direction instead of one per stream.
 #pragma once
+#include <type_traits>
+
 #include "tsx_pack.hpp"
 #include "tsx_peer_dev.hpp"
 
@@ -1215,7 +1217,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   if (GS && hal.wait.mine) tsx_peer_wait_faces(hal.wait, face[1], face[0], face[3], face[2]);  // the records are read in place
   const bool anyface = (hal.E || hal.W || hal.N || hal.S) && !nonbr;  // wave-uniform
   // k = level(l), c = cell(l).  Lanes without a neighbour in a direction get zero words (the slot they would read may hold NaN)
-  auto nbr_load = [&](int k, unsigned c, uint2(&o)[4]) {
+  auto nbr_load = [&](auto halo, int k, unsigned c, uint2(&o)[4]) {
     const int off[4] = {offE, offW, offN, offS};
     const unsigned *hp[4] = {hal.E, hal.W, hal.N, hal.S};
 #pragma unroll
@@ -1224,7 +1226,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       const bool has = off[m] != 0 || face[m];
       if (MODE == 2) o[m] = tsx_ldo(reinterpret_cast<const uint2 *>(zr), (size_t)m * Nc, ci);
       else o[m] = make_uint2(tsx_ldo(zb, (size_t)m * Nc, ci), 0u);
-      if (anyface) {  // unconditional load from a valid address, then select
+      if constexpr (decltype(halo)::value) {  // unconditional load from a valid address, then select
         const size_t hidx = (size_t)(m < 2 ? jrow : icol) * tsx_pcs_halo_nzp(Nz) + k;  // [j][k] resp. [i][k]
         const unsigned hv = *(face[m] ? hp[m] + hidx : zb);
         if (face[m]) o[m].x = hv;
@@ -1269,7 +1271,18 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   unsigned eid[LSEG];
   unsigned pr[LSEG];  // row of the level's recurrence records (the cell, or its entry of the shared table)
   TsxH4 Ekeep[TSX_PCSH_KEEP_E ? LSEG : 1];  // E of the levels, held for the re-run of phase 2 (8 registers per level as fp16)
-  {
+  // (the levels' indices first and the wave-uniform decisions -- shared records or not, rank faces or not -- outside the level
+  // loop: a branch per level fences the levels' loads off from each other)
+  if (pidx) {
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) pr[l] = (unsigned)tsx_ldu(pidx, cell(l));
+  } else {
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) pr[l] = cell(l);
+  }
+#pragma unroll
+  for (int l = 0; l < LSEG; ++l) eid[l] = IDX ? (unsigned)tsx_ldu(cidx, cell(l)) : 0u;
+  auto phase1 = [&](auto halo) {
     float Bl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     TsxM4 Pc;
 #pragma unroll
@@ -1280,8 +1293,6 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     for (int l = LSEG - 1; l >= 0; --l) {
       const unsigned c = cell(l);
       const bool act = l < nl;
-      eid[l] = IDX ? (unsigned)tsx_ldu(cidx, c) : 0u;
-      pr[l] = pidx ? (unsigned)tsx_ldu(pidx, c) : c;
       const TsxH4 F = mat(2, pr[l]);
       float ru[4], rd[4];
 #pragma unroll
@@ -1297,7 +1308,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
         }
       }
       if (GS) {
-        nbr_load(level(l), c, nb[l]);
+        nbr_load(halo, level(l), c, nb[l]);
         float zx[4], zy[4];
         nbr_vals(nb[l], zx, zy);
         if (TSX_PCS_C16) {  // fp16: two top dsts per record; the y sources first, then the x sources (four records live at a time)
@@ -1347,7 +1358,9 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       }
     }
     put_summary(Bl, Pc);
-  }
+  };
+  if (anyface) phase1(std::true_type{});
+  else phase1(std::false_type{});
   __syncthreads();
   float Bin[4];
 #pragma unroll
