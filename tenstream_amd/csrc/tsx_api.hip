@@ -283,7 +283,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
-                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->bsrfc, s->edir_a, s->edir_b, s->dsc, s->abso, s->cell_samp, s->dd_colsum};
+                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->bsrfc, s->edir_a, s->edir_b, s->dsc, s->abso, s->cell_samp, s->dd_colsum, s->flow_state, s->flow_prog, s->flow_zb8};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->vph && s->vph != s->vp) (void)hipFree(s->vph);
@@ -1087,6 +1087,10 @@ static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
     }
     HIPCHK(hipMemcpyAsync(s->scal_host, s->scal, sizeof(TsxScalars), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->scal_host->flow_err) {  // tsx_k_pcs_flow: a bounded wait for a neighbour tile expired (cannot happen by construction)
+      tsx_set_error("preconditioner flow kernel: a wait for a neighbour tile's progress word expired (TSX_PC_FLOW=0 runs a launch per pass)");
+      return TSX_ERR_HIP;
+    }
     const bool was_half = s->scal_host->done && s->scal_host->half;
     if (was_half) {
       // the stop rule was met by s = r - alpha v in the middle of an iteration (TSX_STAGE_HALF): the kernels of its second half
@@ -1411,6 +1415,14 @@ static int pc_apply_t(tsx_solver *s, const double *v, double *z, int where, bool
   if ((rc = export_vec<NTOP, NSIDE>(s, s->vph, zd))) return rc;
   if (where == TSX_HOST) HIPCHK(hipMemcpyAsync(z, s->stage_b, nb, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
+  if (s->flow_state) {  // the flow kernel may have run: did one of its bounded waits expire?
+    int fe = 0;
+    HIPCHK(hipMemcpy(&fe, &s->scal->flow_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (fe) {
+      tsx_set_error("preconditioner flow kernel: a wait for a neighbour tile's progress word expired");
+      return TSX_ERR_HIP;
+    }
+  }
   return TSX_OK;
 }
 

@@ -52,6 +52,7 @@ struct TsxScalars {
   int aux_flag;  // scratch flag for kernels outside the loop (import: is the guess nonzero?)
   int half;      // the stop rule was met by s = r - alpha v, in the middle of an iteration (TSX_STAGE_HALF): x still lacks alpha p-hat
   double half_margin;  // factor on rtol / atol for that test (< 1 where the decision is re-taken on the true residual afterwards)
+  int flow_err;        // a bounded wait of the flow kernel (tsx_k_pcs_flow) expired: the host reports TSX_ERR_HIP at its next look
   double hist[100];
 };
 
@@ -156,6 +157,13 @@ struct tsx_solver {
   int *pcr_idx = nullptr, *pcr_ent = nullptr;
   void *pcr_tab = nullptr;
   long long pcr_n = 0, pcr_cap = 0;
+  // the intermediate passes of an application as one launch (tsx_pcs_flow.hip): ticket / epoch words and the tiles' progress words
+  void *flow_state = nullptr;
+  unsigned *flow_prog = nullptr;
+  void *flow_zb8 = nullptr;       // the iterate records as 8-byte granules {bf16 pair, tag} (fat flow kernel), [4][Nc]
+  unsigned flow_epoch_bound = 0;  // host-side upper bound of the device's epoch word (tags and progress words restart before it wraps)
+  int flow_prog_cap = 0;
+  int flow_capacity[4] = {0, 0, 0, 0};  // resident workgroups of tsx_k_pcs_flow<4, 16, 32 | 16, lean | fat> on this device (0: not asked yet)
   void *dd_scratch;        // work space of the build (hashes, table, scan)
   bool x_is_zero = false;      // the initial guess in vx is known to be zero on every rank (krylov_begin then skips A x0)
   bool dd_hash_ready = false;  // the hashes of the current blocks already sit in dd_scratch (left by tsx_k_lut_diff2diff)

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack(TsxGeo g, const CT *
 
 // ---- the same groups 1..7 per *distinct* block (tsx_dedup.hip): PE[(grp - 1) * nent + id]; an entry whose representative
 // cell lies in a 1-D layer stands for all 1-D cells: zero records
-__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent(int ncol, long long nent, const float *__restrict__ Cd,
+static __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent(int ncol, long long nent, const float *__restrict__ Cd,
                                                                 const int *__restrict__ ent_cell, const uint8_t *__restrict__ l1d,
                                                                 uint4 *__restrict__ PE) {
   constexpr int D = 10;
@@ -197,7 +197,7 @@ constexpr int TSX_PCS_ENT16_SLOTS = 8;
 // every one of a level's eight gathers touches up to 64 different lines and uses 16 bytes of each; entry-major, the first
 // gather brings the lane's line and the other seven hit it.  Bit-identical sharing keeps the slot-major order: there a
 // wave's ids are equal (clear sky: a broadcast) or consecutive (cloud cells in cell order: coalesced).
-__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent16(int ncol, long long nent, const float *__restrict__ Cd,
+static __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent16(int ncol, long long nent, const float *__restrict__ Cd,
                                                                   const int *__restrict__ ent_cell, const uint8_t *__restrict__ l1d,
                                                                   uint4 *__restrict__ PE, int entry_major) {
   constexpr int D = 10;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_ent16(int ncol, long
 
 // ---- record 0 for the intermediate passes where the blocks are shared: they never use A_k (the last fp16 of record 0), so a
 // second copy carries the cell's block index in that word -- one 16-byte load instead of record 0 + index (20 B)
-__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_r0g(long long Nc, const uint4 *__restrict__ P0,
+static __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_pack_r0g(long long Nc, const uint4 *__restrict__ P0,
                                                                 const int *__restrict__ cidx_split, uint4 *__restrict__ P0G) {
   for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
     uint4 v = P0[c];
@@ -261,39 +261,41 @@ __device__ __forceinline__ unsigned tsx_bf16x2(float lo, float hi) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tsx_rsrc(const void *base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
 }
-template <typename T>
+// AUX: the instruction's cache-policy bits; 16 = sc1 (agent scope: the load bypasses this CU's L1, the store is written through
+// the XCD's L2) -- the accesses of data that another workgroup of the SAME launch writes or reads (tsx_k_pcs_flow)
+template <typename T, int AUX = 0>
 __device__ __forceinline__ T tsx_ldu(const T *base, unsigned i) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "dword, dwordx2 or dwordx4");
   const int off = (int)(i * (unsigned)sizeof(T));
-  if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(tsx_rsrc(base), off, 0, 0));
-  else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(tsx_rsrc(base), off, 0, 0));
-  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(tsx_rsrc(base), off, 0, 0));
+  if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(tsx_rsrc(base), off, 0, AUX));
+  else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(tsx_rsrc(base), off, 0, AUX));
+  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(tsx_rsrc(base), off, 0, AUX));
 }
 // the same with a wave-uniform plane offset of `plane` elements carried in the instruction's scalar offset: planes of one array
 // share one descriptor (four scalar registers each -- tsx_k_pcsh_rb walks 50 planes).  Needs plane * sizeof(T) < 2^32 (pcs_config).
-template <typename T>
+template <typename T, int AUX = 0>
 __device__ __forceinline__ T tsx_ldo(const T *base, size_t plane, unsigned i) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "dword, dwordx2 or dwordx4");
   const int off = (int)(i * (unsigned)sizeof(T)), so = (int)(unsigned)(plane * sizeof(T));
-  if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(tsx_rsrc(base), off, so, 0));
-  else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(tsx_rsrc(base), off, so, 0));
-  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(tsx_rsrc(base), off, so, 0));
+  if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(tsx_rsrc(base), off, so, AUX));
+  else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(tsx_rsrc(base), off, so, AUX));
+  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(tsx_rsrc(base), off, so, AUX));
 }
-template <typename T>
+template <typename T, int AUX = 0>
 __device__ __forceinline__ void tsx_sto(T *base, size_t plane, unsigned i, T v) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8, "dword or dwordx2");
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   const int off = (int)(i * (unsigned)sizeof(T)), so = (int)(unsigned)(plane * sizeof(T));
-  if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), tsx_rsrc(base), off, so, 0);
-  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), tsx_rsrc(base), off, so, 0);
+  if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), tsx_rsrc(base), off, so, AUX);
+  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), tsx_rsrc(base), off, so, AUX);
 }
-template <typename T>
+template <typename T, int AUX = 0>
 __device__ __forceinline__ void tsx_stu(T *base, unsigned i, T v) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8, "dword or dwordx2");
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   const int off = (int)(i * (unsigned)sizeof(T));
-  if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), tsx_rsrc(base), off, 0, 0);
-  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), tsx_rsrc(base), off, 0, 0);
+  if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), tsx_rsrc(base), off, 0, AUX);
+  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), tsx_rsrc(base), off, 0, AUX);
 }
 
 // ---- several ranks: the other colour's boundary columns live on the neighbouring rank.  After every pass the records a
@@ -310,7 +312,7 @@ struct TsxPcHalo {
 };
 // my W face sends rec 0 (the -x streams of my columns i = 0: the west rank's E input), E face rec 1 of i = xm-1, S face rec 2
 // of j = 0, N face rec 3 of j = ym-1; zb: bf16 records, or zr (float2 records of the fp32 pass) when from_f32
-__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_pack(TsxGeo g, const unsigned *__restrict__ zb,
+static __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_pack(TsxGeo g, const unsigned *__restrict__ zb,
                                                                  const float2 *__restrict__ zr, int from_f32,
                                                                  unsigned *__restrict__ sW, unsigned *__restrict__ sE,
                                                                  unsigned *__restrict__ sS, unsigned *__restrict__ sN,
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_pack(TsxGeo g, const
 
 // The same records stored straight into the neighbours' mailboxes (peer transport, tsx_peer_dev.hpp): pack and send in one
 // kernel.  My W-face records are the west rank's E input: they land in its slot of face E (q ^ 1), and so on.
-__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_send(TsxGeo g, const unsigned *__restrict__ zb,
+static __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcs_halo_send(TsxGeo g, const unsigned *__restrict__ zb,
                                                                  const float2 *__restrict__ zr, int from_f32, TsxPeerXArgs a) {
   if (!tsx_peer_send_begin(a)) return;
   const int xm = g.xm, ym = g.ym, Nz = g.Nz;
@@ -434,15 +436,62 @@ __device__ __forceinline__ bool tsx_pcs_on_frame(const TsxGeo &g, int jrow, int 
 #else
 #define TSX_FOLDI(x) (x)
 #endif
-template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false, int RQ = 0, bool C16 = false, bool PEER = false>
-__global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) void tsx_k_pcs_rb(TsxGeo g, const uint4 *__restrict__ P, const float *__restrict__ r,
-                                                         float *__restrict__ z, unsigned *__restrict__ zb,
-                                                         float *__restrict__ zfin, const int *__restrict__ done, int rbc,
-                                                         int nonbr, const int *__restrict__ cidx, long long nent,
-                                                         const uint4 *__restrict__ PE, TsxPcHalo hal,
-                                                         unsigned *__restrict__ rb, int part, const int *__restrict__ pidx,
-                                                         const uint4 *__restrict__ PT, TsxPeerXArgs snd, int pe_si) {
+// -DTSX_FLOW_TRACE (analysis builds, scripts/flow_trace.sh): thread 0 of a flow workgroup leaves wall-clock stamps of the stages of
+// every work item in tsx_flow_tl
+#ifdef TSX_FLOW_TRACE
+#define TSX_FLOW_TL_N 32768
+__device__ unsigned long long tsx_flow_tl[TSX_FLOW_TL_N][12];
+#define TSX_TL(k)                                                  \
+  do {                                                             \
+    if (FLOW && tl && threadIdx.x == 0) tl[k] = wall_clock64();    \
+  } while (0)
+#else
+#define TSX_TL(k) \
+  do {            \
+  } while (0)
+#endif
+// FLOW (tsx_k_pcs_flow below: the intermediate passes of one application inside ONE launch, a workgroup per (pass, tile) work
+// item): the iterate records and right-hand side words another workgroup of the same launch wrote or will read travel as sc1
+// (write-through) stores and sc1 loads -- a CU's L1 is never refreshed by another CU's stores and the XCDs' L2s are not coherent
+// with each other; `tile` replaces blockIdx.x.
+// HOIST (the flow kernel on small domains, where a pass is a chain of memory latencies and not bytes): every load that does not
+// depend on the neighbours -- record 0, the per-block records of phase 1 AND phase 3, the right-hand side words, for all LSEG
+// levels -- is issued at the top; then `wait_nbrs()` (the flow kernel: poll of the neighbour tiles' progress words + barrier);
+// then the neighbour records.  About 190 registers of loads in flight: the kernel runs at two waves per SIMD.  Same arithmetic.
+struct TsxNoWait {
+  __device__ __forceinline__ void operator()() const {}
+};
+// GRAN (with HOIST): the iterate records travel as 8-byte granules {bf16 pair, tag}, tag = epoch + index of the pass that wrote
+// them, each written by ONE sc1 store of one lane: the record is its own flag.  The consumer re-loads the sixteen granules of its
+// four levels (sc1) until every tag is the one of the pass before -- no drain of the producer's stores, no barrier, no progress
+// word, no poll of it, no separate load behind the poll: the hand-off costs one store-to-load latency (MI355X guide, R2 /
+// handoff-1to1: 0.8-1.0 us against 1.7-1.9 x that for payload + flag).  A neighbour cannot overwrite a granule this tile still
+// needs: its next pass needs THIS pass's granules of this tile first.  first: the neighbours' records come from the launch before
+// (plain words in zb); last: the pass after this launch reads plain words -- stored beside the granules.
+struct TsxGran {
+  uint2 *zb8;        // [4][Nc] granules
+  unsigned need;     // tag of the neighbours' granules this item reads
+  unsigned tag;      // tag of the granules this item writes
+  int first, last;
+  unsigned long long ticks;
+  int *err;
+};
+template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX, int RQ, bool C16, bool PEER, bool FLOW, bool HOIST = false,
+          typename WaitF = TsxNoWait, bool GRAN = false>
+__device__ __forceinline__ void tsx_pcs_rb_body(const TsxGeo &g, const uint4 *__restrict__ P, const float *__restrict__ r,
+                                                float *__restrict__ z, unsigned *__restrict__ zb, float *__restrict__ zfin, int rbc,
+                                                int nonbr, const int *__restrict__ cidx, long long nent,
+                                                const uint4 *__restrict__ PE, const TsxPcHalo &hal, unsigned *__restrict__ rb,
+                                                int part, const int *__restrict__ pidx, const uint4 *__restrict__ PT,
+                                                const TsxPeerXArgs &snd, int pe_si, int tile,
+                                                unsigned long long *tl = nullptr, WaitF wait_nbrs = WaitF(),
+                                                const TsxGran *gr = nullptr) {
+  (void)tl;
+  static_assert(!GRAN || HOIST, "granules: the flow kernel's fat body");
+  static_assert(!HOIST || (FLOW && GS && MODE == 0 && RQ == 2 && C16), "HOIST: an intermediate pass of the flow kernel");
   static_assert(!PEER || MODE != 2, "the last pass sends nothing");
+  static_assert(!FLOW || (MODE == 0 && !PEER), "the flow kernel runs intermediate passes");
+  constexpr int XA = FLOW ? 16 : 0;  // aux of the accesses another workgroup of the launch is on the other end of: sc1
   // per-block records: PE[slot * pe_ss + id * pe_si]; pe_si = 1: slot-major planes of nent entries, pe_si = 8 (C16 only):
   // entry-major, an entry's eight records in one 128-byte line (tsx_k_pcs_pack_ent16)
   const size_t pe_ss = pe_si == 1 ? (size_t)nent : (size_t)1;
@@ -458,14 +507,13 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   // of the entry of the group's t-th lane, t = 0..7 -- an instruction touches 8 lines instead of 64 (the texture addresser is
   // 80 % busy there, one tag look-up per lane and gather) -- and handed to their lanes through LDS (rows of 7 records: no bank
   // conflicts on the way out).  One wave's rows are private to it: LDS executes a wave's instructions in order, no barrier.
-  constexpr bool COOP = TSX_PCS_COOP && IDX && C16 && GS && !PEER && (CW == 32 || CW == 16) && (CW * NSEG) % 64 == 0;
+  constexpr bool COOP = TSX_PCS_COOP && IDX && C16 && GS && !PEER && !HOIST && (CW == 32 || CW == 16) && (CW * NSEG) % 64 == 0;
   __shared__ uint4 sE[COOP ? CW * NSEG / 64 : 1][COOP ? 64 * 7 : 1];
-  if (done && *done) return;
   // Lane offsets are 32-bit (tsx_ldu / tsx_stu), plane bases 64-bit and wave-uniform.
   const int h = g.xm >> 1;
   const int cl = threadIdx.x % CW, sg = threadIdx.x / CW;
   const int nthr = part == 2 ? tsx_pcs_nframe(g) : g.ym * h;
-  int t_ = blockIdx.x * CW + cl;
+  int t_ = tile * CW + cl;
   bool live = t_ < nthr;  // dead lanes shadow the last column (loads stay valid, nothing is stored)
   if (!live) t_ = nthr - 1;
   if (part == 2) t_ = tsx_pcs_frame_thread(g, rbc, t_);
@@ -537,7 +585,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     for (int m = 0; m < 4; ++m) {
       const unsigned ci = (unsigned)((int)c + off[m]);
       if (MODE == 2) o[m] = tsx_ldo(reinterpret_cast<const uint2 *>(zr), (size_t)m * Nc, ci);
-      else o[m] = make_uint2((TSX_PCS_PROBE & 4) ? 0x3f803f80u : tsx_ldo(zb, (size_t)m * Nc, (unsigned)TSX_FOLDC(ci)), 0u);
+      else o[m] = make_uint2((TSX_PCS_PROBE & 4) ? 0x3f803f80u : tsx_ldo<unsigned, XA>(zb, (size_t)m * Nc, (unsigned)TSX_FOLDC(ci)), 0u);
     }
   };
   auto nbr_halo = [&](int k, unsigned (&hv)[4]) {  // unconditional loads from valid addresses
@@ -594,6 +642,76 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   // The loads are written stage by stage over the levels (indices -> independent words -> records behind the indices), with
   // the wave-uniform decisions outside the loops: a branch per level fences the levels' loads off from each other, and a
   // wave walks the chain index -> record -> block records four times in a row (it did: 33.4 us per pass against 30.1 us)
+  uint4 hw[HOIST ? LSEG : 1][6];     // HOIST: records 2..7 of every level
+  unsigned hrs[HOIST ? LSEG : 1][4];  // ... and the four side-stream right-hand side words
+  if constexpr (HOIST) {
+    unsigned pi[LSEG];
+    if (IDX && pidx) {
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) pi[l] = (unsigned)tsx_ldu(pidx, cell(l));
+    }
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) {
+      const unsigned c = cell(l);
+      const unsigned w = tsx_ldu(rb, c);
+      ru[l] = __uint_as_float(w << 16);
+      rd[l] = __uint_as_float(w & 0xffff0000u);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hrs[l][q] = tsx_ldo(rb, (size_t)(1 + q) * Nc, c);
+    }
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) {
+      if (IDX) r0[l] = pidx ? tsx_ldu(PT, pi[l]) : tsx_ldo(P + (size_t)4 * Nc, (size_t)3 * Nc, cell(l));
+      else r0[l] = tsx_ldu(P, cell(l));
+      eid[l] = IDX ? r0[l].w * (unsigned)pe_si : 0u;
+    }
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) {
+      const unsigned c = cell(l);
+      r1[l] = IDX ? tsx_ldu(PE, eid[l]) : tsx_ldo(P, Nc, c);
+      r1x[l] = IDX ? tsx_ldo(PE, pe_ss, eid[l]) : tsx_ldu(P + (size_t)8 * Nc, c);
+    }
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) hw[l][q] = rec(2 + q, cell(l), eid[l]);
+    }
+    wait_nbrs();  // the neighbour tiles have published the pass before this one
+    if (GRAN && !gr->first) {
+      // (polling one granule per direction and fetching the other twelve behind it was measured slower at every size: a second
+      // latency on the chain -- 64 x 64 columns 1.70 -> 1.95 ms per solve, 128 x 64 2.64 -> 2.86)
+      const int off[4] = {offE, offW, offN, offS};
+      const unsigned long long t0 = wall_clock64();
+      bool gaveup = false;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int l = 0; l < LSEG; ++l) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const uint2 v = tsx_ldo<uint2, 16>(gr->zb8, (size_t)m * Nc, (unsigned)((int)cell(l) + off[m]));
+            nb[l][m] = make_uint2(v.x, 0u);
+            ok = ok && v.y == gr->need;
+          }
+        }
+        if (__all(ok) || gaveup) break;
+        if (wall_clock64() - t0 > gr->ticks || __hip_atomic_load(gr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(gr->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gaveup = true;  // (one more round, then on with whatever the records hold)
+          continue;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    } else {
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) nbr_load(cell(l), nb[l]);
+    }
+    {
+      const unsigned none[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) nbr_select(nb[l], none, false);
+    }
+  } else
   if (TSX_PCS_STAGED || pe_si == 1) {
   unsigned pi[LSEG];
   if (IDX && MODE == 0) {
@@ -609,7 +727,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   for (int l = 0; l < LSEG; ++l) {
     const unsigned c = cell(l);
     if (RQ == 2) {
-      const unsigned w = tsx_ldu(rb, (unsigned)TSX_FOLDC(c));
+      const unsigned w = tsx_ldu<unsigned, XA>(rb, (unsigned)TSX_FOLDC(c));
       ru[l] = __uint_as_float(w << 16);
       rd[l] = __uint_as_float(w & 0xffff0000u);
     } else {
@@ -672,7 +790,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
         r0[l] = tsx_ldu(P, c);
       }
       if (RQ == 2) {
-        const unsigned w = tsx_ldu(rb, (unsigned)TSX_FOLDC(c));
+        const unsigned w = tsx_ldu<unsigned, XA>(rb, (unsigned)TSX_FOLDC(c));
         ru[l] = __uint_as_float(w << 16);
         rd[l] = __uint_as_float(w & 0xffff0000u);
       } else {
@@ -696,7 +814,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
   if (RQ == 1) {
 #pragma unroll
     for (int l = 0; l < LSEG; ++l)
-      if (live && l < nl) tsx_stu(rb, cell(l), tsx_bf16x2(ru[l], rd[l]));
+      if (live && l < nl) tsx_stu<unsigned, XA>(rb, cell(l), tsx_bf16x2(ru[l], rd[l]));
   }
   float Bloc[LSEG], Pcum[LSEG], rdg[LSEG];
   {
@@ -732,7 +850,9 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     }
     sB[sg][cl] = make_float2(Bl, Pc);
   }
+  TSX_TL(3);
   __syncthreads();
+  TSX_TL(4);
   float Bin = rsurf;  // B at the level below this segment
   for (int s2 = NSEG - 1; s2 > sg; --s2) {
     const float2 v = sB[s2][cl];
@@ -759,6 +879,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     sV[sg][cl] = make_float2(Vl, Qc);
   }
   __syncthreads();
+  TSX_TL(5);
   float Vin = V0;  // V at the top level of this segment
   for (int s2 = 0; s2 < sg; ++s2) {
     const float2 v = sV[s2][cl];
@@ -793,6 +914,14 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     };
     const tsx_h8 m = __builtin_bit_cast(tsx_h8, r0[l]);
     uint4 wcu, wcv, wy[2], wx[2];
+    if constexpr (HOIST) {
+      wcu = hw[l][0];
+      wcv = hw[l][1];
+      wy[0] = hw[l][2];
+      wy[1] = hw[l][3];
+      wx[0] = hw[l][4];
+      wx[1] = hw[l][5];
+    } else
     if (COOP && pe_si == TSX_PCS_ENT16_SLOTS) {
       const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6), g8 = lane & 56, j = lane & 7;
       const unsigned jj = (unsigned)(j < 6 ? j : 5);  // (lanes 6 and 7 of a group repeat record 7: no branch around the loads)
@@ -828,7 +957,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
     if (RQ == 2) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const unsigned w = (TSX_PCS_PROBE & 1) ? 0x3f803f80u : tsx_ldo(rb, (size_t)(1 + q) * Nc, (unsigned)TSX_FOLDC(c));
+        const unsigned w = HOIST ? hrs[HOIST ? l : 0][q] : (TSX_PCS_PROBE & 1) ? 0x3f803f80u : tsx_ldo<unsigned, XA>(rb, (size_t)(1 + q) * Nc, (unsigned)TSX_FOLDC(c));
         rs[2 * q] = __uint_as_float(w << 16);
         rs[2 * q + 1] = __uint_as_float(w & 0xffff0000u);
       }
@@ -837,7 +966,7 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       for (int q = 0; q < 8; ++q) rs[q] = tsx_ldo(r, (size_t)(NTOP + q) * Nc, c);
       if (RQ == 1 && st) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tsx_sto(rb, (size_t)(1 + q) * Nc, c, tsx_bf16x2(rs[2 * q], rs[2 * q + 1]));
+        for (int q = 0; q < 4; ++q) tsx_sto<unsigned, XA>(rb, (size_t)(1 + q) * Nc, c, tsx_bf16x2(rs[2 * q], rs[2 * q + 1]));
       }
     }
     float pt[2];
@@ -887,11 +1016,22 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       probe_acc += zo[0] + zo[1] + zo[2] + zo[3] + zo[4] + zo[5] + zo[6] + zo[7];
       if (l == LSEG - 1 && st) tsx_sto(zb, (size_t)0, (unsigned)TSX_FOLDC(c), __float_as_uint(probe_acc));
     } else
+    if (GRAN) {
+      if (st) {
+        const unsigned w4[4] = {tsx_bf16x2(zo[0], zo[2]), tsx_bf16x2(zo[1], zo[3]), tsx_bf16x2(zo[4], zo[6]), tsx_bf16x2(zo[5], zo[7])};
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) tsx_sto<uint2, 16>(gr->zb8, (size_t)m2 * Nc, c, make_uint2(w4[m2], gr->tag));
+        if (gr->last) {
+#pragma unroll
+          for (int m2 = 0; m2 < 4; ++m2) tsx_sto<unsigned, 0>(zb, (size_t)m2 * Nc, c, w4[m2]);
+        }
+      }
+    } else
     if (MODE == 0 && st && !(TSX_PCS_PROBE & 2)) {
-      tsx_sto(zb, (size_t)0 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[0], zo[2]));
-      tsx_sto(zb, (size_t)1 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[1], zo[3]));
-      tsx_sto(zb, (size_t)2 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[4], zo[6]));
-      tsx_sto(zb, (size_t)3 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[5], zo[7]));
+      tsx_sto<unsigned, XA>(zb, (size_t)0 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[0], zo[2]));
+      tsx_sto<unsigned, XA>(zb, (size_t)1 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[1], zo[3]));
+      tsx_sto<unsigned, XA>(zb, (size_t)2 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[4], zo[6]));
+      tsx_sto<unsigned, XA>(zb, (size_t)3 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[5], zo[7]));
     }
     if constexpr (PEER && CW < 32) {
       // small passes (16-column workgroups: at most one workgroup per CU's worth of columns, latency-bound, registers to spare):
@@ -950,6 +1090,184 @@ __global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) vo
       }
     }
     tsx_peer_send_end(snd, snd.blkctr, gridDim.x);
+  }
+}
+
+// one pass per launch: a workgroup per CW columns of the colour
+template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false, int RQ = 0, bool C16 = false, bool PEER = false>
+__global__ __launch_bounds__(CW *NSEG, PEER && MODE == 0 && CW >= 32 ? 4 : 1) void tsx_k_pcs_rb(TsxGeo g, const uint4 *__restrict__ P, const float *__restrict__ r,
+                                                         float *__restrict__ z, unsigned *__restrict__ zb,
+                                                         float *__restrict__ zfin, const int *__restrict__ done, int rbc,
+                                                         int nonbr, const int *__restrict__ cidx, long long nent,
+                                                         const uint4 *__restrict__ PE, TsxPcHalo hal,
+                                                         unsigned *__restrict__ rb, int part, const int *__restrict__ pidx,
+                                                         const uint4 *__restrict__ PT, TsxPeerXArgs snd, int pe_si) {
+  if (done && *done) return;
+  tsx_pcs_rb_body<LSEG, NSEG, CW, GS, MODE, IDX, RQ, C16, PEER, false>(g, P, r, z, zb, zfin, rbc, nonbr, cidx, nent, PE, hal, rb, part,
+                                                                       pidx, PT, snd, pe_si, (int)blockIdx.x);
+}
+
+// ---- the intermediate passes of one application as ONE launch ("flow" kernel, round 5).
+// A pass of a small domain is latency, not bytes: 128 x 64 columns: 10.9 us per launch for 2.9 us of bytes (launch, prologue, the
+// chain index -> record -> block records, two barriers, the drain of the stores; profiles/r04/shard_study.txt), and at
+// 256 x 256 still 8.2 of 30.4 us (profiles/r04/pass_parts.txt) -- times 26 intermediate passes per application.  What a pass
+// needs from the one before is local: a tile of CW columns of one row reads the other colour's records of the same tile
+// position, of the next tile of its row and of the rows above and below -- four tiles.  So the work items (pass p, tile t) of
+// passes [p0, p1) are handed out by ONE ticket counter in the order (p, t) to the workgroups of one launch, and an item waits for
+// the progress words of its four neighbour tiles instead of a kernel boundary: a tile of pass p + 1 starts as soon as ITS
+// neighbours have finished pass p, no prologue, no fill and drain of the chip per pass.
+//  * Deadlock-free whatever the residency: an item waits only for items with SMALLER tickets, and a ticket is taken by a
+//    workgroup that is running -- by induction over the ticket order every taken item completes.  No co-residency assumption,
+//    no cooperative launch; several such launches (config 4's instances on their own streams) cannot starve each other.
+//  * The neighbour relation is symmetric (the tiles whose records I read are the tiles that read mine), so waiting for them to
+//    finish pass p - 1 orders both the reads of their new records and the overwrite of mine that they were still reading.
+//  * Visibility (MI355X: a CU's L1 is never refreshed by other CUs' stores, the XCDs' L2s are not coherent with each other):
+//    the iterate records and progress words are written by sc1 (write-through) stores, every storing wave drains its stores
+//    (s_waitcnt vmcnt(0)) before the workgroup's barrier, then ONE lane publishes the progress word with an agent-scope store;
+//    the consumer polls with agent-scope loads from lanes 0..3, joins the workgroup's barrier, and every load of records is an
+//    sc1 load (tsx_pcs_rb_body<..., FLOW>).  Results are bit-identical to the launch-per-pass path (same arithmetic per cell):
+//    tests/test_gpu_parity.py::test_flow_kernel_is_bit_identical_to_launch_per_pass.
+//  * Every wait is bounded (ticks of the 100 MHz wall clock): on expiry the state's error word is set, the kernel goes on with
+//    whatever the records hold and the host reports TSX_ERR_HIP at its next look at the stop flag (krylov_run).
+struct TsxFlowState {  // device memory, zero at allocation, one per solver
+  unsigned ticket;     // next work item of the running launch; reset by the workgroup that leaves last
+  unsigned exited;     // workgroups that have left the running launch
+  unsigned epoch;      // progress words written by earlier launches are <= epoch; advanced by the workgroup that leaves last
+  unsigned pad;
+};
+struct TsxFlowArgs {
+  TsxFlowState *st;
+  unsigned *prog;      // [2][ntiles]: last finished item of the tile, as epoch + (p - p0) + 1
+  int p0, p1;          // passes [p0, p1) of the application (colour = p & 1)
+  int ntiles, R;       // tiles per pass, tiles per row of columns
+  unsigned long long ticks;
+  int *err;            // set to 1 when a bounded wait expires (TsxScalars::flow_err: the host sees it with the stop flag)
+  uint2 *zb8;          // FAT: the iterate records as granules (TsxGran), [4][Nc]
+};
+// FAT: the body with every neighbour-independent load hoisted in front of the wait (tsx_pcs_rb_body HOIST), two waves per SIMD --
+// for passes of at most as many tiles as workgroups are resident (<= 8192 columns per colour: config 2, the shards of the 2 x 4
+// split), where an item is a chain of latencies; the lean body (four waves per SIMD) for larger passes, which are bound by
+// their instruction stream.
+template <int LSEG, int NSEG, int CW, bool IDX, bool C16, bool FAT, bool GRANV = false>
+__global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g, const uint4 *__restrict__ P,
+                                                                        const float *__restrict__ r, unsigned *__restrict__ zb,
+                                                                        const int *__restrict__ done, const int *__restrict__ cidx,
+                                                                        long long nent, const uint4 *__restrict__ PE,
+                                                                        unsigned *__restrict__ rb, const int *__restrict__ pidx,
+                                                                        const uint4 *__restrict__ PT, int pe_si, TsxFlowArgs f) {
+  if (done && *done) return;
+  __shared__ unsigned s_tk;
+  const unsigned epoch = __hip_atomic_load(&f.st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  TsxPcHalo hal;
+  hal.W = hal.E = hal.S = hal.N = nullptr;
+  hal.wait.mine = nullptr;
+  TsxPeerXArgs snd;
+  snd.bytes[0] = snd.bytes[1] = snd.bytes[2] = snd.bytes[3] = 0;
+  const unsigned ntiles = (unsigned)f.ntiles, nitems = (unsigned)(f.p1 - f.p0) * ntiles;
+  if (threadIdx.x == 0) s_tk = atomicAdd(&f.st->ticket, 1u);
+  __syncthreads();
+  unsigned tk = s_tk;
+  while (tk < nitems) {
+    const unsigned pp = tk / ntiles, t = tk - pp * ntiles;
+    const int rbc = (f.p0 + (int)pp) & 1;
+    [[maybe_unused]] constexpr bool FLOW = true;
+#ifdef TSX_FLOW_TRACE
+    unsigned long long *tl = tsx_flow_tl[tk % TSX_FLOW_TL_N];
+    if (threadIdx.x == 0) {
+      tl[0] = wall_clock64();
+      tl[10] = ((unsigned long long)pp << 32) | t;
+      tl[11] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) | ((unsigned long long)blockIdx.x << 8);  // XCC_ID
+    }
+#else
+    unsigned long long *tl = nullptr;
+#endif
+    unsigned nxt = 0;
+    if (threadIdx.x == 0) nxt = atomicAdd(&f.st->ticket, 1u);  // the next item's ticket travels under this item's work
+    // wait for the four tiles of the other colour whose records this tile reads (and which read this tile's): same position, the
+    // next (previous) tile of the row where the columns' parity shifts them east (west), the rows above and below.  Lanes 0..3
+    // poll one progress word each; the barrier releases the workgroup
+    auto wait_nbrs = [&]() {
+      if (pp > 0 && threadIdx.x < 4) {
+        const int R = f.R, jrow = (int)t / R, tq = (int)t - jrow * R;
+        int dep;
+        if (threadIdx.x == 0) {
+          dep = (int)t;
+        } else if (threadIdx.x == 1) {
+          int nq = ((jrow + rbc) & 1) ? tq + 1 : tq - 1;
+          if (nq < 0) nq = g.wrap_x ? R - 1 : -1;
+          else if (nq >= R) nq = g.wrap_x ? 0 : -1;
+          dep = nq < 0 ? -1 : jrow * R + nq;
+        } else {
+          int jn = threadIdx.x == 2 ? jrow + 1 : jrow - 1;
+          if (jn < 0) jn = g.wrap_y ? g.ym - 1 : -1;
+          else if (jn >= g.ym) jn = g.wrap_y ? 0 : -1;
+          dep = jn < 0 ? -1 : jn * R + tq;
+        }
+        if (dep >= 0) {
+          const unsigned *w = f.prog + (size_t)(1 - rbc) * ntiles + dep;
+          const unsigned need = epoch + pp;  // the neighbour has finished pass p - 1
+          const unsigned long long t0 = wall_clock64();
+          while ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
+            if (wall_clock64() - t0 > f.ticks || __hip_atomic_load(f.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+              __hip_atomic_store(f.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      }
+      TSX_TL(1);
+      __syncthreads();
+      TSX_TL(2);
+    };
+    if constexpr (FAT && GRANV) {
+      // the records are their own flags (TsxGran): nothing to wait for in front of them, nothing to publish behind them
+      auto stamps = [&]() {
+        TSX_TL(1);
+        TSX_TL(2);
+      };
+      TsxGran gr;
+      gr.zb8 = f.zb8;
+      gr.need = epoch + pp;
+      gr.tag = epoch + pp + 1u;
+      gr.first = pp == 0;
+      gr.last = (int)pp == f.p1 - f.p0 - 1;
+      gr.ticks = f.ticks;
+      gr.err = f.err;
+      tsx_pcs_rb_body<LSEG, NSEG, CW, true, 0, IDX, 2, C16, false, true, true, decltype(stamps), true>(
+          g, P, r, nullptr, zb, nullptr, rbc, 0, cidx, nent, PE, hal, rb, 0, pidx, PT, snd, pe_si, (int)t, tl, stamps, &gr);
+      TSX_TL(6);
+      TSX_TL(7);
+      if (threadIdx.x == 0) s_tk = nxt;
+      __syncthreads();
+      TSX_TL(8);
+      tk = s_tk;
+      continue;
+    } else if constexpr (FAT) {
+      tsx_pcs_rb_body<LSEG, NSEG, CW, true, 0, IDX, 2, C16, false, true, true, decltype(wait_nbrs)>(
+          g, P, r, nullptr, zb, nullptr, rbc, 0, cidx, nent, PE, hal, rb, 0, pidx, PT, snd, pe_si, (int)t, tl, wait_nbrs);
+    } else {
+      wait_nbrs();
+      tsx_pcs_rb_body<LSEG, NSEG, CW, true, 0, IDX, 2, C16, false, true>(g, P, r, nullptr, zb, nullptr, rbc, 0, cidx, nent, PE, hal, rb, 0,
+                                                                         pidx, PT, snd, pe_si, (int)t, tl);
+    }
+    TSX_TL(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its records have left the XCD's L2
+    TSX_TL(7);
+    if (threadIdx.x == 0) s_tk = nxt;
+    __syncthreads();
+    TSX_TL(8);
+    if (threadIdx.x == 0)
+      __hip_atomic_store(f.prog + (size_t)rbc * ntiles + t, epoch + pp + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tk = s_tk;
+  }
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(&f.st->exited, 1u);
+    if (prev + 1 == gridDim.x) {  // nobody reads the ticket or the epoch any more: ready for the next launch
+      __hip_atomic_store(&f.st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&f.st->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&f.st->epoch, epoch + (unsigned)(f.p1 - f.p0) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

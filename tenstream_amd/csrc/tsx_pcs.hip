@@ -472,8 +472,24 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
   static const bool overlap_env = !(getenv("TSX_PC_OVERLAP") && atoi(getenv("TSX_PC_OVERLAP")) == 0);
   const bool overlap = halo && overlap_env && tsx_overlap(s) && s->comm_stream != nullptr;  // tsx_overlap: as for the operator
   bool in_flight = false;  // an exchange has been packed and handed to comm_stream (ev_pack) but not issued yet
+  // the intermediate Gauss-Seidel passes that read the bf16 right-hand side words -- passes [fp0, P - 2) -- as ONE launch
+  // (tsx_k_pcs_flow): everything but the first pass (two where this application has to leave the words first) and the two fp32 passes
+  const PcsCfg cfg = pcs_config(s);
+  const int fp0 = words_ready ? 1 : 2;
+  // the flow kernel's tiles are its own: 32 columns from 4096 columns per pass on (measured, scripts/flow_matrix.sh: 128 x 64 columns
+  // 2.51 ms per solve against 2.71 with 16), 16 below; TSX_PCS_CFG's third number overrides as for the launches
+  int fcw = cfg.cw;
+  if (!getenv("TSX_PCS_CFG") && cfg.lseg == 4 && cfg.nseg == 16)
+    fcw = ((long long)s->geo.ym * (s->geo.xm / 2) >= 4096 && (s->geo.xm / 2) % 32 == 0) ? 32 : 16;
+  const bool flow = !halo && s->geo.ntop == 2 && P - 2 - fp0 >= 2 && tsx_pcs_flow_ok(s, cfg.lseg, cfg.nseg, fcw);
   for (int pass = 0; pass < P; ++pass) {
     const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
+    if (flow && pass == fp0) {
+      int rcf = tsx_pcs_flow(s, fcw, fp0, P - 2, done);
+      if (rcf) return rcf;
+      pass = P - 3;
+      continue;
+    }
     // a colour's intermediate visits are passes c, c + 2, ... < P - 2: the first leaves the bf16 right-hand side if another
     // one follows, the later ones read it
     const int rq = !rhs16 || mode != 0 ? 0 : (words_ready ? 2 : (pass >= 2 ? 2 : (pass + 2 < P - 2 ? 1 : 0)));

@@ -1,0 +1,178 @@
+// tsx_pcs_flow.hip -- host side of tsx_k_pcs_flow (tsx_kernels_pcs.hpp): the intermediate red-black passes of one application of
+// the scan preconditioner as ONE launch, a workgroup per (pass, tile) work item, items waiting for their four neighbour tiles'
+// progress words instead of a kernel boundary.  A translation unit of its own so that it compiles next to tsx_pcs.hip.
+//
+// Replaces, per application of M^-1, 24-25 of the 28 launches the reference's PCILU application is replaced by here
+// (src/pprts.F90:4350-4371); same arithmetic per cell, bit-identical results.
+#include <stdio.h>
+#include <string.h>
+
+#include "tsx_host.hpp"
+#include "tsx_peer.hpp"
+#include "tsx_peer_dev.hpp"
+#include "tsx_kernels_pcs.hpp"
+
+#ifndef TSX_PCS_C16
+#define TSX_PCS_C16 1
+#endif
+
+static int flow_env() {
+  const char *e = getenv("TSX_PC_FLOW");  // 0: a launch per pass (A/B knob, and what the parity test compares with); read per call
+  return e ? atoi(e) : 1;
+}
+
+template <int CW, bool IDX, bool FAT>
+static const void *flow_kernel() {
+  return (const void *)tsx_k_pcs_flow<4, 16, CW, IDX, TSX_PCS_C16 != 0, FAT, false>;
+}
+
+// resident workgroups of the flow kernel on this device.  Only a bound on the useful grid: tickets make any grid correct.
+static int flow_capacity(tsx_solver *s, int cw, bool fat) {
+  int &cap = s->flow_capacity[(cw == 32 ? 0 : 1) + (fat ? 2 : 0)];
+  if (cap > 0) return cap;
+  int per_cu = 0, cus = 0;
+  const void *k = cw == 32 ? (fat ? flow_kernel<32, true, true>() : flow_kernel<32, true, false>())
+                           : (fat ? flow_kernel<16, true, true>() : flow_kernel<16, true, false>());
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, cw * 16, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess || cus < 1) cus = 256;
+  cap = per_cu * cus;
+  return cap;
+}
+
+bool tsx_pcs_flow_ok(tsx_solver *s, int lseg, int nseg, int cw) {
+  const TsxGeo &g = s->geo;
+  if (!flow_env()) return false;
+  if (g.ntop != 2 || lseg != 4 || nseg != 16 || (cw != 32 && cw != 16)) return false;  // the instantiated configurations
+  if (!(g.wrap_x && g.wrap_y)) return false;  // rank faces: the records of the neighbour ranks travel between launches
+  if (g.pc_tile_x > 0 || g.pc_tile_y > 0) return false;
+  const int h = g.xm >> 1;
+  if (h % cw != 0) return false;  // a tile is CW columns of ONE row
+  if (!tsx_pcs_rhs16(s)) return false;
+  // beyond about two tiles per resident workgroup a pass is bound by its instruction stream and the launch boundary costs nothing
+  // next to it: 256 x 256 columns (1024 tiles) 12.01 -> 11.65 ms per solve, 512 x 512 (4096 tiles) 53.7 -> 54.4 ms
+  const long long ntiles = (long long)(h / cw) * g.ym;
+  if (!getenv("TSX_FLOW_FAT") && ntiles > 2ll * flow_capacity(s, cw, false)) return false;
+  return true;
+}
+
+// state, progress words, granules.  The epoch only grows (tags and progress words of earlier launches stay behind it); before the
+// host's bound on it reaches 2^30 everything restarts from zero, in stream order.
+static int flow_ensure(tsx_solver *s, int ntiles, bool fat, int npass) {
+  const TsxGeo &g = s->geo;
+  if (!s->flow_state) {
+    HIPCHK(hipMalloc(&s->flow_state, sizeof(TsxFlowState)));
+    HIPCHK(hipMemsetAsync(s->flow_state, 0, sizeof(TsxFlowState), s->stream));
+    s->flow_epoch_bound = 0;
+  }
+  if (s->flow_prog_cap < 2 * ntiles) {
+    if (s->flow_prog) {
+      HIPCHK(hipStreamSynchronize(s->stream));
+      HIPCHK(hipFree(s->flow_prog));
+      s->flow_prog = nullptr;
+    }
+    HIPCHK(hipMalloc((void **)&s->flow_prog, sizeof(unsigned) * 2 * (size_t)ntiles));
+    HIPCHK(hipMemsetAsync(s->flow_prog, 0, sizeof(unsigned) * 2 * (size_t)ntiles, s->stream));  // zero is behind every epoch
+    s->flow_prog_cap = 2 * ntiles;
+  }
+  const size_t zb8_bytes = sizeof(uint2) * 4 * (size_t)g.Nc;
+  if (fat && !s->flow_zb8) {
+    HIPCHK(hipMalloc(&s->flow_zb8, zb8_bytes));
+    HIPCHK(hipMemsetAsync(s->flow_zb8, 0, zb8_bytes, s->stream));
+  }
+  if (s->flow_epoch_bound > (1u << 30)) {
+    HIPCHK(hipMemsetAsync(s->flow_state, 0, sizeof(TsxFlowState), s->stream));
+    HIPCHK(hipMemsetAsync(s->flow_prog, 0, sizeof(unsigned) * (size_t)s->flow_prog_cap, s->stream));
+    if (s->flow_zb8) HIPCHK(hipMemsetAsync(s->flow_zb8, 0, zb8_bytes, s->stream));
+    s->flow_epoch_bound = 0;
+  }
+  s->flow_epoch_bound += (unsigned)npass + 1u;
+  return TSX_OK;
+}
+
+template <int CW>
+static int flow_launch(tsx_solver *s, int p0, int p1, const int *done) {
+  const TsxGeo &g = s->geo;
+  const int h = g.xm >> 1;
+  const int R = h / CW, ntiles = R * g.ym;
+  // FAT (every neighbour-independent load in front of the wait, two waves per SIMD, records as granules): where a pass has at
+  // most as many tiles as such workgroups are resident -- there an item is a chain of latencies; TSX_FLOW_FAT=0 / 1 overrides (A/B)
+  const int cap_fat = flow_capacity(s, CW, true);
+  bool fat = ntiles <= cap_fat;
+  if (const char *e = getenv("TSX_FLOW_FAT")) fat = atoi(e) != 0;
+  int rc = flow_ensure(s, ntiles, fat, p1 - p0);
+  if (rc) return rc;
+  float *zs = (float *)s->vw;
+  unsigned *zb = (unsigned *)(zs + (size_t)g.N);
+  unsigned *rb = zb + (size_t)4 * g.Nc;
+  const uint4 *P = (const uint4 *)s->coef_h;
+  const float *r = (const float *)s->pc_rhs;
+  const bool dd = s->coef_h_dd;
+  const int *cidx = (const int *)s->pc_cidx_split;
+  const long long nent = s->pc_nent;
+  const uint4 *PE = P + g.Nc;
+  const int *pidx = dd && s->pcr_on ? (const int *)s->pcr_idx : (const int *)nullptr;
+  const uint4 *PT = (const uint4 *)s->pcr_tab;
+  TsxFlowArgs f;
+  f.st = (TsxFlowState *)s->flow_state;
+  f.prog = s->flow_prog;
+  f.p0 = p0;
+  f.p1 = p1;
+  f.ntiles = ntiles;
+  f.R = R;
+  f.err = &s->scal->flow_err;
+  f.zb8 = (uint2 *)s->flow_zb8;
+  {
+    static const double tmo = getenv("TSX_FLOW_TIMEOUT_S") ? atof(getenv("TSX_FLOW_TIMEOUT_S")) : 5.0;
+    f.ticks = (unsigned long long)(tmo * 1e8);  // wall_clock64: 100 MHz
+  }
+  // two passes' worth of tiles can be runnable at a time (a tile of pass p + 2 needs its neighbours' pass p + 1); more
+  // workgroups than that only poll
+  long long grid = 2ll * ntiles;
+  const int cap = fat ? cap_fat : flow_capacity(s, CW, false);
+  if (grid > cap) grid = cap;
+  if (const char *e = getenv("TSX_FLOW_GRID")) {
+    const int v = atoi(e);
+    if (v > 0) grid = v;
+  }
+  const long long nitems = (long long)(p1 - p0) * ntiles;
+  if (grid > nitems) grid = nitems;
+  constexpr bool C16 = TSX_PCS_C16 != 0;
+  // granules (the records as their own flags, TsxGran) only where most workgroups would otherwise idle: the workgroups ahead of the
+  // wave front spin on their sixteen 8-byte loads per lane, which slows a chip whose every workgroup has work.  Measured per solve
+  // (gpurun_out/flow_matrix_1.txt -> profiles/r05): 64 x 64 columns, 128 tiles of 16 columns: 1.86 ms with progress words, 1.71 with
+  // granules; 128 x 64, 128 tiles of 32: 2.51 / 2.51; 128 x 128, 256 tiles of 32 on 256 workgroups: 3.64 / 4.37.
+  bool gran = fat && 4 * ntiles <= cap_fat;
+  if (const char *e = getenv("TSX_FLOW_GRAN")) gran = fat && atoi(e) != 0;
+#define TSX_FLOW_GO(IDXV, FATV, GRV)                                                                                               \
+  hipLaunchKernelGGL((tsx_k_pcs_flow<4, 16, CW, IDXV, C16, FATV, GRV>), dim3((unsigned)grid), dim3(CW * 16), 0, s->stream, g, P, r, zb, \
+                     done, IDXV ? cidx : (const int *)nullptr, IDXV ? nent : 0ll, IDXV ? PE : (const uint4 *)nullptr, rb,          \
+                     IDXV ? pidx : (const int *)nullptr, IDXV ? PT : (const uint4 *)nullptr,                                       \
+                     (IDXV && s->pe_entry_major) ? TSX_PCS_ENT16_SLOTS : 1, f)
+  if (dd) {
+    if (gran) TSX_FLOW_GO(true, true, true);
+    else if (fat) TSX_FLOW_GO(true, true, false);
+    else TSX_FLOW_GO(true, false, false);
+  } else {
+    if (gran) TSX_FLOW_GO(false, true, true);
+    else if (fat) TSX_FLOW_GO(false, true, false);
+    else TSX_FLOW_GO(false, false, false);
+  }
+#undef TSX_FLOW_GO
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+int tsx_pcs_flow(tsx_solver *s, int cw, int p0, int p1, const int *done) {
+  if (p1 <= p0) return TSX_OK;
+  return cw == 32 ? flow_launch<32>(s, p0, p1, done) : flow_launch<16>(s, p0, p1, done);
+}
+
+#ifdef TSX_FLOW_TRACE
+// analysis builds only: the stamps of the last flow launch(es), n items of 12 words
+extern "C" int tsx_debug_flow_trace(unsigned long long *out, int n) {
+  if (n > TSX_FLOW_TL_N) n = TSX_FLOW_TL_N;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(tsx_flow_tl), sizeof(unsigned long long) * 12 * (size_t)n));
+  return TSX_OK;
+}
+#endif

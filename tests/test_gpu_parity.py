@@ -917,3 +917,36 @@ def test_sharing_keyed_on_lut_coordinates_is_lossless(gpu, monkeypatch):
     assert np.array_equal(res["0"][2], res["1"][2])
     assert res["0"][4].niter == res["1"][4].niter and np.array_equal(res["0"][4].res_hist, res["1"][4].res_hist)
     assert np.array_equal(res["0"][3], res["1"][3])
+
+
+@pytest.mark.parametrize("Nx,Ny,Nz,field", [(64, 32, 20, "shared"), (128, 128, 12, "shared"), (128, 128, 12, "near"),
+                                             (128, 64, 64, "shared"), (64, 64, 24, "own"), (192, 128, 16, "own")])
+def test_flow_kernel_is_bit_identical_to_launch_per_pass(gpu, monkeypatch, Nx, Ny, Nz, field):
+    """Round 5: the intermediate passes of an application of the scan preconditioner run as ONE launch (tsx_k_pcs_flow: work
+    items (pass, tile) behind a ticket counter, an item waiting for its four neighbour tiles' progress words; records handed
+    between workgroups through sc1 stores / loads).  Same arithmetic per cell as a launch per pass (TSX_PC_FLOW=0): M^-1 v and
+    whole solves must be bit-identical -- any record read before its producer's store became visible, or overwritten while a
+    neighbour still read it, shows here.  Fields: blocks shared bit-identically (per-block records behind an index), grouped
+    near-identical blocks (entry-major records, fetched by lane groups through LDS), every cell its own records."""
+    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+    coeff = P["coeff"]
+    if field == "near":
+        coeff = (coeff * (1 + 1e-3 * np.random.default_rng(11).random(coeff.shape))).astype(np.float32)
+    if field == "own":
+        monkeypatch.setenv("TSX_DEDUP", "0")
+    v = np.random.default_rng(12).standard_normal(P["b"].shape)
+    out = {}
+    for env in ("1", "0"):
+        monkeypatch.setenv("TSX_PC_FLOW", env)
+        s = DiffuseSolver("3_10", Nz, Nx, Ny)
+        s.set_coeffs(coeff, P["l1d"], P["a11"], P["a12"], P["albedo"])
+        res = [s.pc_apply(v, pc=3, sweeps=sw, mixed=True) for sw in (27, 27, 9, 5)]
+        for rtol in (1e-5, 1e-9):
+            x = np.zeros(s.vec_shape)
+            info = s.solve(P["b"], x, rtol=rtol, atol=1e-30)
+            assert info.reason == 2
+            res += [x, np.asarray(info.res_hist)]
+        out[env] = res
+        s.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
