@@ -260,14 +260,23 @@ def main():
                     failed = e
             return None
 
-        for _ in range(args.warmup):
-            one()
+        first = None
+        for q in range(args.warmup):
+            tw = time.perf_counter()
+            iw = one()   # (solve() returns after the stream has been synchronised)
+            if q == 0 and iw is not None:   # the handle's first solve with these options: no iteration-count hint yet
+                first = {"wall_ms": (time.perf_counter() - tw) * 1e3, "solve_ms_device": iw.solve_ms, "iterations": iw.niter}
         barrier()
         t0 = time.perf_counter()
+        marks = [t0]
         for _ in range(args.steps):   # "zero initial guess" is part of the workload: the caller says so, x is not read
             got.append(one())
+            marks.append(time.perf_counter())
         barrier()
         el = time.perf_counter() - t0
+        per = sorted((marks[i + 1] - marks[i]) * 1e3 for i in range(len(marks) - 1))
+        timed_steps.last = {"first_solve": first,
+                            "step_ms_min_med_max": [per[0], per[len(per) // 2], per[-1]] if per else None}
         if world > 1:
             tt = torch.tensor([el, 0.0 if failed is None else 1.0], dtype=torch.float64,
                               device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -303,6 +312,17 @@ def main():
     info = infos[-1]
     # SURVEY 8(d) also asks for a tight run (rtol 1e-8, atol 1e-30 as in tests/test_pprts_symmetry/tenstream.options) and
     # a warm start (previous solution as initial guess, default tolerances): reported in `config`, never part of `value`
+    spread = dict(timed_steps.last)
+    # the timed region repeats ONE system, so the host's first look at the convergence flag comes where the previous solve ended
+    # (check_every = 0, krylov_run): one synchronisation per solve.  Reported beside it: the same steps with the hint off
+    # (check_every fixed at 2, the library's non-adaptive cadence: a look every second iteration) -- never part of `value`
+    no_hint = None
+    if args.check_every is None and not args.explicit and world == 1:
+        dt_nh, infos_nh, failed_nh = timed_steps(check_every=2)
+        if failed_nh is None:
+            no_hint = {"cells_per_s": cells_total * args.steps / dt_nh, "ms_per_step": dt_nh / args.steps * 1e3,
+                       "iterations": infos_nh[-1].niter, "step_ms_min_med_max": timed_steps.last["step_ms_min_med_max"],
+                       "how": "check_every = 2: no iteration-count hint, the host looks at the flag every second iteration"}
     x.zero_()
     tight = s.solve(b, x, rtol=1e-8, atol=1e-30, **kw)
     warm = s.solve(b, x, **kw)
@@ -317,9 +337,15 @@ def main():
     dd_on, dd_nent = s.dedup_info()
     pc_shared = dd_on or bool(getattr(s, "dedup_mode", 0) & 2)   # the preconditioner reads per-block records through an index
     pc_ran, sweeps, scan, rec_shared = s.pc_info()   # what the solves above actually ran (automatic pass count, zebra on odd grids)
+    flow = flow_ms = bytes_flow = None
     if scan and args.pc_sweeps == 0:
         pc_ms = s.bench_kernel(2, args.kernel_reps)
         pass_ms = s.bench_kernel(3, 4 * args.kernel_reps)
+        flow = s.flow_info()   # of the application just timed: do the intermediate passes run as one launch (tsx_k_pcs_flow)?
+        if flow["in_use"]:
+            flow_ms = s.bench_kernel(4, args.kernel_reps)
+            flow = s.flow_info()   # (as the Krylov loop issues it: from pass 1)
+            bytes_flow = s.algorithmic_bytes(4)
     bw = s.probe_bandwidth(1 << 30, 5)   # what plain streaming kernels reach on this box: copy and read-only, best variant each
     copy_gbps = bw["copy_GBps"]
     # the byte counts follow the storage format in use: take them while the solver is in the state that was timed
@@ -373,6 +399,11 @@ def main():
                               "preconditioner": {0: "none", 1: "column-jacobi", 2: f"column-zebra({pcf[1] + 1} passes)",
                                                  3: f"column-red-black({pcf[1] + 1} passes)"}.get(pcf[0], str(pcf[0])),
                               "options": ov}
+        all_fp64["which_one_a_real64_build_gets"] = (
+            "neither by default: tsx_default_ksp_opts sets fp32_directions = 2 whatever the caller's ireals (the headline: x, b, dots, "
+            "operator and stop rule fp64, recurrence vectors fp32 with fp64 residual replacement); recurrence_fp64 is what "
+            "fp32_directions = 1 -- and any rtol < 1e-7 -- selects; everything_fp64 (fp32_directions = 0, pc_coeff_fp16 = 0) is the "
+            "reference's arithmetic end to end and the retry solver")
 
     # ---- fourth leg (config.heterogeneous, never `value`): the general field -- log-normal noise on every cell's kabs / ksca,
     # so no two cells share a transport block (what an LES humidity / aerosol field + gas optics delivers); same generator
@@ -452,6 +483,17 @@ def main():
         # the kernel the solve spends most of its time in: the preconditioner pass (about half of an iteration) when the
         # scan kernels run, else the operator apply
         dominant = r_pass if r_pass is not None else r_spmv
+        r_flow = None
+        if flow_ms is not None:
+            # the intermediate passes of an application run as ONE launch: that launch is where the solve spends its time
+            npass = flow["end_pass"] - flow["first_pass"]
+            r_flow = roof(f"tsx_k_pcs_flow (passes {flow['first_pass']}..{flow['end_pass'] - 1} of one M^-1 application in one launch: "
+                          f"{npass} intermediate red-black passes, work items (pass, tile) behind a ticket counter)", flow_ms,
+                          bytes_flow, ["tsx_k_pcs_flow"])
+            r_flow["passes_per_launch"] = npass
+            r_flow["us_per_pass"] = flow_ms * 1e3 / npass
+            r_flow["the_same_pass_as_its_own_launch_us"] = pass_ms * 1e3
+            dominant = r_flow
         out = {
             "metric": f"pprts {solver} diffuse-solve cells/s" + (" (explicit solver)" if args.explicit else ""),
             "value": value,
@@ -495,6 +537,10 @@ def main():
                 "import_ms": info.import_ms,
                 "export_ms": info.export_ms,
                 "iter_ms": iter_ms,
+                "first_solve": spread["first_solve"],
+                "step_ms_min_med_max": spread["step_ms_min_med_max"],
+                "no_hint": no_hint,
+                "flow_kernel": flow,
                 "tight_run": {"rtol": 1e-8, "iterations": tight.niter, "reason": tight.reason, "solve_ms": tight.solve_ms},
                 "warm_start": {"iterations": warm.niter, "reason": warm.reason, "solve_ms": warm.solve_ms},
                 "iter_GBps": bytes_iter / (iter_ms * 1e-3) / 1e9,
@@ -509,6 +555,7 @@ def main():
                 "baseline_config": baseline_config(solver, Nx, Ny, Nz, world, npx, npy, scaling),
             },
             "roofline": dominant,
+            "roofline_pass": r_pass,
             "roofline_spmv": r_spmv,
             "roofline_iter": r_iter,
             "roofline_pc": r_pc,

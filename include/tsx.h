@@ -352,7 +352,8 @@ int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int 
 /* ---- measurement helpers (bench.py): time `reps` launches of the dominant kernel with HIP events on
  *      the solver's stream.  kernel: 0 = SpMV (diffuse operator apply), 1 = one full BiCGStab iteration,
  *      2 = one application of the default preconditioner (pc_sweeps + 1 half-grid passes), 3 = one intermediate
- *      Gauss-Seidel pass of it (scan kernels) */
+ *      Gauss-Seidel pass of it (scan kernels) as a launch of its own, 4 = the flow kernel (the intermediate passes of an
+ *      application in ONE launch; TSX_ERR_UNSUPPORTED where the configuration runs a launch per pass) */
 int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_ms);
 /* algorithmic bytes per launch of that kernel *in the storage format in use* (with shared storage of identical blocks:
  * every distinct block once + a 4-byte index per cell + the vectors; the preconditioner passes: packed records + fp32
@@ -371,6 +372,10 @@ int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent);
  * on odd grids, pc_sweeps 0 -> 27 or 9): TSX_PC_*, pc_sweeps, and scan: 0 = one-lane-per-column kernels, 1 = scan kernels,
  * 3 = scan kernels reading identical recurrence records through a shared table */
 int tsx_pc_info(const tsx_solver *s, int32_t *pc, int32_t *pc_sweeps, int32_t *scan);
+/* how the last application of M^-1 ran its intermediate passes (tsx_k_pcs_flow, DESIGN.md section 4 "The passes of an application
+ * as one launch"): info8 = {flow kernel used (0: a launch per pass), first pass, one past the last pass of the launch, columns per
+ * tile, fat body (every neighbour-independent load hoisted, two waves per SIMD), records as granules, tiles per pass, workgroups} */
+int tsx_flow_info(const tsx_solver *s, int32_t *info8);
 /* device STREAM-like copy bandwidth probe (GB/s) for reporting against the measured peak */
 int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps);
 /* the same probe in full: out4 = [best copy GB/s (read + written bytes), best read-only GB/s, copy variant, read variant] over

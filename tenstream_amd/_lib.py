@@ -55,7 +55,7 @@ SYMBOLS = (
     "tsx_diff_set_coeffs", "tsx_lut_set_diffuse", "tsx_lut_load_diffuse_mmap4", "tsx_diff_set_optprop",
     "tsx_diff_get_coeffs", "tsx_pprts_set_angles", "tsx_lut_set_direct", "tsx_lut_load_direct_mmap4", "tsx_pprts_set_optprop", "tsx_pprts_set_optical_properties", "tsx_pprts_solve",
     "tsx_pprts_zero_guess", "tsx_pprts_get_result", "tsx_pprts_get_field", "tsx_diff_apply", "tsx_diff_solve", "tsx_diff_pc_apply", "tsx_bench_kernel", "tsx_algorithmic_bytes",
-    "tsx_probe_copy_bandwidth", "tsx_opp_get_coeff", "tsx_opp_get_info", "tsx_pprts_select_solution", "tsx_dedup_info", "tsx_pc_info", "tsx_pprts_set_direct_tolerances",
+    "tsx_probe_copy_bandwidth", "tsx_opp_get_coeff", "tsx_opp_get_info", "tsx_pprts_select_solution", "tsx_dedup_info", "tsx_pc_info", "tsx_flow_info", "tsx_pprts_set_direct_tolerances",
     "tsx_probe_bandwidth", "tsx_diff_apply_r", "tsx_diff_solve_r", "tsx_dir_set_coeffs", "tsx_dir_solve", "tsx_setup_b_solar", "tsx_setup_b_thermal",
 )
 
@@ -118,6 +118,7 @@ def load():
     lib.tsx_dedup_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.tsx_pprts_set_direct_tolerances.argtypes = [vp, C.c_double, C.c_double, C.c_int32]
     lib.tsx_pc_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.tsx_flow_info.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.tsx_opp_get_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
     lib.tsx_diff_apply_r.argtypes = [vp, vp, vp, ip, ip]
     lib.tsx_diff_solve_r.argtypes = [vp, vp, vp, ip, ip, C.POINTER(KspOpts), C.POINTER(KspResult)]

@@ -1516,8 +1516,20 @@ extern "C" int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *by
     if (kernel == 3) *bytes = gs_b * half + e_gs;
     else if (r16) *bytes = ((c[1] + w16) + (c[0] + w16) + gs_b * (ngs - 1.0) + c[2] + c[3]) * half + e_first + ngs * e_gs + 2.0 * e_f32;
     else *bytes = (c[1] + c[0] * ngs + c[2] + c[3]) * half + e_first + ngs * e_gs + 2.0 * e_f32;
+  } else if (kernel == 4) {
+    // the flow kernel (tsx_k_pcs_flow): p1 - p0 intermediate passes in one launch; with granules (TsxGran) the four records a cell
+    // stores and the four it reads are 8 bytes each instead of 4
+    if (!s->flow_last[0]) {
+      tsx_set_error("tsx_algorithmic_bytes: kernel 4: the last application of M^-1 did not use the flow kernel");
+      return TSX_ERR_STATE;
+    }
+    double pass = 0.0;
+    int rc = tsx_algorithmic_bytes(s, 3, &pass);
+    if (rc) return rc;
+    if (s->flow_last[5]) pass += 32.0 * 0.5 * Nc;
+    *bytes = pass * (double)(s->flow_last[2] - s->flow_last[1]);
   } else {
-    tsx_set_error("tsx_algorithmic_bytes: kernel must be 0..3, 10 or 11");
+    tsx_set_error("tsx_algorithmic_bytes: kernel must be 0..4, 10 or 11");
     return TSX_ERR_ARG;
   }
   return TSX_OK;
@@ -1532,22 +1544,34 @@ static int bench_kernel_t(tsx_solver *s, int kernel, int reps, float *avg_ms) {
     for (int q = 0; q < reps; ++q)
       if ((rc = launch_spmv<NTOP, NSIDE, 0>(s, (const double *)s->vp, s->vv, (const double *)nullptr, false))) return rc;
     HIPCHK(hipEventRecord(s->ev1, s->stream));
-  } else if (kernel == 2 || kernel == 3) {
+  } else if (kernel == 2 || kernel == 3 || kernel == 4) {
     // the default preconditioner on the fp32 right-hand side p32: 2 = one application (pc_sweeps + 1 half-grid passes),
-    // 3 = one intermediate Gauss-Seidel pass of the scan kernels
+    // 3 = one intermediate Gauss-Seidel pass of the scan kernels as a launch of its own, 4 = the flow kernel: the intermediate
+    // passes of an application in one launch, as the Krylov loop issues it (the vector update before it has left the bf16 words)
     tsx_ksp_opts o, ou;
     if ((rc = prepare_ksp(s, nullptr, &o))) return rc;
     (void)ou;
     s->pc_rhs = s->p32;
-    if (kernel == 3 && !s->coef_h_scan) {
-      tsx_set_error("tsx_bench_kernel: kernel 3 needs the scan preconditioner (3_10, red-black, TSX_PC_SCAN != 0)");
+    if (kernel >= 3 && !s->coef_h_scan) {
+      tsx_set_error("tsx_bench_kernel: kernel 3 / 4 needs the scan preconditioner (3_10, red-black, TSX_PC_SCAN != 0)");
       return TSX_ERR_UNSUPPORTED;
     }
-    if ((rc = tsx_pc_apply(s, s->vp, s->vph, true, false))) return rc;  // warm
+    if ((rc = tsx_pc_apply(s, s->vp, s->vph, true, false))) return rc;  // warm (and it leaves the bf16 words)
+    int fl[8];
+    memcpy(fl, s->flow_last, sizeof(fl));
+    if (kernel == 4 && !fl[0]) {
+      tsx_set_error("tsx_bench_kernel: kernel 4: this configuration does not run the flow kernel");
+      return TSX_ERR_UNSUPPORTED;
+    }
+    if (kernel == 4 && fl[1] > 1) {  // as inside a solve: pass 0 alone precedes it
+      fl[1] = 1;
+      if ((rc = tsx_pcs_flow(s, fl[3], fl[1], fl[2], nullptr))) return rc;
+    }
     HIPCHK(hipEventRecord(s->ev0, s->stream));
     for (int q = 0; q < reps; ++q) {
       if (kernel == 2) rc = tsx_pc_apply(s, s->vp, s->vph, true, false);
-      else rc = tsx_pcs_pass(s, 2 + (q & 1), 0, (float *)s->vph, nullptr, tsx_pcs_rhs16(s) ? 2 : 0);
+      else if (kernel == 3) rc = tsx_pcs_pass(s, 2 + (q & 1), 0, (float *)s->vph, nullptr, tsx_pcs_rhs16(s) ? 2 : 0);
+      else rc = tsx_pcs_flow(s, fl[3], fl[1], fl[2], nullptr);
       if (rc) return rc;
     }
     HIPCHK(hipEventRecord(s->ev1, s->stream));
@@ -1576,7 +1600,7 @@ static int bench_kernel_t(tsx_solver *s, int kernel, int reps, float *avg_ms) {
 
 extern "C" int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_ms) {
   ARGCHK(s && avg_ms && reps >= 1, "tsx_bench_kernel: bad argument");
-  ARGCHK(kernel >= 0 && kernel <= 3, "tsx_bench_kernel: kernel must be 0..3");
+  ARGCHK(kernel >= 0 && kernel <= 4, "tsx_bench_kernel: kernel must be 0..4");
   if (!s->have_coeffs) {
     tsx_set_error("tsx_bench_kernel: call tsx_diff_set_coeffs first");
     return TSX_ERR_STATE;
@@ -1598,6 +1622,12 @@ extern "C" int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent) {
   // preconditioner (on top of bit 0, or alone where nothing is bit-identical)
   *on = (s->dd_on ? 1 : 0) | (s->dd_pc ? 2 : 0);
   *nent = s->dd_on ? s->dd_nent : (s->dd_pc ? s->pc_nent : s->dd_nent);
+  return TSX_OK;
+}
+
+extern "C" int tsx_flow_info(const tsx_solver *s, int32_t *info8) {
+  ARGCHK(s && info8, "tsx_flow_info: null");
+  for (int q = 0; q < 8; ++q) info8[q] = s->flow_last[q];
   return TSX_OK;
 }
 

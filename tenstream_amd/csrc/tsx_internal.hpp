@@ -161,6 +161,7 @@ struct tsx_solver {
   void *flow_state = nullptr;
   unsigned *flow_prog = nullptr;
   void *flow_zb8 = nullptr;       // the iterate records as 8-byte granules {bf16 pair, tag} (fat flow kernel), [4][Nc]
+  int flow_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the last application of M^-1: {flow kernel used, p0, p1, columns per tile, fat, granules, tiles per pass, workgroups}
   unsigned flow_epoch_bound = 0;  // host-side upper bound of the device's epoch word (tags and progress words restart before it wraps)
   int flow_prog_cap = 0;
   int flow_capacity[4] = {0, 0, 0, 0};  // resident workgroups of tsx_k_pcs_flow<4, 16, 32 | 16, lean | fat> on this device (0: not asked yet)

@@ -482,6 +482,7 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
   if (!getenv("TSX_PCS_CFG") && cfg.lseg == 4 && cfg.nseg == 16)
     fcw = ((long long)s->geo.ym * (s->geo.xm / 2) >= 4096 && (s->geo.xm / 2) % 32 == 0) ? 32 : 16;
   const bool flow = !halo && s->geo.ntop == 2 && P - 2 - fp0 >= 2 && tsx_pcs_flow_ok(s, cfg.lseg, cfg.nseg, fcw);
+  s->flow_last[0] = 0;
   for (int pass = 0; pass < P; ++pass) {
     const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
     if (flow && pass == fp0) {

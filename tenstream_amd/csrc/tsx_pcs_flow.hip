@@ -159,6 +159,8 @@ static int flow_launch(tsx_solver *s, int p0, int p1, const int *done) {
   }
 #undef TSX_FLOW_GO
   HIPCHK(hipGetLastError());
+  const int rec[8] = {1, p0, p1, CW, fat ? 1 : 0, gran ? 1 : 0, ntiles, (int)grid};
+  memcpy(s->flow_last, rec, sizeof(rec));
   return TSX_OK;
 }
 

@@ -427,6 +427,13 @@ class DiffuseSolver:
         _lib.check(self.lib.tsx_pc_info(self.h, C.byref(pc), C.byref(sw), C.byref(scan)))
         return int(pc.value), int(sw.value), bool(scan.value & 1), bool(scan.value & 2)
 
+    def flow_info(self):
+        """how the last application of M^-1 ran its intermediate passes (tsx_flow_info)"""
+        o = (C.c_int32 * 8)()
+        _lib.check(self.lib.tsx_flow_info(self.h, o))
+        return {"in_use": bool(o[0]), "first_pass": int(o[1]), "end_pass": int(o[2]), "columns_per_tile": int(o[3]),
+                "fat": bool(o[4]), "granules": bool(o[5]), "tiles_per_pass": int(o[6]), "workgroups": int(o[7])}
+
     def bench_kernel(self, kernel: int, reps: int) -> float:
         ms = C.c_float()
         _lib.check(self.lib.tsx_bench_kernel(self.h, kernel, reps, C.byref(ms)))
