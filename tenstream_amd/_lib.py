@@ -118,7 +118,8 @@ def load():
     lib.tsx_dedup_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.tsx_pprts_set_direct_tolerances.argtypes = [vp, C.c_double, C.c_double, C.c_int32]
     lib.tsx_pc_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-    lib.tsx_flow_info.argtypes = [vp, C.POINTER(C.c_int32)]
+    if hasattr(lib, "tsx_flow_info"):   # (an older build loaded through TSX_LIB for an A/B run has none)
+        lib.tsx_flow_info.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.tsx_opp_get_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
     lib.tsx_diff_apply_r.argtypes = [vp, vp, vp, ip, ip]
     lib.tsx_diff_solve_r.argtypes = [vp, vp, vp, ip, ip, C.POINTER(KspOpts), C.POINTER(KspResult)]

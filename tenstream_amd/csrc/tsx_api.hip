@@ -67,9 +67,16 @@ static int rccl_load() {
   if (g_rccl.h) return TSX_OK;
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void *h = nullptr;
-  for (const char *n : names) {
-    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (h) break;
+  // TSX_RCCL_LIB: another library with librccl's entry points -- the tests' double (tests/c/fake_rccl.cpp: the same calls over
+  // shared memory, so that this transport's host code runs with several ranks on a one-GPU box).  Never set in production.
+  const char *ov = getenv("TSX_RCCL_LIB");
+  if (ov && *ov) {
+    h = dlopen(ov, RTLD_NOW | RTLD_LOCAL);
+  } else {
+    for (const char *n : names) {
+      h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
   }
   if (!h) {
     tsx_set_error(std::string("cannot dlopen librccl: ") + dlerror());
@@ -283,7 +290,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
-                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->bsrfc, s->edir_a, s->edir_b, s->dsc, s->abso, s->cell_samp, s->dd_colsum, s->flow_state, s->flow_prog, s->flow_zb8};
+                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->bsrfc, s->edir_a, s->edir_b, s->dsc, s->abso, s->cell_samp, s->dd_colsum, s->flow_state, s->flow_prog, s->flow_zb8, s->flow_pr_dev};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->vph && s->vph != s->vp) (void)hipFree(s->vph);
@@ -295,6 +302,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
     if (s->host_recv[q]) (void)hipHostFree(s->host_recv[q]);
   }
   slots_free(s);
+  delete s->flow_pr_shadow;
   if (s->comm_ready && g_rccl.CommDestroy) {
     if (s->nccl_comm_x) g_rccl.CommDestroy(s->nccl_comm_x);
     g_rccl.CommDestroy(s->nccl_comm);
@@ -1043,6 +1051,18 @@ static int krylov_begin(tsx_solver *s, const tsx_ksp_opts *o, bool restart = fal
   return TSX_OK;
 }
 
+// what an iteration-count hint was measured with (krylov_run)
+static unsigned long long hint_key(const tsx_solver *s, const tsx_ksp_opts *o) {
+  unsigned long long h = 0x9e3779b97f4a7c15ull, v;
+  const double d[2] = {o->rtol, o->atol};
+  for (int q = 0; q < 2; ++q) {
+    memcpy(&v, &d[q], sizeof(v));
+    h = (h ^ v) * 0xff51afd7ed558ccdull;
+  }
+  v = ((unsigned long long)(unsigned)s->pc << 40) | ((unsigned long long)(unsigned)s->pc_sweeps << 8) | (s->mixed ? 2u : 0u) | (s->k32 ? 1u : 0u);
+  return (h ^ v) * 0xff51afd7ed558ccdull;
+}
+
 // The Krylov loop on the internal vectors s->vb (rhs) and s->vx (initial guess in, solution out).
 // Records ev0/ev1 around it; leaves the final scalars in s->scal_host.
 template <int NTOP, int NSIDE>
@@ -1068,8 +1088,13 @@ static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
     // the first look at the flag comes where the previous solve of this handle with the same kind of start (cold / warm) ended,
     // less one: a repeated solve (a spectral loop, a time step) then synchronises with the host twice instead of every
     // check_every iterations; overshooting costs the empty launches of the surplus iterations (about 0.1 ms each)
-    if (enq == 0 && o->check_every <= 0) {
-      const int hint = cold ? s->its_hint_cold : s->its_hint_warm;
+    // The hint belongs to the solver settings it was measured with (tolerances, preconditioner, pass count, precision of the
+    // recurrence), and it is capped: on the fp32 recurrence the re-anchoring to the true residual and the breakdown restart
+    // are only evaluated at a look, so a hard solve must not run dozens of iterations before the first one
+    const unsigned long long hkey = hint_key(s, o);
+    if (enq == 0 && o->check_every <= 0 && hkey == s->its_hint_key) {
+      int hint = cold ? s->its_hint_cold : s->its_hint_warm;
+      if (hint - 1 > 8) hint = 9;
       if (hint - 1 > todo) todo = (hint - 1) < (o->maxit - enq) ? hint - 1 : (o->maxit - enq);
     }
     {
@@ -1088,6 +1113,7 @@ static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
     HIPCHK(hipMemcpyAsync(s->scal_host, s->scal, sizeof(TsxScalars), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (s->scal_host->flow_err) {  // tsx_k_pcs_flow: a bounded wait for a neighbour tile expired (cannot happen by construction)
+      if (tsx_peer_check(s) != TSX_OK) return TSX_ERR_COMM;  // ... or for a neighbour rank's message: the mailbox says which
       tsx_set_error("preconditioner flow kernel: a wait for a neighbour tile's progress word expired (TSX_PC_FLOW=0 runs a launch per pass)");
       return TSX_ERR_HIP;
     }
@@ -1145,7 +1171,12 @@ static int krylov_run(tsx_solver *s, const tsx_ksp_opts *o) {
     }
   }
   HIPCHK(hipEventRecord(s->ev1, s->stream));
-  if (s->scal_host->reason > 0) (cold ? s->its_hint_cold : s->its_hint_warm) = s->scal_host->its;
+  if (s->scal_host->reason > 0 && !s->in_retry) {  // (the conservative retry solver's count says nothing about the next default solve)
+    const unsigned long long hkey = hint_key(s, o);
+    if (hkey != s->its_hint_key) s->its_hint_cold = s->its_hint_warm = 0;
+    s->its_hint_key = hkey;
+    (cold ? s->its_hint_cold : s->its_hint_warm) = s->scal_host->its;
+  }
   return TSX_OK;
 }
 
@@ -1229,7 +1260,9 @@ static int krylov_run_with_retry(tsx_solver *s, tsx_ksp_opts *o) {
   hipEvent_t tmp;
   HIPCHK(hipEventCreate(&tmp));
   s->ev0 = tmp;
+  s->in_retry = true;
   rc = krylov_run<NTOP, NSIDE>(s, &o3);
+  s->in_retry = false;
   s->ev0 = keep0;
   (void)hipEventDestroy(tmp);
   if (rc) return rc;

@@ -180,9 +180,84 @@ extern "C" void tsx_f2c_set_comm(int rank, int nranks, tsx_exchange_fn exchange,
   g_comm.ctx = ctx;
 }
 
+#ifdef TSX_F2C_MPI
+// ---- libtsx_f2c_mpi.so: the same library built with an MPI compiler (make mpi; MPICH or any MPI with MPI_Comm_f2c).  `fcomm` is
+// then what the reference says it is -- MPI_Comm_c2f(comm), c_wrapper/f2c_pprts.F90:130-230 -- and a multi-rank C caller written
+// against TenStream (c_wrapper/pprts.c) links and runs unchanged: no tsx_f2c_set_comm.  The two collectives of include/tsx.h over
+// that communicator: the face exchange as non-blocking receives E, W, N, S against sends W, E, S, N with the sender's face as tag
+// (two ranks along a periodic axis are each other's W and E neighbour), the sum as MPI_Allreduce.
+#include <mpi.h>
+namespace {
+MPI_Comm g_mpi_comm = MPI_COMM_NULL;
+int mpi_exchange(void *, const double *const send[4], double *const recv[4], const size_t count[4], const int peer[4]) {
+  static const int want_tag[4] = {1, 0, 3, 2};  // recv[W] <- peer W's send[E] ...
+  MPI_Request req[8];
+  int n = 0, me = 0;
+  MPI_Comm_rank(g_mpi_comm, &me);
+  for (int q = 0; q < 4; ++q)
+    if (count[q] && peer[q] != me) MPI_Irecv(recv[q], (int)count[q], MPI_DOUBLE, peer[q], want_tag[q], g_mpi_comm, &req[n++]);
+  for (int q = 0; q < 4; ++q)
+    if (count[q] && peer[q] != me) MPI_Isend(const_cast<double *>(send[q]), (int)count[q], MPI_DOUBLE, peer[q], q, g_mpi_comm, &req[n++]);
+  for (int q = 0; q < 4; ++q)  // a rank that is its own neighbour in a direction
+    if (count[q] && peer[q] == me) memcpy(recv[q], send[q ^ 1], count[q] * sizeof(double));
+  return MPI_Waitall(n, req, MPI_STATUSES_IGNORE) == MPI_SUCCESS ? 0 : 1;
+}
+int mpi_allreduce(void *, double *inout, int n) {
+  return MPI_Allreduce(MPI_IN_PLACE, inout, n, MPI_DOUBLE, MPI_SUM, g_mpi_comm) == MPI_SUCCESS ? 0 : 1;
+}
+void mpi_attach(int fcomm) {
+  int inited = 0;
+  MPI_Initialized(&inited);
+  if (!inited) die("pprts_f2c_init: MPI is not initialised (the caller owns MPI_Init, as with the reference)");
+  g_mpi_comm = MPI_Comm_f2c((MPI_Fint)fcomm);
+  int rank = 0, size = 1;
+  MPI_Comm_rank(g_mpi_comm, &rank);
+  MPI_Comm_size(g_mpi_comm, &size);
+  tsx_f2c_set_comm(rank, size, size > 1 ? mpi_exchange : nullptr, size > 1 ? mpi_allreduce : nullptr, nullptr);
+}
+}  // namespace
+// test hook (tests/c/f2c_mpi_selftest.c; needs no GPU): the two callbacks over `fcomm` on host buffers, every face a pattern that
+// names sender and face; returns the number of wrong values (summed over the ranks)
+extern "C" int tsx_f2c_mpi_selftest(int fcomm, int nxp, int nyp, int count) {
+  mpi_attach(fcomm);
+  const int rank = g_comm.rank, size = g_comm.nranks;
+  if (nxp * nyp != size) return -1;
+  const int xi = rank % nxp, yi = rank / nxp;  // x fastest, periodic (src/pprts_base.F90:747-790)
+  const int peer[4] = {yi * nxp + (xi + nxp - 1) % nxp, yi * nxp + (xi + 1) % nxp, ((yi + nyp - 1) % nyp) * nxp + xi, ((yi + 1) % nyp) * nxp + xi};
+  std::vector<double> sb[4], rb[4];
+  const double *send[4];
+  double *recv[4];
+  size_t cnt[4];
+  for (int q = 0; q < 4; ++q) {
+    sb[q].resize(count);
+    rb[q].assign(count, -1.0);
+    for (int i = 0; i < count; ++i) sb[q][i] = rank * 1000.0 + q * 100.0 + (i % 97);
+    send[q] = sb[q].data();
+    recv[q] = rb[q].data();
+    cnt[q] = (size_t)count;
+  }
+  double bad = 0;
+  if (size > 1) {
+    if (g_comm.exchange(nullptr, send, recv, cnt, peer)) return -2;
+    for (int q = 0; q < 4; ++q)
+      for (int i = 0; i < count; ++i) bad += rb[q][i] != peer[q] * 1000.0 + (q ^ 1) * 100.0 + (i % 97);
+    double v[3] = {1.0, (double)rank, bad};
+    if (g_comm.allreduce(nullptr, v, 3)) return -3;
+    if (v[0] != size || v[1] != size * (size - 1) / 2.0) return -4;
+    bad = v[2];
+  }
+  g_comm = F2cComm();
+  return (int)bad;
+}
+#endif
+
 extern "C" void pprts_f2c_init(int fcomm, int *solver_id, int *Nz, int *Nx, int *Ny, double *dx, double *dy, float *hhl,
                                float *phi0, float *theta0, int *collapseindex) {
+#ifdef TSX_F2C_MPI
+  if (!g_st.h) mpi_attach(fcomm);  // `fcomm` names the communicator, as in the reference
+#else
   (void)fcomm;
+#endif
   if (g_st.h) {  // already initialised: only the solver type is checked (f2c_pprts.F90:148-182)
     if (*solver_id != g_st.solver_id)
       die("seems you changed the solver type id in between calls... you must destroy the solver first");

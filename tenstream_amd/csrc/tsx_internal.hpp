@@ -97,6 +97,17 @@ struct TsxPeerXArgs {
   const int *done;              // unused (the sequence numbers must stay in step whatever the convergence flag says)
 };
 
+// the flow kernel's view of the peer transport for one launch (tsx_k_pcs_flow FPEER, tsx_peer_flow_view), faces W, E, S, N
+struct TsxFlowPeer {
+  char *mine;
+  char *remote[4];                  // null: face not active (the rank wraps onto itself there)
+  unsigned long long R0[4], S0[4];  // messages received / sent through the face before the launch (host side only)
+  unsigned long long cap, data_off, ticks;
+  unsigned long long tag_off, tag_edge;  // the tags: [face][parity][tag_edge] words at tag_off of a mailbox
+  unsigned *fctr;                   // (unused)
+  int heavy;
+};
+
 struct tsx_solver {
   tsx_grid grid;
   TsxGeo geo;
@@ -152,6 +163,7 @@ struct tsx_solver {
   // answer was agreed for (-1: not yet)
   int pcg_key = -1;
   bool pcg_halo_ok = false;
+  bool pcg_flow_ok = false;   // ... and every rank can run the intermediate passes as one launch with its faces (tsx_k_pcs_flow FPEER)
   // shared storage of identical packed preconditioner records (tsx_records_share): per-cell index, table, capacity (records)
   bool pcr_on = false;
   int *pcr_idx = nullptr, *pcr_ent = nullptr;
@@ -160,6 +172,8 @@ struct tsx_solver {
   // the intermediate passes of an application as one launch (tsx_pcs_flow.hip): ticket / epoch words and the tiles' progress words
   void *flow_state = nullptr;
   unsigned *flow_prog = nullptr;
+  void *flow_pr_dev = nullptr;    // device copy of the flow kernel's view of the peer transport (TsxFlowPeer), and what it holds
+  TsxFlowPeer *flow_pr_shadow = nullptr;
   void *flow_zb8 = nullptr;       // the iterate records as 8-byte granules {bf16 pair, tag} (fat flow kernel), [4][Nc]
   int flow_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the last application of M^-1: {flow kernel used, p0, p1, columns per tile, fat, granules, tiles per pass, workgroups}
   unsigned flow_epoch_bound = 0;  // host-side upper bound of the device's epoch word (tags and progress words restart before it wraps)
@@ -201,6 +215,8 @@ struct tsx_solver {
   float *dirT, *dirS;            // direct coefficient planes (S*S, S*D)
   bool dir_coeffs_valid;
   int its_hint_cold = 0, its_hint_warm = 0;  // iterations of the last converged Krylov solve from a zero / nonzero guess (krylov_run)
+  unsigned long long its_hint_key = 0;       // ... and the settings they belong to (tolerances, preconditioner, passes, precision)
+  bool in_retry = false;                     // the conservative retry solver is running (krylov_run_with_retry)
   bool have_albedo = false;  // s->albedo holds the caller's surface albedo (set_coeffs / set_optprop / set_optical_properties / setup_b_solar)
   bool dir_seam = false, dir_seam_S = false;  // dirT (and dirS) were handed over by tsx_dir_set_coeffs (the direct seam), not looked up
   double *dd_colsum;         // [D][dd_nent]: sum over dst of c(src, dst) per distinct block (absorptivity / emissivity terms of setup_b_thermal, flx_div)

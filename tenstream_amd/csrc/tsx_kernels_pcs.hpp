@@ -490,7 +490,8 @@ __device__ __forceinline__ void tsx_pcs_rb_body(const TsxGeo &g, const uint4 *__
   static_assert(!GRAN || HOIST, "granules: the flow kernel's fat body");
   static_assert(!HOIST || (FLOW && GS && MODE == 0 && RQ == 2 && C16), "HOIST: an intermediate pass of the flow kernel");
   static_assert(!PEER || MODE != 2, "the last pass sends nothing");
-  static_assert(!FLOW || (MODE == 0 && !PEER), "the flow kernel runs intermediate passes");
+  static_assert(!FLOW || MODE == 0, "the flow kernel runs intermediate passes");
+  static_assert(!(FLOW && PEER) || HOIST, "rank faces inside the flow kernel: the fat body only");
   constexpr int XA = FLOW ? 16 : 0;  // aux of the accesses another workgroup of the launch is on the other end of: sc1
   // per-block records: PE[slot * pe_ss + id * pe_si]; pe_si = 1: slot-major planes of nent entries, pe_si = 8 (C16 only):
   // entry-major, an entry's eight records in one 128-byte line (tsx_k_pcs_pack_ent16)
@@ -567,9 +568,11 @@ __device__ __forceinline__ void tsx_pcs_rb_body(const TsxGeo &g, const uint4 *__
   if constexpr (PEER) {
     if (live) sendmask = (snd.bytes[0] && icol == 0 ? 1 : 0) | (snd.bytes[1] && icol == g.xm - 1 ? 2 : 0) |
                          (snd.bytes[2] && jrow == 0 ? 4 : 0) | (snd.bytes[3] && jrow == g.ym - 1 ? 8 : 0);
-    TsxPeerWait w = hal.wait;
-    if (!GS) w.mine = nullptr;
-    tsx_peer_begin_both(w, face[0] || face[1] || face[2] || face[3], true, snd, sendmask != 0);
+    if constexpr (!FLOW) {  // (the flow kernel waits per work item, for sequence numbers and progress words side by side)
+      TsxPeerWait w = hal.wait;
+      if (!GS) w.mine = nullptr;
+      tsx_peer_begin_both(w, face[0] || face[1] || face[2] || face[3], true, snd, sendmask != 0);
+    }
   }
   // word of level k in the run of this column in the slot of face f (my W records land in the west rank's slot of face E ...)
   auto send_word = [&](int f, int k, unsigned w) {
@@ -706,7 +709,14 @@ __device__ __forceinline__ void tsx_pcs_rb_body(const TsxGeo &g, const uint4 *__
 #pragma unroll
       for (int l = 0; l < LSEG; ++l) nbr_load(cell(l), nb[l]);
     }
-    {
+    if (anyface) {  // rank faces: the neighbour rank's records, in place in this rank's mailbox (uncached memory)
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) {
+        unsigned hv[4];
+        nbr_halo(level(l), hv);
+        nbr_select(nb[l], hv, true);
+      }
+    } else {
       const unsigned none[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int l = 0; l < LSEG; ++l) nbr_select(nb[l], none, false);
@@ -1033,7 +1043,7 @@ __device__ __forceinline__ void tsx_pcs_rb_body(const TsxGeo &g, const uint4 *__
       tsx_sto<unsigned, XA>(zb, (size_t)2 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[4], zo[6]));
       tsx_sto<unsigned, XA>(zb, (size_t)3 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[5], zo[7]));
     }
-    if constexpr (PEER && CW < 32) {
+    if constexpr (PEER && (CW < 32 || FLOW)) {
       // small passes (16-column workgroups: at most one workgroup per CU's worth of columns, latency-bound, registers to spare):
       // the boundary columns send from the loop, so that the stores' acknowledgements arrive under the remaining levels;
       // the 32-column kernel sends after the scan (below)
@@ -1066,7 +1076,7 @@ __device__ __forceinline__ void tsx_pcs_rb_body(const TsxGeo &g, const uint4 *__
     }
     V = Vn;
   }
-  if constexpr (PEER) {
+  if constexpr (PEER && !FLOW) {
     // the columns on a rank face: the records just stored (rec 0 of i = 0 westwards, 1 of i = xm - 1, 2 of j = 0, 3 of j = ym - 1,
     // like tsx_k_pcs_halo_pack) go into the neighbours' slots.  Re-read here, after the scan, where few registers are live: the
     // stores inside the level loop cost 35 registers = a wave per SIMD (163 against 128 VGPRs)
@@ -1143,12 +1153,16 @@ struct TsxFlowArgs {
   unsigned long long ticks;
   int *err;            // set to 1 when a bounded wait expires (TsxScalars::flow_err: the host sees it with the stop flag)
   uint2 *zb8;          // FAT: the iterate records as granules (TsxGran), [4][Nc]
+  // several ranks (FPEER, peer transport): the tiles on a rank face store the records the neighbour rank consumes into its
+  // mailbox slot like tsx_k_pcs_rb<..., PEER> does, a face's last tile of a pass publishes that message's sequence number, the
+  // tiles of the next pass wait for the neighbour's.  Message numbers through face q: the pass p0 + pp reads R0[q] + pp (R0: the
+  // message of the launch before, already counted) and sends S0[q] + pp + 1.  No acknowledgements inside the launch: the
+  // neighbour can only overwrite a slot (message n + 2) after it has seen this rank's message n + 1, which this rank sends
+  // after its reads of n.
+  const TsxFlowPeer *prp;           // device-resident: what does not change from launch to launch (the arguments live in scalar registers)
+  unsigned long long R0[4], S0[4];  // messages received / sent through the faces before this launch
 };
-// FAT: the body with every neighbour-independent load hoisted in front of the wait (tsx_pcs_rb_body HOIST), two waves per SIMD --
-// for passes of at most as many tiles as workgroups are resident (<= 8192 columns per colour: config 2, the shards of the 2 x 4
-// split), where an item is a chain of latencies; the lean body (four waves per SIMD) for larger passes, which are bound by
-// their instruction stream.
-template <int LSEG, int NSEG, int CW, bool IDX, bool C16, bool FAT, bool GRANV = false>
+template <int LSEG, int NSEG, int CW, bool IDX, bool C16, bool FAT, bool GRANV = false, bool FPEER = false>
 __global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g, const uint4 *__restrict__ P,
                                                                         const float *__restrict__ r, unsigned *__restrict__ zb,
                                                                         const int *__restrict__ done, const int *__restrict__ cidx,
@@ -1158,11 +1172,25 @@ __global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g
   if (done && *done) return;
   __shared__ unsigned s_tk;
   const unsigned epoch = __hip_atomic_load(&f.st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  static_assert(!FPEER || (FAT && !GRANV), "rank faces: the fat body with progress words");
   TsxPcHalo hal;
   hal.W = hal.E = hal.S = hal.N = nullptr;
   hal.wait.mine = nullptr;
   TsxPeerXArgs snd;
   snd.bytes[0] = snd.bytes[1] = snd.bytes[2] = snd.bytes[3] = 0;
+  TsxFlowPeer pr;
+  if constexpr (FPEER) pr = *f.prp;
+  else memset((void *)&pr, 0, sizeof(pr));
+  if constexpr (FPEER) {
+    snd.mine = pr.mine;
+    snd.cap = pr.cap;
+    snd.data_off = pr.data_off;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      snd.remote[q] = pr.remote[q];
+      snd.bytes[q] = pr.remote[q] ? 1 : 0;
+    }
+  }
   const unsigned ntiles = (unsigned)f.ntiles, nitems = (unsigned)(f.p1 - f.p0) * ntiles;
   if (threadIdx.x == 0) s_tk = atomicAdd(&f.st->ticket, 1u);
   __syncthreads();
@@ -1186,7 +1214,65 @@ __global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g
     // wait for the four tiles of the other colour whose records this tile reads (and which read this tile's): same position, the
     // next (previous) tile of the row where the columns' parity shifts them east (west), the rows above and below.  Lanes 0..3
     // poll one progress word each; the barrier releases the workgroup
+    // which rank faces this tile's columns touch (they read the neighbour rank's records through them and send theirs): W / E where
+    // the row's parity puts this colour's column at i = 0 / i = xm - 1, S / N in the first / last row
+    [[maybe_unused]] int tface = 0;
+    if constexpr (FPEER) {
+      const int R = f.R, jrow = (int)t / R, tq = (int)t - jrow * R, parb = (jrow + rbc) & 1;
+      tface = (pr.remote[0] && tq == 0 && parb == 0 ? 1 : 0) | (pr.remote[1] && tq == R - 1 && parb == 1 ? 2 : 0) |
+              (pr.remote[2] && jrow == 0 ? 4 : 0) | (pr.remote[3] && jrow == g.ym - 1 ? 8 : 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) snd.n[q] = f.S0[q] + pp + 1ull;
+      // the neighbour's message of the pass before, in place: slot of face q, parity of its number
+      const unsigned nzpw = (unsigned)tsx_pcs_halo_nzp(g.Nz);
+      (void)nzpw;
+      hal.W = pr.remote[0] ? reinterpret_cast<const unsigned *>(tsx_peer_data(pr.mine, pr.data_off, pr.cap, 0, (int)((f.R0[0] + pp) & 1))) : nullptr;
+      hal.E = pr.remote[1] ? reinterpret_cast<const unsigned *>(tsx_peer_data(pr.mine, pr.data_off, pr.cap, 1, (int)((f.R0[1] + pp) & 1))) : nullptr;
+      hal.S = pr.remote[2] ? reinterpret_cast<const unsigned *>(tsx_peer_data(pr.mine, pr.data_off, pr.cap, 2, (int)((f.R0[2] + pp) & 1))) : nullptr;
+      hal.N = pr.remote[3] ? reinterpret_cast<const unsigned *>(tsx_peer_data(pr.mine, pr.data_off, pr.cap, 3, (int)((f.R0[3] + pp) & 1))) : nullptr;
+    }
     auto wait_nbrs = [&]() {
+      if constexpr (FPEER) {
+        if (pp == 0) {  // the neighbours' messages of the launch before: their sequence numbers, as any consumer in place
+          if (threadIdx.x >= 4 && threadIdx.x < 8 && (tface & (1 << (threadIdx.x - 4)))) {
+            const int q = (int)threadIdx.x - 4;
+            unsigned long long have = 0;
+            if (!tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(pr.mine)->seq[q], f.R0[q], pr.ticks, &have, pr.heavy, pr.mine)) {
+              tsx_peer_fail(pr.mine, 2, q, f.R0[q], have);
+              __hip_atomic_store(f.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        } else {
+          // inside the launch a face is as fine-grained as the tiles: in the mailbox's tag area (its own: the payload slots serve
+          // every kind of exchange) one word per face, parity and row (W, E) resp. column (S, N) -- the number of the message whose
+          // records for that row / column are complete, stored by the neighbour's tile after its drain.  Lanes 4 / 5 poll this row's W / E tag, lanes 32.. this tile's columns' S or N tags
+          const int lane = (int)threadIdx.x;
+          int q = -1;
+          unsigned idx = 0;
+          if (lane == 4 && (tface & 1)) q = 0, idx = (unsigned)((int)t / f.R);
+          else if (lane == 5 && (tface & 2)) q = 1, idx = (unsigned)((int)t / f.R);
+          else if (lane >= 32 && lane < 32 + CW && (tface & 12)) {
+            const int jrow = (int)t / f.R, tq = (int)t - jrow * f.R;
+            q = (tface & 4) ? 2 : 3;
+            idx = (unsigned)(2 * (tq * CW + (lane - 32)) + ((jrow + rbc) & 1));
+          }
+          if (q >= 0) {
+            const unsigned long long n = f.R0[q] + pp;
+            const unsigned *tag = reinterpret_cast<const unsigned *>(pr.mine + pr.tag_off) + ((size_t)q * 2 + (size_t)(n & 1)) * pr.tag_edge + idx;
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+              const unsigned v = __hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              if ((int)(v - (unsigned)n) >= 0) break;
+              if (wall_clock64() - t0 > pr.ticks || __hip_atomic_load(f.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                tsx_peer_fail(pr.mine, 2, q, n, v);
+                __hip_atomic_store(f.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+        }
+      }
       if (pp > 0 && threadIdx.x < 4) {
         const int R = f.R, jrow = (int)t / R, tq = (int)t - jrow * R;
         int dep;
@@ -1244,7 +1330,7 @@ __global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g
       tk = s_tk;
       continue;
     } else if constexpr (FAT) {
-      tsx_pcs_rb_body<LSEG, NSEG, CW, true, 0, IDX, 2, C16, false, true, true, decltype(wait_nbrs)>(
+      tsx_pcs_rb_body<LSEG, NSEG, CW, true, 0, IDX, 2, C16, FPEER, true, true, decltype(wait_nbrs)>(
           g, P, r, nullptr, zb, nullptr, rbc, 0, cidx, nent, PE, hal, rb, 0, pidx, PT, snd, pe_si, (int)t, tl, wait_nbrs);
     } else {
       wait_nbrs();
@@ -1253,17 +1339,53 @@ __global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g
     }
     TSX_TL(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its records have left the XCD's L2
+    if constexpr (FPEER) {
+      if (pr.heavy) __threadfence_system();
+    }
     TSX_TL(7);
     if (threadIdx.x == 0) s_tk = nxt;
     __syncthreads();
     TSX_TL(8);
     if (threadIdx.x == 0)
       __hip_atomic_store(f.prog + (size_t)rbc * ntiles + t, epoch + pp + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (FPEER) {
+      // every wave's stores into the neighbours' slots have been acknowledged (the drain above covers them): the tags of this
+      // tile's rows / columns in those slots say so
+      {
+        const int lane = (int)threadIdx.x;
+        const int jrow = (int)t / f.R, tq = (int)t - jrow * f.R;
+        int q = -1;
+        unsigned idx = 0;
+        if (lane == 4 && (tface & 1)) q = 0, idx = (unsigned)jrow;
+        else if (lane == 5 && (tface & 2)) q = 1, idx = (unsigned)jrow;
+        else if (lane >= 32 && lane < 32 + CW && (tface & 12)) {
+          q = (tface & 4) ? 2 : 3;
+          idx = (unsigned)(2 * (tq * CW + (lane - 32)) + ((jrow + rbc) & 1));
+        }
+        if (q >= 0) {
+          const unsigned long long n = f.S0[q] + pp + 1ull;
+          unsigned *tag = reinterpret_cast<unsigned *>(pr.remote[q] + pr.tag_off) + ((size_t)(q ^ 1) * 2 + (size_t)(n & 1)) * pr.tag_edge + idx;
+          __hip_atomic_store(tag, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
     tk = s_tk;
   }
   if (threadIdx.x == 0) {
     const unsigned prev = atomicAdd(&f.st->exited, 1u);
     if (prev + 1 == gridDim.x) {  // nobody reads the ticket or the epoch any more: ready for the next launch
+      if constexpr (FPEER) {
+        // every message of the launch but its neighbours' last one has been consumed: acknowledge them, so that the senders after
+        // this launch (which wait for the acknowledgement of their message n - 2) find their slots free
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (pr.remote[q]) {
+            tsx_peer_post(&reinterpret_cast<TsxPeerHdr *>(pr.remote[q])->ack[q ^ 1], f.R0[q] + (unsigned long long)(f.p1 - f.p0) - 1ull, pr.heavy);
+            // ... and every message of this rank is complete: the consumer of the last one is a kernel of its own, which waits for
+            // the face's sequence number
+            tsx_peer_post(&reinterpret_cast<TsxPeerHdr *>(pr.remote[q])->seq[q ^ 1], f.S0[q] + (unsigned long long)(f.p1 - f.p0), pr.heavy);
+          }
+      }
       __hip_atomic_store(&f.st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&f.st->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&f.st->epoch, epoch + (unsigned)(f.p1 - f.p0) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

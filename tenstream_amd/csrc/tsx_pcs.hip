@@ -202,10 +202,21 @@ int tsx_pc_global_agree(tsx_solver *s) {
   if (key == s->pcg_key) return TSX_OK;
   const bool mine = s->pc == TSX_PC_REDBLACK && s->pc_split && tsx_pcs_eligible(s) && pcs_halo_local(s) && s->grid.xs % 2 == 0 &&
                     s->grid.ys % 2 == 0;
-  double v = mine ? 0.0 : 1.0;  // number of ranks that cannot take part
-  int rc = tsx_allreduce_host(s, &v, 1);
+  // ... and the intermediate passes as one launch with the faces inside it (tsx_k_pcs_flow FPEER): its messages need no
+  // acknowledgements, a neighbour that runs a launch per pass waits for them -- so everywhere or nowhere, too
+  bool mine_flow = false;
+  if (mine) {
+    const PcsCfg c = pcs_config(s);
+    const int fcw = (!getenv("TSX_PCS_CFG") && c.lseg == 4 && c.nseg == 16)
+                        ? (((long long)s->geo.ym * (s->geo.xm / 2) >= 4096 && (s->geo.xm / 2) % 32 == 0) ? 32 : 16)
+                        : c.cw;
+    mine_flow = pcs_peer_inkernel(s) && tsx_pcs_flow_ok(s, c.lseg, c.nseg, fcw, true);
+  }
+  double v[2] = {mine ? 0.0 : 1.0, mine_flow ? 0.0 : 1.0};  // number of ranks that cannot take part
+  int rc = tsx_allreduce_host(s, v, 2);
   if (rc) return rc;
-  s->pcg_halo_ok = v == 0.0;
+  s->pcg_halo_ok = v[0] == 0.0;
+  s->pcg_flow_ok = v[0] == 0.0 && v[1] == 0.0;
   s->pcg_key = key;
   return TSX_OK;
 }
@@ -481,13 +492,24 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
   int fcw = cfg.cw;
   if (!getenv("TSX_PCS_CFG") && cfg.lseg == 4 && cfg.nseg == 16)
     fcw = ((long long)s->geo.ym * (s->geo.xm / 2) >= 4096 && (s->geo.xm / 2) % 32 == 0) ? 32 : 16;
-  const bool flow = !halo && s->geo.ntop == 2 && P - 2 - fp0 >= 2 && tsx_pcs_flow_ok(s, cfg.lseg, cfg.nseg, fcw);
+  // several ranks: with the peer transport in its default mode (the passes send and read their boundary records themselves) the
+  // flow kernel does the same inside its launch -- where EVERY rank can (tsx_pc_global_agree)
+  const bool peerflow = halo && !overlap && every == 1 && pcs_peer_inkernel(s) && (s->grid.nranks <= 1 || s->pcg_flow_ok);
+  const bool flow = (!halo || peerflow) && s->geo.ntop == 2 && P - 2 - fp0 >= 2 && tsx_pcs_flow_ok(s, cfg.lseg, cfg.nseg, fcw, halo);
   s->flow_last[0] = 0;
   for (int pass = 0; pass < P; ++pass) {
     const int mode = pass == P - 1 ? 2 : (pass == P - 2 ? 1 : 0);
     if (flow && pass == fp0) {
-      int rcf = tsx_pcs_flow(s, fcw, fp0, P - 2, done);
+      int rcf = tsx_pcs_flow(s, fcw, fp0, P - 2, done, halo);
       if (rcf) return rcf;
+      if (halo) {  // what the pass after the launch reads at the rank faces: the message of the launch's last pass, in place
+        const TsxGeo &g = s->geo;
+        const size_t nzp = (size_t)tsx_pcs_halo_nzp(g.Nz);
+        const size_t bx = g.wrap_x ? 0 : nzp * g.ym * sizeof(unsigned), by = g.wrap_y ? 0 : nzp * g.xm * sizeof(unsigned);
+        const size_t bytes[4] = {bx, bx, by, by};
+        if ((rcf = tsx_peer_expect(s, bytes, &s->pch_wait, s->pch_slot))) return rcf;
+        s->pch_inplace = true;
+      }
       pass = P - 3;
       continue;
     }

@@ -39,15 +39,22 @@ static int flow_capacity(tsx_solver *s, int cw, bool fat) {
   return cap;
 }
 
-bool tsx_pcs_flow_ok(tsx_solver *s, int lseg, int nseg, int cw) {
+// faces: the rank has real neighbours (or force_halo) -- the tiles on its faces exchange their records with the neighbour ranks
+// through the peer transport inside the launch (FPEER: the fat body only)
+bool tsx_pcs_flow_ok(tsx_solver *s, int lseg, int nseg, int cw, bool faces) {
   const TsxGeo &g = s->geo;
   if (!flow_env()) return false;
   if (g.ntop != 2 || lseg != 4 || nseg != 16 || (cw != 32 && cw != 16)) return false;  // the instantiated configurations
-  if (!(g.wrap_x && g.wrap_y)) return false;  // rank faces: the records of the neighbour ranks travel between launches
+  if (!faces && !(g.wrap_x && g.wrap_y)) return false;
   if (g.pc_tile_x > 0 || g.pc_tile_y > 0) return false;
   const int h = g.xm >> 1;
   if (h % cw != 0) return false;  // a tile is CW columns of ONE row
   if (!tsx_pcs_rhs16(s)) return false;
+  if (faces) {
+    if (getenv("TSX_FLOW_PEER") && atoi(getenv("TSX_FLOW_PEER")) == 0) return false;  // A/B: the passes as launches on several ranks
+    if (g.ym % 2 != 0 || (long long)(h / cw) * g.ym > flow_capacity(s, cw, true)) return false;
+    return true;
+  }
   // beyond about two tiles per resident workgroup a pass is bound by its instruction stream and the launch boundary costs nothing
   // next to it: 256 x 256 columns (1024 tiles) 12.01 -> 11.65 ms per solve, 512 x 512 (4096 tiles) 53.7 -> 54.4 ms
   const long long ntiles = (long long)(h / cw) * g.ym;
@@ -90,7 +97,7 @@ static int flow_ensure(tsx_solver *s, int ntiles, bool fat, int npass) {
 }
 
 template <int CW>
-static int flow_launch(tsx_solver *s, int p0, int p1, const int *done) {
+static int flow_launch(tsx_solver *s, int p0, int p1, const int *done, bool faces) {
   const TsxGeo &g = s->geo;
   const int h = g.xm >> 1;
   const int R = h / CW, ntiles = R * g.ym;
@@ -99,6 +106,7 @@ static int flow_launch(tsx_solver *s, int p0, int p1, const int *done) {
   const int cap_fat = flow_capacity(s, CW, true);
   bool fat = ntiles <= cap_fat;
   if (const char *e = getenv("TSX_FLOW_FAT")) fat = atoi(e) != 0;
+  if (faces) fat = true;
   int rc = flow_ensure(s, ntiles, fat, p1 - p0);
   if (rc) return rc;
   float *zs = (float *)s->vw;
@@ -121,6 +129,32 @@ static int flow_launch(tsx_solver *s, int p0, int p1, const int *done) {
   f.R = R;
   f.err = &s->scal->flow_err;
   f.zb8 = (uint2 *)s->flow_zb8;
+  f.prp = nullptr;
+  memset(f.R0, 0, sizeof(f.R0));
+  memset(f.S0, 0, sizeof(f.S0));
+  if (faces) {
+    const size_t nzp = (size_t)tsx_pcs_halo_nzp(g.Nz);
+    const size_t bx = g.wrap_x ? 0 : nzp * g.ym * sizeof(unsigned), by = g.wrap_y ? 0 : nzp * g.xm * sizeof(unsigned);
+    const size_t bytes[4] = {bx, bx, by, by};
+    TsxFlowPeer pr;
+    if ((rc = tsx_peer_flow_view(s, bytes, p1 - p0, &pr))) return rc;
+    memcpy(f.R0, pr.R0, sizeof(f.R0));
+    memcpy(f.S0, pr.S0, sizeof(f.S0));
+    memset(pr.R0, 0, sizeof(pr.R0));
+    memset(pr.S0, 0, sizeof(pr.S0));
+    // the part that does not change between launches lives in device memory (re-sent only when the transport changed)
+    if (!s->flow_pr_dev) {
+      HIPCHK(hipMalloc(&s->flow_pr_dev, sizeof(TsxFlowPeer)));
+      s->flow_pr_shadow = new TsxFlowPeer();
+      memset((void *)s->flow_pr_shadow, 0xff, sizeof(TsxFlowPeer));
+    }
+    if (memcmp((const void *)s->flow_pr_shadow, (const void *)&pr, sizeof(pr)) != 0) {
+      HIPCHK(hipStreamSynchronize(s->stream));
+      HIPCHK(hipMemcpy(s->flow_pr_dev, &pr, sizeof(pr), hipMemcpyHostToDevice));
+      memcpy((void *)s->flow_pr_shadow, (const void *)&pr, sizeof(pr));
+    }
+    f.prp = (const TsxFlowPeer *)s->flow_pr_dev;
+  }
   {
     static const double tmo = getenv("TSX_FLOW_TIMEOUT_S") ? atof(getenv("TSX_FLOW_TIMEOUT_S")) : 5.0;
     f.ticks = (unsigned long long)(tmo * 1e8);  // wall_clock64: 100 MHz
@@ -143,11 +177,21 @@ static int flow_launch(tsx_solver *s, int p0, int p1, const int *done) {
   // granules; 128 x 64, 128 tiles of 32: 2.51 / 2.51; 128 x 128, 256 tiles of 32 on 256 workgroups: 3.64 / 4.37.
   bool gran = fat && 4 * ntiles <= cap_fat;
   if (const char *e = getenv("TSX_FLOW_GRAN")) gran = fat && atoi(e) != 0;
+  if (faces) gran = false;
 #define TSX_FLOW_GO(IDXV, FATV, GRV)                                                                                               \
   hipLaunchKernelGGL((tsx_k_pcs_flow<4, 16, CW, IDXV, C16, FATV, GRV>), dim3((unsigned)grid), dim3(CW * 16), 0, s->stream, g, P, r, zb, \
                      done, IDXV ? cidx : (const int *)nullptr, IDXV ? nent : 0ll, IDXV ? PE : (const uint4 *)nullptr, rb,          \
                      IDXV ? pidx : (const int *)nullptr, IDXV ? PT : (const uint4 *)nullptr,                                       \
                      (IDXV && s->pe_entry_major) ? TSX_PCS_ENT16_SLOTS : 1, f)
+#define TSX_FLOW_GOP(IDXV)                                                                                                          \
+  hipLaunchKernelGGL((tsx_k_pcs_flow<4, 16, CW, IDXV, C16, true, false, true>), dim3((unsigned)grid), dim3(CW * 16), 0, s->stream, g, P, \
+                     r, zb, done, IDXV ? cidx : (const int *)nullptr, IDXV ? nent : 0ll, IDXV ? PE : (const uint4 *)nullptr, rb,   \
+                     IDXV ? pidx : (const int *)nullptr, IDXV ? PT : (const uint4 *)nullptr,                                       \
+                     (IDXV && s->pe_entry_major) ? TSX_PCS_ENT16_SLOTS : 1, f)
+  if (faces) {
+    if (dd) TSX_FLOW_GOP(true);
+    else TSX_FLOW_GOP(false);
+  } else
   if (dd) {
     if (gran) TSX_FLOW_GO(true, true, true);
     else if (fat) TSX_FLOW_GO(true, true, false);
@@ -158,15 +202,16 @@ static int flow_launch(tsx_solver *s, int p0, int p1, const int *done) {
     else TSX_FLOW_GO(false, false, false);
   }
 #undef TSX_FLOW_GO
+#undef TSX_FLOW_GOP
   HIPCHK(hipGetLastError());
-  const int rec[8] = {1, p0, p1, CW, fat ? 1 : 0, gran ? 1 : 0, ntiles, (int)grid};
+  const int rec[8] = {faces ? 2 : 1, p0, p1, CW, fat ? 1 : 0, gran ? 1 : 0, ntiles, (int)grid};
   memcpy(s->flow_last, rec, sizeof(rec));
   return TSX_OK;
 }
 
-int tsx_pcs_flow(tsx_solver *s, int cw, int p0, int p1, const int *done) {
+int tsx_pcs_flow(tsx_solver *s, int cw, int p0, int p1, const int *done, bool faces) {
   if (p1 <= p0) return TSX_OK;
-  return cw == 32 ? flow_launch<32>(s, p0, p1, done) : flow_launch<16>(s, p0, p1, done);
+  return cw == 32 ? flow_launch<32>(s, p0, p1, done, faces) : flow_launch<16>(s, p0, p1, done, faces);
 }
 
 #ifdef TSX_FLOW_TRACE

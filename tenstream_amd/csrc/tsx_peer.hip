@@ -182,11 +182,11 @@ __global__ void tsx_k_peer_verify(const double *__restrict__ b0, const double *_
 
 struct TsxPeer {
   char *mine = nullptr;
-  size_t bytes = 0, cap = 0, data_off = 0, ar_off = 0;
+  size_t bytes = 0, cap = 0, data_off = 0, ar_off = 0, tag_off = 0, tag_edge = 0;
   char *box[kMaxRanks] = {nullptr};      // every rank's mailbox in this process's address space (box[rank] == mine)
   bool opened[kMaxRanks] = {false};      // mapped with hipIpcOpenMemHandle (to be closed)
   unsigned long long sent[4] = {0, 0, 0, 0}, rcvd[4] = {0, 0, 0, 0}, ar_n = 0;
-  unsigned int *blkctr = nullptr;        // [16]: send 0..3, recv 4..7, producer kernels 8
+  unsigned int *blkctr = nullptr;        // [32]: send 0..3, recv 4..7, producer kernels 8, the flow kernel's faces 16..23
   unsigned long long ticks = 0;
   int heavy = 0;                         // TSX_PEER_FENCES / tsx_comm_peer_set_fences (tsx_peer_dev.hpp)
   bool attached = false;
@@ -214,7 +214,13 @@ extern "C" int tsx_comm_peer_export(tsx_solver *s, void *blob) {
     p->ar_off = kHdrBytes;
     p->data_off = p->ar_off + sizeof(PeerArSlot) * 2 * kMaxRanks;
     p->data_off = (p->data_off + 255) & ~(size_t)255;
-    p->bytes = p->data_off + (size_t)4 * 2 * p->cap;
+    // behind the payload slots: the flow kernel's tags (tsx_k_pcs_flow FPEER), one word per row / column of a face and parity
+    p->tag_off = p->data_off + (size_t)4 * 2 * p->cap;
+    {
+      const int gx = s->grid.glob_xm > s->geo.xm ? s->grid.glob_xm : s->geo.xm, gy = s->grid.glob_ym > s->geo.ym ? s->grid.glob_ym : s->geo.ym;
+      p->tag_edge = (size_t)(gx > gy ? gx : gy);
+    }
+    p->bytes = (p->tag_off + (size_t)4 * 2 * p->tag_edge * sizeof(unsigned) + 255) & ~(size_t)255;
     void *m = nullptr;
     // uncached: the counters and payloads are written by other agents while kernels of this rank are running
     hipError_t e = hipExtMallocWithFlags(&m, p->bytes, hipDeviceMallocUncached);
@@ -226,8 +232,8 @@ extern "C" int tsx_comm_peer_export(tsx_solver *s, void *blob) {
     }
     p->mine = (char *)m;
     HIPCHK(hipMemset(p->mine, 0, p->bytes));
-    HIPCHK(hipMalloc((void **)&p->blkctr, sizeof(unsigned int) * 16));
-    HIPCHK(hipMemset(p->blkctr, 0, sizeof(unsigned int) * 16));
+    HIPCHK(hipMalloc((void **)&p->blkctr, sizeof(unsigned int) * 32));
+    HIPCHK(hipMemset(p->blkctr, 0, sizeof(unsigned int) * 32));
     const char *to = getenv("TSX_PEER_TIMEOUT_S");
     const double sec = to ? atof(to) : 20.0;
     p->ticks = (unsigned long long)((sec > 0 ? sec : 20.0) * 1e8);  // wall_clock64: 100 MHz
@@ -434,6 +440,34 @@ int tsx_peer_expect(tsx_solver *s, const size_t bytes[4], TsxPeerWait *w, const 
     }
     w->want[q] = ++p->rcvd[q];
     slot[q] = tsx_peer_data(p->mine, p->data_off, p->cap, q, (int)(w->want[q] & 1));
+  }
+  return TSX_OK;
+}
+
+int tsx_peer_flow_view(tsx_solver *s, const size_t bytes[4], int npass, TsxFlowPeer *v) {
+  TsxPeer *p = s->peer;
+  const tsx_grid &gr = s->grid;
+  const int nb[4] = {gr.neigh_w, gr.neigh_e, gr.neigh_s, gr.neigh_n};
+  memset((void *)v, 0, sizeof(*v));
+  v->mine = p->mine;
+  v->cap = p->cap;
+  v->data_off = p->data_off;
+  v->ticks = p->ticks;
+  v->heavy = p->heavy;
+  v->fctr = p->blkctr + 16;
+  v->tag_off = p->tag_off;
+  v->tag_edge = p->tag_edge;
+  for (int q = 0; q < 4; ++q) {
+    if (!bytes[q]) continue;
+    if (bytes[q] > p->cap || nb[q] < 0 || nb[q] >= gr.nranks || !p->box[nb[q]]) {
+      tsx_set_error("peer flow: message larger than the mailbox slots, or neighbour rank out of range");
+      return TSX_ERR_ARG;
+    }
+    v->remote[q] = p->box[nb[q]];
+    v->R0[q] = p->rcvd[q];
+    v->S0[q] = p->sent[q];
+    p->sent[q] += (unsigned long long)npass;
+    p->rcvd[q] += (unsigned long long)(npass - 1);
   }
   return TSX_OK;
 }

@@ -84,9 +84,12 @@ __device__ __forceinline__ bool tsx_peer_send_begin(const TsxPeerXArgs &a) {
   if (threadIdx.x == 0) ok_ = 1;
   __syncthreads();
 #pragma unroll
+  for (int q = 0; q < 4; ++q)  // (all acknowledgements first, then the waits: see tsx_peer_begin_both)
+    if (blockIdx.x == 0 && (int)threadIdx.x == q && a.bytes[q] && a.ackn[q])
+      tsx_peer_post(&reinterpret_cast<TsxPeerHdr *>(a.remote[q])->ack[q ^ 1], a.ackn[q], a.heavy);
+#pragma unroll
   for (int q = 0; q < 4; ++q) {  // static indices into the kernel arguments: lane q takes face q
     if ((int)threadIdx.x != q || !a.bytes[q]) continue;
-    if (blockIdx.x == 0 && a.ackn[q]) tsx_peer_post(&reinterpret_cast<TsxPeerHdr *>(a.remote[q])->ack[q ^ 1], a.ackn[q], a.heavy);
     const TsxPeerHdr *h = reinterpret_cast<const TsxPeerHdr *>(a.mine);
     unsigned long long have = 0;
     if (a.n[q] > 2 && !tsx_peer_wait_ge(&h->ack[q], a.n[q] - 2, a.ticks, &have, a.heavy, a.mine)) {
@@ -105,6 +108,13 @@ __device__ __forceinline__ void tsx_peer_begin_both(const TsxPeerWait &w, bool n
   const bool rcv = w.mine != nullptr;
   const int any = __syncthreads_or(((rcv && need_recv) || (sending && need_send)) ? 1 : 0);
   if (!any && !(sending && blockIdx.x == 0)) return;
+  // every acknowledgement is posted before any lane of the wave starts to wait: the lanes of a wave run their waits one after the
+  // other, and the acknowledgement one of them waits for may be the one a later lane (of this rank itself with self neighbours,
+  // of the neighbour's wave in the same position otherwise) has yet to post
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (sending && blockIdx.x == 0 && (int)threadIdx.x == 4 + q && a.bytes[q] && a.ackn[q])
+      tsx_peer_post(&reinterpret_cast<TsxPeerHdr *>(a.remote[q])->ack[q ^ 1], a.ackn[q], a.heavy);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (rcv && any && (int)threadIdx.x == q && w.want[q]) {
@@ -113,7 +123,6 @@ __device__ __forceinline__ void tsx_peer_begin_both(const TsxPeerWait &w, bool n
         tsx_peer_fail(w.mine, 2, q, w.want[q], have);
     }
     if (sending && (int)threadIdx.x == 4 + q && a.bytes[q]) {
-      if (blockIdx.x == 0 && a.ackn[q]) tsx_peer_post(&reinterpret_cast<TsxPeerHdr *>(a.remote[q])->ack[q ^ 1], a.ackn[q], a.heavy);
       unsigned long long have = 0;
       if (any && a.n[q] > 2 &&
           !tsx_peer_wait_ge(&reinterpret_cast<const TsxPeerHdr *>(a.mine)->ack[q], a.n[q] - 2, a.ticks, &have, a.heavy, a.mine))

@@ -26,8 +26,13 @@ module m_pprts_hip
     & tsx_pprts_solve, tsx_pprts_zero_guess, tsx_pprts_select_solution, tsx_pprts_get_result, tsx_pprts_get_field, &
     & TSX_HOST, TSX_DEVICE, TSX_PC_NONE, TSX_PC_COLUMN, TSX_PC_ZEBRA, TSX_PC_REDBLACK
 
-  !> the seam's vectors in either real kind: TenStream's ireals is real32 or real64 by build (src/data_parameters.F90), so
-  !> `call hip_ediff(h, solver%b, solution%ediff, ...)` resolves to the matching specific whatever the build chose
+  !> the seam's VECTORS in either real kind: TenStream's ireals is real32 or real64 by build (src/data_parameters.F90), so
+  !> `call hip_ediff(h, solver%b, solution%ediff, ...)` resolves to the matching specific whatever the build chose.
+  !> Only the state vectors (b, ediff, edir, x, y) are kind-generic.  Scalars and fields -- edirTOA, rtol / atol, albedo, planck,
+  !> planck_srfc, kabs, dz, a11 / a12 / a13 / a23 / a33 and the coefficient arrays dir2dir / dir2diff / diff2diff -- are
+  !> real(c_double) in every specific: a real32 build passes `real(x, c_double)` copies of them (they are small next to the
+  !> vectors, or -- the coefficient arrays -- can be handed over as real32 through the C entry points' coeff_kind = 4, which
+  !> tsx_diff_set_coeffs / tsx_dir_set_coeffs take; the reference declares all of them real(ireals), src/pprts_base.F90:112-119, 252)
   interface hip_ediff
     module procedure hip_ediff_r64, hip_ediff_r32
   end interface

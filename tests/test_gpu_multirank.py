@@ -533,3 +533,142 @@ def test_preconditioner_halo_keeps_the_couplings_across_rank_faces(gpu, monkeypa
     assert its["dropped"] > its["halo"]
     for name in ("halo", "dropped"):
         assert np.abs(xs[name] - xs["wrap"]).max() <= 1e-8 * np.abs(xs["wrap"]).max()
+
+
+# ---- the flow kernel with rank faces inside it ----------------------------------------------------------------------------
+def _flow_faces_worker(rank, world, port, Nx, Ny, Nz, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("TSX_PEER_TIMEOUT_S", "20")
+    import torch.distributed as dist
+
+    from tenstream_amd import DiffuseSolver, coord, hostcomm, synthetic
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+        co = coord.coord(rank, world, Nx, Ny)
+        sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
+        loc = lambda k: np.ascontiguousarray(P[k][sl])
+        out = {}
+        for env in ("1", "0"):   # the intermediate passes as ONE launch with the faces inside it / a launch per pass
+            os.environ["TSX_FLOW_PEER"] = env
+            s = DiffuseSolver("3_10", Nz, co.xm, co.ym, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank, nranks=world,
+                              neighbors=(co.west, co.east, co.south, co.north), device=0)
+            hostcomm.attach_peer(s)
+            s.set_coeffs(loc("coeff"), P["l1d"], loc("a11"), loc("a12"), loc("albedo"))
+            res = []
+            for rtol in (1e-5, 1e-9):
+                x = np.zeros(s.vec_shape)
+                info = s.solve(loc("b"), x, rtol=rtol, atol=1e-30)
+                res += [info.reason, info.niter, x, np.asarray(info.res_hist)]
+            fl = s.flow_info()
+            out[env] = (res, fl["in_use"], fl["fat"])
+            s.close()
+        same = all(np.array_equal(a, b) for a, b in zip(out["1"][0], out["0"][0]))
+        ret[rank] = (same, out["1"][1], out["0"][1], out["1"][0][0], out["1"][0][1], out["1"][0][4], out["1"][0][5])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,Nx,Ny,Nz", [(2, 128, 32, 16), (4, 128, 64, 12), (8, 128, 128, 8)])
+def test_flow_kernel_with_rank_faces_equals_launch_per_pass(gpu, world, Nx, Ny, Nz):
+    """Round 5: on several ranks the flow kernel (the intermediate passes of an application of M^-1 in one launch) keeps the
+    exchange of the boundary records inside the launch: a face tile stores its records into the neighbour rank's mailbox slot and,
+    after its drain, the tags of its row / columns; the neighbour's tile of the next pass polls those tags and reads the records
+    in place; no acknowledgements inside the launch, the launch's last workgroup posts them and the faces' sequence numbers
+    (tsx_k_pcs_flow FPEER, src/pprts_explicit.F90:769-843's exchange pattern).  Same message numbering, slots and arithmetic as a
+    launch per pass (TSX_FLOW_PEER=0): solutions and residual histories must be bit-identical on every rank -- rank processes
+    sharing cuda:0, 2 x 1, 2 x 2 and 2 x 4 grids (W and E the same peer on the first)."""
+    ret = _spawn(_flow_faces_worker, world, (Nx, Ny, Nz))
+    for rank, (same, used1, used0, r5, n5, r9, n9) in ret.items():
+        assert used1 and not used0, (rank, used1, used0)   # the flow kernel ran with its faces / did not
+        assert same, rank
+        assert r5 == 2 and r9 == 2, (rank, r5, r9)
+    assert len({v[4] for v in ret.values()}) == 1 and len({v[6] for v in ret.values()}) == 1   # every rank the same counts
+
+
+# ---- the RCCL transport's host code with real ranks, through a test double of librccl -------------------------------------
+def _build_fake_rccl(tmp_path):
+    import subprocess
+
+    so = str(tmp_path / "libfake_rccl.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "c", "fake_rccl.cpp"), "-lrt"],
+                   check=True)
+    return so
+
+
+def _rccl_double_worker(rank, world, port, Nx, Ny, Nz, fake_so, ret):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from tenstream_amd import DiffuseSolver, coord, hostcomm, synthetic
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz, n1d=1)
+        co = coord.coord(rank, world, Nx, Ny)
+        sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
+        loc = lambda k: np.ascontiguousarray(P[k][sl])
+        xg = np.random.default_rng(11).standard_normal((Ny, Nx, Nz + 1, 10))
+
+        def run(attach):
+            s = DiffuseSolver("3_10", Nz, co.xm, co.ym, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank, nranks=world,
+                              neighbors=(co.west, co.east, co.south, co.north), device=0)
+            attach(s)
+            s.set_coeffs(loc("coeff"), P["l1d"], loc("a11"), loc("a12"), loc("albedo"))
+            res = [s.apply(np.ascontiguousarray(xg[sl]))]
+            for kw in (dict(rtol=1e-10, atol=1e-30, pc=1, pc_sweeps=1), dict(rtol=1e-9, atol=1e-30), dict()):
+                x = np.zeros(s.vec_shape)
+                info = s.solve(loc("b"), x, **kw)
+                res += [info.reason, info.niter, x, np.asarray(info.res_hist)]
+            s.close()
+            return res
+
+        def attach_double(s):   # the RCCL transport, librccl replaced by the double (TSX_RCCL_LIB is read at the first bind)
+            uid = [s.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            s.comm_init(uid[0])
+
+        os.environ["TSX_RCCL_LIB"] = fake_so
+        out = {}
+        for ov in ("1", "0"):   # interior / frame split around the exchanges on comm_stream (the default with RCCL), and without
+            os.environ["TSX_OVERLAP"] = ov
+            out["rccl" + ov] = run(attach_double)
+            out["host" + ov] = run(lambda s: hostcomm.attach(s, rank))
+        del os.environ["TSX_OVERLAP"]
+        def agree(a, b):   # the apply bit for bit; the solves up to the order in which the transports sum the dots over the ranks
+            ok = np.array_equal(a[0], b[0])
+            for q in range(1, len(a), 4):
+                ok = ok and a[q] == b[q] and abs(a[q + 1] - b[q + 1]) <= 1 and np.abs(a[q + 2] - b[q + 2]).max() <= 1e-7 * np.abs(b[q + 2]).max()
+            return bool(ok)
+
+        same = {k: agree(out["rccl" + k], out["host" + k]) for k in ("1", "0")}
+        r = out["rccl1"]
+        ret[rank] = (same["1"], same["0"], r[1], r[2], r[5], r[6], r[9], r[10])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,Nx,Ny,Nz", [(2, 24, 8, 6), (4, 24, 16, 6), (8, 32, 32, 6)])
+def test_rccl_transport_host_code_with_real_ranks_through_a_test_double(gpu, tmp_path, world, Nx, Ny, Nz):
+    """librccl refuses two ranks of a communicator on one device (the test above skips), so on this pool the RCCL transport's
+    host code -- ncclCommInitRank, the second communicator from ncclCommSplit for the exchanges on comm_stream, the grouped
+    ncclSend / ncclRecv in the order W, E, S, N against E, W, N, S, the 3-double all-reduces between the scalar stages, the
+    preconditioner's exchanges after every pass, with and without the interior / frame overlap -- never ran with a second rank.
+    tests/c/fake_rccl.cpp implements exactly the entry points libtsx binds over shared memory with NCCL's matching rule
+    (messages between two ranks of a communicator in issue order, groups issued together); TSX_RCCL_LIB selects it.  2 ranks
+    along a periodic axis (W and E the same peer -- the case the receive order exists for), 2 x 2 and 2 x 4: applies, solves and
+    applies bit-identical to the host-staged callbacks on the same ranks, solves equal up to the order in which the two transports
+    sum the dots over the ranks (same reasons, iteration counts within one, solutions to 1e-7 at the loosest tolerance)."""
+    fake = _build_fake_rccl(tmp_path)
+    ret = _spawn(_rccl_double_worker, world, (Nx, Ny, Nz, fake))
+    for rank, v in ret.items():
+        assert v[0] and v[1], (rank, v[:2])
+        assert v[2] == 2 and v[4] == 2 and v[6] == 2, (rank, v)
+    for k in (3, 5, 7):   # every rank the same iteration counts
+        assert len({v[k] for v in ret.values()}) == 1

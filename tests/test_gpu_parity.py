@@ -950,3 +950,34 @@ def test_flow_kernel_is_bit_identical_to_launch_per_pass(gpu, monkeypatch, Nx, N
         s.close()
     for a, b in zip(out["1"], out["0"]):
         assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("Nx,Ny,Nz", [(64, 32, 20), (128, 64, 16)])
+def test_flow_kernel_with_self_neighbour_faces_is_bit_identical(gpu, monkeypatch, Nx, Ny, Nz):
+    """One rank whose four neighbours are itself over the peer transport (force_halo: every face goes through the mailbox, the
+    set-up of scripts/shard_study.py): the flow kernel with its faces inside the launch (tags per row / column, no
+    acknowledgements, tsx_k_pcs_flow FPEER) against a launch per pass with the passes exchanging their records themselves
+    (TSX_FLOW_PEER=0): same arithmetic, bit-identical M^-1 v and solves; and the periodic domain without any halo: the same solution."""
+    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+    v = np.random.default_rng(3).standard_normal(P["b"].shape)
+    out = {}
+    for mode in ("flow", "launches", "periodic"):
+        monkeypatch.setenv("TSX_FLOW_PEER", "0" if mode == "launches" else "1")
+        s = DiffuseSolver("3_10", Nz, Nx, Ny, force_halo=mode != "periodic")
+        if mode != "periodic":
+            s.comm_peer_init(lambda blob: [blob])
+        s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+        res = [s.pc_apply(v, pc=3, sweeps=sw, mixed=True) for sw in (27, 27, 9)]
+        x = np.zeros(s.vec_shape)
+        info = s.solve(P["b"], x, rtol=1e-8, atol=1e-30)
+        assert info.reason == 2
+        fl = s.flow_info()
+        assert fl["in_use"] == (mode != "launches"), (mode, fl)
+        out[mode] = res + [x, np.asarray(info.res_hist)]
+        s.close()
+    for a, b in zip(out["flow"], out["launches"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    # the periodic domain: the same M^-1 up to the precision of the records at the faces (bf16 through the mailbox also where the
+    # last pass reads fp32 records in place), the same solution
+    assert np.abs(out["flow"][0] - out["periodic"][0]).max() <= 2e-2 * np.abs(out["periodic"][0]).max()
+    assert np.abs(out["flow"][3] - out["periodic"][3]).max() <= 1e-6 * np.abs(out["periodic"][3]).max()

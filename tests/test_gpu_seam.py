@@ -105,6 +105,41 @@ def test_direct_seam_rejects_blocks_that_real32_cannot_hold(gpu):
     s.close()
 
 
+def test_direct_seam_ignores_what_the_blocks_hold_in_1d_layers(gpu):
+    """The reference never assigns solver%dir2dir / dir2diff in 1-D layers (alloc_coeff_dir2dir fills `if (.not. atm%l1d(...))`
+    only, src/pprts.F90:3131): whatever that memory holds -- NaN, values real32 cannot hold -- must neither be rejected as lossy
+    nor reach the beam (round-4 ADVICE).  Same beam and source term as with the oracle's clean blocks; and a call that IS rejected
+    leaves no coefficients of an earlier call behind."""
+    Nx, Ny, Nz, phi0, theta0 = 8, 6, 8, 30.0, 20.0
+    Q = _case("3_10", Nx, Ny, Nz, phi0, theta0, 2)   # the two top layers are 1-D
+    assert Q["l1d"].sum() == 2
+    s = DiffuseSolver("3_10", Nz, Nx, Ny)
+    s.set_angles(phi0, theta0)
+    s.dir_set_coeffs(Q["dir2dir"], Q["dir2diff"], Q["l1d"], DX, DY, a33=Q["a33"], a13=Q["a13"], a23=Q["a23"])
+    e0 = np.zeros((Ny, Nx, Nz + 1, Q["S"]))
+    assert s.dir_solve(900.0, e0, rtol=1e-14, atol=1e-12, maxit=500)[2]
+    b0 = s.setup_b_solar(np.zeros(s.vec_shape), albedo=Q["albedo"])
+    t, sd = Q["dir2dir"].copy(), Q["dir2diff"].copy()
+    k1 = np.flatnonzero(Q["l1d"])
+    t[:, :, k1, :] = np.nan          # (j, i, k, coefficient): uninitialised memory in the 1-D layers
+    sd[:, :, k1, :] = 0.1            # ... or values no real32 table delivered
+    s.dir_set_coeffs(t, sd, Q["l1d"], DX, DY, a33=Q["a33"], a13=Q["a13"], a23=Q["a23"])
+    e1 = np.zeros_like(e0)
+    assert s.dir_solve(900.0, e1, rtol=1e-14, atol=1e-12, maxit=500)[2]
+    b1 = s.setup_b_solar(np.zeros(s.vec_shape), albedo=Q["albedo"])
+    assert np.isfinite(e1).all() and np.array_equal(e1, e0) and np.array_equal(b1, b0)
+    # a lossy value in a 3-D layer is still rejected -- and the rejected call leaves nothing usable behind
+    bad = Q["dir2dir"].copy()
+    bad[1, 2, int(np.flatnonzero(Q["l1d"] == 0)[0]), 0] = 0.1
+    with pytest.raises(TsxError):
+        s.dir_set_coeffs(bad, Q["dir2diff"], Q["l1d"], DX, DY, a33=Q["a33"], a13=Q["a13"], a23=Q["a23"])
+    with pytest.raises(TsxError):
+        s.dir_solve(900.0, e1)
+    with pytest.raises(TsxError):
+        s.setup_b_solar(np.zeros(s.vec_shape))
+    s.close()
+
+
 @pytest.mark.parametrize("solver", ["3_10", "8_16"])
 @pytest.mark.parametrize("srfc", [False, True])
 def test_thermal_source_at_the_seam(gpu, solver, srfc):
