@@ -197,6 +197,68 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
                           reasons=sorted({int(i.reason) for i in infos}), diffuse_solve_ms_total=float(sum(i.solve_ms for i in infos)),
                           energy_balance_max=float(max((o[1] for o in out), default=0.0)),
                           toa_net_down_Wm2=float((acc[0][:, :, 0] + acc[3][:, :, 0] - acc[1][:, :, 0]).mean())))
+    # ---- where a g-point's time goes, and the dominant kernel against its roofline (round 5; outside every timed call): a sample
+    # of the g-points once more on instance 0, the device synchronised between the phases of a g-point
+    breakdown = roofline = None
+    if rank == 0 and mine:
+        sample = mine[::max(1, len(mine) // 24)][:24]
+        ph = {"set_optical_properties": 0.0, "solve (direct sweep, setup_b, diffuse solve)": 0.0, "get_result + accumulate + balance sums": 0.0}
+        dsolve, its_s = 0.0, []
+        P0, tmp0, acc0 = Ps[0], tmps[0], accs[0]
+        kw = dict(pc_sweeps=args.pc_sweeps) if args.pc_sweeps > 0 else {}
+        for q in sample:
+            f = float(factors[q])
+            lsolar = q < args.sw
+            sync()
+            t0 = time.perf_counter()
+            P0.set_optical_properties(alb, kabs0 * f, ksca0 * f, g0, dz_d, planck=None if lsolar else planck0 * weights[q],
+                                      planck_srfc=None if lsolar else planck_srfc0 * weights[q])
+            sync()
+            t1 = time.perf_counter()
+            info = P0.solve(1361.0 * weights[q] if lsolar else 0.0, lsolar=lsolar, uid=q, **kw)
+            sync()
+            t2 = time.perf_counter()
+            P0.get_result(out=tmp0)
+            for a, t in zip(acc0, tmp0):
+                a += t
+            (tmp0[2] * dz_d).sum()
+            sync()
+            t3 = time.perf_counter()
+            ph["set_optical_properties"] += t1 - t0
+            ph["solve (direct sweep, setup_b, diffuse solve)"] += t2 - t1
+            ph["get_result + accumulate + balance sums"] += t3 - t2
+            dsolve += info.solve_ms * 1e-3
+            its_s.append(info.niter)
+        tot = sum(ph.values())
+        breakdown = {"sample_gpoints": len(sample), "ms_per_gpoint": tot / len(sample) * 1e3,
+                     "phases_ms_per_gpoint": {k: v / len(sample) * 1e3 for k, v in ph.items()},
+                     "diffuse_solve_ms_per_gpoint_device": dsolve / len(sample) * 1e3,
+                     "fractions": dict({k: v / tot for k, v in ph.items()}, diffuse_solve_of_total=dsolve / tot),
+                     "iterations_mean": float(np.mean(its_s)),
+                     "note": "one instance, the device synchronised after every phase (the timed calls above overlap the phases of "
+                             "different g-points and do not synchronise): a breakdown, not a rate"}
+        core = P0.core
+        try:
+            pc_ran, sweeps, scan, _ = core.pc_info()
+            if scan:
+                pass_ms = core.bench_kernel(3, 80)
+                fl = core.flow_info()
+                if fl["in_use"]:
+                    ms = core.bench_kernel(4, 20)
+                    fl = core.flow_info()
+                    nb = core.algorithmic_bytes(4)
+                    kname = (f"tsx_k_pcs_flow (passes {fl['first_pass']}..{fl['end_pass'] - 1} of one M^-1 application in one launch)")
+                else:
+                    ms, nb, kname = pass_ms, core.algorithmic_bytes(3), "tsx_k_pcs_rb<..., GS, MODE 0, RQ 2> (one intermediate red-black pass of M^-1)"
+                ach = nb / (ms * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                            "traffic": None, "bytes_per_launch": nb, "ms_per_launch": ms, "frac_of_achievable": ach / 6300.0,
+                            "the_same_pass_as_its_own_launch_us": pass_ms * 1e3, "passes_per_application": sweeps + 1,
+                            "basis": "the launch the diffuse solves spend most of their time in, timed alone with HIP events on the "
+                                     "solver's stream on the last sampled g-point's coefficients (tsx_bench_kernel); traffic: "
+                                     "profiles/r05/traffic_3_10_256x256x64.json holds the PMC bytes of the same kernel on the headline field"}
+        except Exception as e:   # noqa: BLE001
+            roofline = {"error": str(e)}
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and args.sw > 0:
         # CPU baseline, one g-point (the solar one with the median optical-depth factor): the very diffuse system the device
@@ -232,7 +294,7 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
                "loop_extrapolated_with_assembly_s": ng * (oi["t_solve"] + oi["t_assemble"] + oi["t_factor"])}
     for Pk in Ps:
         Pk.close()
-    return dict(ng=ng, rank_gpoints=len(mine), n1d_layers=n1d, calls=calls, mu0=mu0, cpu_baseline=cpu)
+    return dict(ng=ng, rank_gpoints=len(mine), n1d_layers=n1d, calls=calls, mu0=mu0, cpu_baseline=cpu, breakdown=breakdown, roofline=roofline)
 
 
 def main():
@@ -265,7 +327,9 @@ def main():
                                    f"g-points dealt in blocks to the GPUs" + (f" and to {args.streams} concurrent solver instances per GPU" if args.streams > 1 else "") + ", results all-reduced once; value = radiation call {last + 1} "
                                    f"of {len(secs)} (call 1 is cold: guess from the previous g-point)",
                        "cells_gpoints_per_s": ng * Nx * Ny * Nz / secs[last], "rank0_gpoints": R["rank_gpoints"],
-                       "calls": [dict(c, seconds=s_, gpoints_per_s=ng / s_) for c, s_ in zip(R["calls"], secs)]},
+                       "calls": [dict(c, seconds=s_, gpoints_per_s=ng / s_) for c, s_ in zip(R["calls"], secs)],
+                       "breakdown": R["breakdown"]},
+            "roofline": R["roofline"],
             "cpu_baseline": R["cpu_baseline"]}))
     if world > 1:
         dist.destroy_process_group()

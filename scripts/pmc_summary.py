@@ -62,6 +62,9 @@ def compose(kernels, P):
             # the vector updates leave the bf16 words: every intermediate pass of an application reads them (P - 2 of them, the
             # first without neighbours), none writes them
             passes = [(rb + r"false,0,\w+,2", 2), (rb + r"true,0,\w+,2", 2 * (P - 3)), (rb + r"true,1", 2), (rb + r"true,2", 2)]
+            if any(k.startswith("tsx_k_pcs_flow") for k in kernels):
+                # round 5: the P - 3 intermediate passes with neighbours run as ONE launch per application (tsx_k_pcs_flow)
+                passes = [(rb + r"false,0,\w+,2", 2), (r"tsx_k_pcs_flow<", 2), (rb + r"true,1", 2), (rb + r"true,2", 2)]
             per_iter = passes + per_iter[len(per_iter) - 5:]
     else:
         per_iter = passes + [(r"tsx_k_spmv_w<\d+,\d+,\w+,1,\d,float,float", 1), (r"tsx_k_spmv_w<\d+,\d+,\w+,5,\d,float,double", 1),

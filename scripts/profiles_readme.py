@@ -16,6 +16,9 @@ c3p, c3h = json.load(open(P("config3_8ranks_one_device_peer_line.json"))), json.
 
 
 def pass_traffic(t):
+    ks = [v for k, v in T[t]["kernels"].items() if "pcs_flow" in k]   # round 5: the dominant launch where it runs
+    if L[t]["roofline"]["kernel"].startswith("tsx_k_pcs_flow") and ks:
+        return ks[0]["traffic_bytes_per_launch"]
     ks = [v for k, v in T[t]["kernels"].items() if ("pcs_rb" in k or "pcsh_rb" in k) and ",true,0,true,2" in k and v["launches"] > 100]
     return ks[0]["traffic_bytes_per_launch"] if ks else None
 

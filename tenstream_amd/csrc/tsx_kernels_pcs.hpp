@@ -1407,6 +1407,9 @@ __global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g
 #ifndef TSX_PCS_C16
 #define TSX_PCS_C16 1  // side -> top couplings in fp16 (see tsx_k_pcs_pack_rec1h); 0: fp8 like the side -> side couplings
 #endif
+#ifndef TSX_PCSH_DEFER_ST
+#define TSX_PCSH_DEFER_ST 0  // 1 (A/B builds): the 8_16 intermediate passes store their four records per level behind phase 4's level loop -- the scheduler then hoists the levels' loads until 105 registers spill (256 VGPRs); off
+#endif
 // With TSX_PCS_C16 the four fp8 records 0..3 of the per-block part become eight fp16 records (two top dsts per record:
 // halfs 4 (t & 1) + q of record t >> 1 for the y sources, of record 4 + (t >> 1) for the x sources) and the others move up by four
 constexpr int TSX_S16H_CELL = 14, TSX_S16H_BLOCK = TSX_PCS_C16 ? 20 : 16, TSX_S16H_BO = TSX_PCS_C16 ? 4 : 0;
@@ -1875,6 +1878,7 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
   }
   for (int s2 = 0; s2 < sg; ++s2) chain(s2, V);
   // ---- phase 4: true V, U; side streams; stores
+  unsigned zw[(MODE == 0 && TSX_PCSH_DEFER_ST) ? LSEG : 1][4];
 #pragma unroll
   for (int l = 0; l < LSEG; ++l) {
     const bool st = live && l < nl;
@@ -1961,11 +1965,18 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
       zo[dd] = acc;
     }
     // records by consumer: side dofs (8,10) (9,11) (12,14) (13,15) = zo[0,2] zo[1,3] zo[4,6] zo[5,7]
-    if (MODE == 0 && st) {
-      tsx_sto(zb, (size_t)0 * Nc, c, tsx_bf16x2(zo[0], zo[2]));
-      tsx_sto(zb, (size_t)1 * Nc, c, tsx_bf16x2(zo[1], zo[3]));
-      tsx_sto(zb, (size_t)2 * Nc, c, tsx_bf16x2(zo[4], zo[6]));
-      tsx_sto(zb, (size_t)3 * Nc, c, tsx_bf16x2(zo[5], zo[7]));
+    if (MODE == 0) {
+      if (TSX_PCSH_DEFER_ST) {  // stored behind the level loop: no (predicated) store between the levels' loads
+        zw[l][0] = tsx_bf16x2(zo[0], zo[2]);
+        zw[l][1] = tsx_bf16x2(zo[1], zo[3]);
+        zw[l][2] = tsx_bf16x2(zo[4], zo[6]);
+        zw[l][3] = tsx_bf16x2(zo[5], zo[7]);
+      } else if (st) {
+        tsx_sto(zb, (size_t)0 * Nc, c, tsx_bf16x2(zo[0], zo[2]));
+        tsx_sto(zb, (size_t)1 * Nc, c, tsx_bf16x2(zo[1], zo[3]));
+        tsx_sto(zb, (size_t)2 * Nc, c, tsx_bf16x2(zo[4], zo[6]));
+        tsx_sto(zb, (size_t)3 * Nc, c, tsx_bf16x2(zo[5], zo[7]));
+      }
     }
     if (MODE == 1 && st) {
       tsx_sto(zr, (size_t)0 * Nc, c, make_float2(zo[0], zo[2]));
@@ -1989,5 +2000,14 @@ __global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PC
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) V[a] = l < nl ? Vn[a] : V[a];
+  }
+  if (MODE == 0 && TSX_PCSH_DEFER_ST) {
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) {
+      if (!(live && l < nl)) continue;
+      const unsigned c = cell(l);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) tsx_sto(zb, (size_t)m * Nc, c, zw[l][m]);
+    }
   }
 }

@@ -52,7 +52,11 @@ bool tsx_pcs_flow_ok(tsx_solver *s, int lseg, int nseg, int cw, bool faces) {
   if (!tsx_pcs_rhs16(s)) return false;
   if (faces) {
     if (getenv("TSX_FLOW_PEER") && atoi(getenv("TSX_FLOW_PEER")) == 0) return false;  // A/B: the passes as launches on several ranks
-    if (g.ym % 2 != 0 || (long long)(h / cw) * g.ym > flow_capacity(s, cw, true)) return false;
+    if (g.ym % 2 != 0) return false;
+    // only where a pass's tiles are resident at once (the fat body: two waves per SIMD).  Larger shards were measured slower with
+    // it than with a launch per pass: 256 x 128 columns 8.85 -> 9.02 ms per solve, 128 x 256 8.68 -> 9.08, 256 x 256 16.1 -> 17.1
+    // (profiles/r05/flow_peer_ab_large.txt); TSX_FLOW_PEER_ANY=1 lifts the bound (A/B)
+    if ((long long)(h / cw) * g.ym > flow_capacity(s, cw, true) && !(getenv("TSX_FLOW_PEER_ANY") && atoi(getenv("TSX_FLOW_PEER_ANY")))) return false;
     return true;
   }
   // beyond about two tiles per resident workgroup a pass is bound by its instruction stream and the launch boundary costs nothing

@@ -33,11 +33,17 @@ def test_bench_one_gpu_line_has_the_contract_keys(gpu):
         assert k in out, k
     assert out["metric"].startswith("pprts 3_10") and out["n_gpus"] == 1 and out["scaling"] == "weak"
     assert out["config"]["reason"] in (2, 3)
-    assert "tsx_k_pcs_rb" in out["roofline"]["kernel"] and out["roofline"]["frac"] > 0
+    # the launch the solve spends most of its time in: the flow kernel (the intermediate passes of an application in ONE launch,
+    # round 5) where it runs -- this domain: 64 x 32 columns, tiles of 16 -- with the single pass beside it
+    assert "tsx_k_pcs_flow" in out["roofline"]["kernel"] and out["roofline"]["frac"] > 0
+    assert out["config"]["flow_kernel"]["in_use"] and "tsx_k_pcs_rb" in out["roofline_pass"]["kernel"]
+    assert out["roofline"]["passes_per_launch"] == out["config"]["flow_kernel"]["end_pass"] - out["config"]["flow_kernel"]["first_pass"]
+    for k in ("first_solve", "step_ms_min_med_max", "no_hint"):
+        assert k in out["config"], k
     # the metric names the solver that ran
     out8 = _line(_run(["--nx", "16", "--ny", "12", "--solver", "8_16"] + SMALL))
     assert out8["metric"].startswith("pprts 8_16") and "tsx_k_pcsh_rb" in out8["roofline"]["kernel"]
-    for r in (out["roofline"], out["roofline_spmv"], out8["roofline"], out8["roofline_spmv"]):
+    for r in (out["roofline"], out["roofline_pass"], out["roofline_spmv"], out8["roofline"], out8["roofline_spmv"]):
         assert 0 < r["frac"] < 1, r   # bytes of the storage format in use: never above the peak
 
 
