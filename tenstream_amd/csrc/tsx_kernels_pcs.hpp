@@ -1270,6 +1270,7 @@ __global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g
               }
               __builtin_amdgcn_s_sleep(1);
             }
+            if (pr.heavy) __threadfence_system();  // (a platform whose peer mapping is cached: full fences, as tsx_peer_peek does)
           }
         }
       }
@@ -1365,6 +1366,7 @@ __global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g
         if (q >= 0) {
           const unsigned long long n = f.S0[q] + pp + 1ull;
           unsigned *tag = reinterpret_cast<unsigned *>(pr.remote[q] + pr.tag_off) + ((size_t)(q ^ 1) * 2 + (size_t)(n & 1)) * pr.tag_edge + idx;
+          if (pr.heavy) __threadfence_system();
           __hip_atomic_store(tag, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }

@@ -90,7 +90,9 @@ static int flow_ensure(tsx_solver *s, int ntiles, bool fat, int npass) {
     HIPCHK(hipMalloc(&s->flow_zb8, zb8_bytes));
     HIPCHK(hipMemsetAsync(s->flow_zb8, 0, zb8_bytes, s->stream));
   }
-  if (s->flow_epoch_bound > (1u << 30)) {
+  // (TSX_FLOW_EPOCH_LIMIT: tests lower the bound so that the restart is exercised)
+  static const unsigned epoch_limit = getenv("TSX_FLOW_EPOCH_LIMIT") ? (unsigned)atoll(getenv("TSX_FLOW_EPOCH_LIMIT")) : (1u << 30);
+  if (s->flow_epoch_bound > epoch_limit) {
     HIPCHK(hipMemsetAsync(s->flow_state, 0, sizeof(TsxFlowState), s->stream));
     HIPCHK(hipMemsetAsync(s->flow_prog, 0, sizeof(unsigned) * (size_t)s->flow_prog_cap, s->stream));
     if (s->flow_zb8) HIPCHK(hipMemsetAsync(s->flow_zb8, 0, zb8_bytes, s->stream));

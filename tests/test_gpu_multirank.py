@@ -420,11 +420,14 @@ def _pipeline_worker(rank, world, port, Nx, Ny, Nz, phi0, theta0, tall_top, tran
             objs = [ref.get(kind)]
             dist.broadcast_object_list(objs, src=0)
             full = objs[0]
-            e = []
+            e, where = [], []
             for got, want in zip(out[kind][2:], full):
                 scale = max(np.abs(want).max(), 1e-30)
-                e.append(float(np.abs(got - want[sl]).max() / scale))
-            errs[kind] = (out[kind][0], out[kind][1], e)
+                d = np.abs(got - want[sl])
+                e.append(float(d.max() / scale))
+                where.append(tuple(int(v) for v in np.unravel_index(int(d.argmax()), d.shape)) + (int((d > 1e-3 * scale).sum()),))
+            # (diagnostics for a failure: rank's block, and per quantity the local (j, i, k) of the largest deviation + how many cells deviate)
+            errs[kind] = (out[kind][0], out[kind][1], e, {"block": (co.xs, co.xm, co.ys, co.ym), "worst": where})
         ret[rank] = errs
         P.close()
     finally:
@@ -438,13 +441,13 @@ def test_sharded_pipeline_equals_one_rank_pipeline(gpu, world, Nx, Ny, phi0, the
     """set_optical_properties -> direct sweep (face exchange per sweep) -> setup_b -> solve -> flux divergence on 2/4
     ranks against the same g-point on one periodic rank; host-staged and device-resident (peer) transport."""
     ret = _spawn(_pipeline_worker, world, (Nx, Ny, 8, phi0, theta0, tall_top, transport))
-    for errs in ret.values():
-        reason, _, e = errs["solar"]
+    for rank, errs in ret.items():
+        reason, _, e, diag = errs["solar"]
         assert reason == 2
         # edn, eup, abso, edir: the direct sweep stops at rtol 1e-5 on both decompositions (different iterates)
-        assert max(e) < 3e-4, e
-        reason, _, e = errs["thermal"]
-        assert reason == 2 and max(e) < 1e-7, e
+        assert max(e) < 3e-4, (rank, e, diag)
+        reason, _, e, diag = errs["thermal"]
+        assert reason == 2 and max(e) < 1e-7, (rank, e, diag)
 
 
 # ---- RCCL with two real peers ---------------------------------------------------------------------------------------

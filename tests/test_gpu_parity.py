@@ -961,11 +961,13 @@ def test_flow_kernel_with_self_neighbour_faces_is_bit_identical(gpu, monkeypatch
     P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
     v = np.random.default_rng(3).standard_normal(P["b"].shape)
     out = {}
-    for mode in ("flow", "launches", "periodic"):
+    for mode in ("flow", "flow_fences", "launches", "periodic"):
         monkeypatch.setenv("TSX_FLOW_PEER", "0" if mode == "launches" else "1")
         s = DiffuseSolver("3_10", Nz, Nx, Ny, force_halo=mode != "periodic")
         if mode != "periodic":
             s.comm_peer_init(lambda blob: [blob])
+        if mode == "flow_fences":   # full system-scope fences around the flags and tags (what a failed self test switches on)
+            s.comm_peer_set_fences(1)
         s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
         res = [s.pc_apply(v, pc=3, sweeps=sw, mixed=True) for sw in (27, 27, 9)]
         x = np.zeros(s.vec_shape)
@@ -975,9 +977,48 @@ def test_flow_kernel_with_self_neighbour_faces_is_bit_identical(gpu, monkeypatch
         assert fl["in_use"] == (mode != "launches"), (mode, fl)
         out[mode] = res + [x, np.asarray(info.res_hist)]
         s.close()
-    for a, b in zip(out["flow"], out["launches"]):
-        assert np.isfinite(a).all() and np.array_equal(a, b)
+    for a, b, c in zip(out["flow"], out["launches"], out["flow_fences"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)
     # the periodic domain: the same M^-1 up to the precision of the records at the faces (bf16 through the mailbox also where the
     # last pass reads fp32 records in place), the same solution
     assert np.abs(out["flow"][0] - out["periodic"][0]).max() <= 2e-2 * np.abs(out["periodic"][0]).max()
     assert np.abs(out["flow"][3] - out["periodic"][3]).max() <= 1e-6 * np.abs(out["periodic"][3]).max()
+
+
+def test_flow_kernel_restarts_its_epoch_before_it_wraps(gpu):
+    """The flow kernel's progress words and granule tags are numbers that only grow (epoch + pass index); before the host's bound on
+    the epoch reaches 2^30 the state, the words and the tags restart from zero in stream order (flow_ensure).  With the bound
+    lowered to 60 (TSX_FLOW_EPOCH_LIMIT, read once per process: a subprocess) the restart happens every second application:
+    repeated applications and solves must stay bit-identical to a launch per pass -- on a domain that uses the progress words
+    and on one that uses granules."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tenstream_amd import DiffuseSolver, synthetic
+for Nx, Ny, Nz in ((128, 64, 12), (64, 32, 16)):
+    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz)
+    v = np.random.default_rng(2).standard_normal(P["b"].shape)
+    out = {}
+    for env in ("1", "0"):
+        os.environ["TSX_PC_FLOW"] = env
+        s = DiffuseSolver("3_10", Nz, Nx, Ny)
+        s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+        res = [s.pc_apply(v, pc=3, sweeps=27, mixed=True) for _ in range(7)]
+        for _ in range(3):
+            x = np.zeros(s.vec_shape)
+            assert s.solve(P["b"], x, rtol=1e-9, atol=1e-30).reason == 2
+            res.append(x)
+        out[env] = res
+        s.close()
+    assert all(np.array_equal(a, b) for a, b in zip(out["1"], out["0"])), (Nx, Ny)
+    assert all(np.array_equal(out["1"][0], a) for a in out["1"][1:7])
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TSX_FLOW_EPOCH_LIMIT="60"))
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-2000:]
