@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -1237,8 +1238,19 @@ static int explicit_run_t(tsx_solver *s, const tsx_ksp_opts *o) {
   return TSX_OK;
 }
 
+// solves in flight in this process: the flow kernel's workgroups spin while they wait for their neighbours, which is time other
+// instances' kernels could have had (bench_specint.py with four instances: 137 g-points/s with it, 140 with a launch per pass; the
+// cold call 71 against 84) -- an application of M^-1 takes the launches while another instance is inside a solve (tsx_pcs_flow_ok)
+static std::atomic<int> g_active_solves{0};
+int tsx_active_solves() { return g_active_solves.load(std::memory_order_relaxed); }
+struct TsxSolveInFlight {
+  TsxSolveInFlight() { g_active_solves.fetch_add(1, std::memory_order_relaxed); }
+  ~TsxSolveInFlight() { g_active_solves.fetch_sub(1, std::memory_order_relaxed); }
+};
+
 template <int NTOP, int NSIDE>
 static int krylov_run_with_retry(tsx_solver *s, tsx_ksp_opts *o) {
+  TsxSolveInFlight in_flight;
   if (o->explicit_solver)
     return s->mixed ? explicit_run_t<NTOP, NSIDE, true>(s, o) : explicit_run_t<NTOP, NSIDE, false>(s, o);
   int rc = krylov_run<NTOP, NSIDE>(s, o);

@@ -151,6 +151,8 @@ int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done
 bool tsx_pcs_rhs16(const tsx_solver *s);
 // passes [p0, p1) of an application (all of them intermediate Gauss-Seidel passes on the bf16 right-hand side words) as ONE
 // launch of tsx_k_pcs_flow (tsx_pcs_flow.hip); tsx_pcs_flow_ok: can this solver's current scan configuration take it
+// solves in flight in this process (several solver instances on streams of their own: config 4's spectral loop)
+int tsx_active_solves();
 bool tsx_pcs_flow_ok(tsx_solver *s, int lseg, int nseg, int cw, bool faces = false);
 int tsx_pcs_flow(tsx_solver *s, int cw, int p0, int p1, const int *done, bool faces = false);
 unsigned *tsx_pcs_words(const tsx_solver *s);

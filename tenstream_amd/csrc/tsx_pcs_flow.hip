@@ -46,6 +46,9 @@ bool tsx_pcs_flow_ok(tsx_solver *s, int lseg, int nseg, int cw, bool faces) {
   if (!flow_env()) return false;
   if (g.ntop != 2 || lseg != 4 || nseg != 16 || (cw != 32 && cw != 16)) return false;  // the instantiated configurations
   if (!faces && !(g.wrap_x && g.wrap_y)) return false;
+  // several instances of this process inside solves at once (their own streams): the launches leave the chip to the others between
+  // the passes, the flow kernel's waiting workgroups do not (tsx_active_solves; TSX_PC_FLOW=1 set explicitly keeps the flow kernel)
+  if (!faces && tsx_active_solves() > 1 && !getenv("TSX_PC_FLOW")) return false;
   if (g.pc_tile_x > 0 || g.pc_tile_y > 0) return false;
   const int h = g.xm >> 1;
   if (h % cw != 0) return false;  // a tile is CW columns of ONE row
