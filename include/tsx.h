@@ -366,7 +366,9 @@ int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes);
  * at most half of the cells need a block of their own; TSX_DEDUP=0 switches it off).  *on bit 0: bit-identical blocks shared
  * (*nent of them); bit 1: blocks that agree to about 1 % are grouped FOR THE PRECONDITIONER ONLY (its per-block records are
  * approximate by design; the operator keeps exact blocks) -- alone where nothing is bit-identical (*nent = the groups), or on top
- * of bit 0 where it halves the preconditioner's table.  TSX_DEDUP_NEAR=0 switches that off */
+ * of bit 0 where it halves the preconditioner's table.  TSX_DEDUP_NEAR=0 switches that off.  Bit 2: the grouping (which cells share a
+ * block) was taken over from the previous coefficient set of this solver after one validation kernel found it still exact for the new
+ * LUT coordinates -- the case of a spectral loop over g-points of one scene; TSX_DEDUP_REUSE=0 rebuilds it every time */
 int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent);
 /* the preconditioner the last solve / tsx_bench_kernel actually ran (after the automatic choices: red-black -> zebra rows
  * on odd grids, pc_sweeps 0 -> 27 or 9): TSX_PC_*, pc_sweeps, and scan: 0 = one-lane-per-column kernels, 1 = scan kernels,

@@ -18,6 +18,9 @@ for r in csv.DictReader(open(f)):
         tot["other"] += t; other.append((t, name[:70]))
 s = sum(tot.values())
 for k, v in tot.most_common(): print(f"{k:32s} {v:9.1f} ms {100*v/s:5.1f} %  ({n[k]} launches)")
+rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs"]))
+for r in rows[:int(__import__("os").environ.get("C4_TOP", "0"))]:
+    print("%9.2f ms %6d x %9.1f us  %s" % (float(r["TotalDurationNs"]) / 1e6, int(r["Calls"]), float(r["AverageNs"]) / 1e3, r["Name"][:120]))
 print("other top:", sorted(other, reverse=True)[:6])
 import json
 x = json.loads([l for l in open("/tmp/c4_line.json") if l.startswith("{")][-1])

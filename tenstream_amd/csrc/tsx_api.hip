@@ -604,6 +604,7 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
   s->dd_valid = false;
   s->dd_on = false;
   s->dd_pc = false;
+  s->dd_from_coords = false;
   s->dd_hash_ready = false;  // imported blocks: tsx_dedup.hip hashes them itself
   s->coef_dense_valid = true;
   return TSX_OK;
@@ -1665,7 +1666,8 @@ extern "C" int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent) {
   if (rc) return rc;
   // bit 0: bit-identical blocks shared (operator and preconditioner); bit 1: near-identical blocks grouped for the
   // preconditioner (on top of bit 0, or alone where nothing is bit-identical)
-  *on = (s->dd_on ? 1 : 0) | (s->dd_pc ? 2 : 0);
+  // bit 2: the grouping is the previous coefficient set's, found still valid for this set's LUT coordinates (tsx_dedup_from_coords)
+  *on = (s->dd_on ? 1 : 0) | (s->dd_pc ? 2 : 0) | ((s->dd_on && s->dd_from_coords && s->dd_reused) ? 4 : 0);
   *nent = s->dd_on ? s->dd_nent : (s->dd_pc ? s->pc_nent : s->dd_nent);
   return TSX_OK;
 }

@@ -47,31 +47,27 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_insert(long long Nc, unsig
   // 40 ms).  A cell therefore looks first (relaxed loads): once the key is in place and the slot's owner is already a
   // smaller cell index, it has nothing to add.  Cells are visited in ascending order within a wave and roughly so across
   // the grid, so after the first arrivals almost nobody issues an atomic.
-  // ... and the lanes of a wave that carry the same hash send one of them (the lowest lane = the smallest cell index).
+  // ... and of a run of neighbouring lanes with the same hash only the first one (the smallest cell index) goes to the table.  The
+  // heads of all runs of a wave probe at the same time: electing one lane per distinct hash in a loop (rounds 1-4) put a wave of 64
+  // different cloudy cells through 64 rounds of dependent loads / atomics, one after the other -- 194 us for 4.2 M cells, a third
+  // of what a g-point's sharing pipeline cost.  Two runs of one wave with the same hash both go: the atomicMin sorts them out.
   for (long long c0 = (long long)blockIdx.x * TSX_BLOCK; c0 < Nc; c0 += (long long)gridDim.x * TSX_BLOCK) {
     const long long c = c0 + threadIdx.x;
     const bool live = c < Nc;
     const unsigned long long hv = live ? h[c] : TSX_DD_EMPTY;
-    bool pending = live;
-    while (__any(pending)) {
-      const unsigned long long todo = __ballot(pending);
-      const int lead = __ffsll((long long)todo) - 1;
-      const unsigned lo = (unsigned)__shfl((int)(unsigned)(hv & 0xffffffffull), lead, 64);
-      const unsigned hi = (unsigned)__shfl((int)(unsigned)(hv >> 32), lead, 64);
-      const unsigned long long lhv = ((unsigned long long)hi << 32) | lo;
-      const bool mine = pending && hv == lhv;
-      if (mine) pending = false;
-      if ((int)(threadIdx.x & 63) == lead) {
-        unsigned long long slot = hv & mask;
-        for (;;) {
-          unsigned long long cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (cur == TSX_DD_EMPTY) cur = atomicCAS(&keys[slot], TSX_DD_EMPTY, hv);
-          if (cur == TSX_DD_EMPTY || cur == hv) {
-            if (__hip_atomic_load(&owner[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int)c) atomicMin(&owner[slot], (int)c);
-            break;
-          }
-          slot = (slot + 1) & mask;
+    const unsigned plo = (unsigned)__shfl_up((int)(unsigned)(hv & 0xffffffffull), 1, 64);
+    const unsigned phi = (unsigned)__shfl_up((int)(unsigned)(hv >> 32), 1, 64);
+    const bool head = live && ((threadIdx.x & 63) == 0 || ((((unsigned long long)phi << 32) | plo) != hv));
+    if (head) {
+      unsigned long long slot = hv & mask;
+      for (;;) {
+        unsigned long long cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == TSX_DD_EMPTY) cur = atomicCAS(&keys[slot], TSX_DD_EMPTY, hv);
+        if (cur == TSX_DD_EMPTY || cur == hv) {
+          if (__hip_atomic_load(&owner[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int)c) atomicMin(&owner[slot], (int)c);
+          break;
         }
+        slot = (slot + 1) & mask;
       }
     }
   }
@@ -493,6 +489,30 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_resolve_coords(TsxGeo g, T
     flag[c] = r == (int)c;
   }
 }
+// Does the grouping of the previous coefficient set still hold for these coordinates?  A spectral loop hands over one set of
+// optical properties per g-point: the values change, but which cells share a tuple mostly does not (every clear-sky cell of a level
+// still equals its neighbours; gas optics are functions of the level).  Every cell compares its clamped tuple with the one of its
+// entry's representative cell, bit for bit; one mismatch anywhere (or a changed set of 1-D layers) and the grouping is rebuilt.  Two
+// entries may have become equal to each other: they stay two entries (lossless, a little less shared).
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_validate_coords(TsxGeo g, TsxLutDev L, const float4 *__restrict__ samp,
+                                                                      const uint8_t *__restrict__ l1d, const int *__restrict__ cidx,
+                                                                      const int *__restrict__ ent_cell, int *__restrict__ bad) {
+  const long long Nc = g.Nc;
+  int mine = 0;
+  for (long long c = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; c < Nc; c += (long long)gridDim.x * TSX_BLOCK) {
+    const int o = ent_cell[cidx[c]];
+    if (o == (int)c) continue;
+    const bool c1 = l1d[(int)(c / g.ncol)] != 0, o1 = l1d[o / g.ncol] != 0;
+    if (c1 || o1) {
+      mine |= (c1 != o1);
+      continue;
+    }
+    const float4 a = tsx_lut_diff_clamp(L, samp[c]), b = tsx_lut_diff_clamp(L, samp[o]);
+    mine |= !(__float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+              __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w));
+  }
+  if (__any(mine) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
 // dense planes from the entries: C[q * Nc + c] = Cd[q * nent + cidx[c]]
 __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_expand(long long Nc, int DD, long long nent, const float *__restrict__ Cd,
                                                              const int *__restrict__ cidx, float *__restrict__ C) {
@@ -529,9 +549,29 @@ int tsx_dedup_from_coords(tsx_solver *s, const TsxLutDev &L, bool *built) {
     if (rc) return rc;
   }
   const float4 *samp = (const float4 *)s->cell_samp;
+  const int nb = grid_for(Nc, 8192);
+  // the previous set's grouping, if it was made from coordinates too and still holds (TSX_DEDUP_REUSE=0: always rebuild)
+  bool reuse = false;
+  {
+    const char *er = getenv("TSX_DEDUP_REUSE");
+    if (s->dd_from_coords && s->dd_cidx && s->dd_ent_cell && s->dd_nent > 0 && !(er && atoi(er) == 0)) {
+      HIPCHK(hipMemsetAsync(w.ttot.p, 0, sizeof(int), s->stream));
+      hipLaunchKernelGGL(tsx_k_dd_validate_coords, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, L, samp, s->l1d, (const int *)s->dd_cidx,
+                         (const int *)s->dd_ent_cell, w.ttot.as<int>());
+      HIPCHK(hipGetLastError());
+      int bad = 1;
+      HIPCHK(hipMemcpyAsync(&bad, w.ttot.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(hipStreamSynchronize(s->stream));
+      reuse = bad == 0;
+    }
+  }
+  s->dd_from_coords = false;
+  int nent = 0;
+  if (reuse) {
+    nent = s->dd_nent;
+  } else {
   HIPCHK(hipMemsetAsync(w.tk.p, 0, sizeof(unsigned long long) * (size_t)w.tsz, s->stream));
   HIPCHK(hipMemsetAsync(w.to.p, 0x7f, sizeof(int) * (size_t)w.tsz, s->stream));
-  const int nb = grid_for(Nc, 8192);
   hipLaunchKernelGGL(tsx_k_dd_hash_coords, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, L, samp, s->l1d, w.th.as<unsigned long long>());
   hipLaunchKernelGGL(tsx_k_dd_insert, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, w.tsz - 1, w.th.as<unsigned long long>(),
                      w.tk.as<unsigned long long>(), w.to.as<int>());
@@ -541,9 +581,9 @@ int tsx_dedup_from_coords(tsx_solver *s, const TsxLutDev &L, bool *built) {
   hipLaunchKernelGGL(tsx_k_scan_top, dim3(1), dim3(1024), 0, s->stream, w.nsb, w.tsum.as<int>(), w.ttot.as<int>());
   hipLaunchKernelGGL(tsx_k_scan_write, dim3(w.nsb), dim3(TSX_BLOCK), 0, s->stream, Nc, w.tflag.as<int>(), w.tsum.as<int>(), w.tpos.as<int>());
   HIPCHK(hipGetLastError());
-  int nent = 0;
   HIPCHK(hipMemcpyAsync(&nent, w.ttot.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
   HIPCHK(hipStreamSynchronize(s->stream));
+  }
   if ((long long)nent * 2 > Nc) return TSX_OK;  // mostly distinct coordinates: dense planes, then the block-based build decides
   s->dd_nent = nent;
   if (!s->dd_cidx) HIPCHK(hipMalloc((void **)&s->dd_cidx, sizeof(int) * (size_t)Nc));
@@ -558,8 +598,9 @@ int tsx_dedup_from_coords(tsx_solver *s, const TsxLutDev &L, bool *built) {
     s->dd_cap = nent;
   }
   const bool split = g.xm % 2 == 0;
-  hipLaunchKernelGGL(tsx_k_dd_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, w.trep.as<int>(), w.tpos.as<int>(), s->dd_cidx,
-                     split ? s->dd_cidx_split : (int *)nullptr, s->dd_ent_cell);
+  if (!reuse)
+    hipLaunchKernelGGL(tsx_k_dd_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, w.trep.as<int>(), w.tpos.as<int>(), s->dd_cidx,
+                       split ? s->dd_cidx_split : (int *)nullptr, s->dd_ent_cell);
   s->dd_coef_e = s->dd_coef + (size_t)DD * s->dd_cap;
   hipLaunchKernelGGL((tsx_k_lut_diff2diff_ent<100>), dim3(grid_for(nent, 8192)), dim3(TSX_BLOCK), 0, s->stream, g, L, s->l1d,
                      (long long)nent, (const int *)s->dd_ent_cell, samp, s->dd_coef, s->dd_coef_e);
@@ -581,6 +622,8 @@ int tsx_dedup_from_coords(tsx_solver *s, const TsxLutDev &L, bool *built) {
   s->pc_ent_cell = s->dd_ent_cell;
   s->pc_nent = s->dd_nent;
   s->coef_dense_valid = false;
+  s->dd_from_coords = true;
+  s->dd_reused = reuse;
   *built = true;
   return TSX_OK;
 }
@@ -598,6 +641,7 @@ int tsx_dedup_ensure(tsx_solver *s) {
   // cell indices are ints and the owner table's "no owner yet" value is 0x7f7f7f7f (byte-wise memset): stay below it
   if (g.Nc >= 0x7f7f7f7fll || !tsx_dd_wave64(s)) return TSX_OK;
   bool pays = false;
+  s->dd_from_coords = false;  // the index is rewritten from the blocks
   int rc = dd_build(s, false, &pays);
   if (rc) return rc;
   s->dd_on = pays;

@@ -132,6 +132,8 @@ struct tsx_solver {
   bool any_l1d;
   // shared storage of bit-identical blocks (tsx_dedup.hip): planes over entries + per-cell entry index
   bool dd_valid, dd_on;
+  bool dd_from_coords = false;  // the current grouping was made from the cells' LUT coordinates (tsx_dedup_from_coords): the next set may reuse it
+  bool dd_reused = false;       // ... and the current one is the previous set's, found still valid
   bool coef_dense_valid = true;  // s->coef holds every cell's block (false: only the shared storage does, tsx_dedup_from_coords)
   bool pe_entry_major = false;  // the scan passes' per-block records are stored entry-major (tsx_k_pcs_pack_ent16)
   bool dd_pc = false;      // the index / entries group NEAR-identical blocks and serve the preconditioner only (tsx_dedup.hip);

@@ -417,7 +417,8 @@ class DiffuseSolver:
         """(in use?, number of distinct transport blocks) of the current coefficients"""
         on, n = C.c_int32(), C.c_int64()
         _lib.check(self.lib.tsx_dedup_info(self.h, C.byref(on), C.byref(n)))
-        self.dedup_mode = int(on.value)   # bit 0: bit-identical blocks shared; bit 1: near-identical blocks grouped for M^-1
+        self.dedup_mode = int(on.value)   # bit 0: bit-identical blocks shared; bit 1: near-identical blocks grouped for M^-1;
+        #                                   bit 2: grouping taken over from the previous coefficient set (validated)
         return bool(on.value & 1), int(n.value)
 
     def pc_info(self):
