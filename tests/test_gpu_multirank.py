@@ -456,11 +456,24 @@ def _pipeline_worker(rank, world, port, Nx, Ny, Nz, phi0, theta0, tall_top, tran
 @pytest.mark.parametrize("transport", ["host", "peer"])
 def test_sharded_pipeline_equals_one_rank_pipeline(gpu, world, Nx, Ny, phi0, theta0, tall_top, transport):
     """set_optical_properties -> direct sweep (face exchange per sweep) -> setup_b -> solve -> flux divergence on 2/4
-    ranks against the same g-point on one periodic rank; host-staged and device-resident (peer) transport."""
+    ranks against the same g-point on one periodic rank; host-staged and device-resident (peer) transport.
+
+    KNOWN, OPEN (rounds 4 and 5; profiles/NEGATIVE_RESULTS.md "a rare deviation in the four-process pipeline test"): the
+    parameter set (4 ranks, 12 x 10, one thick 1-D top layer) deviates in 1-2 % of its runs when the four rank PROCESSES are fresh
+    -- absorption off while the fluxes agree to 1e-10, a NaN residual, once an illegal-instruction abort of one rank's queue --
+    with either transport and with the round-4 library; never in-process (scripts/stress_sharded.py: 2 000 solves and 800 fresh
+    solver instances inside four long-lived processes), never with the other parameter sets (0 of 110).  The test stays strict
+    and single-attempt; on a deviation the workers solve once more and the message (and TSX_TEST_DIAG_DIR) says which
+    decomposition reproduces itself."""
     ret = _spawn(_pipeline_worker, world, (Nx, Ny, 8, phi0, theta0, tall_top, transport))
     for rank, errs in ret.items():
         reason, _, e, diag = errs["solar"]
-        everyone = {r: (v["solar"][2], v["solar"][3], v["thermal"][2], v["thermal"][3]) for r, v in ret.items()}
+        everyone = {r: (v["solar"][:3], v["solar"][3], v["thermal"][:3], v["thermal"][3]) for r, v in ret.items()}
+        if os.environ.get("TSX_TEST_DIAG_DIR") and (reason != 2 or max(e) >= 3e-4 or errs["thermal"][0] != 2 or max(errs["thermal"][2]) >= 1e-7):
+            import json   # (debugging a rare deviation: the assertion message is shortened by pytest)
+
+            with open(os.path.join(os.environ["TSX_TEST_DIAG_DIR"], f"sharded_pipeline_{transport}_{os.getpid()}_{rank}.json"), "w") as fh:
+                json.dump({str(k): v for k, v in everyone.items()}, fh, indent=1)
         assert reason == 2
         # edn, eup, abso, edir: the direct sweep stops at rtol 1e-5 on both decompositions (different iterates)
         assert max(e) < 3e-4, (rank, e, diag, everyone)
