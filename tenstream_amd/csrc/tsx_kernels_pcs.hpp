@@ -596,7 +596,11 @@ __device__ __forceinline__ void tsx_pcs_rb_body(const TsxGeo &g, const uint4 *__
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const size_t hidx = (size_t)(m < 2 ? jrow : icol) * tsx_pcs_halo_nzp(Nz) + k;  // [j][k] resp. [i][k]
-      hv[m] = *(face[m] ? hp[m] + hidx : zb);
+      const unsigned *hq = face[m] ? hp[m] + hidx : zb;
+      // inside the flow kernel a slot is read again two passes later by a workgroup that may sit on the same CU: the load must not
+      // be served by a line that CU's L1 still holds from then (a launch per pass starts with an invalidated L1)
+      if constexpr (FLOW) hv[m] = __hip_atomic_load(hq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      else hv[m] = *hq;
     }
   };
   auto nbr_select = [&](uint2 (&o)[4], const unsigned (&hv)[4], bool halo) {
