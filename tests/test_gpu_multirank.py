@@ -469,6 +469,9 @@ def test_sharded_pipeline_equals_one_rank_pipeline(gpu, world, Nx, Ny, phi0, the
     for rank, errs in ret.items():
         reason, _, e, diag = errs["solar"]
         everyone = {r: (v["solar"][:3], v["solar"][3], v["thermal"][:3], v["thermal"][3]) for r, v in ret.items()}
+        if os.environ.get("TSX_TEST_DIAG_DIR") and rank == min(ret):   # iteration counts of every run: a damaged preconditioner shows there first
+            with open(os.path.join(os.environ["TSX_TEST_DIAG_DIR"], "sharded_pipeline_iterations.txt"), "a") as fh:
+                fh.write(f"{transport} {world} {Nx}x{Ny} solar {errs['solar'][1]} thermal {errs['thermal'][1]}\n")
         if os.environ.get("TSX_TEST_DIAG_DIR") and (reason != 2 or max(e) >= 3e-4 or errs["thermal"][0] != 2 or max(errs["thermal"][2]) >= 1e-7):
             import json   # (debugging a rare deviation: the assertion message is shortened by pytest)
 
