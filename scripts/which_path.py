@@ -1,6 +1,8 @@
+"""Which sharing / preconditioner path every rank of the four-process pipeline case takes (GPU box): python scripts/which_path.py
+Prints per rank and g-point: iterations, tsx_dedup_info mode and entry count, tsx_pc_info, tsx_flow_info."""
 import os, sys
 import numpy as np
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def worker(rank, world, port):
     sys.path.insert(0, ROOT)
     import torch, torch.distributed as dist
