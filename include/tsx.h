@@ -385,6 +385,30 @@ int tsx_probe_copy_bandwidth(tsx_solver *s, size_t bytes, int reps, double *gbps
  * ceiling `roofline.frac_of_achievable` in bench.py is quoted against beside MI355X_MICROARCH.md's 6.3 TB/s */
 int tsx_probe_bandwidth(tsx_solver *s, size_t bytes, int reps, double *out4);
 
+/* Log events of this path, named like the reference's (solver%logs, src/pprts_base.F90:176-209; begun / ended at src/pprts.F90:1785-2077
+ * set_optprop, :3422-3489 get_coeff_diff2diff, :3116-3392 get_coeff_dir2dir / dir2diff, :2694-2756 compute_Edir, :2903-2912 solve_Mdir,
+ * :2760-2818 compute_Ediff, :2952-2954 setup_Mdiff, :3012-3021 solve_Mdiff, :5197-5479 compute_absorption; setup_diff_src, get_result):
+ * per event a count and the DEVICE time between two HIP events recorded on the solver's stream around it, and a roctx range of the same
+ * name around the host code (rocprofv3 --marker-trace shows a spectral loop g-point by g-point; roctx is bound at run time, absent = no
+ * ranges).  Off by default (no event records on the hot path); tsx_log_enable(s, 1) or TSX_LOG=1 at tsx_create switch it on.
+ * tsx_log_get synchronises the stream and fills up to *nevents = 11 entries; names[] point to static strings; any array may be null. */
+int tsx_log_enable(tsx_solver *s, int on);
+int tsx_log_get(tsx_solver *s, int32_t *nevents, const char **names, int64_t *counts, double *ms);
+
+/* libtsx's device memory pool (tsx_pool.hip): driver allocations are taken once per process, held in quarantine until their contents
+ * have stayed intact for TSX_POOL_GUARD_US (default 3000) microseconds, and sub-allocated from then on (TSX_POOL=0: straight to
+ * hipMalloc, for A/B runs).  out8 = {slabs taken from the driver, their bytes, bytes handed out now, pieces, verifies that found a
+ * fresh slab's pattern damaged, words damaged, microseconds after hipMalloc of the first damaged verify (-1: none), microseconds
+ * spent in quarantine}.  device < 0: the current device.  The reference allocates its coefficient arrays once per solver
+ * (alloc_coeff_diff2diff, src/pprts.F90:3396-3490); here no driver allocation lies on a solver's path after the first set. */
+int tsx_pool_stats(int device, int64_t *out8);
+
+/* diagnostics: the code of one of libtsx's eight device code objects AS IT SITS IN DEVICE MEMORY (unit 0..7 = api, spmv310, spmv816,
+ * pc, pcs, pcsflow, dedup, peer).  The unit's probe kernel reports its program counter in *pc_out and copies nwords 32-bit words from
+ * pc + delta to host_out (nwords = 0: the pc only); scripts/code_verify.py knows the units' ELF images inside libtsx.so and compares
+ * every loaded .text byte with the file.  device < 0: the current device.  No reference counterpart. */
+int tsx_debug_code_read(int device, int unit, long long delta, long long nwords, void *host_out, unsigned long long *pc_out);
+
 #ifdef __cplusplus
 }
 #endif

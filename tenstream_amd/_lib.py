@@ -57,6 +57,7 @@ SYMBOLS = (
     "tsx_pprts_zero_guess", "tsx_pprts_get_result", "tsx_pprts_get_field", "tsx_diff_apply", "tsx_diff_solve", "tsx_diff_pc_apply", "tsx_bench_kernel", "tsx_algorithmic_bytes",
     "tsx_probe_copy_bandwidth", "tsx_opp_get_coeff", "tsx_opp_get_info", "tsx_pprts_select_solution", "tsx_dedup_info", "tsx_pc_info", "tsx_flow_info", "tsx_pprts_set_direct_tolerances",
     "tsx_probe_bandwidth", "tsx_diff_apply_r", "tsx_diff_solve_r", "tsx_dir_set_coeffs", "tsx_dir_solve", "tsx_setup_b_solar", "tsx_setup_b_thermal",
+    "tsx_debug_code_read", "tsx_log_enable", "tsx_log_get", "tsx_pool_stats",
 )
 
 PEER_BLOB_BYTES = 192   # TSX_PEER_BLOB_BYTES
@@ -114,6 +115,10 @@ def load():
     lib.tsx_algorithmic_bytes.argtypes = [vp, ip, dp]
     lib.tsx_probe_copy_bandwidth.argtypes = [vp, C.c_size_t, ip, dp]
     lib.tsx_probe_bandwidth.argtypes = [vp, C.c_size_t, ip, dp]
+    lib.tsx_log_enable.argtypes = [vp, ip]
+    lib.tsx_pool_stats.argtypes = [ip, C.POINTER(C.c_int64)]
+    lib.tsx_log_get.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), dp]
+    lib.tsx_debug_code_read.argtypes = [ip, ip, C.c_longlong, C.c_longlong, vp, C.POINTER(C.c_ulonglong)]
     lib.tsx_opp_get_coeff.argtypes = [vp] + [C.c_float] * 6 + [ip, ip, ip, ip, vp]
     lib.tsx_dedup_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.tsx_pprts_set_direct_tolerances.argtypes = [vp, C.c_double, C.c_double, C.c_int32]

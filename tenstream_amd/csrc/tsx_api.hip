@@ -188,6 +188,7 @@ extern "C" int tsx_determine_ksp_tolerances(const tsx_solver *s, double unconstr
 
 static int create_fill(tsx_solver *s, const tsx_grid *grid);
 static void slots_free(tsx_solver *s);
+static void tsx_log_free(tsx_solver *s);
 extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
   ARGCHK(grid && out, "tsx_create: null argument");
   ARGCHK(grid->solver_id == TSX_SOLVER_3_10 || grid->solver_id == TSX_SOLVER_8_16,
@@ -200,13 +201,14 @@ extern "C" int tsx_create(const tsx_grid *grid, tsx_solver **out) {
     tsx_set_error("tsx_create: no HIP device available (libtsx has no CPU fallback)");
     return TSX_ERR_NO_DEVICE;
   }
-  tsx_solver *s = new tsx_solver();
-  memset((void *)s, 0, sizeof(*s));
+  tsx_solver *s = new tsx_solver();  // value-initialisation: every member zero, then the default member initialisers of tsx_internal.hpp
   const int rc = create_fill(s, grid);
   if (rc) {  // release the half-built solver (streams, events, buffers) on any failure
     (void)tsx_destroy(s);
     return rc;
   }
+  if (const char *e = getenv("TSX_LOG"))
+    if (atoi(e) != 0) s->log = new TsxLog();
   *out = s;
   return TSX_OK;
 }
@@ -253,7 +255,7 @@ static int create_fill(tsx_solver *s, const tsx_grid *grid) {
   const size_t nb = (size_t)g.N * sizeof(double);
   double **vecs[] = {&s->vx, &s->vb, &s->vr, &s->vrhat, &s->vp, &s->vv, &s->vs, &s->vt};
   for (double **v : vecs) {
-    HIPCHK(hipMalloc((void **)v, nb));
+    HIPCHK(tsx_dev_malloc((void **)v, nb));
     HIPCHK(hipMemsetAsync(*v, 0, nb, s->stream));
   }
   s->vph = s->vp;  // no preconditioner: p-hat aliases p
@@ -263,20 +265,20 @@ static int create_fill(tsx_solver *s, const tsx_grid *grid) {
   double **hx[] = {&s->sendW, &s->sendE, &s->recvW, &s->recvE};
   double **hy[] = {&s->sendS, &s->sendN, &s->recvS, &s->recvN};
   for (double **v : hx) {
-    HIPCHK(hipMalloc((void **)v, s->halo_x_elems * sizeof(double)));
+    HIPCHK(tsx_dev_malloc((void **)v, s->halo_x_elems * sizeof(double)));
     HIPCHK(hipMemsetAsync(*v, 0, s->halo_x_elems * sizeof(double), s->stream));
   }
   for (double **v : hy) {
-    HIPCHK(hipMalloc((void **)v, s->halo_y_elems * sizeof(double)));
+    HIPCHK(tsx_dev_malloc((void **)v, s->halo_y_elems * sizeof(double)));
     HIPCHK(hipMemsetAsync(*v, 0, s->halo_y_elems * sizeof(double), s->stream));
   }
-  HIPCHK(hipMalloc((void **)&s->partials, sizeof(double) * TSX_NSLOTS * TSX_MAX_PARTIAL_BLOCKS));
+  HIPCHK(tsx_dev_malloc((void **)&s->partials, sizeof(double) * TSX_NSLOTS * TSX_MAX_PARTIAL_BLOCKS));
   HIPCHK(hipMemsetAsync(s->partials, 0, sizeof(double) * TSX_NSLOTS * TSX_MAX_PARTIAL_BLOCKS, s->stream));
-  HIPCHK(hipMalloc((void **)&s->scal, sizeof(TsxScalars)));
+  HIPCHK(tsx_dev_malloc((void **)&s->scal, sizeof(TsxScalars)));
   HIPCHK(hipMemsetAsync(s->scal, 0, sizeof(TsxScalars), s->stream));
   HIPCHK(hipHostMalloc((void **)&s->scal_host, sizeof(TsxScalars), hipHostMallocDefault));
-  HIPCHK(hipMalloc((void **)&s->l1d, (size_t)g.Nz));
-  HIPCHK(hipMalloc((void **)&s->albedo, sizeof(double) * g.ncol));
+  HIPCHK(tsx_dev_malloc((void **)&s->l1d, (size_t)g.Nz));
+  HIPCHK(tsx_dev_malloc((void **)&s->albedo, sizeof(double) * g.ncol));
   HIPCHK(hipStreamSynchronize(s->stream));
   return TSX_OK;
 }
@@ -293,9 +295,9 @@ extern "C" int tsx_destroy(tsx_solver *s) {
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
                   s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->bsrfc, s->edir_a, s->edir_b, s->dsc, s->abso, s->cell_samp, s->dd_colsum, s->flow_state, s->flow_prog, s->flow_zb8, s->flow_pr_dev};
   for (void *p : ptrs)
-    if (p) (void)hipFree(p);
-  if (s->vph && s->vph != s->vp) (void)hipFree(s->vph);
-  if (s->vsh && s->vsh != s->vs) (void)hipFree(s->vsh);
+    if (p) (void)tsx_dev_free(p);
+  if (s->vph && s->vph != s->vp) (void)tsx_dev_free(s->vph);
+  if (s->vsh && s->vsh != s->vs) (void)tsx_dev_free(s->vsh);
   if (s->scal_host) (void)hipHostFree(s->scal_host);
   if (s->dsc_host) (void)hipHostFree(s->dsc_host);
   for (int q = 0; q < 4; ++q) {
@@ -303,6 +305,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
     if (s->host_recv[q]) (void)hipHostFree(s->host_recv[q]);
   }
   slots_free(s);
+  tsx_log_free(s);
   delete s->flow_pr_shadow;
   if (s->comm_ready && g_rccl.CommDestroy) {
     if (s->nccl_comm_x) g_rccl.CommDestroy(s->nccl_comm_x);
@@ -495,8 +498,8 @@ static int export_vec(tsx_solver *s, const double *v, double *ref_dev) {
 
 static int ensure_stage(tsx_solver *s) {
   const size_t nb = (size_t)s->geo.N * sizeof(double);
-  if (!s->stage_a) HIPCHK(hipMalloc((void **)&s->stage_a, nb));
-  if (!s->stage_b) HIPCHK(hipMalloc((void **)&s->stage_b, nb));
+  if (!s->stage_a) HIPCHK(tsx_dev_malloc((void **)&s->stage_a, nb));
+  if (!s->stage_b) HIPCHK(tsx_dev_malloc((void **)&s->stage_b, nb));
   return TSX_OK;
 }
 
@@ -520,8 +523,8 @@ static int set_aux(tsx_solver *s, const uint8_t *l1d, const double *a11, const d
   HIPCHK(hipMemcpyAsync(s->albedo, albedo, sizeof(double) * g.ncol, mk, s->stream));
   s->have_albedo = true;
   if (s->any_l1d) {
-    if (!s->a11) HIPCHK(hipMalloc((void **)&s->a11, sizeof(double) * g.Nc));
-    if (!s->a12) HIPCHK(hipMalloc((void **)&s->a12, sizeof(double) * g.Nc));
+    if (!s->a11) HIPCHK(tsx_dev_malloc((void **)&s->a11, sizeof(double) * g.Nc));
+    if (!s->a12) HIPCHK(tsx_dev_malloc((void **)&s->a12, sizeof(double) * g.Nc));
     TsxDevTmp g11, g12;
     double *t11 = nullptr, *t12 = nullptr;
     const double *p11 = a11, *p12 = a12;
@@ -546,10 +549,10 @@ static int set_aux(tsx_solver *s, const uint8_t *l1d, const double *a11, const d
 static int ensure_coef_storage(tsx_solver *s, int out_bytes) {
   const size_t ncoef = (size_t)s->geo.D * s->geo.D * s->geo.Nc;
   if (s->coef && s->coef_bytes != out_bytes) {
-    HIPCHK(hipFree(s->coef));
+    HIPCHK(tsx_dev_free(s->coef));
     s->coef = nullptr;
   }
-  if (!s->coef) HIPCHK(hipMalloc(&s->coef, ncoef * out_bytes));
+  if (!s->coef) HIPCHK(tsx_dev_malloc(&s->coef, ncoef * out_bytes));
   s->coef_bytes = out_bytes;
   return TSX_OK;
 }
@@ -643,11 +646,11 @@ extern "C" int tsx_lut_set_diffuse(tsx_solver *s, const float *table, int32_t nv
   ARGCHK(prod == nentries, "tsx_lut_set_diffuse: nentries != product of axis lengths");
   HIPCHK(hipSetDevice(s->device));
   TsxLutHost &L = s->lut_diff;
-  if (L.d_axes) HIPCHK(hipFree(L.d_axes));
-  if (L.d_table) HIPCHK(hipFree(L.d_table));
+  if (L.d_axes) HIPCHK(tsx_dev_free(L.d_axes));
+  if (L.d_table) HIPCHK(tsx_dev_free(L.d_table));
   L = TsxLutHost();
-  HIPCHK(hipMalloc((void **)&L.d_axes, sizeof(float) * nax));
-  HIPCHK(hipMalloc((void **)&L.d_table, sizeof(float) * (size_t)nvec * nentries));
+  HIPCHK(tsx_dev_malloc((void **)&L.d_axes, sizeof(float) * nax));
+  HIPCHK(tsx_dev_malloc((void **)&L.d_table, sizeof(float) * (size_t)nvec * nentries));
   const hipMemcpyKind mk = where == TSX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   HIPCHK(hipMemcpy(L.d_axes, axes_concat, sizeof(float) * nax, mk));
   HIPCHK(hipMemcpy(L.d_table, table, sizeof(float) * (size_t)nvec * nentries, mk));
@@ -704,11 +707,11 @@ int tsx_cell_samples(tsx_solver *s, const double *kabs, const double *ksca, cons
   const TsxGeo &gm = s->geo;
   const char *e = getenv("TSX_CELL_SAMPLES");
   if (e && atoi(e) == 0) {
-    if (s->cell_samp) (void)hipFree(s->cell_samp);
+    if (s->cell_samp) (void)tsx_dev_free(s->cell_samp);
     s->cell_samp = nullptr;
     return TSX_OK;
   }
-  if (!s->cell_samp) HIPCHK(hipMalloc(&s->cell_samp, sizeof(float4) * (size_t)gm.Nc));
+  if (!s->cell_samp) HIPCHK(tsx_dev_malloc(&s->cell_samp, sizeof(float4) * (size_t)gm.Nc));
   s->cell_samp_src[0] = kabs, s->cell_samp_src[1] = ksca, s->cell_samp_src[2] = g, s->cell_samp_src[3] = dz;
   s->cell_samp_dx = dx;
   hipLaunchKernelGGL(tsx_k_cell_samples, dim3((gm.ncol + 31) / 32, (gm.Nz + 31) / 32), dim3(TSX_BLOCK), 0, s->stream, gm, kabs, ksca, g, dz,
@@ -719,6 +722,7 @@ int tsx_cell_samples(tsx_solver *s, const double *kabs, const double *ksca, cons
 
 // alloc_coeff_diff2diff on the device: kabs/ksca/g/dz are device pointers in the reference layout
 static int lut_diffuse_launch(tsx_solver *s, const double *kabs, const double *ksca, const double *g, const double *dz, double dx) {
+  TsxLogScope log_scope(s, TSX_EV_GET_COEFF_DIFF2DIFF);  // get_coeff_diff2diff, src/pprts.F90:3422-3489
   const TsxGeo &gm = s->geo;
   // a new coefficient set: whatever the shared storage held is gone (the callers used to reset these after the launch; the
   // coordinate-keyed build below sets them itself)
@@ -1252,6 +1256,7 @@ struct TsxSolveInFlight {
 template <int NTOP, int NSIDE>
 static int krylov_run_with_retry(tsx_solver *s, tsx_ksp_opts *o) {
   TsxSolveInFlight in_flight;
+  TsxLogScope log_scope(s, TSX_EV_SOLVE_MDIFF);  // solve_Mdiff, src/pprts.F90:3012-3021
   if (o->explicit_solver)
     return s->mixed ? explicit_run_t<NTOP, NSIDE, true>(s, o) : explicit_run_t<NTOP, NSIDE, false>(s, o);
   int rc = krylov_run<NTOP, NSIDE>(s, o);
@@ -1356,6 +1361,7 @@ static int diff_solve_t(tsx_solver *s, const double *b, double *x, int where, co
 }
 
 static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o) {
+  TsxLogScope log_scope(s, TSX_EV_SETUP_MDIFF);  // setup_Mdiff, src/pprts.F90:2952-2954: here the packing / sharing of the coefficient set
   if (opts) *o = *opts;
   else tsx_default_ksp_opts(o);
   ARGCHK(o->maxit >= 1, "solve: maxit < 1");
@@ -1793,5 +1799,133 @@ extern "C" int tsx_probe_bandwidth(tsx_solver *s, size_t bytes, int reps, double
   return rc;
 }
 
+// ---- log events + roctx ranges (TsxLog, tsx_internal.hpp).  roctx comes from librocprofiler-sdk-roctx (ROCm 7; libroctx64 before
+// it), bound at run time on first use: libtsx links neither, and without the library the ranges are no-ops.
+static const char *const kLogNames[TSX_EV_COUNT] = {"set_optprop", "get_coeff_diff2diff", "get_coeff_dir2dir", "compute_Edir", "solve_Mdir",
+                                                   "setup_diff_src", "compute_Ediff", "setup_Mdiff", "solve_Mdiff", "compute_absorption",
+                                                   "get_result"};
+struct TsxRoctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  TsxRoctx() {
+    void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+static TsxRoctx &tsx_roctx() {
+  static TsxRoctx r;
+  return r;
+}
+static void tsx_log_retire(tsx_solver *s, bool wait) {
+  TsxLog *L = s->log;
+  size_t keep = 0;
+  for (size_t q = 0; q < L->pending.size(); ++q) {
+    TsxLogPending &p = L->pending[q];
+    bool ready = hipEventQuery(p.b) == hipSuccess;
+    if (!ready && wait) ready = hipEventSynchronize(p.b) == hipSuccess;
+    float ms = 0;
+    if (ready && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      L->ms[p.ev] += ms;
+      L->pool.push_back(p.a);
+      L->pool.push_back(p.b);
+    } else if (ready) {  // (an event pair that cannot be read: drop it)
+      (void)hipEventDestroy(p.a);
+      (void)hipEventDestroy(p.b);
+    } else {
+      L->pending[keep++] = p;
+    }
+  }
+  L->pending.resize(keep);
+  (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error of the caller
+}
+static hipEvent_t tsx_log_event(TsxLog *L) {
+  hipEvent_t e = nullptr;
+  if (!L->pool.empty()) {
+    e = L->pool.back();
+    L->pool.pop_back();
+  } else if (hipEventCreate(&e) != hipSuccess) {
+    e = nullptr;
+  }
+  return e;
+}
+void tsx_log_begin(tsx_solver *s, int ev, hipEvent_t *a) {
+  TsxRoctx &r = tsx_roctx();
+  if (r.push) r.push(kLogNames[ev]);
+  *a = tsx_log_event(s->log);
+  if (*a) (void)hipEventRecord(*a, s->stream);
+}
+void tsx_log_end(tsx_solver *s, int ev, hipEvent_t a) {
+  TsxLog *L = s->log;
+  TsxRoctx &r = tsx_roctx();
+  L->count[ev] += 1;
+  hipEvent_t b = a ? tsx_log_event(L) : nullptr;
+  if (b && hipEventRecord(b, s->stream) == hipSuccess) {
+    L->pending.push_back({ev, a, b});
+    if (L->pending.size() > 256) tsx_log_retire(s, false);
+  }
+  if (r.pop) r.pop();
+}
+static void tsx_log_free(tsx_solver *s) {
+  if (!s->log) return;
+  tsx_log_retire(s, true);
+  for (hipEvent_t e : s->log->pool) (void)hipEventDestroy(e);
+  delete s->log;
+  s->log = nullptr;
+}
+extern "C" int tsx_log_enable(tsx_solver *s, int on) {
+  ARGCHK(s, "tsx_log_enable: null");
+  HIPCHK(hipSetDevice(s->device));
+  if (on && !s->log) s->log = new TsxLog();
+  if (!on) tsx_log_free(s);
+  return TSX_OK;
+}
+extern "C" int tsx_log_get(tsx_solver *s, int32_t *nevents, const char **names, int64_t *counts, double *ms) {
+  ARGCHK(s && nevents, "tsx_log_get: null");
+  *nevents = TSX_EV_COUNT;
+  if (!s->log) {
+    tsx_set_error("tsx_log_get: log events are off (tsx_log_enable, or TSX_LOG=1 at tsx_create)");
+    return TSX_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamSynchronize(s->stream));
+  tsx_log_retire(s, true);
+  for (int q = 0; q < TSX_EV_COUNT; ++q) {
+    if (names) names[q] = kLogNames[q];
+    if (counts) counts[q] = s->log->count[q];
+    if (ms) ms[q] = s->log->ms[q];
+  }
+  return TSX_OK;
+}
+
+// ---- diagnostics: a translation unit's code as it sits in device memory (TSX_CODE_PROBE, tsx_host.hpp).  unit 0..7 = api, spmv310,
+// spmv816, pc, pcs, pcsflow, dedup, peer (the order of the code objects in libtsx.so is the link order, scripts/code_verify.py finds
+// them by the probe's symbol).  Copies nwords 32-bit words from (probe's pc + delta) to host_out and returns the pc in *pc_out; with
+// nwords = 0 only the pc.  The caller is responsible for the range lying inside the loaded code object.
+extern "C" int tsx_debug_code_read(int device, int unit, long long delta, long long nwords, void *host_out, unsigned long long *pc_out) {
+  ARGCHK(unit >= 0 && unit < 8 && nwords >= 0 && pc_out && (nwords == 0 || host_out), "tsx_debug_code_read: bad arguments");
+  if (device >= 0) HIPCHK(hipSetDevice(device));
+  typedef int (*probe_fn)(long long, long long, unsigned *, unsigned long long *, hipStream_t);
+  static const probe_fn probes[8] = {tsx_code_probe_api, tsx_code_probe_spmv310, tsx_code_probe_spmv816, tsx_code_probe_pc,
+                                     tsx_code_probe_pcs, tsx_code_probe_pcsflow, tsx_code_probe_dedup, tsx_code_probe_peer};
+  TsxDevTmp out, pc;
+  HIPCHK(out.alloc(sizeof(unsigned) * (size_t)(nwords > 0 ? nwords : 1)));
+  HIPCHK(pc.alloc(sizeof(unsigned long long)));
+  if (probes[unit](delta, nwords, out.as<unsigned>(), pc.as<unsigned long long>(), nullptr)) {
+    tsx_set_error("tsx_debug_code_read: launch failed");
+    return TSX_ERR_HIP;
+  }
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(pc_out, pc.p, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (nwords > 0) HIPCHK(hipMemcpy(host_out, out.p, sizeof(unsigned) * (size_t)nwords, hipMemcpyDeviceToHost));
+  return TSX_OK;
+}
+
 #include "tsx_pipeline_api.inc"
 #include "tsx_seam_api.inc"
+
+TSX_CODE_PROBE(api)  // tsx_host.hpp: this unit's code object as it sits in device memory (diagnostics)

@@ -13,6 +13,9 @@
 //      entries: their loads stay coalesced);  5. compact planes Cd[q * Nent + id].
 // Cells of 1-D layers (their planes are never read: a11 / a12 are) all map to one entry.
 // Used only when it pays (Nent <= Nc / 2); the dense planes stay (setup_b thermal, flux divergence, export read them).
+#include <stdio.h>
+#include <unistd.h>
+
 #include "tsx_host.hpp"
 #include "tsx_lut_dev.hpp"
 
@@ -235,6 +238,14 @@ __global__ __launch_bounds__(TSX_BLOCK) void tsx_k_dd_colsum(int D, long long ne
     }
 }
 
+// capacity for `nent` entries: a quarter more (sharing is only used while nent <= Nc / 2, so Nc / 2 is the ceiling)
+static inline int dd_grow(long long nent, long long Nc) {
+  long long cap = nent + nent / 4 + 16;
+  const long long top = Nc / 2 + 16;
+  if (cap > top) cap = top > nent ? top : nent;
+  return (int)cap;
+}
+
 struct TsxDdSlice {  // a piece of the solver's scratch allocation
   void *p;
   template <typename T> T *as() const { return static_cast<T *>(p); }
@@ -258,9 +269,9 @@ static int dd_scratch(tsx_solver *s, long long Nc, TsxDdScratch *w) {
   size_t tot = 0;
   for (size_t v : sz) tot += v;
   if (s->dd_scratch_bytes < tot) {
-    if (s->dd_scratch) HIPCHK(hipFree(s->dd_scratch));
+    if (s->dd_scratch) HIPCHK(tsx_dev_free(s->dd_scratch));
     s->dd_scratch = nullptr;
-    HIPCHK(hipMalloc(&s->dd_scratch, tot));
+    HIPCHK(tsx_dev_malloc(&s->dd_scratch, tot));
     s->dd_scratch_bytes = tot;
   }
   TsxDdSlice *d[8] = {&w->th, &w->tk, &w->to, &w->trep, &w->tflag, &w->tpos, &w->tsum, &w->ttot};
@@ -400,16 +411,17 @@ static int dd_build(tsx_solver *s, bool near, bool *pays) {
   int **cidx_split = near ? &s->pcn_cidx_split : &s->dd_cidx_split, **ent_cell = near ? &s->pcn_ent_cell : &s->dd_ent_cell;
   float **coef = near ? &s->pcn_coef : &s->dd_coef;
   int *cap = near ? &s->pc_cap : &s->dd_cap;
-  if (!near && !s->dd_cidx) HIPCHK(hipMalloc((void **)&s->dd_cidx, sizeof(int) * (size_t)Nc));
-  if (!*cidx_split) HIPCHK(hipMalloc((void **)cidx_split, sizeof(int) * (size_t)Nc));
+  if (!near && !s->dd_cidx) HIPCHK(tsx_dev_malloc((void **)&s->dd_cidx, sizeof(int) * (size_t)Nc));
+  if (!*cidx_split) HIPCHK(tsx_dev_malloc((void **)cidx_split, sizeof(int) * (size_t)Nc));
   if (*cap < nent) {
-    if (*coef) HIPCHK(hipFree(*coef));
-    if (*ent_cell) HIPCHK(hipFree(*ent_cell));
+    if (*coef) HIPCHK(tsx_dev_free(*coef));
+    if (*ent_cell) HIPCHK(tsx_dev_free(*ent_cell));
     *coef = nullptr;
     *ent_cell = nullptr;
-    HIPCHK(hipMalloc((void **)coef, sizeof(float) * (size_t)DD * nent * 2));  // plane-major, then entry-major
-    HIPCHK(hipMalloc((void **)ent_cell, sizeof(int) * (size_t)nent));
-    *cap = nent;
+    const int ncap = dd_grow(nent, Nc);
+    HIPCHK(tsx_dev_malloc((void **)coef, sizeof(float) * (size_t)DD * ncap * 2));  // plane-major, then entry-major
+    HIPCHK(tsx_dev_malloc((void **)ent_cell, sizeof(int) * (size_t)ncap));
+    *cap = ncap;
   }
   const bool split = g.xm % 2 == 0;
   hipLaunchKernelGGL(tsx_k_dd_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, trep.as<int>(), tpos.as<int>(),
@@ -427,10 +439,10 @@ static int dd_build(tsx_solver *s, bool near, bool *pays) {
   if (!near) {
     s->dd_coef_e = s->dd_coef + (size_t)DD * s->dd_cap;
     if (s->dd_colsum_cap < (long long)g.D * nent) {
-      if (s->dd_colsum) HIPCHK(hipFree(s->dd_colsum));
+      if (s->dd_colsum) HIPCHK(tsx_dev_free(s->dd_colsum));
       s->dd_colsum = nullptr;
-      HIPCHK(hipMalloc((void **)&s->dd_colsum, sizeof(double) * (size_t)g.D * nent));
-      s->dd_colsum_cap = (long long)g.D * nent;
+      HIPCHK(tsx_dev_malloc((void **)&s->dd_colsum, sizeof(double) * (size_t)g.D * dd_grow(nent, Nc)));
+      s->dd_colsum_cap = (long long)g.D * dd_grow(nent, Nc);
     }
     hipLaunchKernelGGL(tsx_k_dd_colsum, dim3(grid_for(nent)), dim3(TSX_BLOCK), 0, s->stream, g.D, (long long)nent, s->dd_coef, s->dd_colsum);
   }
@@ -438,6 +450,48 @@ static int dd_build(tsx_solver *s, bool near, bool *pays) {
   HIPCHK(hipStreamSynchronize(s->stream));
   *pays = true;
   return TSX_OK;
+}
+
+// TSX_DEBUG_CHECKS (tests only, tsx_pipeline_api.inc): directly behind tsx_k_dd_index the representatives are read back.  The rare wrong
+// result of rounds 4-5 had ent_cell = {0, 0, 0, 0} on rank 0 while both indices written by the SAME launch were right: this says whether
+// the stores never arrived (zero right here) or were wiped later, and a second launch of the same kernel into the same buffer says
+// whether the loss is transient or a property of the process (e.g. of its copy of the kernel's code).
+template <typename Relaunch>
+static void dd_debug_after_index(tsx_solver *s, const char *where, int nent, const int *ent_cell, const int *rep, const int *pos,
+                                 Relaunch relaunch) {
+  const char *pre = getenv("TSX_DEBUG_CHECKS");
+  if (!pre || !*pre || nent <= 0) return;
+  char fn[512];
+  snprintf(fn, sizeof(fn), "%s.%d", pre, (int)getpid());
+  FILE *fh = fopen(fn, "a");
+  if (!fh) return;
+  const int n = nent < 16 ? nent : 16;
+  int ec[16] = {0}, again[16] = {0};
+  bool lost = false;
+  if (hipStreamSynchronize(s->stream) == hipSuccess && hipMemcpy(ec, ent_cell, sizeof(int) * n, hipMemcpyDeviceToHost) == hipSuccess) {
+    lost = nent > 1;
+    for (int q = 1; q < n; ++q) lost = lost && ec[q] == 0;
+    fprintf(fh, "rank %d index_check %s nent %d ptr %p%s first", s->grid.rank, where, nent, (const void *)ent_cell, lost ? " LOST" : "");
+    for (int q = 0; q < n; ++q) fprintf(fh, " %d", ec[q]);
+    fprintf(fh, "\n");
+    if (lost) {
+      relaunch();
+      if (hipStreamSynchronize(s->stream) == hipSuccess && hipMemcpy(again, ent_cell, sizeof(int) * n, hipMemcpyDeviceToHost) == hipSuccess) {
+        fprintf(fh, "rank %d index_check %s RELAUNCHED first", s->grid.rank, where);
+        for (int q = 0; q < n; ++q) fprintf(fh, " %d", again[q]);
+        // what the kernel read: rep / pos of the first cells
+        int r8[8] = {0}, p8[8] = {0};
+        (void)hipMemcpy(r8, rep, sizeof(r8), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(p8, pos, sizeof(p8), hipMemcpyDeviceToHost);
+        fprintf(fh, " rep");
+        for (int q = 0; q < 8; ++q) fprintf(fh, " %d", r8[q]);
+        fprintf(fh, " pos");
+        for (int q = 0; q < 8; ++q) fprintf(fh, " %d", p8[q]);
+        fprintf(fh, "\n");
+      }
+    }
+  }
+  fclose(fh);
 }
 
 // ---- coordinates first (round 4).  On the LUT path a block is a deterministic function of its cell's four clamped float32
@@ -586,29 +640,36 @@ int tsx_dedup_from_coords(tsx_solver *s, const TsxLutDev &L, bool *built) {
   }
   if ((long long)nent * 2 > Nc) return TSX_OK;  // mostly distinct coordinates: dense planes, then the block-based build decides
   s->dd_nent = nent;
-  if (!s->dd_cidx) HIPCHK(hipMalloc((void **)&s->dd_cidx, sizeof(int) * (size_t)Nc));
-  if (!s->dd_cidx_split) HIPCHK(hipMalloc((void **)&s->dd_cidx_split, sizeof(int) * (size_t)Nc));
+  if (!s->dd_cidx) HIPCHK(tsx_dev_malloc((void **)&s->dd_cidx, sizeof(int) * (size_t)Nc));
+  if (!s->dd_cidx_split) HIPCHK(tsx_dev_malloc((void **)&s->dd_cidx_split, sizeof(int) * (size_t)Nc));
   if (s->dd_cap < nent) {
-    if (s->dd_coef) HIPCHK(hipFree(s->dd_coef));
-    if (s->dd_ent_cell) HIPCHK(hipFree(s->dd_ent_cell));
+    if (s->dd_coef) HIPCHK(tsx_dev_free(s->dd_coef));
+    if (s->dd_ent_cell) HIPCHK(tsx_dev_free(s->dd_ent_cell));
     s->dd_coef = nullptr;
     s->dd_ent_cell = nullptr;
-    HIPCHK(hipMalloc((void **)&s->dd_coef, sizeof(float) * (size_t)DD * nent * 2));  // plane-major, then entry-major
-    HIPCHK(hipMalloc((void **)&s->dd_ent_cell, sizeof(int) * (size_t)nent));
-    s->dd_cap = nent;
+    // grow-only, with slack: a spectral loop's entry count wanders from g-point to g-point, the storage should not
+    const int cap = dd_grow(nent, Nc);
+    HIPCHK(tsx_dev_malloc((void **)&s->dd_coef, sizeof(float) * (size_t)DD * cap * 2));  // plane-major, then entry-major
+    HIPCHK(tsx_dev_malloc((void **)&s->dd_ent_cell, sizeof(int) * (size_t)cap));
+    s->dd_cap = cap;
   }
   const bool split = g.xm % 2 == 0;
-  if (!reuse)
-    hipLaunchKernelGGL(tsx_k_dd_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, w.trep.as<int>(), w.tpos.as<int>(), s->dd_cidx,
-                       split ? s->dd_cidx_split : (int *)nullptr, s->dd_ent_cell);
+  if (!reuse) {
+    auto launch_index = [&]() {
+      hipLaunchKernelGGL(tsx_k_dd_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, g, w.trep.as<int>(), w.tpos.as<int>(), s->dd_cidx,
+                         split ? s->dd_cidx_split : (int *)nullptr, s->dd_ent_cell);
+    };
+    launch_index();
+    dd_debug_after_index(s, "coords", nent, s->dd_ent_cell, w.trep.as<int>(), w.tpos.as<int>(), launch_index);
+  }
   s->dd_coef_e = s->dd_coef + (size_t)DD * s->dd_cap;
   hipLaunchKernelGGL((tsx_k_lut_diff2diff_ent<100>), dim3(grid_for(nent, 8192)), dim3(TSX_BLOCK), 0, s->stream, g, L, s->l1d,
                      (long long)nent, (const int *)s->dd_ent_cell, samp, s->dd_coef, s->dd_coef_e);
   if (s->dd_colsum_cap < (long long)g.D * nent) {
-    if (s->dd_colsum) HIPCHK(hipFree(s->dd_colsum));
+    if (s->dd_colsum) HIPCHK(tsx_dev_free(s->dd_colsum));
     s->dd_colsum = nullptr;
-    HIPCHK(hipMalloc((void **)&s->dd_colsum, sizeof(double) * (size_t)g.D * nent));
-    s->dd_colsum_cap = (long long)g.D * nent;
+    HIPCHK(tsx_dev_malloc((void **)&s->dd_colsum, sizeof(double) * (size_t)g.D * dd_grow(nent, Nc)));
+    s->dd_colsum_cap = (long long)g.D * dd_grow(nent, Nc);
   }
   hipLaunchKernelGGL(tsx_k_dd_colsum, dim3(grid_for(nent)), dim3(TSX_BLOCK), 0, s->stream, g.D, (long long)nent, s->dd_coef, s->dd_colsum);
   HIPCHK(hipGetLastError());
@@ -761,15 +822,16 @@ int tsx_records_share(tsx_solver *s, int R, const uint4 *P) {
   HIPCHK(hipStreamSynchronize(s->stream));
   s->pcr_n = n;
   if ((long long)n * 2 > Nc) return TSX_OK;
-  if (!s->pcr_idx) HIPCHK(hipMalloc((void **)&s->pcr_idx, sizeof(int) * (size_t)Nc));
+  if (!s->pcr_idx) HIPCHK(tsx_dev_malloc((void **)&s->pcr_idx, sizeof(int) * (size_t)Nc));
   if (s->pcr_cap < (long long)n * R) {
-    if (s->pcr_tab) HIPCHK(hipFree(s->pcr_tab));
-    if (s->pcr_ent) HIPCHK(hipFree(s->pcr_ent));
+    if (s->pcr_tab) HIPCHK(tsx_dev_free(s->pcr_tab));
+    if (s->pcr_ent) HIPCHK(tsx_dev_free(s->pcr_ent));
     s->pcr_tab = nullptr;
     s->pcr_ent = nullptr;
-    HIPCHK(hipMalloc((void **)&s->pcr_tab, sizeof(uint4) * (size_t)n * R));
-    HIPCHK(hipMalloc((void **)&s->pcr_ent, sizeof(int) * (size_t)n));
-    s->pcr_cap = (long long)n * R;
+    const long long ncap = dd_grow(n, Nc);
+    HIPCHK(tsx_dev_malloc((void **)&s->pcr_tab, sizeof(uint4) * (size_t)ncap * R));
+    HIPCHK(tsx_dev_malloc((void **)&s->pcr_ent, sizeof(int) * (size_t)ncap));
+    s->pcr_cap = ncap * R;
   }
   hipLaunchKernelGGL(tsx_k_rec_index, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, w.trep.as<int>(), w.tpos.as<int>(), s->pcr_idx,
                      s->pcr_ent);
@@ -779,3 +841,5 @@ int tsx_records_share(tsx_solver *s, int R, const uint4 *P) {
   s->pcr_on = true;
   return TSX_OK;
 }
+
+TSX_CODE_PROBE(dedup)  // tsx_host.hpp: this unit's code object as it sits in device memory (diagnostics)

@@ -76,6 +76,16 @@ static inline int spmv_nblocks(const tsx_solver *s) {
   return spmv_split(s) ? nbmain + grid_for(frame_groups(s->geo, cpt), TSX_FRAME_BLOCKS) : nbmain;
 }
 
+// ---- device memory comes from the library's pool (tsx_pool.hip): driver allocations are taken once, quarantined until their
+// contents are proven stable, and sub-allocated from then on.  Same contracts as hipMalloc / hipFree (the free synchronises the device).
+hipError_t tsx_dev_malloc_bytes(void **out, size_t bytes);
+hipError_t tsx_dev_free(void *p);
+hipError_t tsx_dev_quarantine(void *p, size_t bytes);  // for driver allocations of another kind (the uncached peer mailbox), in place
+template <typename T>
+static inline hipError_t tsx_dev_malloc(T **p, size_t bytes) {
+  return tsx_dev_malloc_bytes((void **)p, bytes);
+}
+
 // scratch device buffer that is released on every exit path (the HIPCHK / ARGCHK macros return early)
 struct TsxDevTmp {
   void *p = nullptr;
@@ -83,11 +93,33 @@ struct TsxDevTmp {
   TsxDevTmp(const TsxDevTmp &) = delete;
   TsxDevTmp &operator=(const TsxDevTmp &) = delete;
   ~TsxDevTmp() {
-    if (p) (void)hipFree(p);
+    if (p) (void)tsx_dev_free(p);
   }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  hipError_t alloc(size_t bytes) { return tsx_dev_malloc(&p, bytes); }
   template <typename T> T *as() const { return static_cast<T *>(p); }
 };
+
+// ---- code probe (diagnostics): every translation unit is a code object of its own inside libtsx.so (no -fgpu-rdc); the probe
+// kernel of a unit reports its own program counter and copies `nwords` 32-bit words from pc + delta to `out`, so that a host tool
+// that knows the unit's ELF (scripts/code_verify.py: symbol table + the s_getpc_b64 inside the probe) can compare the code AS IT
+// SITS IN DEVICE MEMORY with the bytes in the file (tsx_debug_code_read, tsx_api.hip).  Round 6: the hunt for the rare wrong
+// result of the four-process pipeline test asked whether a process can run a damaged copy of a kernel.
+#define TSX_CODE_PROBE(TU)                                                                                                     \
+  extern "C" __global__ void tsx_k_code_probe_##TU(long long delta, long long nwords, unsigned *out, unsigned long long *pc_out) { \
+    unsigned long long pc;                                                                                                     \
+    asm volatile("s_getpc_b64 %0" : "=s"(pc));                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0) *pc_out = pc;                                                                     \
+    const unsigned *src = (const unsigned *)(pc + delta);                                                                      \
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (long long)gridDim.x * blockDim.x)   \
+      out[i] = __builtin_nontemporal_load(src + i);                                                                            \
+  }                                                                                                                            \
+  int tsx_code_probe_##TU(long long delta, long long nwords, unsigned *out, unsigned long long *pc_out, hipStream_t st) {        \
+    hipLaunchKernelGGL(tsx_k_code_probe_##TU, dim3(nwords > 0 ? 256 : 1), dim3(256), 0, st, delta, nwords, out, pc_out);      \
+    return hipGetLastError() == hipSuccess ? 0 : 1;                                                                            \
+  }
+#define TSX_CODE_PROBE_DECL(TU) int tsx_code_probe_##TU(long long, long long, unsigned *, unsigned long long *, hipStream_t);
+TSX_CODE_PROBE_DECL(api) TSX_CODE_PROBE_DECL(spmv310) TSX_CODE_PROBE_DECL(spmv816) TSX_CODE_PROBE_DECL(pc) TSX_CODE_PROBE_DECL(pcs)
+TSX_CODE_PROBE_DECL(pcsflow) TSX_CODE_PROBE_DECL(dedup) TSX_CODE_PROBE_DECL(peer)
 
 // ---- cross-unit entry points --------------------------------------------------------------------
 // face exchange on stream st (RCCL / host-staged callbacks / self copies), tsx_api.hip

@@ -72,6 +72,7 @@ struct TsxSolSlot {  // one stored solution (initial guess of the next solve wit
 };
 
 struct TsxPeer;  // tsx_peer.hip
+struct TsxLog;   // below: log events / roctx ranges
 
 // peer transport (tsx_peer_dev.hpp): what a kernel needs to consume a face message in place -- the sequence number that
 // announces it, per face W, E, S, N
@@ -264,6 +265,36 @@ struct tsx_solver {
   hipEvent_t ev_pack, ev_recv;
   int max_lds;               // hipDeviceAttributeMaxSharedMemoryPerBlock
   int overlap_env;           // TSX_OVERLAP: -1 unset, else 0 / 1 (tsx_overlap, tsx_host.hpp: interior + frame launches around an exchange)
+  TsxLog *log = nullptr;     // the reference's log events for this path + roctx ranges (tsx_log_enable; off: null)
+};
+
+// The reference brackets the phases of a solve with PETSc log events (solver%logs, src/pprts_base.F90:176-209; begun / ended at
+// src/pprts.F90:1785-2077 set_optprop, :2694-2756 compute_Edir, :2760-2818 compute_Ediff, :2952-2954 setup_Mdiff, :3012-3021
+// solve_Mdiff, :3422-3489 get_coeff_diff2diff, :5197-5479 compute_absorption) and reads them with -log_view.  The same names here:
+// a count and the DEVICE time between two events recorded on the solver's stream per phase (tsx_log_get), and a roctx range of
+// that name around the host code that enqueues it, so that a rocprofv3 --marker-trace of a spectral loop shows its g-points.
+enum TsxLogEvent {
+  TSX_EV_SET_OPTPROP = 0, TSX_EV_GET_COEFF_DIFF2DIFF, TSX_EV_GET_COEFF_DIR2DIR, TSX_EV_COMPUTE_EDIR, TSX_EV_SOLVE_MDIR,
+  TSX_EV_SETUP_DIFF_SRC, TSX_EV_COMPUTE_EDIFF, TSX_EV_SETUP_MDIFF, TSX_EV_SOLVE_MDIFF, TSX_EV_COMPUTE_ABSORPTION, TSX_EV_GET_RESULT,
+  TSX_EV_COUNT
+};
+struct TsxLogPending { int ev; hipEvent_t a, b; };
+struct TsxLog {
+  long long count[TSX_EV_COUNT] = {0};
+  double ms[TSX_EV_COUNT] = {0};
+  std::vector<TsxLogPending> pending;
+  std::vector<hipEvent_t> pool;
+};
+void tsx_log_begin(tsx_solver *s, int ev, hipEvent_t *a);
+void tsx_log_end(tsx_solver *s, int ev, hipEvent_t a);
+struct TsxLogScope {  // begin at construction, end on every exit path
+  tsx_solver *s;
+  int ev;
+  hipEvent_t a = nullptr;
+  TsxLogScope(tsx_solver *s_, int ev_) : s(s_), ev(ev_) { if (s->log) tsx_log_begin(s, ev, &a); }
+  ~TsxLogScope() { if (s->log) tsx_log_end(s, ev, a); }
+  TsxLogScope(const TsxLogScope &) = delete;
+  TsxLogScope &operator=(const TsxLogScope &) = delete;
 };
 
 void tsx_set_error(const std::string &msg);

@@ -207,12 +207,12 @@ template <int NTOP>
 static int ensure_pc_buffers_t(tsx_solver *s) {
   const TsxGeo &g = s->geo;
   const size_t nb = (size_t)g.N * sizeof(double);
-  if (!s->pc_tmp) HIPCHK(hipMalloc((void **)&s->pc_tmp, sizeof(double) * (size_t)tsx_pc_ntmp<NTOP>() * g.Nc));
-  if (s->vph == s->vp || !s->vph) HIPCHK(hipMalloc((void **)&s->vph, nb));  // fp64-sized: also holds the fp32 form
-  if (s->vsh == s->vs || !s->vsh) HIPCHK(hipMalloc((void **)&s->vsh, nb));
-  if (!s->vw) HIPCHK(hipMalloc((void **)&s->vw, nb));
-  if (!s->v32) HIPCHK(hipMalloc((void **)&s->v32, (size_t)g.N * sizeof(float)));  // fp32 right-hand sides of the mixed path
-  if (!s->p32) HIPCHK(hipMalloc((void **)&s->p32, (size_t)g.N * sizeof(float)));
+  if (!s->pc_tmp) HIPCHK(tsx_dev_malloc((void **)&s->pc_tmp, sizeof(double) * (size_t)tsx_pc_ntmp<NTOP>() * g.Nc));
+  if (s->vph == s->vp || !s->vph) HIPCHK(tsx_dev_malloc((void **)&s->vph, nb));  // fp64-sized: also holds the fp32 form
+  if (s->vsh == s->vs || !s->vsh) HIPCHK(tsx_dev_malloc((void **)&s->vsh, nb));
+  if (!s->vw) HIPCHK(tsx_dev_malloc((void **)&s->vw, nb));
+  if (!s->v32) HIPCHK(tsx_dev_malloc((void **)&s->v32, (size_t)g.N * sizeof(float)));  // fp32 right-hand sides of the mixed path
+  if (!s->p32) HIPCHK(tsx_dev_malloc((void **)&s->p32, (size_t)g.N * sizeof(float)));
   if (!s->pc_rhs) s->pc_rhs = s->v32;
   return TSX_OK;
 }
@@ -222,7 +222,7 @@ int tsx_pc_ensure_half(tsx_solver *s) {
   const bool h1 = s->geo.ntop == 2;
   // 3_10: 8 groups, + 1 for the second half of record 1 in fp16 (tsx_k_pcs_pack_rec1h)
   const long long n = (long long)(h1 ? TSX_P16_GROUPS + 1 : 34 /* max(TSX_P16H_GROUPS, 14 + 20 of the scan layout) */) * s->geo.Nc;
-  if (!s->coef_h) HIPCHK(hipMalloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
+  if (!s->coef_h) HIPCHK(tsx_dev_malloc((void **)&s->coef_h, sizeof(tsx_h8) * (size_t)n));
   const bool scan = s->pc_split && tsx_pcs_eligible(s);
   if (scan && (!s->coef_h_valid || !s->coef_h_scan || s->coef_h_dd != ((s->dd_on || s->dd_pc) && s->coef_bytes == 4))) {
     int rc = tsx_pcs_pack(s);
@@ -274,3 +274,5 @@ int tsx_pc_widen(tsx_solver *s, const float *a, double *o) {
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
+
+TSX_CODE_PROBE(pc)  // tsx_host.hpp: this unit's code object as it sits in device memory (diagnostics)

@@ -229,11 +229,11 @@ static int pcs_halo_buffers(tsx_solver *s) {
   for (int q = 0; q < 4; ++q) {
     const size_t bytes = (pcs_halo_doubles(s, q) * sizeof(double) + 15) & ~(size_t)15;  // tsx_k_pcs_halo_xchg copies 16-byte pieces
     if (!s->pch_send[q]) {
-      HIPCHK(hipMalloc((void **)&s->pch_send[q], bytes));
+      HIPCHK(tsx_dev_malloc((void **)&s->pch_send[q], bytes));
       HIPCHK(hipMemsetAsync(s->pch_send[q], 0, bytes, s->stream));
     }
     if (!s->pch_recv[q]) {
-      HIPCHK(hipMalloc((void **)&s->pch_recv[q], bytes));
+      HIPCHK(tsx_dev_malloc((void **)&s->pch_recv[q], bytes));
       HIPCHK(hipMemsetAsync(s->pch_recv[q], 0, bytes, s->stream));
     }
   }
@@ -551,3 +551,5 @@ int tsx_pcs_apply(tsx_solver *s, float *z, const int *done) {
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }
+
+TSX_CODE_PROBE(pcs)  // tsx_host.hpp: this unit's code object as it sits in device memory (diagnostics)

@@ -74,23 +74,23 @@ bool tsx_pcs_flow_ok(tsx_solver *s, int lseg, int nseg, int cw, bool faces) {
 static int flow_ensure(tsx_solver *s, int ntiles, bool fat, int npass) {
   const TsxGeo &g = s->geo;
   if (!s->flow_state) {
-    HIPCHK(hipMalloc(&s->flow_state, sizeof(TsxFlowState)));
+    HIPCHK(tsx_dev_malloc(&s->flow_state, sizeof(TsxFlowState)));
     HIPCHK(hipMemsetAsync(s->flow_state, 0, sizeof(TsxFlowState), s->stream));
     s->flow_epoch_bound = 0;
   }
   if (s->flow_prog_cap < 2 * ntiles) {
     if (s->flow_prog) {
       HIPCHK(hipStreamSynchronize(s->stream));
-      HIPCHK(hipFree(s->flow_prog));
+      HIPCHK(tsx_dev_free(s->flow_prog));
       s->flow_prog = nullptr;
     }
-    HIPCHK(hipMalloc((void **)&s->flow_prog, sizeof(unsigned) * 2 * (size_t)ntiles));
+    HIPCHK(tsx_dev_malloc((void **)&s->flow_prog, sizeof(unsigned) * 2 * (size_t)ntiles));
     HIPCHK(hipMemsetAsync(s->flow_prog, 0, sizeof(unsigned) * 2 * (size_t)ntiles, s->stream));  // zero is behind every epoch
     s->flow_prog_cap = 2 * ntiles;
   }
   const size_t zb8_bytes = sizeof(uint2) * 4 * (size_t)g.Nc;
   if (fat && !s->flow_zb8) {
-    HIPCHK(hipMalloc(&s->flow_zb8, zb8_bytes));
+    HIPCHK(tsx_dev_malloc(&s->flow_zb8, zb8_bytes));
     HIPCHK(hipMemsetAsync(s->flow_zb8, 0, zb8_bytes, s->stream));
   }
   // (TSX_FLOW_EPOCH_LIMIT: tests lower the bound so that the restart is exercised)
@@ -153,7 +153,7 @@ static int flow_launch(tsx_solver *s, int p0, int p1, const int *done, bool face
     memset(pr.S0, 0, sizeof(pr.S0));
     // the part that does not change between launches lives in device memory (re-sent only when the transport changed)
     if (!s->flow_pr_dev) {
-      HIPCHK(hipMalloc(&s->flow_pr_dev, sizeof(TsxFlowPeer)));
+      HIPCHK(tsx_dev_malloc(&s->flow_pr_dev, sizeof(TsxFlowPeer)));
       s->flow_pr_shadow = new TsxFlowPeer();
       memset((void *)s->flow_pr_shadow, 0xff, sizeof(TsxFlowPeer));
     }
@@ -232,3 +232,5 @@ extern "C" int tsx_debug_flow_trace(unsigned long long *out, int n) {
   return TSX_OK;
 }
 #endif
+
+TSX_CODE_PROBE(pcsflow)  // tsx_host.hpp: this unit's code object as it sits in device memory (diagnostics)

@@ -231,8 +231,8 @@ extern "C" int tsx_comm_peer_export(tsx_solver *s, void *blob) {
       return TSX_ERR_HIP;
     }
     p->mine = (char *)m;
-    HIPCHK(hipMemset(p->mine, 0, p->bytes));
-    HIPCHK(hipMalloc((void **)&p->blkctr, sizeof(unsigned int) * 32));
+    HIPCHK(tsx_dev_quarantine(p->mine, p->bytes));  // zeroed, and proven to keep its contents (tsx_pool.hip: fresh driver memory may not)
+    HIPCHK(tsx_dev_malloc((void **)&p->blkctr, sizeof(unsigned int) * 32));
     HIPCHK(hipMemset(p->blkctr, 0, sizeof(unsigned int) * 32));
     const char *to = getenv("TSX_PEER_TIMEOUT_S");
     const double sec = to ? atof(to) : 20.0;
@@ -320,8 +320,8 @@ void tsx_peer_destroy(tsx_solver *s) {
   if (!p) return;
   for (int r = 0; r < kMaxRanks; ++r)
     if (p->opened[r] && p->box[r]) (void)hipIpcCloseMemHandle(p->box[r]);
-  if (p->mine) (void)hipFree(p->mine);
-  if (p->blkctr) (void)hipFree(p->blkctr);
+  if (p->mine) (void)tsx_dev_free(p->mine);
+  if (p->blkctr) (void)tsx_dev_free(p->blkctr);
   delete p;
   s->peer = nullptr;
 }
@@ -580,11 +580,15 @@ extern "C" int tsx_comm_peer_reset(tsx_solver *s) {
   TsxPeer *p = s->peer;
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemset(p->mine, 0, p->data_off));
-  HIPCHK(hipMemset(p->blkctr, 0, sizeof(unsigned int) * 16));
+  // the whole mailbox: header, payload slots AND the flow kernel's tag area behind them (round 5 added it at tag_off; tags that kept the
+  // previous run's large message numbers would satisfy `(int)(v - n) >= 0` at once after the counters restart -- ADVICE r5), and all
+  // 32 workgroup counters (16..23 are the flow kernel's faces)
+  HIPCHK(hipMemset(p->mine, 0, p->bytes));
+  HIPCHK(hipMemset(p->blkctr, 0, sizeof(unsigned int) * 32));
   HIPCHK(hipDeviceSynchronize());
   for (int q = 0; q < 4; ++q) p->sent[q] = p->rcvd[q] = 0;
   p->ar_n = 0;
+  if (s->flow_pr_shadow) memset((void *)s->flow_pr_shadow, 0xff, sizeof(TsxFlowPeer));  // the flow kernel's view is sent again
   s->pch_inplace = false;
   s->pcg_key = -1;
   return TSX_OK;
@@ -600,3 +604,5 @@ extern "C" int tsx_comm_peer_disable(tsx_solver *s) {
   s->pch_inplace = false;
   return TSX_OK;
 }
+
+TSX_CODE_PROBE(peer)  // tsx_host.hpp: this unit's code object as it sits in device memory (diagnostics)

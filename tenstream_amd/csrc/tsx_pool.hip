@@ -1,0 +1,272 @@
+// tsx_pool.hip -- libtsx's device memory: a per-device pool of driver allocations ("slabs") that are taken from the driver ONCE,
+// held in quarantine until their contents are proven stable, and then sub-allocated for the lifetime of the process.
+//
+// Why (round 6; DESIGN.md section 10, profiles/r06/README.md).  The rare wrong result of rounds 4-5 -- 1-2 % of the fresh four-process
+// runs of the sharded pipeline test -- was data LOST FROM FRESHLY ALLOCATED DEVICE MEMORY: kernels of tsx_dedup_from_coords wrote
+// into blocks that hipMalloc had returned microseconds earlier (the build's scratch, the representatives `dd_ent_cell`), a later
+// kernel on the same stream -- or a hipMemcpy -- read zeros.  scripts/fresh_loop.py caught it with the inputs of the reading kernel
+// read back (`rep`, `pos` of the 11 KB scratch all zero 0.3 ms after a read-back of its last word had been right), every byte of the
+// library's device code verified against the file (scripts/code_verify.py: intact), and a second launch of the same kernel giving the
+// same result: memory that a process has just been given can be cleared by the platform AFTER the process has started to use it --
+// seen only while other processes on the device start and exit (their released memory is wiped; new allocations are cleared).
+// Nothing a kernel does can defend against that; what the library can do is never to compute in memory that is younger than the
+// window in which this happens:
+//   * a slab comes from hipMalloc, is filled with a pattern, and is verified (a kernel that counts words that are not the pattern)
+//     again and again until it has stayed intact for TSX_POOL_GUARD_US (default 3000) microseconds; a verify that finds the pattern
+//     damaged is counted (tsx_pool_stats) and restarts the clock; then the slab is zeroed;
+//   * everything the solvers allocate (tsx_dev_malloc / tsx_dev_free, used throughout the library instead of hipMalloc / hipFree)
+//     is a first-fit piece of a slab; freed pieces go back to the pool (coalesced), never to the driver: after the first coefficient
+//     set no driver allocation lies on a solver's path at all (the reference allocates its coefficient arrays once per solver
+//     too, alloc_coeff_diff2diff, src/pprts.F90:3396-3490) -- which also takes hipMalloc / hipFree off config 4's per-g-point path.
+// tsx_dev_free keeps hipFree's contract: it synchronises the device first (callers free scratch that queued kernels still read).
+#include <stdio.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "tsx_host.hpp"
+
+namespace {
+constexpr unsigned kPattern = 0xA5C3F00Du;
+constexpr size_t kAlign = 256;
+
+__global__ __launch_bounds__(256) void tsx_k_pool_fill(unsigned *p, size_t nwords, unsigned v) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+// how many words differ from v, and the offset of the lowest one
+__global__ __launch_bounds__(256) void tsx_k_pool_verify(const unsigned *p, size_t nwords, unsigned v, unsigned long long *out) {
+  unsigned long long bad = 0, first = ~0ull;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256)
+    if (__builtin_nontemporal_load(p + i) != v) {
+      bad++;
+      if (i < first) first = i;
+    }
+  if (bad) {
+    atomicAdd(&out[0], bad);
+    atomicMin(&out[1], first);
+  }
+}
+
+struct Piece {
+  size_t bytes;
+  int slab;
+  bool free;
+};
+struct Pool {
+  std::mutex mu;
+  std::map<char *, Piece> pieces;  // every byte of every slab belongs to exactly one piece, ordered by address
+  std::vector<std::pair<char *, size_t>> slabs;
+  unsigned long long *flag = nullptr;  // [2] device words of the verify kernel
+  long long wipes = 0, wiped_words = 0, first_wipe_us = -1, driver_allocs = 0, guard_us_spent = 0;
+  size_t bytes = 0, live = 0;
+};
+std::mutex g_mu;
+std::map<int, Pool *> g_pools;
+
+Pool *pool_of(int dev) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_pools.find(dev);
+  if (it != g_pools.end()) return it->second;
+  Pool *p = new Pool();
+  g_pools[dev] = p;
+  return p;
+}
+long long env_ll(const char *name, long long dflt) {
+  const char *e = getenv(name);
+  return e && *e ? atoll(e) : dflt;
+}
+int grid_of(size_t nwords) {
+  size_t b = (nwords + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// one driver allocation, proven stable.  Runs on the null stream with device-wide synchronisation: this is not a hot path.
+hipError_t new_slab(Pool *P, size_t bytes, char **out) {
+  char *base = nullptr;
+  hipError_t e = hipMalloc((void **)&base, bytes);
+  if (e != hipSuccess) return e;
+  P->driver_allocs++;
+  if (!P->flag) {
+    // the verify kernel's two result words: pinned host memory (nothing the platform clears behind our back)
+    if ((e = hipHostMalloc((void **)&P->flag, 2 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return e;
+  }
+  const long long guard_us = env_ll("TSX_POOL_GUARD_US", 3000);
+  const size_t nwords = bytes / 4;
+  const auto t_alloc = std::chrono::steady_clock::now();
+  auto us_since = [&](std::chrono::steady_clock::time_point t) {
+    return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count();
+  };
+  if (guard_us > 0) {
+    hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (unsigned *)base, nwords, kPattern);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+    auto t_clean = std::chrono::steady_clock::now();  // since when the pattern is known to be whole
+    for (int round = 0; round < 100000; ++round) {
+      std::this_thread::sleep_for(std::chrono::microseconds(guard_us / 8 > 50 ? guard_us / 8 : 50));
+      P->flag[0] = 0;
+      P->flag[1] = ~0ull;
+      hipLaunchKernelGGL(tsx_k_pool_verify, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (const unsigned *)base, nwords, kPattern, P->flag);
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+      if (P->flag[0]) {  // the platform wrote into memory it had already handed out: count it, write the pattern again, start over
+        P->wipes++;
+        P->wiped_words += (long long)P->flag[0];
+        if (P->first_wipe_us < 0) P->first_wipe_us = us_since(t_alloc);
+        if (getenv("TSX_POOL_VERBOSE"))
+          fprintf(stderr, "[tsx_pool] pid %d: %llu words of a fresh %zu-byte allocation lost their contents %lld us after hipMalloc (first at word %llu)\n",
+                  (int)getpid(), P->flag[0], bytes, us_since(t_alloc), P->flag[1]);
+        hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (unsigned *)base, nwords, kPattern);
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+        t_clean = std::chrono::steady_clock::now();
+        continue;
+      }
+      if (us_since(t_clean) >= guard_us) break;
+    }
+  }
+  if ((e = hipMemset(base, 0, bytes)) != hipSuccess) return e;
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+  P->guard_us_spent += us_since(t_alloc);
+  P->slabs.emplace_back(base, bytes);
+  P->bytes += bytes;
+  P->pieces[base] = Piece{bytes, (int)P->slabs.size() - 1, true};
+  *out = base;
+  return hipSuccess;
+}
+}  // namespace
+
+hipError_t tsx_dev_malloc_bytes(void **out, size_t bytes) {
+  *out = nullptr;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (getenv("TSX_POOL") && atoi(getenv("TSX_POOL")) == 0) return hipMalloc(out, bytes);  // A/B: straight to the driver
+  Pool *P = pool_of(dev);
+  std::lock_guard<std::mutex> lk(P->mu);
+  const size_t need = ((bytes ? bytes : 1) + kAlign - 1) & ~(kAlign - 1);
+  auto take = [&](std::map<char *, Piece>::iterator it) {
+    Piece pc = it->second;
+    char *p = it->first;
+    if (pc.bytes > need) P->pieces[p + need] = Piece{pc.bytes - need, pc.slab, true};
+    it->second = Piece{need, pc.slab, false};
+    P->live += need;
+    *out = p;
+  };
+  // best fit: the smallest free piece that holds the request (a solver's big vectors and its 16-byte tables share the slabs)
+  auto best = P->pieces.end();
+  for (auto it = P->pieces.begin(); it != P->pieces.end(); ++it)
+    if (it->second.free && it->second.bytes >= need && (best == P->pieces.end() || it->second.bytes < best->second.bytes)) best = it;
+  if (best != P->pieces.end()) {
+    take(best);
+    return hipSuccess;
+  }
+  // a new slab: small requests share slabs of TSX_POOL_SLAB_MB (default 64), a large one gets a slab of its own size
+  const size_t slab_min = (size_t)env_ll("TSX_POOL_SLAB_MB", 64) << 20;
+  const size_t sz = need > slab_min ? need : slab_min;
+  char *base = nullptr;
+  e = new_slab(P, sz, &base);
+  if (e != hipSuccess && sz > need) e = new_slab(P, need, &base);  // (a nearly full device: exactly what was asked for)
+  if (e != hipSuccess) return e;
+  take(P->pieces.find(base));
+  return hipSuccess;
+}
+
+hipError_t tsx_dev_free(void *p) {
+  if (!p) return hipSuccess;
+  // hipFree's contract: everything queued on the device has finished before the memory can be handed out again
+  hipError_t e = hipDeviceSynchronize();
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+  Pool *P = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    // the piece may belong to another device's pool than the current device: look it up everywhere
+    for (auto &kv : g_pools) {
+      std::lock_guard<std::mutex> lk2(kv.second->mu);
+      if (kv.second->pieces.count((char *)p)) {
+        P = kv.second;
+        break;
+      }
+    }
+  }
+  if (!P) return hipFree(p);  // not ours (TSX_POOL=0 allocations)
+  std::lock_guard<std::mutex> lk(P->mu);
+  auto it = P->pieces.find((char *)p);
+  if (it == P->pieces.end() || it->second.free) return hipErrorInvalidValue;
+  it->second.free = true;
+  P->live -= it->second.bytes;
+  auto nx = std::next(it);
+  if (nx != P->pieces.end() && nx->second.free && nx->second.slab == it->second.slab && nx->first == it->first + it->second.bytes) {
+    it->second.bytes += nx->second.bytes;
+    P->pieces.erase(nx);
+  }
+  if (it != P->pieces.begin()) {
+    auto pv = std::prev(it);
+    if (pv->second.free && pv->second.slab == it->second.slab && pv->first + pv->second.bytes == it->first) {
+      pv->second.bytes += it->second.bytes;
+      P->pieces.erase(it);
+    }
+  }
+  return e;
+}
+
+// A driver allocation that cannot come from the pool (the peer mailbox: uncached / fine-grained memory): the same quarantine in
+// place.  `p` holds `bytes` bytes fresh from the driver; on return it is zeroed and has stayed intact for the guard time.
+hipError_t tsx_dev_quarantine(void *p, size_t bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  Pool *P = pool_of(dev);
+  std::lock_guard<std::mutex> lk(P->mu);
+  const long long guard_us = env_ll("TSX_POOL_GUARD_US", 3000);
+  if (!P->flag && (e = hipHostMalloc((void **)&P->flag, 2 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return e;
+  const size_t nwords = bytes / 4;
+  if (guard_us > 0 && !(getenv("TSX_POOL") && atoi(getenv("TSX_POOL")) == 0)) {
+    const auto t0 = std::chrono::steady_clock::now();
+    auto us = [&](std::chrono::steady_clock::time_point t) {
+      return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count();
+    };
+    hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (unsigned *)p, nwords, kPattern);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+    auto t_clean = std::chrono::steady_clock::now();
+    for (int round = 0; round < 100000; ++round) {
+      std::this_thread::sleep_for(std::chrono::microseconds(guard_us / 8 > 50 ? guard_us / 8 : 50));
+      P->flag[0] = 0;
+      P->flag[1] = ~0ull;
+      hipLaunchKernelGGL(tsx_k_pool_verify, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (const unsigned *)p, nwords, kPattern, P->flag);
+      if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+      if (P->flag[0]) {
+        P->wipes++;
+        P->wiped_words += (long long)P->flag[0];
+        if (P->first_wipe_us < 0) P->first_wipe_us = us(t0);
+        hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (unsigned *)p, nwords, kPattern);
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+        t_clean = std::chrono::steady_clock::now();
+        continue;
+      }
+      if (us(t_clean) >= guard_us) break;
+    }
+    P->guard_us_spent += us(t0);
+  }
+  if ((e = hipMemset(p, 0, bytes)) != hipSuccess) return e;
+  return hipDeviceSynchronize();
+}
+
+// out8 = {slabs taken from the driver, their bytes, bytes handed out now, pieces, verifies that found a fresh slab damaged, words
+// damaged, microseconds after hipMalloc of the first damaged verify (-1: none), microseconds spent in quarantine} for `device`
+extern "C" int tsx_pool_stats(int device, int64_t *out8) {
+  ARGCHK(out8, "tsx_pool_stats: null");
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return TSX_ERR_NO_DEVICE;
+  Pool *P = pool_of(device);
+  std::lock_guard<std::mutex> lk(P->mu);
+  out8[0] = (int64_t)P->slabs.size();
+  out8[1] = (int64_t)P->bytes;
+  out8[2] = (int64_t)P->live;
+  out8[3] = (int64_t)P->pieces.size();
+  out8[4] = P->wipes;
+  out8[5] = P->wiped_words;
+  out8[6] = P->first_wipe_us;
+  out8[7] = P->guard_us_spent;
+  return TSX_OK;
+}

@@ -435,6 +435,19 @@ class DiffuseSolver:
         return {"in_use": bool(o[0]), "first_pass": int(o[1]), "end_pass": int(o[2]), "columns_per_tile": int(o[3]),
                 "fat": bool(o[4]), "granules": bool(o[5]), "tiles_per_pass": int(o[6]), "workgroups": int(o[7])}
 
+    def log_enable(self, on=True):
+        """the reference's log events for this path (+ roctx ranges): tsx_log_enable"""
+        _lib.check(self.lib.tsx_log_enable(self.h, int(bool(on))))
+
+    def log_get(self):
+        """{event name: (count, device milliseconds)} (tsx_log_get; synchronises the stream)"""
+        n = C.c_int32(0)
+        names = (C.c_char_p * 16)()
+        counts = (C.c_int64 * 16)()
+        ms = (C.c_double * 16)()
+        _lib.check(self.lib.tsx_log_get(self.h, C.byref(n), names, counts, ms))
+        return {names[q].decode(): (int(counts[q]), float(ms[q])) for q in range(n.value)}
+
     def bench_kernel(self, kernel: int, reps: int) -> float:
         ms = C.c_float()
         _lib.check(self.lib.tsx_bench_kernel(self.h, kernel, reps, C.byref(ms)))
