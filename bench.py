@@ -343,9 +343,12 @@ def main():
         pass_ms = s.bench_kernel(3, 4 * args.kernel_reps)
         flow = s.flow_info()   # of the application just timed: do the intermediate passes run as one launch (tsx_k_pcs_flow)?
         if flow["in_use"]:
-            flow_ms = s.bench_kernel(4, args.kernel_reps)
-            flow = s.flow_info()   # (as the Krylov loop issues it: from pass 1)
-            bytes_flow = s.algorithmic_bytes(4)
+            try:
+                flow_ms = s.bench_kernel(4, args.kernel_reps)
+                flow = s.flow_info()   # (as the Krylov loop issues it: from pass 1)
+                bytes_flow = s.algorithmic_bytes(4)
+            except Exception:   # several ranks: the launch holds the rank faces and cannot be timed alone (tsx_bench_kernel says so)
+                flow_ms = bytes_flow = None
     bw = s.probe_bandwidth(1 << 30, 5)   # what plain streaming kernels reach on this box: copy and read-only, best variant each
     copy_gbps = bw["copy_GBps"]
     # the byte counts follow the storage format in use: take them while the solver is in the state that was timed

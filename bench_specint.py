@@ -206,6 +206,7 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
         dsolve, its_s = 0.0, []
         P0, tmp0, acc0 = Ps[0], tmps[0], accs[0]
         kw = dict(pc_sweeps=args.pc_sweeps) if args.pc_sweeps > 0 else {}
+        P0.core.log_enable(True)   # the reference's log events (solver%logs): device time per phase, roctx ranges for a trace
         for q in sample:
             f = float(factors[q])
             lsolar = q < args.sw
@@ -230,7 +231,11 @@ def run_loop(args, dev, rank=0, world=1, all_reduce=None):
             dsolve += info.solve_ms * 1e-3
             its_s.append(info.niter)
         tot = sum(ph.values())
+        events = P0.core.log_get()
+        P0.core.log_enable(False)
         breakdown = {"sample_gpoints": len(sample), "ms_per_gpoint": tot / len(sample) * 1e3,
+                     "log_events_device_ms_per_gpoint": {k: round(v[1] / len(sample), 4) for k, v in events.items()},
+                     "log_events_counts": {k: v[0] for k, v in events.items()},
                      "phases_ms_per_gpoint": {k: v / len(sample) * 1e3 for k, v in ph.items()},
                      "diffuse_solve_ms_per_gpoint_device": dsolve / len(sample) * 1e3,
                      "fractions": dict({k: v / tot for k, v in ph.items()}, diffuse_solve_of_total=dsolve / tot),

@@ -37,6 +37,15 @@ def worker(rank, it, outdir):
     Tdir, Sdir = lut.synthetic_direct_tables(dax)
     co = coord.coord(rank, world, Nx, Ny)
     sl = (slice(co.ys, co.ys + co.ym), slice(co.xs, co.xs + co.xm))
+
+    def barrier(tag):
+        open(os.path.join(outdir, f"{tag}.{it}.{rank}"), "w").close()
+        t0 = time.time()
+        while len(glob.glob(os.path.join(outdir, f"{tag}.{it}.*"))) < world and time.time() - t0 < 60:
+            time.sleep(0.0005)
+
+    if os.environ.get("FRESH_EARLY_BARRIER", "1") != "0":
+        barrier("early")   # the four processes take their first device memory (tsx_create: the pool's first slabs) at the same time
     P = PprtsSolver(Nz, co.xm, co.ym, 100.0, 100.0, phi0, theta0, device=0, xs=co.xs, ys=co.ys, glob_xm=Nx, glob_ym=Ny, rank=rank,
                     nranks=world, neighbors=(co.west, co.east, co.south, co.north))
     P.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
@@ -50,10 +59,7 @@ def worker(rank, it, outdir):
 
     P.core.comm_set_callbacks(exchange, allreduce)
     # file barrier: the four processes enter set_optical_properties together (as they do behind gloo's rendezvous in the test)
-    open(os.path.join(outdir, f"ready.{it}.{rank}"), "w").close()
-    t0 = time.time()
-    while len(glob.glob(os.path.join(outdir, f"ready.{it}.*"))) < world and time.time() - t0 < 60:
-        time.sleep(0.0005)
+    barrier("ready")
     loc = lambda a: np.ascontiguousarray(a[sl])
     P.set_optical_properties(0.15, loc(kabs), loc(ksca), loc(g), loc(dz), planck=None)
     import code_verify
@@ -102,7 +108,7 @@ def main():
             if "LOST" in txt or "a31e272015f12c43" in txt:
                 hit = True
                 lost.append((it, [l for l in txt.splitlines() if "index_check" in l or "detail" in l][:12]))
-        for fn in glob.glob(os.path.join(outdir, f"ready.{it}.*")) + ([] if hit else glob.glob(os.path.join(outdir, f"chk.{it}.*"))):
+        for fn in glob.glob(os.path.join(outdir, f"ready.{it}.*")) + glob.glob(os.path.join(outdir, f"early.{it}.*")) + ([] if hit else glob.glob(os.path.join(outdir, f"chk.{it}.*"))):
             os.remove(fn)
     summary = {"iterations": N, "seconds": round(time.time() - t0, 1), "lost": lost, "code_bad": codebad, "crashed": crashed,
                "pool_quarantine_caught_a_wipe": wiped, "processes": nproc, "mean_quarantine_us_per_process": guard_us / max(nproc, 1),

@@ -4,11 +4,12 @@ import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from tenstream_amd import DiffuseSolver, synthetic as S, lut as LUT
+SOLVER = os.environ.get("SOLVER", "3_10")
 Nx = Ny = int(os.environ.get("NX", 256)); Nz = int(os.environ.get("NZ", 64))
 dev = torch.device("cuda", 0)
 kabs, ksca, g = S.cloud_field(Nx, Ny, Nz, heterogeneous=os.environ.get("FIELD", "clouds") == "heterogeneous"); kabs, ksca, g = S.delta_scale(kabs, ksca, g)
 alb = np.full((Ny, Nx), 0.1)
-b = torch.tensor(S.solar_source("3_10", kabs, ksca, g, 50.0, 100.0, alb), device=dev)
+b = torch.tensor(S.solar_source(SOLVER, kabs, ksca, g, 50.0, 100.0, alb), device=dev)
 t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
 cfgs = [c for c in os.environ.get("CFGS", "old;4,16,64;8,8,64;4,16,32;8,8,32;4,16,16").split(";") if c]
 for cfg in cfgs:
@@ -20,8 +21,8 @@ for cfg in cfgs:
         os.environ["TSX_PC_SCAN"] = "0"; os.environ.pop("TSX_PCS_CFG", None)
     else:
         os.environ["TSX_PC_SCAN"] = "1"; os.environ["TSX_PCS_CFG"] = cfg
-    s = DiffuseSolver("3_10", Nz, Nx, Ny)
-    s.set_lut_diffuse(LUT.synthetic_diffuse_table("3_10"), LUT.diffuse_axes("3_10"))
+    s = DiffuseSolver(SOLVER, Nz, Nx, Ny)
+    s.set_lut_diffuse(LUT.synthetic_diffuse_table(SOLVER), LUT.diffuse_axes(SOLVER))
     s.set_optprop(t(kabs), t(ksca), t(g), torch.full((Ny, Nx, Nz), 50.0, dtype=torch.float64, device=dev), 100.0,
                   torch.zeros(Nz, dtype=torch.uint8, device=dev), t(np.zeros_like(kabs)), t(np.zeros_like(kabs)), t(alb))
     x = torch.zeros_like(b)

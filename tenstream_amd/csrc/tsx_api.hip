@@ -293,7 +293,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
-                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->bsrfc, s->edir_a, s->edir_b, s->dsc, s->abso, s->cell_samp, s->dd_colsum, s->flow_state, s->flow_prog, s->flow_zb8, s->flow_pr_dev};
+                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->bsrfc, s->edir_a, s->edir_b, s->dsc, s->abso, s->cell_samp, s->dd_colsum, s->pcx_rec, s->flow_state, s->flow_prog, s->flow_zb8, s->flow_pr_dev};
   for (void *p : ptrs)
     if (p) (void)tsx_dev_free(p);
   if (s->vph && s->vph != s->vp) (void)tsx_dev_free(s->vph);
@@ -604,6 +604,7 @@ extern "C" int tsx_diff_set_coeffs(tsx_solver *s, const void *diff2diff, int coe
   HIPCHK(hipStreamSynchronize(s->stream));
   s->have_coeffs = true;
   s->coef_h_valid = false;
+  s->pcx_valid = false;
   s->dd_valid = false;
   s->dd_on = false;
   s->dd_pc = false;
@@ -802,6 +803,7 @@ extern "C" int tsx_diff_set_optprop(tsx_solver *s, const double *kabs, const dou
   HIPCHK(hipStreamSynchronize(s->stream));
   s->have_coeffs = true;
   s->coef_h_valid = false;
+  s->pcx_valid = false;
   return TSX_OK;
 }
 
@@ -1268,8 +1270,8 @@ static int krylov_run_with_retry(tsx_solver *s, tsx_ksp_opts *o) {
   tsx_ksp_opts o2 = *o;
   o2.fp32_directions = 0;
   o2.pc_coeff_fp16 = 0;
-  o2.pc = TSX_PC_ZEBRA;
-  o2.pc_sweeps = 5;
+  o2.pc = TSX_PC_REDBLACK;  // on the exact blocks (tsx_pcx.hip); zebra rows where that is not available (prepare_ksp)
+  o2.pc_sweeps = 0;         // ... with that path's own pass count
   tsx_ksp_opts o3;
   if ((rc = prepare_ksp(s, &o2, &o3))) return rc;
   HIPCHK(hipMemsetAsync(s->vx, 0, sizeof(double) * (size_t)s->geo.N, s->stream));
@@ -1384,10 +1386,11 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
   // number of rows where the rank wraps onto itself in y (a periodic seam between equal colours) -- else zebra rows
   if (s->pc == TSX_PC_REDBLACK) {
     const TsxGeo &g = s->geo;
-    const bool ok = s->mixed && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0);
+    // ... and, round 6, on the exact blocks with fp64 iterates (tsx_pcx.hip: what fp32_directions = 0 / pc_coeff_fp16 = 0 get)
+    const bool ok = (s->mixed && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0)) || (!s->mixed && tsx_pcx_eligible(s));
     if (!ok) s->pc = TSX_PC_ZEBRA;
   }
-  s->pc_split = s->pc == TSX_PC_REDBLACK;
+  s->pc_split = s->pc == TSX_PC_REDBLACK && s->mixed;  // the colour-split layout belongs to the packed fp32 path
   s->pc_half = false;
   {
     int rc = tsx_dedup_ensure(s);  // shared storage of identical blocks (operator apply and scan preconditioner)
@@ -1395,7 +1398,8 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
     // dense per-cell planes: the operator and the scan passes on the packed path read the shared storage; everything else (exact
     // fp64 preconditioner blocks, one-lane kernels, zebra rows on odd grids, 8_16) reads s->coef
     const bool shared_only = s->dd_on && s->geo.ntop == 2 &&
-                             (s->pc == TSX_PC_NONE || (s->mixed && s->pc_split && tsx_pcs_eligible(s)));
+                             (s->pc == TSX_PC_NONE || (s->mixed && s->pc_split && tsx_pcs_eligible(s)) ||
+                              (!s->mixed && s->pc == TSX_PC_REDBLACK && s->coef_bytes == 4));  // (the exact scan passes read the entries too)
     if (!shared_only && (rc = tsx_coef_ensure_dense(s))) return rc;
     if ((rc = tsx_pc_global_agree(s))) return rc;  // several ranks: the preconditioner's halo exchange is on everywhere or nowhere
   }
@@ -1404,7 +1408,8 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
     // g-points (scripts/ab_env.sh, scripts/sweeps_study.py): 20 passes where the scan kernels run -- a
     // pass (36 us on 256 x 256 x 64) is cheap next to the operator and the vector updates of an iteration (1.3 ms), and 20
     // passes need 6 iterations where 10 need 10 -- and 10 passes with the one-lane-per-column kernels (zebra rows, odd grids)
-    const bool scan = s->pc == TSX_PC_REDBLACK && tsx_pcs_eligible(s);
+    const bool scan = s->pc == TSX_PC_REDBLACK && s->mixed && tsx_pcs_eligible(s);
+    const bool exact_scan = s->pc == TSX_PC_REDBLACK && !s->mixed;  // tsx_pcx.hip: the pass count measured in round 6 (profiles/r06)
     // round 3: with the side -> top couplings in fp16 (3_10 scan kernels, C16) the residual after 5 iterations of 20 passes
     // sits at 1.02-1.08e-5 on every measured domain -- 22 passes take it below the reference's rtol 1e-5: 5 iterations instead
     // of 6 (256 x 256 x 64: 18.7 -> 16.4 ms; 128 x 128: 6.05 -> 5.29 ms; all blocks distinct: 35.7 -> 31.5 ms; 24 / 26 passes:
@@ -1416,7 +1421,7 @@ static int prepare_ksp(tsx_solver *s, const tsx_ksp_opts *opts, tsx_ksp_opts *o)
     // a 128 x 64 shard 3.55 -> 3.36 ms; slower on three of the ten (full cloud cover, cover 0.6 of another seed, 64 x 64 columns:
     // BiCGStab's iteration counts are integers); 24 / 26 passes: still five iterations, 30 / 32: four, more expensive ones
     const int auto_scan = 27;
-    o->pc_sweeps = (s->pc == TSX_PC_REDBLACK || s->pc == TSX_PC_ZEBRA) ? (scan ? auto_scan : 9) : 1;
+    o->pc_sweeps = (s->pc == TSX_PC_REDBLACK || s->pc == TSX_PC_ZEBRA) ? (scan ? auto_scan : (exact_scan ? 19 : 9)) : 1;
     s->pc_sweeps = o->pc_sweeps;
   }
   if (o->pc != TSX_PC_NONE) {
@@ -1490,9 +1495,9 @@ extern "C" int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int 
   s->pc_sweeps = pc_sweeps;
   if (s->pc == TSX_PC_REDBLACK) {  // same eligibility rule as prepare_ksp
     const TsxGeo &g = s->geo;
-    if (!(mixed && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0))) s->pc = TSX_PC_ZEBRA;
+    if (!((mixed && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0)) || (!mixed && tsx_pcx_eligible(s)))) s->pc = TSX_PC_ZEBRA;
   }
-  s->pc_split = s->pc == TSX_PC_REDBLACK;
+  s->pc_split = s->pc == TSX_PC_REDBLACK && mixed;
   s->mixed = mixed != 0;
   int rc = tsx_dedup_ensure(s);
   if (rc) return rc;
@@ -1613,6 +1618,10 @@ static int bench_kernel_t(tsx_solver *s, int kernel, int reps, float *avg_ms) {
     memcpy(fl, s->flow_last, sizeof(fl));
     if (kernel == 4 && !fl[0]) {
       tsx_set_error("tsx_bench_kernel: kernel 4: this configuration does not run the flow kernel");
+      return TSX_ERR_UNSUPPORTED;
+    }
+    if (kernel == 4 && fl[0] == 2) {  // (timing the variant without faces on a shard with real neighbours is another kernel)
+      tsx_set_error("tsx_bench_kernel: kernel 4: the last application ran the flow kernel with rank faces inside; it cannot be timed alone");
       return TSX_ERR_UNSUPPORTED;
     }
     if (kernel == 4 && fl[1] > 1) {  // as inside a solve: pass 0 alone precedes it

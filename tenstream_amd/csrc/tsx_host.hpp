@@ -189,4 +189,7 @@ bool tsx_pcs_flow_ok(tsx_solver *s, int lseg, int nseg, int cw, bool faces = fal
 int tsx_pcs_flow(tsx_solver *s, int cw, int p0, int p1, const int *done, bool faces = false);
 unsigned *tsx_pcs_words(const tsx_solver *s);
 int tsx_records_share(tsx_solver *s, int R, const uint4 *P);
+// the red-black passes on the exact blocks with fp64 iterates, as a segmented scan (tsx_pcx.hip): what fp32_directions = 0 gets
+bool tsx_pcx_eligible(const tsx_solver *s);
+int tsx_pcx_apply(tsx_solver *s, const double *v, double *z, const int *done);
 int tsx_dedup_hash_buffer(tsx_solver *s, unsigned long long **h);

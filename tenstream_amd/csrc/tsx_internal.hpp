@@ -181,7 +181,7 @@ struct tsx_solver {
   int flow_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the last application of M^-1: {flow kernel used, p0, p1, columns per tile, fat, granules, tiles per pass, workgroups}
   unsigned flow_epoch_bound = 0;  // host-side upper bound of the device's epoch word (tags and progress words restart before it wraps)
   int flow_prog_cap = 0;
-  int flow_capacity[4] = {0, 0, 0, 0};  // resident workgroups of tsx_k_pcs_flow<4, 16, 32 | 16, lean | fat> on this device (0: not asked yet)
+  int flow_capacity[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // resident workgroups of tsx_k_pcs_flow<4, 16, 32 | 16, lean | fat, records per block | per cell> on this device (0: not asked yet)
   void *dd_scratch;        // work space of the build (hashes, table, scan)
   bool x_is_zero = false;      // the initial guess in vx is known to be zero on every rank (krylov_begin then skips A x0)
   bool dd_hash_ready = false;  // the hashes of the current blocks already sit in dd_scratch (left by tsx_k_lut_diff2diff)
@@ -265,6 +265,8 @@ struct tsx_solver {
   hipEvent_t ev_pack, ev_recv;
   int max_lds;               // hipDeviceAttributeMaxSharedMemoryPerBlock
   int overlap_env;           // TSX_OVERLAP: -1 unset, else 0 / 1 (tsx_overlap, tsx_host.hpp: interior + frame launches around an exchange)
+  double *pcx_rec = nullptr;  // [7][Nc] fp64 column recurrences of the exact scan preconditioner (tsx_pcx.hip), natural cell order
+  bool pcx_valid = false;     // ... belong to the current coefficient set
   TsxLog *log = nullptr;     // the reference's log events for this path + roctx ranges (tsx_log_enable; off: null)
 };
 

@@ -1597,7 +1597,7 @@ __device__ __forceinline__ TsxM4 tsx_mm4(const TsxH4 &X, const TsxM4 &Y) {
 #define TSX_PCSH_WAVES 2
 #endif
 template <int LSEG, int NSEG, int CW, bool GS, int MODE, bool IDX = false, int RQ = 0>
-__global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(TSX_PCSH_WAVES, TSX_PCSH_WAVES))) void tsx_k_pcsh_rb(TsxGeo g, const uint4 *__restrict__ P, const uint4 *__restrict__ PB,
+__global__ __launch_bounds__(CW *NSEG) __attribute__((amdgpu_waves_per_eu(LSEG == 2 ? 3 : TSX_PCSH_WAVES, LSEG == 2 ? 3 : TSX_PCSH_WAVES))) void tsx_k_pcsh_rb(TsxGeo g, const uint4 *__restrict__ P, const uint4 *__restrict__ PB,
                                                           long long bstride, const int *__restrict__ cidx,
                                                           const float *__restrict__ r, float *__restrict__ z,
                                                           unsigned *__restrict__ zb, float *__restrict__ zfin,

@@ -162,6 +162,9 @@ static int apply_pc(tsx_solver *s, const double *v, ZT *z, bool in_solve) {
       return TSX_OK;
     }
   }
+  if constexpr (std::is_same<ZT, double>::value && NTOP == 2) {
+    if (s->pc == TSX_PC_REDBLACK) return tsx_pcx_apply(s, v, z, done);  // exact blocks, fp64 iterates, scan over the levels (tsx_pcx.hip)
+  }
   if (s->pc == TSX_PC_ZEBRA) {
     const int P = s->pc_sweeps + 1;
     ZT *alt = (ZT *)s->vw;

@@ -12,7 +12,7 @@ struct PcsCfg {
 };
 
 // (LSEG, NSEG) pairs that are instantiated; CW in {64, 32, 16}
-static const int k_pairs[][2] = {{4, 16}, {8, 8}, {8, 16}, {16, 16}};
+static const int k_pairs[][2] = {{4, 16}, {8, 8}, {8, 16}, {16, 16}, {2, 32}};  // (2, 32): 8_16 only, A/B (round 6)
 
 static PcsCfg pcs_config(const tsx_solver *s) {
   const TsxGeo &g = s->geo;
@@ -37,9 +37,13 @@ static PcsCfg pcs_config(const tsx_solver *s) {
     }
     if (c.lseg == 16 || (c.lseg == 8 && c.nseg == 8)) c.lseg = c.nseg = 0;  // not instantiated for 8_16
     if (!c.lseg) return c;
-    c.cw = (e_cw == 32 || e_cw == 16) ? e_cw : (nthr >= 8192 ? 32 : 16);
+    // two levels per thread (TSX_PCS_CFG=2,32,8|16): half the per-level state in registers -- three workgroups of 8 columns x 32
+    // segments per CU instead of one of 32 x 16 (round 6 A/B, profiles/r06)
+    if (c.lseg == 2) c.cw = e_cw == 16 ? 16 : 8;
+    else c.cw = (e_cw == 32 || e_cw == 16) ? e_cw : (nthr >= 8192 ? 32 : 16);
     return c;
   }
+  if (c.lseg == 2) c.lseg = c.nseg = 0;  // 3_10: not instantiated
   if (!c.lseg) {
     // measured (scripts/pcsbench.py): 8 levels x 8 segments on large passes (>= 16 K columns: fewer, fatter threads),
     // 4 x 16 on small ones (more waves); deeper columns take the smallest pair that holds them
@@ -443,7 +447,9 @@ int tsx_pcs_pass(tsx_solver *s, int pass, int mode, float *zfin, const int *done
     const bool first8 = pass == 0, gs8 = !(first8 && mode == 0);
     const int nonbr8 = first8 && mode != 0, rbc8 = pass & 1;
     if (mode != 0) rq = 0;
-    if (c.lseg == 4 && c.cw == 32) pcsh_launch<4, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);
+    if (c.lseg == 2 && c.cw == 16) pcsh_launch<2, 32, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);
+    else if (c.lseg == 2) pcsh_launch<2, 32, 8>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);
+    else if (c.lseg == 4 && c.cw == 32) pcsh_launch<4, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);
     else if (c.lseg == 4) pcsh_launch<4, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);
     else if (c.cw == 32) pcsh_launch<8, 16, 32>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);
     else pcsh_launch<8, 16, 16>(s, gs8, mode, rbc8, nonbr8, zs8, zb8, zfin, done, rq, part);

@@ -28,11 +28,16 @@ static const void *flow_kernel() {
 
 // resident workgroups of the flow kernel on this device.  Only a bound on the useful grid: tickets make any grid correct.
 static int flow_capacity(tsx_solver *s, int cw, bool fat) {
-  int &cap = s->flow_capacity[(cw == 32 ? 0 : 1) + (fat ? 2 : 0)];
+  // the instantiation that will be launched: per-block records behind the index (IDX) or every cell's own -- their register use, and
+  // so their residency, differs; the granule and rank-face variants of a body are within a few registers of it
+  const bool idx = s->coef_h_dd;
+  int &cap = s->flow_capacity[(cw == 32 ? 0 : 1) + (fat ? 2 : 0) + (idx ? 0 : 4)];
   if (cap > 0) return cap;
   int per_cu = 0, cus = 0;
-  const void *k = cw == 32 ? (fat ? flow_kernel<32, true, true>() : flow_kernel<32, true, false>())
-                           : (fat ? flow_kernel<16, true, true>() : flow_kernel<16, true, false>());
+  const void *k = idx ? (cw == 32 ? (fat ? flow_kernel<32, true, true>() : flow_kernel<32, true, false>())
+                                  : (fat ? flow_kernel<16, true, true>() : flow_kernel<16, true, false>()))
+                      : (cw == 32 ? (fat ? flow_kernel<32, false, true>() : flow_kernel<32, false, false>())
+                                  : (fat ? flow_kernel<16, false, true>() : flow_kernel<16, false, false>()));
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, cw * 16, 0) != hipSuccess || per_cu < 1) per_cu = 1;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess || cus < 1) cus = 256;
   cap = per_cu * cus;

@@ -1,0 +1,287 @@
+// tsx_pcx.hip -- the red-black column-block preconditioner in the reference's default arithmetic: exact blocks, fp64 iterates,
+// fp64 recurrences -- as a segmented scan over the levels (round 6).
+//
+// The reference preconditions in `ireals` (real64 by default: PCILU / PCBJACOBI + ILU(0) on the assembled matrix,
+// src/pprts.F90:4350-4371).  Until round 5 the only preconditioner of this library that rounded nothing was round 1's zebra-row
+// sweep with one lane per column (tsx_k_pc_column_h1: 14 iterations, 36 M cells/s on the metric domain) -- what
+// `fp32_directions = 0, pc_coeff_fp16 = 0` got, and what the retry after a failed solve ran (krylov_run_with_retry).  This is the
+// same M^-1 as the mixed-precision scan kernels apply (tsx_kernels_pcs.hpp: exact two-stream solve per column, colours
+// (i + j) & 1 alternately, the other colour's latest side streams on the right-hand side), evaluated the same way -- the column
+// recurrences split into a matrix-only part (tsx_k_pcx_pack_col, once per coefficient set) and affine recurrences that NSEG
+// segments of a column scan concurrently -- but on the operator's own blocks (fp32 as the LUT delivers them, lossless, or fp64)
+// with every intermediate in fp64, directly in the Krylov vectors' dst-owned layout: a pass reads the other colour's side streams
+// from z where the operator would read them from x (tsx_k_spmv_w's gather) and writes its colour's ten streams to z.  Nothing is
+// packed, nothing is rounded; rank faces are treated like the reference's PCBJACOBI treats them (couplings across them dropped).
+//     upward    B_k     = (ru_k + F_k rd_k) + E_k B_{k+1}       B_Nz = ru_Nz        U_k = A_k V_k + B_k
+//     downward  V_{k+1} = (G_k rd_k + H_k B_{k+1}) + GT_k V_k   V_0  = rd_TOA
+//     E = Tuu G, F = Tuu A_{k+1} G, G = 1 / (1 - Rdu A_{k+1}), H = G Rdu, GT = G Tdd, A_k = Rud + Tuu A_{k+1} GT, A_Nz = albedo
+// 3_10 only (8_16 keeps the zebra rows on this path).
+#include "tsx_host.hpp"
+
+namespace {
+constexpr int PCX_CW = 16, PCX_NSEG = 16, PCX_REC = 7;
+
+// matrix-only part, one lane per column: rec[q * Nc + c], q = E F G H GT A_{k+1} A_k (natural cell order)
+template <typename CT, bool IDX>
+__global__ __launch_bounds__(64) void tsx_k_pcx_pack_col(TsxGeo g, const CT *__restrict__ C, const int *__restrict__ cidx,
+                                                         const uint8_t *__restrict__ l1d, const double *__restrict__ a11,
+                                                         const double *__restrict__ a12, const double *__restrict__ albedo,
+                                                         double *__restrict__ rec) {
+  constexpr int D = 10;
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= g.ncol) return;
+  const size_t Nc = (size_t)g.Nc;
+  double A = albedo[col];
+  for (int k = g.Nz - 1; k >= 0; --k) {
+    const size_t c = (size_t)k * g.ncol + col;
+    double tuu, rud, rdu, tdd;
+    if (l1d[k]) {
+      tuu = tdd = a11[c];
+      rud = rdu = a12[c];
+    } else if (IDX) {  // entry-major shared blocks Ce[id * D*D + dst * D + src]
+      const CT *b = C + (size_t)cidx[c] * (D * D);
+      tuu = (double)b[0 * D + 0];
+      rud = (double)b[0 * D + 1];
+      rdu = (double)b[1 * D + 0];
+      tdd = (double)b[1 * D + 1];
+    } else {
+      tuu = (double)C[(size_t)(0 * D + 0) * Nc + c];
+      rud = (double)C[(size_t)(0 * D + 1) * Nc + c];
+      rdu = (double)C[(size_t)(1 * D + 0) * Nc + c];
+      tdd = (double)C[(size_t)(1 * D + 1) * Nc + c];
+    }
+    const double G = 1.0 / (1.0 - rdu * A);
+    const double GT = G * tdd;
+    const double Ao = rud + tuu * A * GT;
+    rec[0 * Nc + c] = tuu * G;
+    rec[1 * Nc + c] = tuu * A * G;
+    rec[2 * Nc + c] = G;
+    rec[3 * Nc + c] = G * rdu;
+    rec[4 * Nc + c] = GT;
+    rec[5 * Nc + c] = A;
+    rec[6 * Nc + c] = Ao;
+    A = Ao;
+  }
+}
+
+// one half-grid pass: the columns of colour rbc.  gs: the other colour's side streams (from z) enter the right-hand side
+template <typename CT, int LSEG, bool IDX>
+__global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const CT *__restrict__ C, const int *__restrict__ cidx,
+                                                                 const double *__restrict__ rec, const uint8_t *__restrict__ l1d,
+                                                                 const double *__restrict__ r, double *__restrict__ z,
+                                                                 const double *__restrict__ zo, const int *__restrict__ done, int rbc,
+                                                                 int gs) {
+  // zo aliases z; it is only read at columns of the OTHER colour, which this launch never writes (a separate restrict pointer
+  // lets the compiler issue those loads ahead of the stores to z)
+  constexpr int D = 10, CW = PCX_CW, NSEG = PCX_NSEG;
+  __shared__ double2 sS[NSEG][CW];
+  if (done && *done) return;
+  const int xm = g.xm, ym = g.ym, Nz = g.Nz, ncol = g.ncol;
+  const size_t Nc = (size_t)g.Nc;
+  const int h = xm >> 1;
+  const int cl = threadIdx.x % CW, sg = threadIdx.x / CW;
+  int t = blockIdx.x * CW + cl;
+  const bool live = t < ym * h;
+  if (!live) t = ym * h - 1;
+  const int jrow = t / h, qh = t - jrow * h;
+  const int i = 2 * qh + ((jrow + rbc) & 1);
+  const int col = jrow * xm + i;
+  // the neighbour a side source stream comes from (tsx_k_spmv_w's gather): inward x streams from the west, the others from the
+  // east; inward y streams from the south, the others from the north.  0 = no neighbour (rank face, or gs off)
+  long long offW = i > 0 ? -1 : (g.wrap_x ? xm - 1 : 0), offE = i + 1 < xm ? 1 : (g.wrap_x ? 1 - xm : 0);
+  long long offS = jrow > 0 ? -(long long)xm : (g.wrap_y ? (long long)(ym - 1) * xm : 0);
+  long long offN = jrow + 1 < ym ? (long long)xm : (g.wrap_y ? -(long long)(ym - 1) * xm : 0);
+  if (g.pc_tile_x > 0) {
+    if ((i + 1) % g.pc_tile_x == 0) offE = 0;
+    if (i % g.pc_tile_x == 0) offW = 0;
+  }
+  if (g.pc_tile_y > 0) {
+    if ((jrow + 1) % g.pc_tile_y == 0) offN = 0;
+    if (jrow % g.pc_tile_y == 0) offS = 0;
+  }
+  if (!gs) offW = offE = offS = offN = 0;
+  const long long soff[8] = {offE, offW, offE, offW, offN, offS, offN, offS};  // source stream 2 + q: tsx_inward(q) = q & 1
+  const double *__restrict__ rt = r + (size_t)D * Nc;
+  double *__restrict__ zt = z + (size_t)D * Nc;
+  const int k0 = sg * LSEG;
+  auto lev = [&](int l) { return k0 + l < Nz ? k0 + l : Nz - 1; };
+  auto coef = [&](size_t c, int id, int dst, int src) -> double {
+    return IDX ? (double)C[(size_t)id * (D * D) + dst * D + src] : (double)C[(size_t)(dst * D + src) * Nc + c];
+  };
+  auto nbrs = [&](size_t c, double(&zn)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double v = zo[(size_t)(2 + q) * Nc + c + soff[q]];  // unconditional load from a valid address, then select
+      zn[q] = soff[q] ? v : 0.0;
+    }
+  };
+  // ---- phase 1: local upward scan with zero inflow
+  double beta[LSEG], rdv[LSEG], Ek[LSEG];
+  {
+    double Bl = 0.0, Pe = 1.0;
+#pragma unroll
+    for (int l = LSEG - 1; l >= 0; --l) {
+      const bool act = k0 + l < Nz;
+      const int k = lev(l);
+      const size_t c = (size_t)k * ncol + col;
+      double ru = r[0 * Nc + c], rd = r[1 * Nc + c];
+      if (gs && !l1d[k]) {
+        const int id = IDX ? cidx[c] : 0;
+        double zn[8];
+        nbrs(c, zn);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          ru += coef(c, id, 0, 2 + q) * zn[q];
+          rd += coef(c, id, 1, 2 + q) * zn[q];
+        }
+      }
+      const double E = rec[0 * Nc + c], F = rec[1 * Nc + c];
+      Ek[l] = E;
+      rdv[l] = rd;
+      beta[l] = act ? ru + F * rd : 0.0;
+      if (act) {
+        Bl = beta[l] + E * Bl;
+        Pe = E * Pe;
+      }
+    }
+    sS[sg][cl] = make_double2(Bl, Pe);
+  }
+  __syncthreads();
+  double Bin = rt[(size_t)0 * ncol + col];  // B_Nz = ru_Nz
+  for (int s2 = NSEG - 1; s2 > sg; --s2) {
+    const double2 m = sS[s2][cl];
+    Bin = m.x + m.y * Bin;
+  }
+  // ---- phase 2: the true B of every level
+  double Bk[LSEG];
+  {
+    double Bc = Bin;
+#pragma unroll
+    for (int l = LSEG - 1; l >= 0; --l) {
+      if (k0 + l < Nz) Bc = beta[l] + Ek[l] * Bc;
+      Bk[l] = Bc;
+    }
+  }
+  __syncthreads();  // the upward summaries have been read: the buffer is free for the downward ones
+  // ---- phase 3: local downward scan with zero inflow
+  double gam[LSEG], GTk[LSEG];
+  {
+    double Vl = 0.0, Q = 1.0;
+#pragma unroll
+    for (int l = 0; l < LSEG; ++l) {
+      const bool act = k0 + l < Nz;
+      const size_t c = (size_t)lev(l) * ncol + col;
+      const double Bn = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l] : Bin;
+      const double G = rec[2 * Nc + c], H = rec[3 * Nc + c], GT = rec[4 * Nc + c];
+      GTk[l] = GT;
+      gam[l] = act ? G * rdv[l] + H * Bn : 0.0;
+      if (act) {
+        Vl = gam[l] + GT * Vl;
+        Q = GT * Q;
+      }
+    }
+    sS[sg][cl] = make_double2(Vl, Q);
+  }
+  __syncthreads();
+  double V = rt[(size_t)1 * ncol + col];  // V_0 = rd_TOA
+  if (sg == 0 && live) {  // tail rows: the TOA identity row and the side dummies at level Nz
+    zt[(size_t)1 * ncol + col] = V;
+#pragma unroll
+    for (int d = 2; d < D; ++d) zt[(size_t)d * ncol + col] = rt[(size_t)d * ncol + col];
+  }
+  for (int s2 = 0; s2 < sg; ++s2) {
+    const double2 m = sS[s2][cl];
+    V = m.x + m.y * V;
+  }
+  // ---- phase 4: true V, U; side streams; stores
+#pragma unroll
+  for (int l = 0; l < LSEG; ++l) {
+    if (k0 + l >= Nz) break;
+    const int k = k0 + l;
+    const size_t c = (size_t)k * ncol + col;
+    const double Bn = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l] : Bin;
+    const double Vn = gam[l] + GTk[l] * V;
+    const double Un = rec[5 * Nc + c] * Vn + Bn;      // U_{k+1} = A_{k+1} V_{k+1} + B_{k+1}
+    const double Uk = rec[6 * Nc + c] * V + Bk[l];    // U_k
+    if (live) {
+      z[0 * Nc + c] = Uk;
+      z[1 * Nc + c] = Vn;
+    }
+    const bool one = l1d[k] != 0;
+    const int id = IDX && !one ? cidx[c] : 0;
+    double zn[8];
+    if (gs && !one) nbrs(c, zn);
+#pragma unroll
+    for (int d = 2; d < D; ++d) {
+      double acc = r[(size_t)d * Nc + c];
+      if (!one) {
+        acc += coef(c, id, d, 0) * Un + coef(c, id, d, 1) * V;
+        if (gs) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc += coef(c, id, d, 2 + q) * zn[q];
+        }
+      }
+      if (live) z[(size_t)d * Nc + c] = acc;
+    }
+    if (k == Nz - 1 && live) zt[(size_t)0 * ncol + col] = Un;  // U_Nz = albedo V_Nz + ru_Nz: the surface row
+    V = Vn;
+  }
+}
+}  // namespace
+
+// exact scan passes available for this solver's grid?  (3_10, an even number of columns per row, an even number of rows where
+// the rank wraps onto itself in y, at most 256 levels); TSX_PC_EXACT_SCAN=0 keeps the zebra rows (A/B)
+bool tsx_pcx_eligible(const tsx_solver *s) {
+  const TsxGeo &g = s->geo;
+  const char *e = getenv("TSX_PC_EXACT_SCAN");
+  if (e && atoi(e) == 0) return false;
+  return g.ntop == 2 && g.xm % 2 == 0 && g.xm >= 2 && (!g.wrap_y || g.ym % 2 == 0) && g.Nz <= 16 * PCX_NSEG && g.Nc < (1ll << 31);
+}
+
+template <typename CT>
+static int pcx_apply_t(tsx_solver *s, const CT *C, bool idx, const double *v, double *z, const int *done) {
+  const TsxGeo &g = s->geo;
+  if (!s->pcx_rec) HIPCHK(tsx_dev_malloc((void **)&s->pcx_rec, sizeof(double) * (size_t)PCX_REC * g.Nc));
+  const int *cidx = idx ? (const int *)s->dd_cidx : (const int *)nullptr;
+  if (!s->pcx_valid) {
+    const int nbc = (g.ncol + 63) / 64;
+    if (idx)
+      hipLaunchKernelGGL((tsx_k_pcx_pack_col<CT, true>), dim3(nbc), dim3(64), 0, s->stream, g, C, cidx, s->l1d, s->a11, s->a12, s->albedo,
+                         s->pcx_rec);
+    else
+      hipLaunchKernelGGL((tsx_k_pcx_pack_col<CT, false>), dim3(nbc), dim3(64), 0, s->stream, g, C, cidx, s->l1d, s->a11, s->a12, s->albedo,
+                         s->pcx_rec);
+    HIPCHK(hipGetLastError());
+    s->pcx_valid = true;
+  }
+  const int nthr = g.ym * (g.xm / 2), nb = (nthr + PCX_CW - 1) / PCX_CW;
+  const int P = s->pc_sweeps + 1;
+#define TSX_PCX_GO(L)                                                                                                                    \
+  do {                                                                                                                                   \
+    if (idx)                                                                                                                             \
+      hipLaunchKernelGGL((tsx_k_pcx_rb<CT, L, true>), dim3(nb), dim3(PCX_CW *PCX_NSEG), 0, s->stream, g, C, cidx, (const double *)s->pcx_rec, \
+                         s->l1d, v, z, (const double *)z, done, pass & 1, pass > 0 ? 1 : 0);                                              \
+    else                                                                                                                                 \
+      hipLaunchKernelGGL((tsx_k_pcx_rb<CT, L, false>), dim3(nb), dim3(PCX_CW *PCX_NSEG), 0, s->stream, g, C, cidx, (const double *)s->pcx_rec, \
+                         s->l1d, v, z, (const double *)z, done, pass & 1, pass > 0 ? 1 : 0);                                              \
+  } while (0)
+  for (int pass = 0; pass < P; ++pass) {
+    if (g.Nz <= 4 * PCX_NSEG) TSX_PCX_GO(4);
+    else if (g.Nz <= 8 * PCX_NSEG) TSX_PCX_GO(8);
+    else TSX_PCX_GO(16);
+  }
+#undef TSX_PCX_GO
+  HIPCHK(hipGetLastError());
+  return TSX_OK;
+}
+
+// z = M^-1 v, both fp64 in the Krylov layout; pc_sweeps + 1 half-grid passes, colours alternately
+int tsx_pcx_apply(tsx_solver *s, const double *v, double *z, const int *done) {
+  if (s->dd_on && s->coef_bytes == 4) return pcx_apply_t<float>(s, (const float *)s->dd_coef_e, true, v, z, done);
+  if (!s->coef_dense_valid) {
+    tsx_set_error("exact scan preconditioner: neither shared blocks nor dense planes are valid (internal state error)");
+    return TSX_ERR_STATE;
+  }
+  if (s->coef_bytes == 4) return pcx_apply_t<float>(s, (const float *)s->coef, false, v, z, done);
+  return pcx_apply_t<double>(s, (const double *)s->coef, false, v, z, done);
+}

@@ -258,6 +258,77 @@ def test_red_black_preconditioner_is_checkerboard_gauss_seidel(gpu, solver, Nx, 
     s.close()
 
 
+@pytest.mark.parametrize("Nx,Ny,Nz,n1d", [(8, 6, 6, 1), (6, 8, 5, 0), (12, 4, 7, 2), (34, 6, 70, 3), (6, 4, 130, 0), (2, 2, 3, 0)])
+@pytest.mark.parametrize("sweeps", [1, 2, 5])
+def test_exact_scan_preconditioner_is_checkerboard_gauss_seidel_to_rounding(gpu, Nx, Ny, Nz, n1d, sweeps):
+    """Round 6 (tsx_pcx.hip): with fp64 directions (fp32_directions = 0 -- the reference's default `ireals`) TSX_PC_REDBLACK is the
+    same checkerboard Gauss-Seidel over exact column-block solves, evaluated as a segmented scan over the levels on the operator's
+    own blocks with fp64 intermediates: equal to the sparse-direct model to rounding, for 4, 8 and 16 levels per thread."""
+    import scipy.sparse.linalg as spla
+
+    P = synthetic.make_problem("3_10", Nx=Nx, Ny=Ny, Nz=Nz, n1d=n1d)
+    lay = O.layout("3_10", Nz, Nx, Ny)
+    M, A = _column_block_matrix(P, lay)
+    D, L = lay.D, Nz + 1
+    idx = np.arange(A.shape[0])
+    d, k = idx % D, (idx // D) % L
+    i, j = (idx // (D * L)) % Nx, idx // (D * L * Nx)
+    oi, oj = i.copy(), j.copy()
+    qx, qy = d - lay.ntop, d - lay.ntop - lay.nside
+    mx = (qx >= 0) & (qx < lay.nside) & (qx % 2 == 1) & (k < Nz)
+    my = (qy >= 0) & (qy < lay.nside) & (qy % 2 == 1) & (k < Nz)
+    oi[mx] = (i[mx] - 1) % Nx
+    oj[my] = (j[my] - 1) % Ny
+    colour = (oi + oj) % 2
+    Noff = (A - M.tocsr()).tocsr()
+    lu = spla.splu(M.tocsc(), permc_spec="NATURAL")
+    v = np.random.default_rng(4).standard_normal(P["b"].shape)
+    x = np.zeros(v.size)
+    for p_ in range(sweeps + 1):
+        rhs = v.ravel() - (Noff @ x if p_ > 0 else 0.0)
+        mk = colour == (p_ % 2)
+        x[mk] = lu.solve(rhs)[mk]
+    s = DiffuseSolver("3_10", Nz, Nx, Ny)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    z = s.pc_apply(v, pc=3, sweeps=sweeps, mixed=False)
+    assert np.abs(z.ravel() - x).max() <= 1e-11 * np.abs(x).max()
+    # nothing reduced anywhere: the solve with fp64 directions on the exact blocks reaches the sparse-direct solution
+    xs = np.zeros(s.vec_shape)
+    info = s.solve(P["b"], xs, rtol=1e-12, atol=1e-30, pc=3, pc_sweeps=sweeps, fp32_directions=0, pc_coeff_fp16=0)
+    assert info.reason == 2
+    x_ref = spla.spsolve(A.tocsc(), P["b"].ravel()).reshape(P["b"].shape)
+    assert np.abs(xs - x_ref).max() <= 1e-9 * np.abs(x_ref).max()
+    assert s.pc_info()[0] == 3   # red-black ran (not the zebra fallback)
+    s.close()
+
+
+def test_exact_scan_preconditioner_reads_shared_blocks_like_dense_ones(gpu, monkeypatch):
+    """On the LUT path the blocks live in the shared storage only (tsx_dedup_from_coords); the exact scan passes read the
+    entry-major entries through the per-cell index: same z, bit for bit, as with every cell's block stored (TSX_DEDUP=0)."""
+    from tenstream_amd import lut
+
+    Nx, Ny, Nz = 16, 12, 10
+    kabs, ksca, g = synthetic.cloud_field(Nx, Ny, Nz, seed=3)
+    kabs, ksca, g = synthetic.delta_scale(kabs, ksca, g)
+    dz = np.full((Ny, Nx, Nz), 50.0)
+    l1d = np.zeros(Nz, dtype=np.uint8)
+    l1d[0] = 1
+    a11, a12 = 0.6 + 0.0 * kabs, 0.1 + 0.0 * kabs
+    alb = np.full((Ny, Nx), 0.2)
+    v = np.random.default_rng(1).standard_normal((Ny, Nx, Nz + 1, 10))
+    out = {}
+    for dd in ("1", "0"):
+        monkeypatch.setenv("TSX_DEDUP", dd)
+        s = DiffuseSolver("3_10", Nz, Nx, Ny)
+        s.set_lut_diffuse(lut.synthetic_diffuse_table("3_10"), lut.diffuse_axes("3_10"))
+        s.set_optprop(kabs, ksca, g, dz, 100.0, l1d, a11, a12, alb)
+        out[dd] = s.pc_apply(v, pc=3, sweeps=3, mixed=False)
+        if dd == "1":
+            assert s.dedup_info()[0]
+        s.close()
+    assert np.array_equal(out["1"], out["0"])
+
+
 @pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [
     ("3_10", 2, 2, 3, 0), ("3_10", 2, 3, 2, 0), ("3_10", 4, 2, 1, 0), ("3_10", 64, 2, 5, 1), ("3_10", 2, 64, 4, 0),
     ("3_10", 130, 4, 3, 0), ("3_10", 6, 6, 70, 3),   # Nz = 70: the sweep temporaries no longer fit the LDS block -> global
