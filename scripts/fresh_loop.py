@@ -54,8 +54,29 @@ def worker(rank, it, outdir):
     def exchange(send, recv, peers):
         raise RuntimeError("no exchange expected before the solve")
 
-    def allreduce(buf):   # the 1-D layer flags are the same on every rank of this case: OR over ranks = identity
-        return None
+    # The test's allreduce (gloo) lines the four ranks up INSIDE set_optical_properties, a few hundred microseconds before the block-
+    # sharing build takes its fresh device memory; a spin barrier over a shared page does the same here (the values need no exchange:
+    # the 1-D layer flags are the same on every rank of this case, OR over ranks = identity)
+    import mmap
+    import struct
+
+    shm = None
+    if os.environ.get("FRESH_TIGHT", "1") != "0":
+        fd = os.open(f"/dev/shm/tsx_fresh_{os.path.basename(outdir)}_{it}", os.O_RDWR)
+        shm = mmap.mmap(fd, 64)
+    gen = [0]
+
+    def allreduce(buf):
+        if shm is None:
+            return None
+        gen[0] += 1
+        struct.pack_into("<q", shm, 8 * rank, gen[0])
+        t0 = time.time()
+        while True:
+            if all(struct.unpack_from("<q", shm, 8 * r)[0] >= gen[0] for r in range(world)):
+                return None
+            if time.time() - t0 > 30:
+                raise RuntimeError("spin barrier timed out")
 
     P.core.comm_set_callbacks(exchange, allreduce)
     # file barrier: the four processes enter set_optical_properties together (as they do behind gloo's rendezvous in the test)
@@ -83,6 +104,9 @@ def main():
     t0 = time.time()
     for it in range(N):
         env = dict(os.environ, TSX_DEBUG_CHECKS=os.path.join(outdir, f"chk.{it}"))
+        shm_path = f"/dev/shm/tsx_fresh_{os.path.basename(outdir)}_{it}"
+        with open(shm_path, "wb") as fh:
+            fh.write(b"\0" * 64)
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(r), str(it), outdir], env=env,
                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(4)]
         for r, p in enumerate(procs):
@@ -102,6 +126,7 @@ def main():
                         wiped.append(d)
                     nproc += 1
                     guard_us += d.get("pool", [0] * 8)[7]
+        os.remove(shm_path)
         hit = False
         for fn in glob.glob(os.path.join(outdir, f"chk.{it}.*")):
             txt = open(fn).read()

@@ -491,7 +491,8 @@ __device__ __forceinline__ void tsx_pcs_rb_body(const TsxGeo &g, const uint4 *__
   static_assert(!HOIST || (FLOW && GS && MODE == 0 && RQ == 2 && C16), "HOIST: an intermediate pass of the flow kernel");
   static_assert(!PEER || MODE != 2, "the last pass sends nothing");
   static_assert(!FLOW || MODE == 0, "the flow kernel runs intermediate passes");
-  static_assert(!(FLOW && PEER) || HOIST, "rank faces inside the flow kernel: the fat body only");
+  // (round 6: rank faces inside the flow kernel with the lean body too -- shards whose passes are not resident at once; it sends
+  // after the scan like the 32-column pass kernel, the fat body from the level loop)
   constexpr int XA = FLOW ? 16 : 0;  // aux of the accesses another workgroup of the launch is on the other end of: sc1
   // per-block records: PE[slot * pe_ss + id * pe_si]; pe_si = 1: slot-major planes of nent entries, pe_si = 8 (C16 only):
   // entry-major, an entry's eight records in one 128-byte line (tsx_k_pcs_pack_ent16)
@@ -1047,7 +1048,7 @@ __device__ __forceinline__ void tsx_pcs_rb_body(const TsxGeo &g, const uint4 *__
       tsx_sto<unsigned, XA>(zb, (size_t)2 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[4], zo[6]));
       tsx_sto<unsigned, XA>(zb, (size_t)3 * Nc, (unsigned)TSX_FOLDC(c), tsx_bf16x2(zo[5], zo[7]));
     }
-    if constexpr (PEER && (CW < 32 || FLOW)) {
+    if constexpr (PEER && (FLOW ? HOIST : CW < 32)) {
       // small passes (16-column workgroups: at most one workgroup per CU's worth of columns, latency-bound, registers to spare):
       // the boundary columns send from the loop, so that the stores' acknowledgements arrive under the remaining levels;
       // the 32-column kernel sends after the scan (below)
@@ -1079,6 +1080,23 @@ __device__ __forceinline__ void tsx_pcs_rb_body(const TsxGeo &g, const uint4 *__
       if (FINAL) wpair(zfin + (size_t)D * Nc, ncp, Un, zt[(size_t)((int)col + oc)]);
     }
     V = Vn;
+  }
+  if constexpr (PEER && FLOW && !HOIST) {
+    // the flow kernel's lean body (four waves per SIMD: no registers for stores inside the level loop): the face columns re-read
+    // the records they have just stored -- their own sc1 stores, in program order -- and store them into the neighbours' slots; the
+    // flow kernel's drain and tags follow (tsx_k_pcs_flow)
+    if (sendmask) {
+#pragma unroll
+      for (int l = 0; l < LSEG; ++l) {
+        if (l >= nl) continue;
+        const unsigned c = cell(l);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          if (!(sendmask & (1 << f))) continue;
+          send_word(f, k0 + l, tsx_ldo<unsigned, XA>(zb, (size_t)f * Nc, c));
+        }
+      }
+    }
   }
   if constexpr (PEER && !FLOW) {
     // the columns on a rank face: the records just stored (rec 0 of i = 0 westwards, 1 of i = xm - 1, 2 of j = 0, 3 of j = ym - 1,
@@ -1176,7 +1194,7 @@ __global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g
   if (done && *done) return;
   __shared__ unsigned s_tk;
   const unsigned epoch = __hip_atomic_load(&f.st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  static_assert(!FPEER || (FAT && !GRANV), "rank faces: the fat body with progress words");
+  static_assert(!FPEER || !GRANV, "rank faces: progress words (fat or lean body)");
   TsxPcHalo hal;
   hal.W = hal.E = hal.S = hal.N = nullptr;
   hal.wait.mine = nullptr;
@@ -1339,7 +1357,7 @@ __global__ __launch_bounds__(CW *NSEG, FAT ? 2 : 4) void tsx_k_pcs_flow(TsxGeo g
           g, P, r, nullptr, zb, nullptr, rbc, 0, cidx, nent, PE, hal, rb, 0, pidx, PT, snd, pe_si, (int)t, tl, wait_nbrs);
     } else {
       wait_nbrs();
-      tsx_pcs_rb_body<LSEG, NSEG, CW, true, 0, IDX, 2, C16, false, true>(g, P, r, nullptr, zb, nullptr, rbc, 0, cidx, nent, PE, hal, rb, 0,
+      tsx_pcs_rb_body<LSEG, NSEG, CW, true, 0, IDX, 2, C16, FPEER, true>(g, P, r, nullptr, zb, nullptr, rbc, 0, cidx, nent, PE, hal, rb, 0,
                                                                          pidx, PT, snd, pe_si, (int)t, tl);
     }
     TSX_TL(6);

@@ -61,11 +61,16 @@ bool tsx_pcs_flow_ok(tsx_solver *s, int lseg, int nseg, int cw, bool faces) {
   if (faces) {
     if (getenv("TSX_FLOW_PEER") && atoi(getenv("TSX_FLOW_PEER")) == 0) return false;  // A/B: the passes as launches on several ranks
     if (g.ym % 2 != 0) return false;
-    // only where a pass's tiles are resident at once (the fat body: two waves per SIMD).  Larger shards were measured slower with
-    // it than with a launch per pass: 256 x 128 columns 8.85 -> 9.02 ms per solve, 128 x 256 8.68 -> 9.08, 256 x 256 16.1 -> 17.1
-    // (profiles/r05/flow_peer_ab_large.txt); TSX_FLOW_PEER_ANY=1 lifts the bound (A/B)
-    if ((long long)(h / cw) * g.ym > flow_capacity(s, cw, true) && !(getenv("TSX_FLOW_PEER_ANY") && atoi(getenv("TSX_FLOW_PEER_ANY")))) return false;
-    return true;
+    // round 5: only where a pass's tiles are resident at once (the fat body: two waves per SIMD) -- larger shards were measured
+    // slower with the fat body than with a launch per pass: 256 x 128 columns 8.85 -> 9.02 ms per solve, 128 x 256 8.68 -> 9.08
+    // (profiles/r05/flow_peer_ab_large.txt).  Round 6: beyond that the LEAN body carries the faces (four waves per SIMD, sends
+    // after the scan), up to the size where the flow kernel stops paying on one rank (two tiles per resident workgroup);
+    // TSX_FLOW_PEER_LEAN=0 keeps round 5's bound (A/B), TSX_FLOW_PEER_ANY=1 lifts every bound
+    const long long nt = (long long)(h / cw) * g.ym;
+    if (getenv("TSX_FLOW_PEER_ANY") && atoi(getenv("TSX_FLOW_PEER_ANY"))) return true;
+    if (nt <= flow_capacity(s, cw, true)) return true;
+    if (getenv("TSX_FLOW_PEER_LEAN") && atoi(getenv("TSX_FLOW_PEER_LEAN")) == 0) return false;
+    return nt <= 2ll * flow_capacity(s, cw, false);
   }
   // beyond about two tiles per resident workgroup a pass is bound by its instruction stream and the launch boundary costs nothing
   // next to it: 256 x 256 columns (1024 tiles) 12.01 -> 11.65 ms per solve, 512 x 512 (4096 tiles) 53.7 -> 54.4 ms
@@ -120,7 +125,6 @@ static int flow_launch(tsx_solver *s, int p0, int p1, const int *done, bool face
   const int cap_fat = flow_capacity(s, CW, true);
   bool fat = ntiles <= cap_fat;
   if (const char *e = getenv("TSX_FLOW_FAT")) fat = atoi(e) != 0;
-  if (faces) fat = true;
   int rc = flow_ensure(s, ntiles, fat, p1 - p0);
   if (rc) return rc;
   float *zs = (float *)s->vw;
@@ -197,14 +201,19 @@ static int flow_launch(tsx_solver *s, int p0, int p1, const int *done, bool face
                      done, IDXV ? cidx : (const int *)nullptr, IDXV ? nent : 0ll, IDXV ? PE : (const uint4 *)nullptr, rb,          \
                      IDXV ? pidx : (const int *)nullptr, IDXV ? PT : (const uint4 *)nullptr,                                       \
                      (IDXV && s->pe_entry_major) ? TSX_PCS_ENT16_SLOTS : 1, f)
-#define TSX_FLOW_GOP(IDXV)                                                                                                          \
-  hipLaunchKernelGGL((tsx_k_pcs_flow<4, 16, CW, IDXV, C16, true, false, true>), dim3((unsigned)grid), dim3(CW * 16), 0, s->stream, g, P, \
+#define TSX_FLOW_GOP(IDXV, FATV)                                                                                                    \
+  hipLaunchKernelGGL((tsx_k_pcs_flow<4, 16, CW, IDXV, C16, FATV, false, true>), dim3((unsigned)grid), dim3(CW * 16), 0, s->stream, g, P, \
                      r, zb, done, IDXV ? cidx : (const int *)nullptr, IDXV ? nent : 0ll, IDXV ? PE : (const uint4 *)nullptr, rb,   \
                      IDXV ? pidx : (const int *)nullptr, IDXV ? PT : (const uint4 *)nullptr,                                       \
                      (IDXV && s->pe_entry_major) ? TSX_PCS_ENT16_SLOTS : 1, f)
   if (faces) {
-    if (dd) TSX_FLOW_GOP(true);
-    else TSX_FLOW_GOP(false);
+    if (dd) {
+      if (fat) TSX_FLOW_GOP(true, true);
+      else TSX_FLOW_GOP(true, false);
+    } else {
+      if (fat) TSX_FLOW_GOP(false, true);
+      else TSX_FLOW_GOP(false, false);
+    }
   } else
   if (dd) {
     if (gran) TSX_FLOW_GO(true, true, true);

@@ -65,12 +65,12 @@ __global__ __launch_bounds__(64) void tsx_k_pcx_pack_col(TsxGeo g, const CT *__r
 }
 
 // one half-grid pass: the columns of colour rbc.  gs: the other colour's side streams (from z) enter the right-hand side
-template <typename CT, int LSEG, bool IDX>
+template <typename CT, int LSEG, bool IDX, bool GS>
 __global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const CT *__restrict__ C, const int *__restrict__ cidx,
                                                                  const double *__restrict__ rec, const uint8_t *__restrict__ l1d,
                                                                  const double *__restrict__ r, double *__restrict__ z,
-                                                                 const double *__restrict__ zo, const int *__restrict__ done, int rbc,
-                                                                 int gs) {
+                                                                 const double *__restrict__ zo, const int *__restrict__ done, int rbc) {
+  constexpr bool gs = GS;
   // zo aliases z; it is only read at columns of the OTHER colour, which this launch never writes (a separate restrict pointer
   // lets the compiler issue those loads ahead of the stores to z)
   constexpr int D = 10, CW = PCX_CW, NSEG = PCX_NSEG;
@@ -105,8 +105,27 @@ __global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const
   double *__restrict__ zt = z + (size_t)D * Nc;
   const int k0 = sg * LSEG;
   auto lev = [&](int l) { return k0 + l < Nz ? k0 + l : Nz - 1; };
-  auto coef = [&](size_t c, int id, int dst, int src) -> double {
-    return IDX ? (double)C[(size_t)id * (D * D) + dst * D + src] : (double)C[(size_t)(dst * D + src) * Nc + c];
+  // src 2..9 of row dst (the couplings to the side streams that enter from the neighbouring columns) and src 0, 1 (the column's own
+  // top streams), all loads unconditional -- a load under a branch ends a basic block and costs a full wait per level;
+  // shared blocks are entry-major, a row is 40 contiguous bytes: five 8-byte loads instead of ten 4-byte ones
+  auto row = [&](size_t c, int id, int dst, double(&top)[2], double(&side)[8]) {
+    if constexpr (IDX && sizeof(CT) == 4) {
+      const float2 *rw = reinterpret_cast<const float2 *>(C + (size_t)id * (D * D) + dst * D);
+      const float2 t = rw[0];
+      top[0] = (double)t.x;
+      top[1] = (double)t.y;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float2 v = rw[1 + q];
+        side[2 * q] = (double)v.x;
+        side[2 * q + 1] = (double)v.y;
+      }
+    } else {
+      top[0] = (double)C[(size_t)(dst * D + 0) * Nc + c];
+      top[1] = (double)C[(size_t)(dst * D + 1) * Nc + c];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) side[q] = (double)C[(size_t)(dst * D + 2 + q) * Nc + c];
+    }
   };
   auto nbrs = [&](size_t c, double(&zn)[8]) {
 #pragma unroll
@@ -125,15 +144,21 @@ __global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const
       const int k = lev(l);
       const size_t c = (size_t)k * ncol + col;
       double ru = r[0 * Nc + c], rd = r[1 * Nc + c];
-      if (gs && !l1d[k]) {
+      if constexpr (GS) {
+        const bool one = l1d[k] != 0;
         const int id = IDX ? cidx[c] : 0;
-        double zn[8];
+        double zn[8], t0[2], t1[2], c0[8], c1[8];
         nbrs(c, zn);
+        row(c, id, 0, t0, c0);
+        row(c, id, 1, t1, c1);
+        double gu = 0.0, gd = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          ru += coef(c, id, 0, 2 + q) * zn[q];
-          rd += coef(c, id, 1, 2 + q) * zn[q];
+          gu += c0[q] * zn[q];
+          gd += c1[q] * zn[q];
         }
+        ru += one ? 0.0 : gu;  // (a select, not a product: a 1-D layer's block may hold anything)
+        rd += one ? 0.0 : gd;
       }
       const double E = rec[0 * Nc + c], F = rec[1 * Nc + c];
       Ek[l] = E;
@@ -208,19 +233,19 @@ __global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const
       z[1 * Nc + c] = Vn;
     }
     const bool one = l1d[k] != 0;
-    const int id = IDX && !one ? cidx[c] : 0;
-    double zn[8];
-    if (gs && !one) nbrs(c, zn);
+    const int id = IDX ? cidx[c] : 0;
+    double zn[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if constexpr (GS) nbrs(c, zn);
 #pragma unroll
     for (int d = 2; d < D; ++d) {
-      double acc = r[(size_t)d * Nc + c];
-      if (!one) {
-        acc += coef(c, id, d, 0) * Un + coef(c, id, d, 1) * V;
-        if (gs) {
+      double tp[2], sd[8];
+      row(c, id, d, tp, sd);
+      double acc = tp[0] * Un + tp[1] * V;
+      if constexpr (GS) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) acc += coef(c, id, d, 2 + q) * zn[q];
-        }
+        for (int q = 0; q < 8; ++q) acc += sd[q] * zn[q];
       }
+      acc = r[(size_t)d * Nc + c] + (one ? 0.0 : acc);
       if (live) z[(size_t)d * Nc + c] = acc;
     }
     if (k == Nz - 1 && live) zt[(size_t)0 * ncol + col] = Un;  // U_Nz = albedo V_Nz + ru_Nz: the surface row
@@ -258,12 +283,18 @@ static int pcx_apply_t(tsx_solver *s, const CT *C, bool idx, const double *v, do
   const int P = s->pc_sweeps + 1;
 #define TSX_PCX_GO(L)                                                                                                                    \
   do {                                                                                                                                   \
-    if (idx)                                                                                                                             \
-      hipLaunchKernelGGL((tsx_k_pcx_rb<CT, L, true>), dim3(nb), dim3(PCX_CW *PCX_NSEG), 0, s->stream, g, C, cidx, (const double *)s->pcx_rec, \
-                         s->l1d, v, z, (const double *)z, done, pass & 1, pass > 0 ? 1 : 0);                                              \
+    if (idx && pass > 0)                                                                                                                 \
+      hipLaunchKernelGGL((tsx_k_pcx_rb<CT, L, true, true>), dim3(nb), dim3(PCX_CW *PCX_NSEG), 0, s->stream, g, C, cidx,                   \
+                         (const double *)s->pcx_rec, s->l1d, v, z, (const double *)z, done, pass & 1);                                    \
+    else if (idx)                                                                                                                        \
+      hipLaunchKernelGGL((tsx_k_pcx_rb<CT, L, true, false>), dim3(nb), dim3(PCX_CW *PCX_NSEG), 0, s->stream, g, C, cidx,                  \
+                         (const double *)s->pcx_rec, s->l1d, v, z, (const double *)z, done, pass & 1);                                    \
+    else if (pass > 0)                                                                                                                   \
+      hipLaunchKernelGGL((tsx_k_pcx_rb<CT, L, false, true>), dim3(nb), dim3(PCX_CW *PCX_NSEG), 0, s->stream, g, C, cidx,                  \
+                         (const double *)s->pcx_rec, s->l1d, v, z, (const double *)z, done, pass & 1);                                    \
     else                                                                                                                                 \
-      hipLaunchKernelGGL((tsx_k_pcx_rb<CT, L, false>), dim3(nb), dim3(PCX_CW *PCX_NSEG), 0, s->stream, g, C, cidx, (const double *)s->pcx_rec, \
-                         s->l1d, v, z, (const double *)z, done, pass & 1, pass > 0 ? 1 : 0);                                              \
+      hipLaunchKernelGGL((tsx_k_pcx_rb<CT, L, false, false>), dim3(nb), dim3(PCX_CW *PCX_NSEG), 0, s->stream, g, C, cidx,                 \
+                         (const double *)s->pcx_rec, s->l1d, v, z, (const double *)z, done, pass & 1);                                    \
   } while (0)
   for (int pass = 0; pass < P; ++pass) {
     if (g.Nz <= 4 * PCX_NSEG) TSX_PCX_GO(4);

@@ -308,6 +308,18 @@ extern "C" int tsx_comm_peer_attach(tsx_solver *s, const void *blobs) {
       p->opened[r] = true;
     }
   }
+  // Ordering around the mailbox flags.  The light ordering (tsx_peer_dev.hpp: uncached mailboxes, s_waitcnt + relaxed stores) has
+  // only ever run between processes sharing ONE device; the first contact across devices (xGMI, another GPU's HBM) starts with the
+  // textbook full system-scope fences.  TSX_PEER_FENCES=0 relaxes, =1 forces; tsx_comm_peer_set_fences overrides either.
+  if (!getenv("TSX_PEER_FENCES")) {
+    bool cross = false;
+    for (int r = 0; r < R; ++r) {
+      PeerBlob b;
+      memcpy(&b, (const char *)blobs + (size_t)r * TSX_PEER_BLOB_BYTES, sizeof(b));
+      cross = cross || b.device != s->device;
+    }
+    p->heavy = cross;
+  }
   p->attached = true;
   s->pcg_key = -1;  // decisions agreed over the previous transport are agreed again (tsx_pc_global_agree)
   return TSX_OK;

@@ -609,8 +609,9 @@ def _flow_faces_worker(rank, world, port, Nx, Ny, Nz, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,Nx,Ny,Nz", [(2, 128, 32, 16), (4, 128, 64, 12), (8, 128, 128, 8)])
-def test_flow_kernel_with_rank_faces_equals_launch_per_pass(gpu, world, Nx, Ny, Nz):
+@pytest.mark.parametrize("world,Nx,Ny,Nz,body", [(2, 128, 32, 16, "auto"), (4, 128, 64, 12, "auto"), (8, 128, 128, 8, "auto"),
+                                                 (4, 128, 64, 12, "lean")])
+def test_flow_kernel_with_rank_faces_equals_launch_per_pass(gpu, monkeypatch, world, Nx, Ny, Nz, body):
     """Round 5: on several ranks the flow kernel (the intermediate passes of an application of M^-1 in one launch) keeps the
     exchange of the boundary records inside the launch: a face tile stores its records into the neighbour rank's mailbox slot and,
     after its drain, the tags of its row / columns; the neighbour's tile of the next pass polls those tags and reads the records
@@ -618,6 +619,8 @@ def test_flow_kernel_with_rank_faces_equals_launch_per_pass(gpu, world, Nx, Ny, 
     (tsx_k_pcs_flow FPEER, src/pprts_explicit.F90:769-843's exchange pattern).  Same message numbering, slots and arithmetic as a
     launch per pass (TSX_FLOW_PEER=0): solutions and residual histories must be bit-identical on every rank -- rank processes
     sharing cuda:0, 2 x 1, 2 x 2 and 2 x 4 grids (W and E the same peer on the first)."""
+    if body == "lean":   # round 6: the rank faces inside the lean body (shards whose passes are not resident at once), forced here
+        monkeypatch.setenv("TSX_FLOW_FAT", "0")
     ret = _spawn(_flow_faces_worker, world, (Nx, Ny, Nz))
     for rank, (same, used1, used0, r5, n5, r9, n9) in ret.items():
         assert used1 and not used0, (rank, used1, used0)   # the flow kernel ran with its faces / did not
