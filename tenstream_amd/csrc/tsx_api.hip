@@ -293,7 +293,7 @@ extern "C" int tsx_destroy(tsx_solver *s) {
                   s->vv,    s->vs,    s->vt,    s->stage_a, s->stage_b, s->sendW, s->sendE, s->sendS, s->sendN, s->recvW,
                   s->recvE, s->recvS, s->recvN, s->partials, s->scal, s->vw, s->pc_tmp, s->lut_diff.d_axes, s->lut_diff.d_table,
                   s->lut_T.d_axes, s->lut_T.d_table, s->lut_S.d_axes, s->lut_S.d_table, s->dirT, s->dirS, s->d_kabs, s->d_ksca,
-                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->bsrfc, s->edir_a, s->edir_b, s->dsc, s->abso, s->cell_samp, s->dd_colsum, s->pcx_rec, s->flow_state, s->flow_prog, s->flow_zb8, s->flow_pr_dev};
+                  s->d_g, s->d_dz, s->a13, s->a23, s->a33, s->planck, s->bsrfc, s->edir_a, s->edir_b, s->dsc, s->abso, s->cell_samp, s->dd_colsum, s->pcx_rec, s->pcx_vz, s->flow_state, s->flow_prog, s->flow_zb8, s->flow_pr_dev};
   for (void *p : ptrs)
     if (p) (void)tsx_dev_free(p);
   if (s->vph && s->vph != s->vp) (void)tsx_dev_free(s->vph);

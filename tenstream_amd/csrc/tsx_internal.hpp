@@ -267,6 +267,7 @@ struct tsx_solver {
   int overlap_env;           // TSX_OVERLAP: -1 unset, else 0 / 1 (tsx_overlap, tsx_host.hpp: interior + frame launches around an exchange)
   double *pcx_rec = nullptr;  // [7][Nc] fp64 column recurrences of the exact scan preconditioner (tsx_pcx.hip), natural cell order
   bool pcx_valid = false;     // ... belong to the current coefficient set
+  double *pcx_vz = nullptr;   // [2][N]: colour-split copies of the right-hand side and the iterate of that path
   TsxLog *log = nullptr;     // the reference's log events for this path + roctx ranges (tsx_log_enable; off: null)
 };
 

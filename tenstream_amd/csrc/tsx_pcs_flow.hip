@@ -61,15 +61,17 @@ bool tsx_pcs_flow_ok(tsx_solver *s, int lseg, int nseg, int cw, bool faces) {
   if (faces) {
     if (getenv("TSX_FLOW_PEER") && atoi(getenv("TSX_FLOW_PEER")) == 0) return false;  // A/B: the passes as launches on several ranks
     if (g.ym % 2 != 0) return false;
-    // round 5: only where a pass's tiles are resident at once (the fat body: two waves per SIMD) -- larger shards were measured
-    // slower with the fat body than with a launch per pass: 256 x 128 columns 8.85 -> 9.02 ms per solve, 128 x 256 8.68 -> 9.08
-    // (profiles/r05/flow_peer_ab_large.txt).  Round 6: beyond that the LEAN body carries the faces (four waves per SIMD, sends
-    // after the scan), up to the size where the flow kernel stops paying on one rank (two tiles per resident workgroup);
-    // TSX_FLOW_PEER_LEAN=0 keeps round 5's bound (A/B), TSX_FLOW_PEER_ANY=1 lifts every bound
+    // only where a pass's tiles are resident at once (the fat body: two waves per SIMD).  Larger shards were measured slower with the
+    // faces inside the launch than with a launch per pass, twice: round 5 with the fat body (256 x 128 columns 8.85 -> 9.02 ms per
+    // solve, 128 x 256 8.68 -> 9.08, profiles/r05/flow_peer_ab_large.txt), round 6 with the LEAN body carrying the faces (four waves
+    // per SIMD, the face columns send after the scan; bit-identical, tests force it with TSX_FLOW_FAT=0): 256 x 128 8.76 -> 10.58,
+    // 128 x 256 8.58 -> 10.57, 256 x 256 15.98 -> 18.17 ms (profiles/r06/flow_peer_lean_ab.txt) -- a workgroup there runs ~25 items
+    // one after the other, and every face item carries the drain of its uncached stores and the tag round trip on its own back.
+    // TSX_FLOW_PEER_LEAN=1 switches the lean variant on up to two tiles per resident workgroup, TSX_FLOW_PEER_ANY=1 lifts every bound
     const long long nt = (long long)(h / cw) * g.ym;
     if (getenv("TSX_FLOW_PEER_ANY") && atoi(getenv("TSX_FLOW_PEER_ANY"))) return true;
     if (nt <= flow_capacity(s, cw, true)) return true;
-    if (getenv("TSX_FLOW_PEER_LEAN") && atoi(getenv("TSX_FLOW_PEER_LEAN")) == 0) return false;
+    if (!(getenv("TSX_FLOW_PEER_LEAN") && atoi(getenv("TSX_FLOW_PEER_LEAN")) != 0)) return false;
     return nt <= 2ll * flow_capacity(s, cw, false);
   }
   // beyond about two tiles per resident workgroup a pass is bound by its instruction stream and the launch boundary costs nothing

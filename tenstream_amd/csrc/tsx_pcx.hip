@@ -15,6 +15,10 @@
 //     upward    B_k     = (ru_k + F_k rd_k) + E_k B_{k+1}       B_Nz = ru_Nz        U_k = A_k V_k + B_k
 //     downward  V_{k+1} = (G_k rd_k + H_k B_{k+1}) + GT_k V_k   V_0  = rd_TOA
 //     E = Tuu G, F = Tuu A_{k+1} G, G = 1 / (1 - Rdu A_{k+1}), H = G Rdu, GT = G Tdd, A_k = Rud + Tuu A_{k+1} GT, A_Nz = albedo
+// The passes work on colour-split copies of v and z (within a row the xm / 2 columns of colour 0, then colour 1: tsx_split_pos) and on
+// recurrence planes in the same order, so that a pass over one colour reads and writes contiguous memory -- in the Krylov vectors'
+// natural order the lanes sit on every other column, every access touches twice the cache lines it uses, and the first version of
+// this kernel was bound by exactly that (0.31 ms per pass, profiles/r06/exact_pc_bench.txt); two permuting copies per application.
 // 3_10 only (8_16 keeps the zebra rows on this path).
 #include "tsx_host.hpp"
 
@@ -31,9 +35,11 @@ __global__ __launch_bounds__(64) void tsx_k_pcx_pack_col(TsxGeo g, const CT *__r
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col >= g.ncol) return;
   const size_t Nc = (size_t)g.Nc;
+  const size_t sp = (size_t)tsx_split_col(col % g.xm, col / g.xm, g.xm);  // the records live in colour-split order
   double A = albedo[col];
   for (int k = g.Nz - 1; k >= 0; --k) {
     const size_t c = (size_t)k * g.ncol + col;
+    const size_t o = (size_t)k * g.ncol + sp;
     double tuu, rud, rdu, tdd;
     if (l1d[k]) {
       tuu = tdd = a11[c];
@@ -53,18 +59,29 @@ __global__ __launch_bounds__(64) void tsx_k_pcx_pack_col(TsxGeo g, const CT *__r
     const double G = 1.0 / (1.0 - rdu * A);
     const double GT = G * tdd;
     const double Ao = rud + tuu * A * GT;
-    rec[0 * Nc + c] = tuu * G;
-    rec[1 * Nc + c] = tuu * A * G;
-    rec[2 * Nc + c] = G;
-    rec[3 * Nc + c] = G * rdu;
-    rec[4 * Nc + c] = GT;
-    rec[5 * Nc + c] = A;
-    rec[6 * Nc + c] = Ao;
+    rec[0 * Nc + o] = tuu * G;
+    rec[1 * Nc + o] = tuu * A * G;
+    rec[2 * Nc + o] = G;
+    rec[3 * Nc + o] = G * rdu;
+    rec[4 * Nc + o] = GT;
+    rec[5 * Nc + o] = A;
+    rec[6 * Nc + o] = Ao;
     A = Ao;
   }
 }
 
-// one half-grid pass: the columns of colour rbc.  gs: the other colour's side streams (from z) enter the right-hand side
+// o[split position] = a[natural position] (to_split) or the reverse, over the N unknowns (body planes and tail rows)
+__global__ __launch_bounds__(TSX_BLOCK) void tsx_k_pcx_permute(TsxGeo g, int to_split, const double *__restrict__ a, double *__restrict__ o,
+                                                               const int *__restrict__ done) {
+  if (done && *done) return;
+  for (long long q = (long long)blockIdx.x * TSX_BLOCK + threadIdx.x; q < g.N; q += (long long)gridDim.x * TSX_BLOCK) {
+    const long long p = tsx_split_pos(q, g);
+    if (to_split) o[p] = a[q];
+    else o[q] = a[p];
+  }
+}
+
+// one half-grid pass: the columns of colour rbc.  r, z, zo, rec: colour-split order; C (dense planes) and cidx: natural order.  gs: the other colour's side streams (from z) enter the right-hand side
 template <typename CT, int LSEG, bool IDX, bool GS>
 __global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const CT *__restrict__ C, const int *__restrict__ cidx,
                                                                  const double *__restrict__ rec, const uint8_t *__restrict__ l1d,
@@ -84,13 +101,18 @@ __global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const
   const bool live = t < ym * h;
   if (!live) t = ym * h - 1;
   const int jrow = t / h, qh = t - jrow * h;
-  const int i = 2 * qh + ((jrow + rbc) & 1);
-  const int col = jrow * xm + i;
+  const int par = (jrow + rbc) & 1;
+  const int i = 2 * qh + par;
+  const int coln = jrow * xm + i;            // natural column (dense coefficient planes, per-cell index)
+  const int col = jrow * xm + rbc * h + qh;  // colour-split column (r, z, rec)
   // the neighbour a side source stream comes from (tsx_k_spmv_w's gather): inward x streams from the west, the others from the
-  // east; inward y streams from the south, the others from the north.  0 = no neighbour (rank face, or gs off)
-  long long offW = i > 0 ? -1 : (g.wrap_x ? xm - 1 : 0), offE = i + 1 < xm ? 1 : (g.wrap_x ? 1 - xm : 0);
-  long long offS = jrow > 0 ? -(long long)xm : (g.wrap_y ? (long long)(ym - 1) * xm : 0);
-  long long offN = jrow + 1 < ym ? (long long)xm : (g.wrap_y ? -(long long)(ym - 1) * xm : 0);
+  // east; inward y streams from the south, the others from the north -- all of the other colour, i.e. in the other half of a row
+  // in split order (as tsx_pcs_rb_body addresses them).  0 = no neighbour (rank face, or gs off)
+  const int oc = (1 - 2 * rbc) * h;
+  const int jn = jrow + 1 < ym ? jrow + 1 : (g.wrap_y ? 0 : -1), js = jrow > 0 ? jrow - 1 : (g.wrap_y ? ym - 1 : -1);
+  const int qw = par ? qh : (qh > 0 ? qh - 1 : (g.wrap_x ? h - 1 : -1)), qe = par ? (qh + 1 < h ? qh + 1 : (g.wrap_x ? 0 : -1)) : qh;
+  long long offN = jn >= 0 ? (long long)(jn - jrow) * xm + oc : 0, offS = js >= 0 ? (long long)(js - jrow) * xm + oc : 0;
+  long long offE = qe >= 0 ? (long long)oc + (qe - qh) : 0, offW = qw >= 0 ? (long long)oc + (qw - qh) : 0;
   if (g.pc_tile_x > 0) {
     if ((i + 1) % g.pc_tile_x == 0) offE = 0;
     if (i % g.pc_tile_x == 0) offW = 0;
@@ -146,11 +168,12 @@ __global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const
       double ru = r[0 * Nc + c], rd = r[1 * Nc + c];
       if constexpr (GS) {
         const bool one = l1d[k] != 0;
-        const int id = IDX ? cidx[c] : 0;
+        const size_t cn = (size_t)k * ncol + coln;
+        const int id = IDX ? cidx[cn] : 0;
         double zn[8], t0[2], t1[2], c0[8], c1[8];
         nbrs(c, zn);
-        row(c, id, 0, t0, c0);
-        row(c, id, 1, t1, c1);
+        row(cn, id, 0, t0, c0);
+        row(cn, id, 1, t1, c1);
         double gu = 0.0, gd = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -233,13 +256,14 @@ __global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const
       z[1 * Nc + c] = Vn;
     }
     const bool one = l1d[k] != 0;
-    const int id = IDX ? cidx[c] : 0;
+    const size_t cn = (size_t)k * ncol + coln;
+    const int id = IDX ? cidx[cn] : 0;
     double zn[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if constexpr (GS) nbrs(c, zn);
 #pragma unroll
     for (int d = 2; d < D; ++d) {
       double tp[2], sd[8];
-      row(c, id, d, tp, sd);
+      row(cn, id, d, tp, sd);
       double acc = tp[0] * Un + tp[1] * V;
       if constexpr (GS) {
 #pragma unroll
@@ -281,6 +305,14 @@ static int pcx_apply_t(tsx_solver *s, const CT *C, bool idx, const double *v, do
   }
   const int nthr = g.ym * (g.xm / 2), nb = (nthr + PCX_CW - 1) / PCX_CW;
   const int P = s->pc_sweeps + 1;
+  // colour-split copies of the right-hand side and the iterate (one allocation: [v | z])
+  if (!s->pcx_vz) HIPCHK(tsx_dev_malloc((void **)&s->pcx_vz, sizeof(double) * 2 * (size_t)g.N));
+  double *vs = s->pcx_vz, *zs = s->pcx_vz + (size_t)g.N;
+  hipLaunchKernelGGL(tsx_k_pcx_permute, dim3(grid_for(g.N, 8192)), dim3(TSX_BLOCK), 0, s->stream, g, 1, v, vs, done);
+  const double *vin = v;
+  double *zout = z;
+  v = vs;
+  z = zs;
 #define TSX_PCX_GO(L)                                                                                                                    \
   do {                                                                                                                                   \
     if (idx && pass > 0)                                                                                                                 \
@@ -302,6 +334,8 @@ static int pcx_apply_t(tsx_solver *s, const CT *C, bool idx, const double *v, do
     else TSX_PCX_GO(16);
   }
 #undef TSX_PCX_GO
+  (void)vin;
+  hipLaunchKernelGGL(tsx_k_pcx_permute, dim3(grid_for(g.N, 8192)), dim3(TSX_BLOCK), 0, s->stream, g, 0, (const double *)zs, zout, done);
   HIPCHK(hipGetLastError());
   return TSX_OK;
 }

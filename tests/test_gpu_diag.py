@@ -63,3 +63,39 @@ def test_device_code_equals_the_file(gpu):
     bad = code_verify.verify(P.lib, info=info)
     assert bad == [], bad[:5]
     P.close()
+
+
+def test_pool_takes_driver_memory_once_and_reuses_it(gpu, monkeypatch):
+    """tsx_pool.hip: solvers come and go, the driver is asked once -- the second and third solver of the same size run in the
+    first one's memory (no new slab), the pool has spent time in quarantine for what it did take, and never saw a fresh slab's
+    pattern damaged; TSX_POOL=0 sends allocations straight to hipMalloc (the A/B switch of profiles/r06/DEFECT.md)."""
+    import ctypes
+
+    def stats():
+        st = (ctypes.c_int64 * 8)()
+        assert gpu.tsx_pool_stats(-1, st) == 0
+        return [int(v) for v in st]
+
+    P, fields = _solver(16, 12, 10)
+    P.set_optical_properties(0.15, *fields)
+    assert P.solve(1000.0).reason in (2, 3)
+    P.close()
+    s1 = stats()
+    assert s1[0] >= 1 and s1[1] >= s1[2] and s1[7] > 0 and s1[4] == 0, s1
+    for _ in range(2):
+        P, fields = _solver(16, 12, 10)
+        P.set_optical_properties(0.15, *fields)
+        assert P.solve(1000.0).reason in (2, 3)
+        edn = P.get_result()[0]
+        P.close()
+    s2 = stats()
+    assert s2[0] == s1[0] and s2[1] == s1[1] and s2[2] <= s1[2], (s1, s2)   # same slabs, everything handed back
+    monkeypatch.setenv("TSX_POOL", "0")
+    P, fields = _solver(16, 12, 10)
+    P.set_optical_properties(0.15, *fields)
+    assert P.solve(1000.0).reason in (2, 3)
+    edn0 = P.get_result()[0]
+    P.close()
+    s3 = stats()
+    assert s3[0] == s2[0] and s3[2] <= s2[2], (s2, s3)
+    assert np.array_equal(np.asarray(edn), np.asarray(edn0))

@@ -458,13 +458,14 @@ def test_sharded_pipeline_equals_one_rank_pipeline(gpu, world, Nx, Ny, phi0, the
     """set_optical_properties -> direct sweep (face exchange per sweep) -> setup_b -> solve -> flux divergence on 2/4
     ranks against the same g-point on one periodic rank; host-staged and device-resident (peer) transport.
 
-    KNOWN, OPEN (rounds 4 and 5; profiles/NEGATIVE_RESULTS.md "a rare deviation in the four-process pipeline test"): the
-    parameter set (4 ranks, 12 x 10, one thick 1-D top layer) deviates in 1-2 % of its runs when the four rank PROCESSES are fresh
-    -- absorption off while the fluxes agree to 1e-10, a NaN residual, once an illegal-instruction abort of one rank's queue --
-    with either transport and with the round-4 library; never in-process (scripts/stress_sharded.py: 2 000 solves and 800 fresh
-    solver instances inside four long-lived processes), never with the other parameter sets (0 of 110).  The test stays strict
-    and single-attempt; on a deviation the workers solve once more and the message (and TSX_TEST_DIAG_DIR) says which
-    decomposition reproduces itself."""
+    History (profiles/r06/DEFECT.md): the parameter set (4 ranks, 12 x 10, one thick 1-D top layer) deviated in 1-2 % of its fresh
+    four-process runs in rounds 4 and 5.  Round 6 caught the event with scripts/fresh_loop.py: the contents of device blocks that a
+    rank process had been handed by hipMalloc -- and had filled -- a few hundred microseconds earlier (the block-sharing build's
+    scratch, the representatives dd_ent_cell) read back as zeros; the library's device code was intact, a relaunch gave the same.
+    The library now takes its device memory from a pool of driver allocations that are quarantined before first use and never
+    handed back (tsx_pool.hip): no driver allocation lies on a solver's path after tsx_create's.  The test stays strict and
+    single-attempt; on a deviation the workers solve once more and the message (and TSX_TEST_DIAG_DIR) says which decomposition
+    reproduces itself."""
     ret = _spawn(_pipeline_worker, world, (Nx, Ny, 8, phi0, theta0, tall_top, transport))
     for rank, errs in ret.items():
         reason, _, e, diag = errs["solar"]
