@@ -16,7 +16,7 @@ import subprocess
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "r05", "scale_projection.json")
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "r06", "scale_projection.json")
 HOP_US = 1.5
 PASSES = 28
 

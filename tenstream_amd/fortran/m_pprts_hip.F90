@@ -28,25 +28,32 @@ module m_pprts_hip
 
   !> the seam's VECTORS in either real kind: TenStream's ireals is real32 or real64 by build (src/data_parameters.F90), so
   !> `call hip_ediff(h, solver%b, solution%ediff, ...)` resolves to the matching specific whatever the build chose.
-  !> Only the state vectors (b, ediff, edir, x, y) are kind-generic.  Scalars and fields -- edirTOA, rtol / atol, albedo, planck,
-  !> planck_srfc, kabs, dz, a11 / a12 / a13 / a23 / a33 and the coefficient arrays dir2dir / dir2diff / diff2diff -- are
-  !> real(c_double) in every specific: a real32 build passes `real(x, c_double)` copies of them (they are small next to the
-  !> vectors, or -- the coefficient arrays -- can be handed over as real32 through the C entry points' coeff_kind = 4, which
-  !> tsx_diff_set_coeffs / tsx_dir_set_coeffs take; the reference declares all of them real(ireals), src/pprts_base.F90:112-119, 252)
+  !> Three specifics per entry: everything real64 (`_r64`); real32 vectors with real64 scalars and fields (`_r32`, rounds 4-5: a
+  !> caller that converts its small arrays itself); and, round 6, EVERYTHING real32 (`_k4`): a TenStream built with ireals = real32
+  !> declares edirTOA, rtol / atol, albedo, planck, planck_srfc, kabs, dz, a11 / a12 / a13 / a23 / a33 and the coefficient arrays
+  !> dir2dir / dir2diff / diff2diff real(ireals) too (src/pprts_base.F90:112-119, 252) and calls with them as they are -- the
+  !> coefficient arrays cross as real32 (coeff_kind = 4, lossless: the LUT delivers real32), the small fields and scalars are
+  !> widened in here.
   interface hip_ediff
-    module procedure hip_ediff_r64, hip_ediff_r32
+    module procedure hip_ediff_r64, hip_ediff_r32, hip_ediff_k4
   end interface
   interface hip_diff_apply
     module procedure hip_diff_apply_r64, hip_diff_apply_r32
   end interface
   interface hip_edir
-    module procedure hip_edir_r64, hip_edir_r32
+    module procedure hip_edir_r64, hip_edir_r32, hip_edir_k4
   end interface
   interface hip_setup_b_solar
-    module procedure hip_setup_b_solar_r64, hip_setup_b_solar_r32
+    module procedure hip_setup_b_solar_r64, hip_setup_b_solar_r32, hip_setup_b_solar_k4
   end interface
   interface hip_setup_b_thermal
-    module procedure hip_setup_b_thermal_r64, hip_setup_b_thermal_r32
+    module procedure hip_setup_b_thermal_r64, hip_setup_b_thermal_r32, hip_setup_b_thermal_k4
+  end interface
+  interface hip_diff_set_coeffs
+    module procedure hip_diff_set_coeffs_r64, hip_diff_set_coeffs_k4
+  end interface
+  interface hip_dir_set_coeffs
+    module procedure hip_dir_set_coeffs_r64, hip_dir_set_coeffs_k4
   end interface
 
   integer(c_int), parameter :: TSX_HOST = 0, TSX_DEVICE = 1
@@ -375,7 +382,7 @@ contains
 
   !> replaces set_diff_coeff (src/pprts.F90:5511-5796): hand over solver%diff2diff and the 1-D layer data.
   !> l1d is passed as 0/1 bytes (atm%l1d(atmk(atm,k)) for k = zs..ze-1).
-  subroutine hip_diff_set_coeffs(handle, diff2diff, l1d, a11, a12, albedo, ierr)
+  subroutine hip_diff_set_coeffs_r64(handle, diff2diff, l1d, a11, a12, albedo, ierr)
     type(c_ptr), intent(in) :: handle
     real(c_double), target, contiguous, intent(in) :: diff2diff(:, :, :, :) ! (D*D, zs:ze-1, xs:xe, ys:ye)
     integer(c_int8_t), target, contiguous, intent(in) :: l1d(:)              ! (zs:ze-1)
@@ -467,7 +474,7 @@ contains
 
   !> replaces set_dir_coeff (src/pprts.F90:4493-4630): hand over solver%dir2dir / solver%dir2diff (c_null_ptr-able through the
   !> optional) and the 1-D layer data atm%a33 / a13 / a23.  set_angles (tsx_pprts_set_angles) comes first.
-  subroutine hip_dir_set_coeffs(handle, dir2dir, l1d, dx, dy, ierr, dir2diff, a33, a13, a23)
+  subroutine hip_dir_set_coeffs_r64(handle, dir2dir, l1d, dx, dy, ierr, dir2diff, a33, a13, a23)
     type(c_ptr), intent(in) :: handle
     real(c_double), target, contiguous, intent(in) :: dir2dir(:, :, :, :)             ! (S*S, zs:ze-1, xs:xe, ys:ye)
     integer(c_int8_t), target, contiguous, intent(in) :: l1d(:)
@@ -560,6 +567,104 @@ contains
     ps = c_null_ptr
     if (present(planck_srfc)) ps = c_loc(planck_srfc)
     ierr = tsx_setup_b_thermal(handle, c_loc(planck), ps, c_loc(kabs), c_loc(dz), dx, dy, c_loc(b), 4_c_int, TSX_HOST)
+  end subroutine
+
+  ! ---- ireals = real32 throughout (round 6): the same entries with every real argument real(c_float)
+  subroutine hip_diff_set_coeffs_k4(handle, diff2diff, l1d, a11, a12, albedo, ierr)
+    type(c_ptr), intent(in) :: handle
+    real(c_float), target, contiguous, intent(in) :: diff2diff(:, :, :, :)
+    integer(c_int8_t), target, contiguous, intent(in) :: l1d(:)
+    real(c_float), contiguous, intent(in) :: a11(:, :, :), a12(:, :, :)
+    real(c_float), contiguous, intent(in) :: albedo(:, :)
+    integer(c_int), intent(out) :: ierr
+    real(c_double), allocatable, target :: d11(:, :, :), d12(:, :, :), dalb(:, :)
+    allocate (d11, source=real(a11, c_double))
+    allocate (d12, source=real(a12, c_double))
+    allocate (dalb, source=real(albedo, c_double))
+    ierr = tsx_diff_set_coeffs(handle, c_loc(diff2diff), 4_c_int, c_loc(l1d), c_loc(d11), c_loc(d12), c_loc(dalb), TSX_HOST)
+  end subroutine
+  subroutine hip_dir_set_coeffs_k4(handle, dir2dir, l1d, dx, dy, ierr, dir2diff, a33, a13, a23)
+    type(c_ptr), intent(in) :: handle
+    real(c_float), target, contiguous, intent(in) :: dir2dir(:, :, :, :)
+    integer(c_int8_t), target, contiguous, intent(in) :: l1d(:)
+    real(c_float), intent(in) :: dx, dy
+    integer(c_int), intent(out) :: ierr
+    real(c_float), target, contiguous, intent(in), optional :: dir2diff(:, :, :, :)
+    real(c_float), contiguous, intent(in), optional :: a33(:, :, :), a13(:, :, :), a23(:, :, :)
+    real(c_double), allocatable, target :: d33(:, :, :), d13(:, :, :), d23(:, :, :)
+    type(c_ptr) :: p_sd, p33, p13, p23
+    p_sd = c_null_ptr; p33 = c_null_ptr; p13 = c_null_ptr; p23 = c_null_ptr
+    if (present(dir2diff)) p_sd = c_loc(dir2diff)
+    if (present(a33)) then
+      allocate (d33, source=real(a33, c_double))
+      p33 = c_loc(d33)
+    end if
+    if (present(a13)) then
+      allocate (d13, source=real(a13, c_double))
+      p13 = c_loc(d13)
+    end if
+    if (present(a23)) then
+      allocate (d23, source=real(a23, c_double))
+      p23 = c_loc(d23)
+    end if
+    ierr = tsx_dir_set_coeffs(handle, c_loc(dir2dir), p_sd, 4_c_int, c_loc(l1d), p33, p13, p23, real(dx, c_double), real(dy, c_double), &
+      & TSX_HOST)
+  end subroutine
+  subroutine hip_ediff_k4(handle, vb, vediff, rtol, atol, maxit, pc, niter, res_hist, reason, ierr)
+    type(c_ptr), intent(in) :: handle
+    real(c_float), target, contiguous, intent(in) :: vb(:, :, :, :)
+    real(c_float), target, contiguous, intent(inout) :: vediff(:, :, :, :)
+    real(c_float), intent(in) :: rtol, atol
+    integer(c_int), intent(in) :: maxit, pc
+    integer(c_int), intent(out) :: niter
+    real(c_float), intent(inout) :: res_hist(:)
+    integer(c_int), intent(out) :: reason
+    integer(c_int), intent(out) :: ierr
+    real(c_double) :: h(size(res_hist))
+    h = real(res_hist, c_double)
+    call hip_ediff_r32(handle, vb, vediff, real(rtol, c_double), real(atol, c_double), maxit, pc, niter, h, reason, ierr)
+    res_hist = real(h, c_float)
+  end subroutine
+  subroutine hip_edir_k4(handle, edirTOA, vedir, rtol, atol, maxit, niter, residual, lconverged, ierr)
+    type(c_ptr), intent(in) :: handle
+    real(c_float), intent(in) :: edirTOA
+    real(c_float), target, contiguous, intent(inout) :: vedir(:, :, :, :)
+    real(c_float), intent(in) :: rtol, atol
+    integer(c_int), intent(in) :: maxit
+    integer(c_int), intent(out) :: niter
+    real(c_float), intent(out) :: residual
+    logical, intent(out) :: lconverged
+    integer(c_int), intent(out) :: ierr
+    real(c_double) :: r8
+    call hip_edir_r32(handle, real(edirTOA, c_double), vedir, real(rtol, c_double), real(atol, c_double), maxit, niter, r8, lconverged, ierr)
+    residual = real(r8, c_float)
+  end subroutine
+  subroutine hip_setup_b_solar_k4(handle, albedo, b, ierr)
+    type(c_ptr), intent(in) :: handle
+    real(c_float), contiguous, intent(in) :: albedo(:, :)
+    real(c_float), target, contiguous, intent(inout) :: b(:, :, :, :)
+    integer(c_int), intent(out) :: ierr
+    real(c_double), allocatable, target :: dalb(:, :)
+    allocate (dalb, source=real(albedo, c_double))
+    call hip_setup_b_solar_r32(handle, dalb, b, ierr)
+  end subroutine
+  subroutine hip_setup_b_thermal_k4(handle, planck, kabs, dz, dx, dy, b, ierr, planck_srfc)
+    type(c_ptr), intent(in) :: handle
+    real(c_float), contiguous, intent(in) :: planck(:, :, :), kabs(:, :, :), dz(:, :, :)
+    real(c_float), intent(in) :: dx, dy
+    real(c_float), target, contiguous, intent(inout) :: b(:, :, :, :)
+    integer(c_int), intent(out) :: ierr
+    real(c_float), contiguous, intent(in), optional :: planck_srfc(:, :)
+    real(c_double), allocatable, target :: dpl(:, :, :), dka(:, :, :), ddz(:, :, :), dps(:, :)
+    allocate (dpl, source=real(planck, c_double))
+    allocate (dka, source=real(kabs, c_double))
+    allocate (ddz, source=real(dz, c_double))
+    if (present(planck_srfc)) then
+      allocate (dps, source=real(planck_srfc, c_double))
+      call hip_setup_b_thermal_r32(handle, dpl, dka, ddz, real(dx, c_double), real(dy, c_double), b, ierr, dps)
+    else
+      call hip_setup_b_thermal_r32(handle, dpl, dka, ddz, real(dx, c_double), real(dy, c_double), b, ierr)
+    end if
   end subroutine
 
   !> text of the last library error on this thread

@@ -97,6 +97,7 @@ program test_shim
   print '(a,i0,a,i0,a,es10.3,a,es10.3)', 'shim ok: iterations ', niter, ' reason ', reason, ' r0 ', hist(1), ' max|Ax-b| ', err
   if (err .gt. 1e-9_c_double .or. reason .ne. 2) stop 5
   call check_real32()
+  call check_all_real32()
   call check_direct_seam()
   call check_thermal_source()
   call check_comm_bindings()
@@ -129,6 +130,42 @@ contains
     call hip_diff_apply(h, x4, y4, ie)
     call must(ie .eq. 0 .and. maxval(abs(y4 - b4)) .le. 1e-5, 12, 'real32 hip_diff_apply')
     print '(a,i0,a,es10.3)', 'shim real32 ok: iterations ', it4, ' max|x32-x64| ', maxval(abs(real(x4, c_double) - x))
+  end subroutine
+
+  !> ireals = real32 THROUGHOUT (round 6, the `_k4` specifics): coefficients, 1-D layer data, albedo, tolerances, history and vectors
+  !> all real(c_float), as a TenStream built with real32 ireals holds them (src/pprts_base.F90:112-119, 252) -- a second solver
+  !> gets the same blocks as real32 (lossless: 0.04, 0.54 ... are rounded the same way on both sides once they are real32) and must
+  !> reproduce the real32-vector solve of the first one
+  subroutine check_all_real32()
+    type(c_ptr) :: h2
+    real(c_float), allocatable, target :: c4(:, :, :, :), a114(:, :, :), a124(:, :, :), alb4(:, :), b4(:, :, :, :), x4(:, :, :, :), xr(:, :, :, :)
+    real(c_double), allocatable, target :: c8(:, :, :, :), a118(:, :, :), a128(:, :, :), alb8(:, :)
+    real(c_float) :: h4(100)
+    real(c_double) :: h8(100)
+    integer(c_int) :: it4, rs4, it8, rs8, ie
+    allocate (c4(D * D, Nz, Nx, Ny), a114(Nz, Nx, Ny), a124(Nz, Nx, Ny), alb4(Nx, Ny))
+    allocate (b4(D, Nz + 1, Nx, Ny), x4(D, Nz + 1, Nx, Ny), xr(D, Nz + 1, Nx, Ny))
+    c4 = real(c, c_float); a114 = real(a11, c_float); a124 = real(a12, c_float); alb4 = real(alb, c_float)
+    b4 = real(b, c_float)
+    call hip_diff_create(grid, h2, ie)
+    call must(ie .eq. 0, 60, 'second solver')
+    ! reference: the same real32-representable numbers handed over as real64, real32 vectors
+    c8 = real(c4, c_double); a118 = real(a114, c_double); a128 = real(a124, c_double); alb8 = real(alb4, c_double)
+    call hip_diff_set_coeffs(h2, c8, l1d, a118, a128, alb8, ie)
+    call must(ie .eq. 0, 61, 'real64 coefficients')
+    xr = 0; h8 = -1
+    call hip_ediff(h2, b4, xr, 1e-6_c_double, 1e-30_c_double, 1000_c_int, TSX_PC_REDBLACK, it8, h8, rs8, ie)
+    call must(ie .eq. 0 .and. rs8 .eq. 2, 62, 'reference solve')
+    ! everything real32
+    call hip_diff_set_coeffs(h2, c4, l1d, a114, a124, alb4, ie)
+    call must(ie .eq. 0, 63, 'all-real32 hip_diff_set_coeffs')
+    x4 = 0; h4 = -1
+    call hip_ediff(h2, b4, x4, 1e-6_c_float, 1e-30_c_float, 1000_c_int, TSX_PC_REDBLACK, it4, h4, rs4, ie)
+    call must(ie .eq. 0 .and. rs4 .eq. 2 .and. it4 .eq. it8, 64, 'all-real32 hip_ediff')
+    call must(all(x4 .eq. xr), 65, 'all-real32 solve equals the real64-argument solve bit for bit')
+    call must(abs(h4(1) - real(h8(1), c_float)) .le. 1e-6 * abs(h4(1)), 66, 'all-real32 residual history')
+    call hip_diff_destroy(h2, ie)
+    print '(a,i0)', 'shim all-real32 ok: iterations ', it4
   end subroutine
 
   !> the direct seam (src/pprts.F90:2698-2755): sun overhead, a homogeneous box whose cells pass 7/8 of the top stream on and

@@ -146,3 +146,22 @@ def test_f2c_over_an_mpi_communicator_runs_its_collectives_under_mpiexec(tmp_pat
     for n, nxp, nyp in ((2, 2, 1), (4, 2, 2), (3, 3, 1), (1, 1, 1)):
         p = subprocess.run([mpiexec, "-n", str(n), exe, str(nxp), str(nyp)], capture_output=True, text=True, env=env, timeout=120)
         assert p.returncode == 0 and "0 wrong values" in p.stdout, (n, p.stdout, p.stderr)
+
+
+def test_every_code_object_of_the_library_carries_its_probe():
+    """scripts/code_verify.py (round 6): libtsx.so holds one gfx950 code object per translation unit; eight of them carry a probe kernel
+    (TSX_CODE_PROBE) whose s_getpc_b64 the script finds in the ELF image, so that the loaded .text can be compared with the file on
+    the GPU box (tests/test_gpu_diag.py).  Here: the parsing -- bundles, section and symbol tables -- on the built library."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import code_verify
+
+    info = code_verify.units(_lib.LIB_PATH)
+    assert set(info) == set(code_verify.UNITS)
+    for u, d in info.items():
+        assert len(d["text"]) > 1000 and len(d["text"]) % 4 == 0, u
+        assert d["delta"] < 0 and -d["delta"] <= len(d["text"]) + 64, (u, d["delta"])   # the probe lies inside its unit's .text
+        assert any(k.startswith("tsx_k_code_probe_") for k in d["syms"]), u
+    # the kernels the round-6 hunt looked at live where the script says
+    assert "tsx_k_dd_index" in " ".join(info["dedup"]["syms"])
