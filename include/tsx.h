@@ -368,7 +368,8 @@ int tsx_algorithmic_bytes(const tsx_solver *s, int kernel, double *bytes);
  * approximate by design; the operator keeps exact blocks) -- alone where nothing is bit-identical (*nent = the groups), or on top
  * of bit 0 where it halves the preconditioner's table.  TSX_DEDUP_NEAR=0 switches that off.  Bit 2: the grouping (which cells share a
  * block) was taken over from the previous coefficient set of this solver after one validation kernel found it still exact for the new
- * LUT coordinates -- the case of a spectral loop over g-points of one scene; TSX_DEDUP_REUSE=0 rebuilds it every time */
+ * LUT coordinates -- the case of a spectral loop over g-points of one scene; TSX_DEDUP_REUSE=0 rebuilds it every time.  Bit 3: likewise
+ * the grouping of the cells by their packed column-recurrence records (tsx_records_share), as of the last packing */
 int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent);
 /* the preconditioner the last solve / tsx_bench_kernel actually ran (after the automatic choices: red-black -> zebra rows
  * on odd grids, pc_sweeps 0 -> 27 or 9): TSX_PC_*, pc_sweeps, and scan: 0 = one-lane-per-column kernels, 1 = scan kernels,

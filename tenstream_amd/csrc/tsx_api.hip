@@ -253,6 +253,10 @@ static int create_fill(tsx_solver *s, const tsx_grid *grid) {
   }
 
   const size_t nb = (size_t)g.N * sizeof(double);
+  // what this solver will hold after its first solve, roughly: 8 Krylov vectors here, then 4-5 more for the preconditioned
+  // directions and staging, the fp32 copies, the coefficient planes (fp32) with their packed copy, the pipeline's fields -- one slab
+  // for all of it instead of a quarantine per buffer (tsx_pool.hip)
+  tsx_dev_reserve((size_t)15 * nb + (size_t)g.Nc * g.D * g.D * 4 * 3 / 2 + (size_t)g.Nc * 16 * (g.ntop == 2 ? 10 : 36) + ((size_t)32 << 20));
   double **vecs[] = {&s->vx, &s->vb, &s->vr, &s->vrhat, &s->vp, &s->vv, &s->vs, &s->vt};
   for (double **v : vecs) {
     HIPCHK(tsx_dev_malloc((void **)v, nb));
@@ -1682,7 +1686,9 @@ extern "C" int tsx_dedup_info(tsx_solver *s, int32_t *on, int64_t *nent) {
   // bit 0: bit-identical blocks shared (operator and preconditioner); bit 1: near-identical blocks grouped for the
   // preconditioner (on top of bit 0, or alone where nothing is bit-identical)
   // bit 2: the grouping is the previous coefficient set's, found still valid for this set's LUT coordinates (tsx_dedup_from_coords)
-  *on = (s->dd_on ? 1 : 0) | (s->dd_pc ? 2 : 0) | ((s->dd_on && s->dd_from_coords && s->dd_reused) ? 4 : 0);
+  // bit 3 (round 6): the grouping of the cells by their packed recurrence records (tsx_records_share) was the previous set's as well
+  *on = (s->dd_on ? 1 : 0) | (s->dd_pc ? 2 : 0) | ((s->dd_on && s->dd_from_coords && s->dd_reused) ? 4 : 0) |
+        ((s->pcr_on && s->pcr_reused) ? 8 : 0);
   *nent = s->dd_on ? s->dd_nent : (s->dd_pc ? s->pc_nent : s->dd_nent);
   return TSX_OK;
 }

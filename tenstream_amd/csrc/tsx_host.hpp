@@ -80,7 +80,8 @@ static inline int spmv_nblocks(const tsx_solver *s) {
 // contents are proven stable, and sub-allocated from then on.  Same contracts as hipMalloc / hipFree (the free synchronises the device).
 hipError_t tsx_dev_malloc_bytes(void **out, size_t bytes);
 hipError_t tsx_dev_free(void *p);
-hipError_t tsx_dev_quarantine(void *p, size_t bytes);  // for driver allocations of another kind (the uncached peer mailbox), in place
+hipError_t tsx_dev_quarantine(void *p, size_t bytes);
+void tsx_dev_reserve(size_t bytes);  // a hint: one slab for what a solver is about to allocate piece by piece  // for driver allocations of another kind (the uncached peer mailbox), in place
 template <typename T>
 static inline hipError_t tsx_dev_malloc(T **p, size_t bytes) {
   return tsx_dev_malloc_bytes((void **)p, bytes);

@@ -172,6 +172,9 @@ struct tsx_solver {
   int *pcr_idx = nullptr, *pcr_ent = nullptr;
   void *pcr_tab = nullptr;
   long long pcr_n = 0, pcr_cap = 0;
+  int pcr_have_R = 0;           // > 0: pcr_idx / pcr_ent hold a grouping of the cells by their R records (of some earlier coefficient set)
+  const void *pcr_have_P = nullptr;  // ... of the record planes at this address
+  bool pcr_reused = false;      // the last tsx_records_share took the previous grouping over
   // the intermediate passes of an application as one launch (tsx_pcs_flow.hip): ticket / epoch words and the tiles' progress words
   void *flow_state = nullptr;
   unsigned *flow_prog = nullptr;

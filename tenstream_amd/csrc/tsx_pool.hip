@@ -211,6 +211,25 @@ hipError_t tsx_dev_free(void *p) {
   return e;
 }
 
+// Make sure the pool holds a free piece of at least `bytes` (one slab, one quarantine) before a solver takes its dozens of large
+// buffers one by one: without it every vector of a first solver is a slab of its own with its own 3 ms in quarantine (round 6: the
+// first solve of a process 33 -> 64 ms wall, config 4's cold call 75 -> 65 g-points/s).  A hint: failure to get that much is not an
+// error, the allocations then come as they did.
+void tsx_dev_reserve(size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  if (getenv("TSX_POOL") && atoi(getenv("TSX_POOL")) == 0) return;
+  Pool *P = pool_of(dev);
+  std::lock_guard<std::mutex> lk(P->mu);
+  const size_t need = (bytes + kAlign - 1) & ~(kAlign - 1);
+  size_t free_total = 0;
+  for (auto &kv : P->pieces)
+    if (kv.second.free) free_total += kv.second.bytes;
+  if (free_total >= need) return;  // (pieces of earlier solvers will serve; fragmentation costs a slab later, not correctness)
+  char *base = nullptr;
+  if (new_slab(P, need - free_total > ((size_t)64 << 20) ? need - free_total : ((size_t)64 << 20), &base) != hipSuccess) (void)hipGetLastError();
+}
+
 // A driver allocation that cannot come from the pool (the peer mailbox: uncached / fine-grained memory): the same quarantine in
 // place.  `p` holds `bytes` bytes fresh from the driver; on return it is zeroed and has stayed intact for the guard time.
 hipError_t tsx_dev_quarantine(void *p, size_t bytes) {

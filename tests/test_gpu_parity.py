@@ -827,11 +827,28 @@ def test_shared_recurrence_records_are_lossless(gpu, monkeypatch, solver, Nx, Ny
         s.set_coeffs(coeff, P["l1d"], P["a11"], P["a12"], P["albedo"])
         xs = np.zeros(s.vec_shape)
         info = s.solve(P["b"], xs, rtol=1e-9, atol=1e-30)
-        res[share] = (s.pc_info(), xs, info)
+        # round 6: a second coefficient set with the same structure (every block scaled): the grouping of the records is taken over
+        # after one validation kernel (tsx_k_rec_validate) instead of being rebuilt; a third with another structure rebuilds
+        s.set_coeffs((coeff * np.float32(0.97)).astype(np.float32), P["l1d"], P["a11"], P["a12"], P["albedo"])
+        x2 = np.zeros(s.vec_shape)
+        info2 = s.solve(P["b"], x2, rtol=1e-9, atol=1e-30)
+        s.dedup_info()
+        reused2 = bool(s.dedup_mode & 8)
+        c3 = coeff.copy()
+        c3[keep] = (c3[keep] * np.float32(0.9)).astype(np.float32)   # now the three columns differ down to the surface
+        s.set_coeffs(c3, P["l1d"], P["a11"], P["a12"], P["albedo"])
+        x3 = np.zeros(s.vec_shape)
+        info3 = s.solve(P["b"], x3, rtol=1e-9, atol=1e-30)
+        s.dedup_info()
+        reused3 = bool(s.dedup_mode & 8)
+        res[share] = (s.pc_info(), xs, info, x2, info2, x3, info3, reused2, reused3)
         s.close()
     assert res["0"][0][2] and not res["0"][0][3] and res["1"][0][3], (res["0"][0], res["1"][0])
     assert res["0"][2].reason == 2 and res["0"][2].niter == res["1"][2].niter
     assert np.array_equal(res["0"][2].res_hist, res["1"][2].res_hist) and np.array_equal(res["0"][1], res["1"][1])
+    assert res["1"][7] and not res["1"][8] and not res["0"][7], (res["1"][7:], res["0"][7:])
+    for q in (3, 5):   # the taken-over grouping and the rebuilt one: bit-identical to no sharing at all
+        assert np.array_equal(res["0"][q], res["1"][q]) and np.array_equal(res["0"][q + 1].res_hist, res["1"][q + 1].res_hist)
 
 
 @pytest.mark.parametrize("solver,Nx,Ny,Nz,n1d", [("3_10", 16, 12, 9, 2), ("3_10", 10, 6, 5, 0), ("8_16", 8, 6, 5, 1)])
