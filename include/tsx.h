@@ -353,7 +353,8 @@ int tsx_diff_pc_apply(tsx_solver *s, const double *v, double *z, int where, int 
  *      the solver's stream.  kernel: 0 = SpMV (diffuse operator apply), 1 = one full BiCGStab iteration,
  *      2 = one application of the default preconditioner (pc_sweeps + 1 half-grid passes), 3 = one intermediate
  *      Gauss-Seidel pass of it (scan kernels) as a launch of its own, 4 = the flow kernel (the intermediate passes of an
- *      application in ONE launch; TSX_ERR_UNSUPPORTED where the configuration runs a launch per pass) */
+ *      application in ONE launch; TSX_ERR_UNSUPPORTED where the configuration runs a launch per pass), 5 = kernel 1's iteration
+ *      replayed from a hipGraph captured from the solver's stream (one rank; a measurement of what graph replay buys) */
 int tsx_bench_kernel(tsx_solver *s, int kernel, int reps, float *avg_ms);
 /* algorithmic bytes per launch of that kernel *in the storage format in use* (with shared storage of identical blocks:
  * every distinct block once + a 4-byte index per cell + the vectors; the preconditioner passes: packed records + fp32

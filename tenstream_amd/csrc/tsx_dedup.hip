@@ -829,7 +829,10 @@ int tsx_records_share(tsx_solver *s, int R, const uint4 *P) {
     // round 6: the previous set's grouping, if one validation kernel finds it still exact (TSX_DEDUP_REUSE=0: always rebuild -- the
     // switch of the block grouping's reuse, so that the test that compares against a solver rebuilding everything covers both)
     const char *er = getenv("TSX_DEDUP_REUSE");
-    if (s->pcr_have_R == R && s->pcr_have_P == (const void *)P && s->pcr_idx && s->pcr_ent && s->pcr_tab && n_have > 0 &&
+    // (on the LUT path only where the block grouping itself was taken over: a rebuilt one renumbers the block indices inside the
+    // records, and the validation -- 0.12 ms on 4.2 M cells -- would be spent to learn that; config 4, profiles/r06)
+    const bool plausible = !s->dd_from_coords || s->dd_reused;
+    if (plausible && s->pcr_have_R == R && s->pcr_have_P == (const void *)P && s->pcr_idx && s->pcr_ent && s->pcr_tab && n_have > 0 &&
         n_have * 2 <= Nc && !(er && atoi(er) == 0)) {
       HIPCHK(hipMemsetAsync(w.ttot.p, 0, sizeof(int), s->stream));
       hipLaunchKernelGGL(tsx_k_rec_validate, dim3(nb), dim3(TSX_BLOCK), 0, s->stream, Nc, R, P, (const int *)s->pcr_idx, (const int *)s->pcr_ent,

@@ -242,16 +242,19 @@ __global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const
     V = m.x + m.y * V;
   }
   // ---- phase 4: true V, U; side streams; stores
+  // (no early exit from the level loop: a branch between the levels fences their loads off from each other -- the loads of absent
+  // levels go to the clamped level and only the stores are predicated)
 #pragma unroll
   for (int l = 0; l < LSEG; ++l) {
-    if (k0 + l >= Nz) break;
-    const int k = k0 + l;
+    const bool act = k0 + l < Nz;
+    const bool st = live && act;
+    const int k = lev(l);
     const size_t c = (size_t)k * ncol + col;
     const double Bn = l + 1 < LSEG ? Bk[l + 1 < LSEG ? l + 1 : l] : Bin;
     const double Vn = gam[l] + GTk[l] * V;
     const double Un = rec[5 * Nc + c] * Vn + Bn;      // U_{k+1} = A_{k+1} V_{k+1} + B_{k+1}
     const double Uk = rec[6 * Nc + c] * V + Bk[l];    // U_k
-    if (live) {
+    if (st) {
       z[0 * Nc + c] = Uk;
       z[1 * Nc + c] = Vn;
     }
@@ -270,10 +273,10 @@ __global__ __launch_bounds__(PCX_CW *PCX_NSEG) void tsx_k_pcx_rb(TsxGeo g, const
         for (int q = 0; q < 8; ++q) acc += sd[q] * zn[q];
       }
       acc = r[(size_t)d * Nc + c] + (one ? 0.0 : acc);
-      if (live) z[(size_t)d * Nc + c] = acc;
+      if (st) z[(size_t)d * Nc + c] = acc;
     }
-    if (k == Nz - 1 && live) zt[(size_t)0 * ncol + col] = Un;  // U_Nz = albedo V_Nz + ru_Nz: the surface row
-    V = Vn;
+    if (k0 + l == Nz - 1 && live) zt[(size_t)0 * ncol + col] = Un;  // U_Nz = albedo V_Nz + ru_Nz: the surface row
+    V = act ? Vn : V;
   }
 }
 }  // namespace

@@ -61,6 +61,7 @@ struct Pool {
   std::map<char *, Piece> pieces;  // every byte of every slab belongs to exactly one piece, ordered by address
   std::vector<std::pair<char *, size_t>> slabs;
   unsigned long long *flag = nullptr;  // [2] device words of the verify kernel
+  hipStream_t st = nullptr;            // the pool's own non-blocking stream: its kernels never wait for, or hold up, a solver's
   long long wipes = 0, wiped_words = 0, first_wipe_us = -1, driver_allocs = 0, guard_us_spent = 0;
   size_t bytes = 0, live = 0;
 };
@@ -84,16 +85,22 @@ int grid_of(size_t nwords) {
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-// one driver allocation, proven stable.  Runs on the null stream with device-wide synchronisation: this is not a hot path.
-hipError_t new_slab(Pool *P, size_t bytes, char **out) {
-  char *base = nullptr;
-  hipError_t e = hipMalloc((void **)&base, bytes);
-  if (e != hipSuccess) return e;
-  P->driver_allocs++;
-  if (!P->flag) {
-    // the verify kernel's two result words: pinned host memory (nothing the platform clears behind our back)
-    if ((e = hipHostMalloc((void **)&P->flag, 2 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return e;
-  }
+// The pool works on a stream of its own and synchronises only that stream.  It must NOT synchronise the device: a rank process of a
+// multi-rank run allocates lazily while kernels of its solver are in flight that wait for a neighbour rank's message (peer
+// transport: in-kernel waits), and that neighbour may in turn wait for a kernel this rank's host has yet to enqueue -- a
+// hipDeviceSynchronize here closes the cycle (caught by the pytest loop of round 6: one peer-transport all-reduce timed out in 231
+// runs of the four-process pipeline case, profiles/r06/flaky_loop_pytest_pool_both_transports.txt; hipMalloc itself never waited).
+hipError_t pool_tools(Pool *P) {
+  hipError_t e = hipSuccess;
+  if (!P->st && (e = hipStreamCreateWithFlags(&P->st, hipStreamNonBlocking)) != hipSuccess) return e;
+  // the verify kernel's two result words: pinned host memory (nothing the platform clears behind our back)
+  if (!P->flag && (e = hipHostMalloc((void **)&P->flag, 2 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return e;
+  return e;
+}
+
+// pattern, watch, zero: `p` (bytes) has just come from the driver
+hipError_t quarantine(Pool *P, void *p, size_t bytes) {
+  hipError_t e;
   const long long guard_us = env_ll("TSX_POOL_GUARD_US", 3000);
   const size_t nwords = bytes / 4;
   const auto t_alloc = std::chrono::steady_clock::now();
@@ -101,15 +108,15 @@ hipError_t new_slab(Pool *P, size_t bytes, char **out) {
     return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count();
   };
   if (guard_us > 0) {
-    hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (unsigned *)base, nwords, kPattern);
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+    hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, P->st, (unsigned *)p, nwords, kPattern);
+    if ((e = hipStreamSynchronize(P->st)) != hipSuccess) return e;
     auto t_clean = std::chrono::steady_clock::now();  // since when the pattern is known to be whole
     for (int round = 0; round < 100000; ++round) {
       std::this_thread::sleep_for(std::chrono::microseconds(guard_us / 8 > 50 ? guard_us / 8 : 50));
       P->flag[0] = 0;
       P->flag[1] = ~0ull;
-      hipLaunchKernelGGL(tsx_k_pool_verify, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (const unsigned *)base, nwords, kPattern, P->flag);
-      if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+      hipLaunchKernelGGL(tsx_k_pool_verify, dim3(grid_of(nwords)), dim3(256), 0, P->st, (const unsigned *)p, nwords, kPattern, P->flag);
+      if ((e = hipStreamSynchronize(P->st)) != hipSuccess) return e;
       if (P->flag[0]) {  // the platform wrote into memory it had already handed out: count it, write the pattern again, start over
         P->wipes++;
         P->wiped_words += (long long)P->flag[0];
@@ -117,17 +124,31 @@ hipError_t new_slab(Pool *P, size_t bytes, char **out) {
         if (getenv("TSX_POOL_VERBOSE"))
           fprintf(stderr, "[tsx_pool] pid %d: %llu words of a fresh %zu-byte allocation lost their contents %lld us after hipMalloc (first at word %llu)\n",
                   (int)getpid(), P->flag[0], bytes, us_since(t_alloc), P->flag[1]);
-        hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (unsigned *)base, nwords, kPattern);
-        if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+        hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, P->st, (unsigned *)p, nwords, kPattern);
+        if ((e = hipStreamSynchronize(P->st)) != hipSuccess) return e;
         t_clean = std::chrono::steady_clock::now();
         continue;
       }
       if (us_since(t_clean) >= guard_us) break;
     }
   }
-  if ((e = hipMemset(base, 0, bytes)) != hipSuccess) return e;
-  if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+  hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, P->st, (unsigned *)p, nwords, 0u);
+  if (bytes & 3) {  // (a tail shorter than a word)
+    if ((e = hipMemsetAsync((char *)p + (bytes & ~(size_t)3), 0, bytes & 3, P->st)) != hipSuccess) return e;
+  }
+  if ((e = hipStreamSynchronize(P->st)) != hipSuccess) return e;
   P->guard_us_spent += us_since(t_alloc);
+  return hipSuccess;
+}
+
+// one driver allocation, proven stable.  Not a hot path; synchronises the pool's own stream only.
+hipError_t new_slab(Pool *P, size_t bytes, char **out) {
+  char *base = nullptr;
+  hipError_t e = pool_tools(P);
+  if (e != hipSuccess) return e;
+  if ((e = hipMalloc((void **)&base, bytes)) != hipSuccess) return e;
+  P->driver_allocs++;
+  if ((e = quarantine(P, base, bytes)) != hipSuccess) return e;
   P->slabs.emplace_back(base, bytes);
   P->bytes += bytes;
   P->pieces[base] = Piece{bytes, (int)P->slabs.size() - 1, true};
@@ -238,38 +259,12 @@ hipError_t tsx_dev_quarantine(void *p, size_t bytes) {
   if (e != hipSuccess) return e;
   Pool *P = pool_of(dev);
   std::lock_guard<std::mutex> lk(P->mu);
-  const long long guard_us = env_ll("TSX_POOL_GUARD_US", 3000);
-  if (!P->flag && (e = hipHostMalloc((void **)&P->flag, 2 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return e;
-  const size_t nwords = bytes / 4;
-  if (guard_us > 0 && !(getenv("TSX_POOL") && atoi(getenv("TSX_POOL")) == 0)) {
-    const auto t0 = std::chrono::steady_clock::now();
-    auto us = [&](std::chrono::steady_clock::time_point t) {
-      return (long long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count();
-    };
-    hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (unsigned *)p, nwords, kPattern);
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
-    auto t_clean = std::chrono::steady_clock::now();
-    for (int round = 0; round < 100000; ++round) {
-      std::this_thread::sleep_for(std::chrono::microseconds(guard_us / 8 > 50 ? guard_us / 8 : 50));
-      P->flag[0] = 0;
-      P->flag[1] = ~0ull;
-      hipLaunchKernelGGL(tsx_k_pool_verify, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (const unsigned *)p, nwords, kPattern, P->flag);
-      if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
-      if (P->flag[0]) {
-        P->wipes++;
-        P->wiped_words += (long long)P->flag[0];
-        if (P->first_wipe_us < 0) P->first_wipe_us = us(t0);
-        hipLaunchKernelGGL(tsx_k_pool_fill, dim3(grid_of(nwords)), dim3(256), 0, nullptr, (unsigned *)p, nwords, kPattern);
-        if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
-        t_clean = std::chrono::steady_clock::now();
-        continue;
-      }
-      if (us(t_clean) >= guard_us) break;
-    }
-    P->guard_us_spent += us(t0);
+  if ((e = pool_tools(P)) != hipSuccess) return e;
+  if (getenv("TSX_POOL") && atoi(getenv("TSX_POOL")) == 0) {
+    if ((e = hipMemsetAsync(p, 0, bytes, P->st)) != hipSuccess) return e;
+    return hipStreamSynchronize(P->st);
   }
-  if ((e = hipMemset(p, 0, bytes)) != hipSuccess) return e;
-  return hipDeviceSynchronize();
+  return quarantine(P, p, bytes);
 }
 
 // out8 = {slabs taken from the driver, their bytes, bytes handed out now, pieces, verifies that found a fresh slab damaged, words

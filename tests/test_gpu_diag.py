@@ -99,3 +99,23 @@ def test_pool_takes_driver_memory_once_and_reuses_it(gpu, monkeypatch):
     s3 = stats()
     assert s3[0] == s2[0] and s3[2] <= s2[2], (s2, s3)
     assert np.array_equal(np.asarray(edn), np.asarray(edn0))
+
+
+def test_an_iteration_replayed_from_a_graph_leaves_the_solver_usable(gpu):
+    """tsx_bench_kernel(5): one BiCGStab iteration captured from the solver's stream into a hipGraph and replayed (the measurement of
+    what graph replay buys, scripts/graph_ab.py).  Here: it runs next to the eager timing, and a solve after it still reaches the same
+    solution -- the capture left no host-side state behind."""
+    from tenstream_amd import DiffuseSolver
+
+    P = synthetic.make_problem("3_10", Nx=32, Ny=32, Nz=16)
+    s = DiffuseSolver("3_10", 16, 32, 32)
+    s.set_coeffs(P["coeff"], P["l1d"], P["a11"], P["a12"], P["albedo"])
+    x0 = np.zeros(s.vec_shape)
+    assert s.solve(P["b"], x0, rtol=1e-10, atol=1e-30).reason == 2
+    eager = s.bench_kernel(1, 5)
+    graph = s.bench_kernel(5, 5)
+    assert eager > 0 and graph > 0
+    x1 = np.zeros(s.vec_shape)
+    assert s.solve(P["b"], x1, rtol=1e-10, atol=1e-30).reason == 2
+    assert np.abs(x1 - x0).max() <= 1e-8 * np.abs(x0).max()
+    s.close()
