@@ -182,7 +182,14 @@ static int flow_launch(tsx_solver *s, int p0, int p1, const int *done, bool face
   // two passes' worth of tiles can be runnable at a time (a tile of pass p + 2 needs its neighbours' pass p + 1); more
   // workgroups than that only poll
   long long grid = 2ll * ntiles;
-  const int cap = fat ? cap_fat : flow_capacity(s, CW, false);
+  int cap = fat ? cap_fat : flow_capacity(s, CW, false);
+  // rank processes that share this device (the multi-process tests, a one-GPU box): each rank's resident grid spins on its
+  // neighbours' tags, and a grid that fills the device keeps the neighbours' workgroups from being dispatched until the driver
+  // time-slices the processes -- leave them their share.  One process per device (production): unchanged
+  if (faces) {
+    const int co = tsx_peer_colocated(s);
+    if (co > 1) cap = cap / co > 1 ? cap / co : 1;
+  }
   if (grid > cap) grid = cap;
   if (const char *e = getenv("TSX_FLOW_GRID")) {
     const int v = atoi(e);

@@ -190,6 +190,7 @@ struct TsxPeer {
   unsigned long long ticks = 0;
   int heavy = 0;                         // TSX_PEER_FENCES / tsx_comm_peer_set_fences (tsx_peer_dev.hpp)
   bool attached = false;
+  int colocated = 1;  // ranks of the job on this rank's device (tests and one-GPU boxes: all of them)
 };
 
 static size_t peer_capacity(const tsx_solver *s) {
@@ -311,14 +312,17 @@ extern "C" int tsx_comm_peer_attach(tsx_solver *s, const void *blobs) {
   // Ordering around the mailbox flags.  The light ordering (tsx_peer_dev.hpp: uncached mailboxes, s_waitcnt + relaxed stores) has
   // only ever run between processes sharing ONE device; the first contact across devices (xGMI, another GPU's HBM) starts with the
   // textbook full system-scope fences.  TSX_PEER_FENCES=0 relaxes, =1 forces; tsx_comm_peer_set_fences overrides either.
-  if (!getenv("TSX_PEER_FENCES")) {
+  {
     bool cross = false;
+    int here = 0;
     for (int r = 0; r < R; ++r) {
       PeerBlob b;
       memcpy(&b, (const char *)blobs + (size_t)r * TSX_PEER_BLOB_BYTES, sizeof(b));
       cross = cross || b.device != s->device;
+      here += b.device == s->device ? 1 : 0;
     }
-    p->heavy = cross;
+    if (!getenv("TSX_PEER_FENCES")) p->heavy = cross;
+    p->colocated = here > 0 ? here : 1;
   }
   p->attached = true;
   s->pcg_key = -1;  // decisions agreed over the previous transport are agreed again (tsx_pc_global_agree)
@@ -326,6 +330,7 @@ extern "C" int tsx_comm_peer_attach(tsx_solver *s, const void *blobs) {
 }
 
 bool tsx_peer_ready(const tsx_solver *s) { return s->peer && s->peer->attached; }
+int tsx_peer_colocated(const tsx_solver *s) { return s->peer && s->peer->attached ? s->peer->colocated : 1; }
 
 void tsx_peer_destroy(tsx_solver *s) {
   TsxPeer *p = s->peer;

@@ -25,3 +25,5 @@ int tsx_peer_ar_args(tsx_solver *s, int nvals, TsxPeerArArgs *a);
 // the flow kernel (tsx_k_pcs_flow FPEER) sends and consumes `npass` messages per face by itself: its view of the transport, the
 // counters advanced by what it will have sent (npass) and consumed beyond the message already expected (npass - 1)
 int tsx_peer_flow_view(tsx_solver *s, const size_t bytes[4], int npass, TsxFlowPeer *v);
+// rank processes of this job whose mailbox lives on this rank's device, this rank included (1: a device of its own)
+int tsx_peer_colocated(const tsx_solver *s);
