@@ -29,10 +29,11 @@
 #include <vector>
 
 #include "tsx_host.hpp"
+#include "tsx_pool_map.hpp"
 
 namespace {
 constexpr unsigned kPattern = 0xA5C3F00Du;
-constexpr size_t kAlign = 256;
+constexpr size_t kAlign = TsxPieceMap::kAlign;
 
 __global__ __launch_bounds__(256) void tsx_k_pool_fill(unsigned *p, size_t nwords, unsigned v) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) p[i] = v;
@@ -51,19 +52,12 @@ __global__ __launch_bounds__(256) void tsx_k_pool_verify(const unsigned *p, size
   }
 }
 
-struct Piece {
-  size_t bytes;
-  int slab;
-  bool free;
-};
 struct Pool {
   std::mutex mu;
-  std::map<char *, Piece> pieces;  // every byte of every slab belongs to exactly one piece, ordered by address
-  std::vector<std::pair<char *, size_t>> slabs;
+  TsxPieceMap m;  // every byte of every slab belongs to exactly one piece (tsx_pool_map.hpp)
   unsigned long long *flag = nullptr;  // [2] device words of the verify kernel
   hipStream_t st = nullptr;            // the pool's own non-blocking stream: its kernels never wait for, or hold up, a solver's
   long long wipes = 0, wiped_words = 0, first_wipe_us = -1, driver_allocs = 0, guard_us_spent = 0;
-  size_t bytes = 0, live = 0;
 };
 std::mutex g_mu;
 std::map<int, Pool *> g_pools;
@@ -149,9 +143,7 @@ hipError_t new_slab(Pool *P, size_t bytes, char **out) {
   if ((e = hipMalloc((void **)&base, bytes)) != hipSuccess) return e;
   P->driver_allocs++;
   if ((e = quarantine(P, base, bytes)) != hipSuccess) return e;
-  P->slabs.emplace_back(base, bytes);
-  P->bytes += bytes;
-  P->pieces[base] = Piece{bytes, (int)P->slabs.size() - 1, true};
+  P->m.add_slab(base, bytes);
   *out = base;
   return hipSuccess;
 }
@@ -165,23 +157,8 @@ hipError_t tsx_dev_malloc_bytes(void **out, size_t bytes) {
   if (getenv("TSX_POOL") && atoi(getenv("TSX_POOL")) == 0) return hipMalloc(out, bytes);  // A/B: straight to the driver
   Pool *P = pool_of(dev);
   std::lock_guard<std::mutex> lk(P->mu);
-  const size_t need = ((bytes ? bytes : 1) + kAlign - 1) & ~(kAlign - 1);
-  auto take = [&](std::map<char *, Piece>::iterator it) {
-    Piece pc = it->second;
-    char *p = it->first;
-    if (pc.bytes > need) P->pieces[p + need] = Piece{pc.bytes - need, pc.slab, true};
-    it->second = Piece{need, pc.slab, false};
-    P->live += need;
-    *out = p;
-  };
-  // best fit: the smallest free piece that holds the request (a solver's big vectors and its 16-byte tables share the slabs)
-  auto best = P->pieces.end();
-  for (auto it = P->pieces.begin(); it != P->pieces.end(); ++it)
-    if (it->second.free && it->second.bytes >= need && (best == P->pieces.end() || it->second.bytes < best->second.bytes)) best = it;
-  if (best != P->pieces.end()) {
-    take(best);
-    return hipSuccess;
-  }
+  const size_t need = TsxPieceMap::rounded(bytes);
+  if ((*out = P->m.take(need))) return hipSuccess;
   // a new slab: small requests share slabs of TSX_POOL_SLAB_MB (default 64), a large one gets a slab of its own size
   const size_t slab_min = (size_t)env_ll("TSX_POOL_SLAB_MB", 64) << 20;
   const size_t sz = need > slab_min ? need : slab_min;
@@ -189,8 +166,8 @@ hipError_t tsx_dev_malloc_bytes(void **out, size_t bytes) {
   e = new_slab(P, sz, &base);
   if (e != hipSuccess && sz > need) e = new_slab(P, need, &base);  // (a nearly full device: exactly what was asked for)
   if (e != hipSuccess) return e;
-  take(P->pieces.find(base));
-  return hipSuccess;
+  *out = P->m.take(need);
+  return *out ? hipSuccess : hipErrorOutOfMemory;
 }
 
 hipError_t tsx_dev_free(void *p) {
@@ -205,7 +182,7 @@ hipError_t tsx_dev_free(void *p) {
     // the piece may belong to another device's pool than the current device: look it up everywhere
     for (auto &kv : g_pools) {
       std::lock_guard<std::mutex> lk2(kv.second->mu);
-      if (kv.second->pieces.count((char *)p)) {
+      if (kv.second->m.owns((const char *)p)) {
         P = kv.second;
         break;
       }
@@ -213,22 +190,7 @@ hipError_t tsx_dev_free(void *p) {
   }
   if (!P) return hipFree(p);  // not ours (TSX_POOL=0 allocations)
   std::lock_guard<std::mutex> lk(P->mu);
-  auto it = P->pieces.find((char *)p);
-  if (it == P->pieces.end() || it->second.free) return hipErrorInvalidValue;
-  it->second.free = true;
-  P->live -= it->second.bytes;
-  auto nx = std::next(it);
-  if (nx != P->pieces.end() && nx->second.free && nx->second.slab == it->second.slab && nx->first == it->first + it->second.bytes) {
-    it->second.bytes += nx->second.bytes;
-    P->pieces.erase(nx);
-  }
-  if (it != P->pieces.begin()) {
-    auto pv = std::prev(it);
-    if (pv->second.free && pv->second.slab == it->second.slab && pv->first + pv->second.bytes == it->first) {
-      pv->second.bytes += it->second.bytes;
-      P->pieces.erase(it);
-    }
-  }
+  if (!P->m.give((char *)p)) return hipErrorInvalidValue;
   return e;
 }
 
@@ -243,9 +205,7 @@ void tsx_dev_reserve(size_t bytes) {
   Pool *P = pool_of(dev);
   std::lock_guard<std::mutex> lk(P->mu);
   const size_t need = (bytes + kAlign - 1) & ~(kAlign - 1);
-  size_t free_total = 0;
-  for (auto &kv : P->pieces)
-    if (kv.second.free) free_total += kv.second.bytes;
+  const size_t free_total = P->m.free_total();
   if (free_total >= need) return;  // (pieces of earlier solvers will serve; fragmentation costs a slab later, not correctness)
   char *base = nullptr;
   if (new_slab(P, need - free_total > ((size_t)64 << 20) ? need - free_total : ((size_t)64 << 20), &base) != hipSuccess) (void)hipGetLastError();
@@ -274,10 +234,10 @@ extern "C" int tsx_pool_stats(int device, int64_t *out8) {
   if (device < 0 && hipGetDevice(&device) != hipSuccess) return TSX_ERR_NO_DEVICE;
   Pool *P = pool_of(device);
   std::lock_guard<std::mutex> lk(P->mu);
-  out8[0] = (int64_t)P->slabs.size();
-  out8[1] = (int64_t)P->bytes;
-  out8[2] = (int64_t)P->live;
-  out8[3] = (int64_t)P->pieces.size();
+  out8[0] = (int64_t)P->m.slabs.size();
+  out8[1] = (int64_t)P->m.bytes;
+  out8[2] = (int64_t)P->m.live;
+  out8[3] = (int64_t)P->m.pieces.size();
   out8[4] = P->wipes;
   out8[5] = P->wiped_words;
   out8[6] = P->first_wipe_us;

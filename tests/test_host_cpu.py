@@ -165,3 +165,14 @@ def test_every_code_object_of_the_library_carries_its_probe():
         assert any(k.startswith("tsx_k_code_probe_") for k in d["syms"]), u
     # the kernels the round-6 hunt looked at live where the script says
     assert "tsx_k_dd_index" in " ".join(info["dedup"]["syms"])
+
+
+def test_pool_bookkeeping_keeps_its_invariants_under_random_requests(tmp_path):
+    """tsx_pool_map.hpp (the piece map of libtsx's device memory pool, plain C++): 200 000 random requests and returns over three
+    slabs, two of them adjacent -- live pieces never overlap, pieces tile the slabs, free neighbours of ONE slab are merged, best fit,
+    a double or foreign return is refused, everything returned = one free piece per slab (tests/c/pool_map_test.cpp)."""
+    exe = str(tmp_path / "pool_map_test")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "tenstream_amd", "csrc"), "-o", exe,
+                    os.path.join(ROOT, "tests", "c", "pool_map_test.cpp")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "pool map ok" in r.stdout, r.stdout + r.stderr
