@@ -63,6 +63,7 @@ struct PeerBlob {  // what tsx_comm_peer_export hands to the host's all-gather (
   void *ptr;  // valid in the exporting process only (ranks living in one process use it directly)
   int pid, device, rank, nranks;
   char host[32];
+  int pci[3];  // PCI domain, bus, device of `device`: rank processes that each see ONE GPU (HIP_VISIBLE_DEVICES) all call it device 0
 };
 static_assert(sizeof(PeerBlob) <= TSX_PEER_BLOB_BYTES, "blob size");
 
@@ -251,6 +252,12 @@ extern "C" int tsx_comm_peer_export(tsx_solver *s, void *blob) {
   b.ptr = p->mine;
   b.pid = (int)getpid();
   b.device = s->device;
+  if (hipDeviceGetAttribute(&b.pci[0], hipDeviceAttributePciDomainID, s->device) != hipSuccess ||
+      hipDeviceGetAttribute(&b.pci[1], hipDeviceAttributePciBusId, s->device) != hipSuccess ||
+      hipDeviceGetAttribute(&b.pci[2], hipDeviceAttributePciDeviceId, s->device) != hipSuccess) {
+    b.pci[0] = b.pci[1] = b.pci[2] = -1;
+    (void)hipGetLastError();
+  }
   b.rank = s->grid.rank;
   b.nranks = s->grid.nranks;
   gethostname(b.host, sizeof(b.host) - 1);
@@ -315,11 +322,17 @@ extern "C" int tsx_comm_peer_attach(tsx_solver *s, const void *blobs) {
   {
     bool cross = false;
     int here = 0;
+    PeerBlob mine;
+    memcpy(&mine, (const char *)blobs + (size_t)me * TSX_PEER_BLOB_BYTES, sizeof(mine));
     for (int r = 0; r < R; ++r) {
       PeerBlob b;
       memcpy(&b, (const char *)blobs + (size_t)r * TSX_PEER_BLOB_BYTES, sizeof(b));
-      cross = cross || b.device != s->device;
-      here += b.device == s->device ? 1 : 0;
+      // the same physical device: by PCI address where both sides could read it (the ordinals of processes that each see one GPU
+      // coincide), else by ordinal
+      const bool pci_ok = mine.pci[1] >= 0 && b.pci[1] >= 0;
+      const bool same = pci_ok ? (b.pci[0] == mine.pci[0] && b.pci[1] == mine.pci[1] && b.pci[2] == mine.pci[2]) : b.device == s->device;
+      cross = cross || !same;
+      here += same ? 1 : 0;
     }
     if (!getenv("TSX_PEER_FENCES")) p->heavy = cross;
     p->colocated = here > 0 ? here : 1;

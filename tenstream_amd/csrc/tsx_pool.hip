@@ -56,7 +56,7 @@ struct Pool {
   std::mutex mu;
   TsxPieceMap m;  // every byte of every slab belongs to exactly one piece (tsx_pool_map.hpp)
   unsigned long long *flag = nullptr;  // [2] device words of the verify kernel
-  hipStream_t st = nullptr;            // the pool's own non-blocking stream: its kernels never wait for, or hold up, a solver's
+  hipStream_t st = nullptr;            // the NULL stream, synchronised as a stream (never the device): see pool_tools
   long long wipes = 0, wiped_words = 0, first_wipe_us = -1, driver_allocs = 0, guard_us_spent = 0;
 };
 std::mutex g_mu;
@@ -79,14 +79,19 @@ int grid_of(size_t nwords) {
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-// The pool works on a stream of its own and synchronises only that stream.  It must NOT synchronise the device: a rank process of a
-// multi-rank run allocates lazily while kernels of its solver are in flight that wait for a neighbour rank's message (peer
-// transport: in-kernel waits), and that neighbour may in turn wait for a kernel this rank's host has yet to enqueue -- a
-// hipDeviceSynchronize here closes the cycle (caught by the pytest loop of round 6: one peer-transport all-reduce timed out in 231
-// runs of the four-process pipeline case, profiles/r06/flaky_loop_pytest_pool_both_transports.txt; hipMalloc itself never waited).
+// The pool's kernels run on the NULL stream and only that stream is synchronised.
+//  * It must NOT synchronise the device: a rank process of a multi-rank run allocates lazily while kernels of its solver are in flight
+//    that wait for a neighbour rank's message (peer transport: in-kernel waits), and that neighbour may in turn wait for a kernel this
+//    rank's host has yet to enqueue -- a hipDeviceSynchronize here closes the cycle (caught by the pytest loop of round 6: one
+//    peer-transport all-reduce timed out in 231 runs of the four-process pipeline case,
+//    profiles/r06/flaky_loop_pytest_pool_both_transports.txt; hipMalloc itself never waited).  The solvers' streams are non-blocking:
+//    the null stream neither waits for them nor holds them up.
+//  * It must NOT own a stream either: a stream is a hardware queue, eight rank processes sharing one device (the config-3 test) hold
+//    four each already, and a fifth per process oversubscribed the queue slots -- the scheduler then multiplexes the queues with a
+//    coarse quantum and the peer transport's in-kernel waits ran into their bound (tests/test_gpu_config3.py failed 3 of 3 with the
+//    stream, passed with the same library before it and passes without it).
 hipError_t pool_tools(Pool *P) {
   hipError_t e = hipSuccess;
-  if (!P->st && (e = hipStreamCreateWithFlags(&P->st, hipStreamNonBlocking)) != hipSuccess) return e;
   // the verify kernel's two result words: pinned host memory (nothing the platform clears behind our back)
   if (!P->flag && (e = hipHostMalloc((void **)&P->flag, 2 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return e;
   return e;
