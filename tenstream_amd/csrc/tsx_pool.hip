@@ -140,7 +140,7 @@ hipError_t quarantine(Pool *P, void *p, size_t bytes) {
   return hipSuccess;
 }
 
-// one driver allocation, proven stable.  Not a hot path; synchronises the pool's own stream only.
+// one driver allocation, proven stable.  Not a hot path; synchronises the null stream only (never the device).
 hipError_t new_slab(Pool *P, size_t bytes, char **out) {
   char *base = nullptr;
   hipError_t e = pool_tools(P);
